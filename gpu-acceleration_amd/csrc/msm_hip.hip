@@ -1,0 +1,579 @@
+// msm_hip.hip -- host runtime + C ABI (include/msm_hip.h) of the MI355X-native BN254 G1 MSM.
+//
+// Replaces, for the one path metal_variable_base_msm (metal_msm.rs:642-695):
+//   MetalMSMPipeline::{new,execute_pipeline,final_reduction}      metal_msm.rs:48-261
+//   ShaderManager / MetalHelper / gpu::{create_buffer,read_buffer} host/shader_manager.rs:98-167,
+//                                                                 host/metal_wrapper.rs:55-217, host/gpu.rs:3-31
+// Design differences (MI355X-first):
+//   * a persistent context owns the device, one HIP stream, the HBM workspace and the hipEvents; the
+//     reference re-opens the device, reloads the metallib twice and builds six pipeline states on
+//     EVERY call (metal_msm.rs:693 -> 64 -> 48, window_size_optimizer.rs:79-92);
+//   * all intermediates stay in HBM -- the reference round-trips every stage through a host Vec<u32>
+//     (metal_msm.rs:331-339, 403-407, 505-507, 630-632);
+//   * launches are queued back to back on one stream; the only host synchronisation is the final
+//     copy of W window sums (W*96 bytes).  The reference blocks after each of its 9 submits.
+// There is NO CPU fallback: without a HIP device every compute entry point returns MSM_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/msm_hip.h"
+#include "host_g1.hpp"
+#include "msm_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+enum { EV_START, EV_H2D, EV_CONVERT, EV_DECOMP, EV_SORT, EV_ACC0, EV_ACC1, EV_REDUCE, EV_COUNT };
+
+}  // namespace
+
+struct msm_ctx {
+    std::mutex mu;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    msm_config_t cfg{};
+    std::string err;
+    hipEvent_t ev[EV_COUNT]{};
+    // HBM workspace
+    DevBuf bases, inf, scalars, digits, ranks, sorted, hist, offsets, blocksums, buckets, gpoints, winsums, flags,
+        pow2;
+    bool pow2_ready = false;
+    uint32_t* h_winsums = nullptr;  // pinned
+    uint32_t* h_flags = nullptr;    // pinned
+    // resident bases
+    size_t resident_n = 0;
+    bool resident_has_inf = false;
+    msm_timings_t tm{};
+    double acc_ms_sum = 0;
+    uint64_t acc_launches = 0;
+};
+
+namespace {
+
+int32_t fail(msm_ctx* c, int32_t code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                                              \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? MSM_ERR_OOM : MSM_ERR_HIP, "%s failed: %s (%s:%d)", #call, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                    \
+    } while (0)
+
+int32_t ensure(msm_ctx* c, DevBuf& b, size_t bytes) {
+    if (b.cap >= bytes) return MSM_OK;
+    if (b.p) HIPCHK(c, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    size_t want = bytes + bytes / 8;  // a little slack so slowly growing n does not realloc each call
+    HIPCHK(c, hipMalloc(&b.p, want));
+    b.cap = want;
+    return MSM_OK;
+}
+void release(DevBuf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+// ---- planner: replaces the N -> window_size / scale_factor tables (metal_msm.rs:661-691) and takes the
+// cuZK cost model (utils/window_size_optimizer.rs:38-51) as its shape: per window N mixed adds (10
+// modmul each) plus 2 full adds per bucket (14 modmul each) for the running-sum reduction.
+uint32_t plan_window_bits(size_t n, bool is_signed) {
+    double best = 1e300;
+    uint32_t best_c = 8;
+    for (uint32_t c = 4; c <= 18; c++) {
+        double W = is_signed ? (double)(254 / c + 1) : (double)((254 + c - 1) / c);
+        double nb = is_signed ? (double)(1u << (c - 1)) : (double)(1u << c);
+        double cost = W * ((double)n * 10.0 + nb * 2.0 * 14.0 * 1.5);
+        if (cost < best) {
+            best = cost;
+            best_c = c;
+        }
+    }
+    return best_c;
+}
+int32_t make_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_plan_t* out) {
+    if (flags & ~MSM_FLAG_UNSIGNED_DIGITS) return MSM_ERR_BAD_ARG;
+    bool is_signed = !(flags & MSM_FLAG_UNSIGNED_DIGITS);
+    uint32_t c = window_bits ? window_bits : plan_window_bits(n, is_signed);
+    if (c < 2 || c > 20) return MSM_ERR_BAD_ARG;
+    out->window_bits = c;
+    out->signed_digits = is_signed;
+    // signed: one spare window position so the top digit never overflows (r < 2^254): W = floor(254/c) + 1
+    out->num_windows = is_signed ? (254 / c + 1) : ((254 + c - 1) / c);
+    out->num_buckets = is_signed ? (1u << (c - 1)) : (1u << c);
+    size_t pairs = (size_t)out->num_windows * n;
+    size_t tb = (size_t)out->num_windows * out->num_buckets;
+    out->workspace_bytes = n * (64 + 32 + 1) + pairs * 12 + tb * (8 + 128) + tb * 128 / 4;
+    return MSM_OK;
+}
+uint32_t reduce_chunk_len(uint32_t nb) {
+    uint32_t L = nb / 2048;  // aim at >= 2048 chunk threads per window
+    if (L < 1) L = 1;
+    if (L > 16) L = 16;
+    return L;
+}
+
+int32_t ensure_pow2_table(msm_ctx* c) {
+    if (c->pow2_ready) return MSM_OK;
+    using namespace hostg1;
+    std::vector<uint32_t> tab((size_t)msmk::SCALAR_BITS * 16);
+    Jac g{ONE, dbl(ONE), ONE};  // (1, 2) -- SH/constants.metal:121-174
+    for (int j = 0; j < msmk::SCALAR_BITS; j++) {
+        Fq zi = inv(g.z), zi2 = sqr(zi);
+        Fq x = mul(g.x, zi2), y = mul(g.y, mul(zi2, zi));  // Montgomery affine
+        store_words(&tab[(size_t)j * 16], x);
+        store_words(&tab[(size_t)j * 16 + 8], y);
+        g = jdbl(g);
+    }
+    int32_t rc = ensure(c, c->pow2, tab.size() * 4);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->pow2.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->pow2_ready = true;
+    return MSM_OK;
+}
+
+void finish_outputs(const hostg1::Jac& r, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf) {
+    if (out_jac) hostg1::store_jac(out_jac, r);
+    if (out_aff || out_inf) {
+        hostg1::Fq x, y;
+        bool inf = hostg1::to_affine_std(r, x, y);
+        if (out_aff) {
+            hostg1::store_words(out_aff, x);
+            hostg1::store_words(out_aff + 8, y);
+        }
+        if (out_inf) *out_inf = inf ? 1 : 0;
+    }
+}
+
+inline dim3 grid1(size_t n, unsigned block) { return dim3((unsigned)((n + block - 1) / block)); }
+
+// The pipeline proper: everything in HBM, one stream.  d_bases Montgomery.
+int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, const uint32_t* d_scalars, size_t n,
+                     hipStream_t st, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf) {
+    if (n > 0x7FFFFFFFull) return fail(c, MSM_ERR_BAD_ARG, "n = %zu exceeds 2^31-1 points per context call", n);
+    msm_plan_t pl;
+    int32_t rc = make_plan(n, c->cfg.window_bits, c->cfg.flags, &pl);
+    if (rc) return fail(c, rc, "bad window_bits/flags (%u, 0x%x)", c->cfg.window_bits, c->cfg.flags);
+    const uint32_t W = pl.num_windows, nb = pl.num_buckets, cbits = pl.window_bits;
+    const size_t pairs = (size_t)W * n, tb = (size_t)W * nb;
+    if (pairs > 0xFFFFFFFFull) return fail(c, MSM_ERR_BAD_ARG, "n*W = %zu does not fit 32-bit offsets", pairs);
+    const uint32_t L = reduce_chunk_len(nb);
+    const uint32_t cpw = (nb + L - 1) / L;
+    const uint32_t ntiles = (uint32_t)((tb + msmk::SCAN_TILE - 1) / msmk::SCAN_TILE);
+    if ((rc = ensure(c, c->digits, pairs * 4))) return rc;
+    if ((rc = ensure(c, c->ranks, pairs * 4))) return rc;
+    if ((rc = ensure(c, c->sorted, pairs * 4))) return rc;
+    if ((rc = ensure(c, c->hist, tb * 4))) return rc;
+    if ((rc = ensure(c, c->offsets, (tb + 1) * 4))) return rc;
+    if ((rc = ensure(c, c->blocksums, ((size_t)ntiles + 1) * 4))) return rc;
+    if ((rc = ensure(c, c->buckets, tb * 128))) return rc;
+    if ((rc = ensure(c, c->gpoints, (size_t)W * cpw * 128))) return rc;
+    if ((rc = ensure(c, c->winsums, (size_t)W * 96))) return rc;
+    if ((rc = ensure(c, c->flags, 64))) return rc;
+
+    uint32_t* hist = (uint32_t*)c->hist.p;
+    uint32_t* offsets = (uint32_t*)c->offsets.p;
+    uint32_t* flags = (uint32_t*)c->flags.p;
+    HIPCHK(c, hipMemsetAsync(hist, 0, tb * 4, st));
+    HIPCHK(c, hipMemsetAsync(flags, 0, 64, st));
+    HIPCHK(c, hipEventRecord(c->ev[EV_CONVERT], st));
+    // K1b + K2/1: digits, signed recode, bucket histogram with arrival ranks
+    if (pl.signed_digits)
+        msmk::k_decompose<true><<<grid1(n, 256), 256, 0, st>>>(d_scalars, d_inf, (uint32_t)n, cbits, W, nb, hist,
+                                                               (uint32_t*)c->digits.p, (uint32_t*)c->ranks.p, flags);
+    else
+        msmk::k_decompose<false><<<grid1(n, 256), 256, 0, st>>>(d_scalars, d_inf, (uint32_t)n, cbits, W, nb, hist,
+                                                                (uint32_t*)c->digits.p, (uint32_t*)c->ranks.p, flags);
+    HIPCHK(c, hipEventRecord(c->ev[EV_DECOMP], st));
+    // K2/2: bucket offsets
+    msmk::k_scan_tiles<<<ntiles, msmk::SCAN_BLOCK, 0, st>>>(hist, offsets, (uint32_t*)c->blocksums.p, (uint32_t)tb);
+    msmk::k_scan_block_sums<<<1, msmk::SCAN_BLOCK, 0, st>>>((uint32_t*)c->blocksums.p, ntiles, flags + 4);
+    msmk::k_scan_add<<<grid1(tb, 256), 256, 0, st>>>(offsets, (uint32_t*)c->blocksums.p, (uint32_t)tb, flags + 4);
+    // K2/3: scatter
+    {
+        dim3 g((unsigned)((n + 255) / 256), W);
+        msmk::k_scatter<<<g, 256, 0, st>>>((uint32_t*)c->digits.p, (uint32_t*)c->ranks.p, offsets, (uint32_t*)c->sorted.p,
+                                          (uint32_t)n, nb);
+    }
+    HIPCHK(c, hipEventRecord(c->ev[EV_SORT], st));
+    // K3: bucket accumulation (the graded kernel) -- bracketed by its own events on its own stream
+    HIPCHK(c, hipEventRecord(c->ev[EV_ACC0], st));
+    msmk::k_accumulate<<<grid1(tb, 256), 256, 0, st>>>(d_bases, (uint32_t*)c->sorted.p, offsets, (uint32_t*)c->buckets.p,
+                                                      (uint32_t)tb);
+    HIPCHK(c, hipEventRecord(c->ev[EV_ACC1], st));
+    // K4/K5: bucket reduction
+    {
+        uint32_t total_chunks = W * cpw;
+        msmk::k_reduce_chunks<<<grid1(total_chunks, 64), 64, 0, st>>>((uint32_t*)c->buckets.p, (uint32_t*)c->gpoints.p, nb, L,
+                                                                     cpw, total_chunks);
+        msmk::k_reduce_windows<<<W, 256, 0, st>>>((uint32_t*)c->gpoints.p, cpw, (uint32_t*)c->winsums.p);
+    }
+    HIPCHK(c, hipEventRecord(c->ev[EV_REDUCE], st));
+    HIPCHK(c, hipMemcpyAsync(c->h_winsums, c->winsums.p, (size_t)W * 96, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(c->h_flags, flags, 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    auto t_fin0 = std::chrono::steady_clock::now();
+    if (c->h_flags[0] & 1u) return fail(c, MSM_ERR_BAD_ARG, "a scalar is >= 2^254 (not a canonical Fr element)");
+    if (c->h_flags[0] & 2u) return fail(c, MSM_ERR_HIP, "internal: signed-digit carry out of the top window");
+    // final_reduction (metal_msm.rs:249-258): Horner over windows, high -> low, on the CPU
+    hostg1::Jac total = hostg1::identity();
+    for (int w = (int)W - 1; w >= 0; w--) {
+        for (uint32_t k = 0; k < cbits; k++) total = hostg1::jdbl(total);
+        total = hostg1::jadd(total, hostg1::load_jac(c->h_winsums + (size_t)w * 24));
+    }
+    finish_outputs(total, out_jac, out_aff, out_inf);
+    auto t_fin1 = std::chrono::steady_clock::now();
+    // timings
+    float ms = 0;
+    msm_timings_t& tm = c->tm;
+    (void)hipEventElapsedTime(&ms, c->ev[EV_CONVERT], c->ev[EV_DECOMP]);
+    tm.decompose_ms = ms;
+    (void)hipEventElapsedTime(&ms, c->ev[EV_DECOMP], c->ev[EV_SORT]);
+    tm.sort_ms = ms;
+    (void)hipEventElapsedTime(&ms, c->ev[EV_ACC0], c->ev[EV_ACC1]);
+    tm.accumulate_ms = ms;
+    c->acc_ms_sum += ms;
+    c->acc_launches += 1;
+    (void)hipEventElapsedTime(&ms, c->ev[EV_ACC1], c->ev[EV_REDUCE]);
+    tm.reduce_ms = ms;
+    tm.finish_ms = std::chrono::duration<float, std::milli>(t_fin1 - t_fin0).count();
+    tm.num_points = n;
+    tm.num_adds = c->h_flags[4];
+    return MSM_OK;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+int32_t check_common(msm_ctx* c, const void* a, const void* b, size_t n) {
+    if (!c) return MSM_ERR_BAD_ARG;
+    if (n == 0) return fail(c, MSM_ERR_EMPTY, "Empty input");  // metal_msm.rs:647-649
+    if (!a || !b) return fail(c, MSM_ERR_BAD_ARG, "NULL bases/scalars pointer");
+    return MSM_OK;
+}
+
+int32_t upload_bases_locked(msm_ctx* c, const uint32_t* bases_xy, uint32_t form, const uint8_t* inf_mask, size_t n) {
+    if (form != MSM_FORM_STD && form != MSM_FORM_MONT) return fail(c, MSM_ERR_BAD_ARG, "unknown base_form %u", form);
+    int32_t rc;
+    if ((rc = ensure(c, c->bases, n * 64))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->bases.p, bases_xy, n * 64, hipMemcpyHostToDevice, c->stream));
+    if (inf_mask) {
+        if ((rc = ensure(c, c->inf, n))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->inf.p, inf_mask, n, hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(c, hipEventRecord(c->ev[EV_H2D], c->stream));
+    if (form == MSM_FORM_STD) msmk::k_convert_bases<<<grid1(2 * n, 256), 256, 0, c->stream>>>((uint32_t*)c->bases.p, (uint32_t)n);
+    return MSM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t msm_abi_version(void) { return MSM_HIP_ABI_VERSION; }
+
+const char* msm_last_error(const msm_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int32_t msm_ctx_create(const msm_config_t* cfg, msm_ctx** out) {
+    if (!out) return fail(nullptr, MSM_ERR_BAD_ARG, "out == NULL");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(nullptr, MSM_ERR_NO_DEVICE, "no HIP device visible: this engine has no CPU fallback");
+    msm_config_t c0{};
+    c0.device = -1;
+    if (cfg) c0 = *cfg;
+    msm_plan_t probe;
+    if (make_plan(1, c0.window_bits, c0.flags, &probe) != MSM_OK)
+        return fail(nullptr, MSM_ERR_BAD_ARG, "bad window_bits/flags (%u, 0x%x)", c0.window_bits, c0.flags);
+    int dev = c0.device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return fail(nullptr, MSM_ERR_NO_DEVICE, "hipGetDevice failed");
+    if (dev >= ndev) return fail(nullptr, MSM_ERR_NO_DEVICE, "device %d out of range (%d visible)", dev, ndev);
+    msm_ctx* c = new (std::nothrow) msm_ctx();
+    if (!c) return fail(nullptr, MSM_ERR_OOM, "host allocation failed");
+    c->device = dev;
+    c->cfg = c0;
+    DeviceGuard g(dev);
+    hipError_t e = g.ok ? hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) : hipErrorInvalidDevice;
+    for (int i = 0; i < EV_COUNT && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_winsums, 256 * 96, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_flags, 64, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        fail(nullptr, MSM_ERR_HIP, "context setup failed: %s", hipGetErrorString(e));
+        msm_ctx_destroy(c);
+        return MSM_ERR_HIP;
+    }
+    if (c0.max_points) {
+        msm_plan_t pl;
+        make_plan(c0.max_points, c0.window_bits, c0.flags, &pl);
+        size_t pairs = (size_t)pl.num_windows * c0.max_points, tb = (size_t)pl.num_windows * pl.num_buckets;
+        int32_t rc = MSM_OK;
+        if (!rc) rc = ensure(c, c->bases, c0.max_points * 64);
+        if (!rc) rc = ensure(c, c->scalars, c0.max_points * 32);
+        if (!rc) rc = ensure(c, c->digits, pairs * 4);
+        if (!rc) rc = ensure(c, c->ranks, pairs * 4);
+        if (!rc) rc = ensure(c, c->sorted, pairs * 4);
+        if (!rc) rc = ensure(c, c->buckets, tb * 128);
+        if (rc) {
+            g_create_error = c->err;
+            msm_ctx_destroy(c);
+            return rc;
+        }
+    }
+    *out = c;
+    return MSM_OK;
+}
+
+void msm_ctx_destroy(msm_ctx* c) {
+    if (!c) return;
+    {
+        DeviceGuard g(c->device);
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        DevBuf* bufs[] = {&c->bases,   &c->inf,       &c->scalars, &c->digits,  &c->ranks,  &c->sorted, &c->hist,
+                          &c->offsets, &c->blocksums, &c->buckets, &c->gpoints, &c->winsums, &c->flags,  &c->pow2};
+        for (DevBuf* b : bufs) release(*b);
+        if (c->h_winsums) (void)hipHostFree(c->h_winsums);
+        if (c->h_flags) (void)hipHostFree(c->h_flags);
+        for (int i = 0; i < EV_COUNT; i++)
+            if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+    }
+    delete c;
+}
+
+int32_t msm_bn254_g1(msm_ctx* c, const uint32_t* bases_xy, uint32_t base_form, const uint8_t* inf_mask,
+                     const uint32_t* scalars, size_t n, uint32_t out_jac[24], uint32_t out_aff[16], uint8_t* out_inf) {
+    int32_t rc = check_common(c, bases_xy, scalars, n);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    auto t0 = std::chrono::steady_clock::now();
+    HIPCHK(c, hipEventRecord(c->ev[EV_START], c->stream));
+    if ((rc = ensure(c, c->scalars, n * 32))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->scalars.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
+    if ((rc = upload_bases_locked(c, bases_xy, base_form, inf_mask, n))) return rc;
+    c->resident_n = 0;  // the scratch copy is not a resident set
+    rc = run_pipeline(c, (const uint32_t*)c->bases.p, inf_mask ? (const uint8_t*)c->inf.p : nullptr,
+                      (const uint32_t*)c->scalars.p, n, c->stream, out_jac, out_aff, out_inf);
+    if (rc) return rc;
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, c->ev[EV_START], c->ev[EV_H2D]);
+    c->tm.h2d_ms = ms;
+    (void)hipEventElapsedTime(&ms, c->ev[EV_H2D], c->ev[EV_CONVERT]);
+    c->tm.convert_ms = ms;
+    c->tm.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return MSM_OK;
+}
+
+int32_t msm_bn254_g1_upload_bases(msm_ctx* c, const uint32_t* bases_xy, uint32_t base_form, const uint8_t* inf_mask,
+                                  size_t n) {
+    int32_t rc = check_common(c, bases_xy, bases_xy, n);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    c->resident_n = 0;
+    if ((rc = upload_bases_locked(c, bases_xy, base_form, inf_mask, n))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    c->resident_n = n;
+    c->resident_has_inf = inf_mask != nullptr;
+    return MSM_OK;
+}
+
+int32_t msm_bn254_g1_resident(msm_ctx* c, const uint32_t* scalars, size_t n, uint32_t out_jac[24], uint32_t out_aff[16],
+                              uint8_t* out_inf) {
+    int32_t rc = check_common(c, scalars, scalars, n);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->resident_n == 0) return fail(c, MSM_ERR_STATE, "no resident bases: call msm_bn254_g1_upload_bases first");
+    if (n > c->resident_n) n = c->resident_n;  // unequal lengths truncate to the shorter (metal_msm.rs:652-656)
+    DeviceGuard g(c->device);
+    auto t0 = std::chrono::steady_clock::now();
+    HIPCHK(c, hipEventRecord(c->ev[EV_START], c->stream));
+    if ((rc = ensure(c, c->scalars, n * 32))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->scalars.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[EV_H2D], c->stream));
+    rc = run_pipeline(c, (const uint32_t*)c->bases.p, c->resident_has_inf ? (const uint8_t*)c->inf.p : nullptr,
+                      (const uint32_t*)c->scalars.p, n, c->stream, out_jac, out_aff, out_inf);
+    if (rc) return rc;
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, c->ev[EV_START], c->ev[EV_H2D]);
+    c->tm.h2d_ms = ms;
+    c->tm.convert_ms = 0;
+    c->tm.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return MSM_OK;
+}
+
+int32_t msm_bn254_g1_device(msm_ctx* c, const void* d_bases_mont, const void* d_inf_mask, const void* d_scalars, size_t n,
+                            void* hip_stream, uint32_t out_jac[24], uint32_t out_aff[16], uint8_t* out_inf) {
+    int32_t rc = check_common(c, d_bases_mont, d_scalars, n);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    auto t0 = std::chrono::steady_clock::now();
+    rc = run_pipeline(c, (const uint32_t*)d_bases_mont, (const uint8_t*)d_inf_mask, (const uint32_t*)d_scalars, n, st, out_jac,
+                      out_aff, out_inf);
+    if (rc) return rc;
+    c->tm.h2d_ms = 0;
+    c->tm.convert_ms = 0;
+    c->tm.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return MSM_OK;
+}
+
+int32_t msm_bn254_g1_combine(const uint32_t* partials, size_t k, uint32_t out_jac[24], uint32_t out_aff[16],
+                             uint8_t* out_inf) {
+    if (!partials) return MSM_ERR_BAD_ARG;
+    if (k == 0) return MSM_ERR_EMPTY;
+    hostg1::Jac total = hostg1::identity();
+    for (size_t i = 0; i < k; i++) total = hostg1::jadd(total, hostg1::load_jac(partials + i * 24));  // fixed rank order
+    finish_outputs(total, out_jac, out_aff, out_inf);
+    return MSM_OK;
+}
+
+int32_t msm_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_plan_t* out) {
+    if (!out) return MSM_ERR_BAD_ARG;
+    if (n == 0) return MSM_ERR_EMPTY;
+    return make_plan(n, window_bits, flags, out);
+}
+
+int32_t msm_get_timings(const msm_ctx* c, msm_timings_t* out) {
+    if (!c || !out) return MSM_ERR_BAD_ARG;
+    *out = c->tm;
+    return MSM_OK;
+}
+int32_t msm_get_accumulate_kernel_stats(const msm_ctx* c, double* avg_ms, uint64_t* launches) {
+    if (!c) return MSM_ERR_BAD_ARG;
+    if (avg_ms) *avg_ms = c->acc_launches ? c->acc_ms_sum / (double)c->acc_launches : 0.0;
+    if (launches) *launches = c->acc_launches;
+    return MSM_OK;
+}
+void msm_reset_kernel_stats(msm_ctx* c) {
+    if (!c) return;
+    c->acc_ms_sum = 0;
+    c->acc_launches = 0;
+}
+
+int32_t msm_bn254_g1_generate_device(msm_ctx* c, uint64_t base_seed, uint64_t scalar_seed, size_t n, void* d_bases_out,
+                                     void* d_scalars_out) {
+    if (!c) return MSM_ERR_BAD_ARG;
+    if (n == 0) return fail(c, MSM_ERR_EMPTY, "Empty input");
+    if (n > 0x7FFFFFFFull) return fail(c, MSM_ERR_BAD_ARG, "n too large");
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    int32_t rc;
+    if (d_bases_out) {
+        if ((rc = ensure_pow2_table(c))) return rc;
+        msmk::k_gen_bases<<<grid1(n, 128), 128, 0, c->stream>>>(base_seed, (uint32_t)n, (const uint32_t*)c->pow2.p,
+                                                             (uint32_t*)d_bases_out);
+    }
+    if (d_scalars_out) msmk::k_gen_scalars<<<grid1(n, 256), 256, 0, c->stream>>>(scalar_seed, (uint32_t)n, (uint32_t*)d_scalars_out);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    return MSM_OK;
+}
+
+int32_t msm_bn254_generate_scalars_host(uint64_t seed, size_t n, int nonzero, uint32_t* out) {
+    if (!out) return MSM_ERR_BAD_ARG;
+    for (size_t i = 0; i < n; i++) msmk::gen_scalar(seed, i, nonzero != 0, out + i * 8);
+    return MSM_OK;
+}
+
+// ---- device-math unit-test hooks --------------------------------------------------------------------
+static int32_t run_test_kernel(msm_ctx* c, bool g1, uint32_t op, const uint32_t* a, size_t a_words, const uint32_t* b,
+                               size_t b_words, uint32_t* out, size_t out_words, size_t n) {
+    if (!c || !a || !out) return MSM_ERR_BAD_ARG;
+    if (n == 0) return MSM_ERR_EMPTY;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    void *da = nullptr, *db = nullptr, *dout = nullptr;
+    HIPCHK(c, hipMalloc(&da, n * a_words * 4));
+    HIPCHK(c, hipMalloc(&dout, n * out_words * 4));
+    HIPCHK(c, hipMemcpy(da, a, n * a_words * 4, hipMemcpyHostToDevice));
+    if (b) {
+        HIPCHK(c, hipMalloc(&db, n * b_words * 4));
+        HIPCHK(c, hipMemcpy(db, b, n * b_words * 4, hipMemcpyHostToDevice));
+    }
+    if (g1) msmk::k_test_g1<<<grid1(n, 64), 64, 0, c->stream>>>(op, (uint32_t*)da, (uint32_t*)db, (uint32_t*)dout, (uint32_t)n);
+    else msmk::k_test_fp<<<grid1(n, 64), 64, 0, c->stream>>>(op, (uint32_t*)da, (uint32_t*)db, (uint32_t*)dout, (uint32_t)n);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpy(out, dout, n * out_words * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(da);
+    (void)hipFree(dout);
+    if (db) (void)hipFree(db);
+    return MSM_OK;
+}
+int32_t msm_test_fp_op(msm_ctx* c, uint32_t op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n) {
+    if (op > MSM_OP_FP_INV) return MSM_ERR_BAD_ARG;
+    if (op <= MSM_OP_FP_MONT_MUL && !b) return MSM_ERR_BAD_ARG;
+    return run_test_kernel(c, false, op, a, 8, op <= MSM_OP_FP_MONT_MUL ? b : nullptr, 8, out, 8, n);
+}
+int32_t msm_test_g1_op(msm_ctx* c, uint32_t op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n) {
+    if (op > MSM_OP_G1_DBL) return MSM_ERR_BAD_ARG;
+    if (op != MSM_OP_G1_DBL && !b) return MSM_ERR_BAD_ARG;
+    return run_test_kernel(c, true, op, a, 24, op == MSM_OP_G1_DBL ? nullptr : b, op == MSM_OP_G1_MADD ? 16 : 24, out, 24, n);
+}
+int32_t msm_test_decompose(msm_ctx* c, const uint32_t* scalars, size_t n, uint32_t window_bits, int32_t* digits) {
+    if (!c || !scalars || !digits) return MSM_ERR_BAD_ARG;
+    if (n == 0) return MSM_ERR_EMPTY;
+    msm_plan_t pl;
+    if (make_plan(n, window_bits ? window_bits : c->cfg.window_bits, c->cfg.flags, &pl)) return MSM_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    void *ds = nullptr, *dd = nullptr;
+    size_t out_bytes = (size_t)pl.num_windows * n * 4;
+    HIPCHK(c, hipMalloc(&ds, n * 32));
+    HIPCHK(c, hipMalloc(&dd, out_bytes));
+    HIPCHK(c, hipMemcpy(ds, scalars, n * 32, hipMemcpyHostToDevice));
+    if (pl.signed_digits)
+        msmk::k_decompose_plain<true><<<grid1(n, 256), 256, 0, c->stream>>>((uint32_t*)ds, (uint32_t)n, pl.window_bits,
+                                                                         pl.num_windows, (int32_t*)dd);
+    else
+        msmk::k_decompose_plain<false><<<grid1(n, 256), 256, 0, c->stream>>>((uint32_t*)ds, (uint32_t)n, pl.window_bits,
+                                                                          pl.num_windows, (int32_t*)dd);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpy(digits, dd, out_bytes, hipMemcpyDeviceToHost));
+    (void)hipFree(ds);
+    (void)hipFree(dd);
+    return MSM_OK;
+}
+
+}  // extern "C"

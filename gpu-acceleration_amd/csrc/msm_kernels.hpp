@@ -1,0 +1,410 @@
+// msm_kernels.hpp -- the gfx950 kernels of the BN254 G1 MSM pipeline.
+//
+// Stage map against the reference (shader/cuzk/*.metal):
+//   K1 convert_point_coords_and_decompose_scalars -> k_convert_bases (only for MSM_FORM_STD input; one
+//        Montgomery product by R^2 instead of two Barrett multiplications) + k_decompose
+//   K2 transpose (ONE thread per window, serial 2N+C loop) -> k_decompose's histogram/rank atomics,
+//        k_scan_* (bucket offsets) and k_scatter: a counting sort with N*W-way parallelism
+//   K3 smvp (full 16-mul Jacobian add, one thread per bucket pair) -> k_accumulate (XYZZ mixed add)
+//   K4/K5 bpr_stage_1/2 -> k_reduce_chunks (+ k_reduce_windows: wavefront-shuffle tree)
+//   final_reduction (CPU) -> stays on the CPU: host_g1.hpp
+//
+// Data layout in HBM (all little-endian u32 words):
+//   bases    n x 16   affine Montgomery x||y, 64 B per point = one half cache line per gather
+//   scalars  n x 8    standard form
+//   digits   W x n    bucket index (bit 31 = negate, 0xFFFFFFFF = digit 0 / base at infinity), window-major
+//   ranks    W x n    arrival rank inside the bucket (return value of the histogram atomic)
+//   offsets  W*nb + 1 exclusive prefix sum of bucket sizes == CSC column pointer of the reference
+//   sorted   W x n    point index | sign<<31 grouped by bucket        == val_idxs of the reference
+//   buckets  W*nb x 32  XYZZ bucket sums
+#pragma once
+#include "ec_bn254.hpp"
+
+namespace msmk {
+using namespace bn254;
+
+constexpr uint32_t DIGIT_SKIP = 0xFFFFFFFFu;
+constexpr uint32_t SIGN_BIT = 0x80000000u;
+constexpr int SCALAR_BITS = 254;
+
+struct alignas(16) affine_words {
+    uint32_t w[16];
+};
+
+__device__ __forceinline__ fp load_fp(const uint32_t* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 a = q[0], b = q[1];
+    return fp{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+}
+__device__ __forceinline__ void store_fp(uint32_t* p, const fp& v) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
+    q[1] = make_uint4(v.v[4], v.v[5], v.v[6], v.v[7]);
+}
+__device__ __forceinline__ xyzz load_xyzz(const uint32_t* p) {
+    return xyzz{load_fp(p), load_fp(p + 8), load_fp(p + 16), load_fp(p + 24)};
+}
+__device__ __forceinline__ void store_xyzz(uint32_t* p, const xyzz& v) {
+    store_fp(p, v.x);
+    store_fp(p + 8, v.y);
+    store_fp(p + 16, v.zz);
+    store_fp(p + 24, v.zzz);
+}
+
+// ---------------------------------------------------------------------------------------------
+// bases given in standard form -> Montgomery, in place (K1's coordinate half)
+__global__ void k_convert_bases(uint32_t* bases, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per coordinate
+    if (i >= 2u * n) return;
+    uint32_t* p = bases + (size_t)i * 8;
+    store_fp(p, fp_to_mont(load_fp(p)));
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1 scalar half + K2 phase 1.  One thread per point: slice the scalar into W radix-2^c digits,
+// recode to signed digits d in [-(H-1), H] (v > H  =>  d = v - 2H, carry 1), and count the bucket.
+// bits [off, off+c) of a 256-bit little-endian scalar
+__device__ __forceinline__ uint32_t scalar_window(const uint32_t s[8], uint32_t off, uint32_t c) {
+    uint32_t wi = off >> 5, sh = off & 31;
+    if (wi >= 8) return 0;
+    uint64_t lo = s[wi];
+    uint64_t hi = (wi + 1 < 8) ? s[wi + 1] : 0u;
+    uint64_t v = (lo | (hi << 32)) >> sh;
+    return (uint32_t)v & ((1u << c) - 1u);
+}
+
+template <bool SIGNED>
+__global__ void k_decompose(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_mask, uint32_t n,
+                            uint32_t c, uint32_t W, uint32_t nb, uint32_t* __restrict__ hist,
+                            uint32_t* __restrict__ digits, uint32_t* __restrict__ ranks, uint32_t* __restrict__ err) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+    uint4 a = sp[0], b = sp[1];
+    uint32_t s[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    if (s[7] >> 30) atomicOr(err, 1u);  // scalar >= 2^254 cannot be a canonical Fr
+    bool skip = inf_mask != nullptr && inf_mask[i] != 0;
+    const uint32_t H = 1u << (c - 1);
+    uint32_t carry = 0;
+    for (uint32_t w = 0; w < W; w++) {
+        uint32_t v = scalar_window(s, w * c, c) + carry;
+        uint32_t mag = v, neg = 0;
+        if (SIGNED) {
+            if (v > H) {
+                mag = (2u * H) - v;
+                neg = SIGN_BIT;
+                carry = 1;
+            } else {
+                carry = 0;
+            }
+        }
+        size_t o = (size_t)w * n + i;
+        if (mag == 0 || skip) {
+            digits[o] = DIGIT_SKIP;
+        } else {
+            uint32_t bkt = mag - 1;
+            ranks[o] = atomicAdd(&hist[(size_t)w * nb + bkt], 1u);
+            digits[o] = bkt | neg;
+        }
+    }
+    if (SIGNED && carry) atomicOr(err, 2u);  // cannot happen for scalars < 2^254 with W = 254/c + 1
+}
+
+// test hook: plain signed digits as int32
+template <bool SIGNED>
+__global__ void k_decompose_plain(const uint32_t* __restrict__ scalars, uint32_t n, uint32_t c, uint32_t W,
+                                  int32_t* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s[8];
+    for (int k = 0; k < 8; k++) s[k] = scalars[(size_t)i * 8 + k];
+    const uint32_t H = 1u << (c - 1);
+    uint32_t carry = 0;
+    for (uint32_t w = 0; w < W; w++) {
+        uint32_t v = scalar_window(s, w * c, c) + carry;
+        int32_t d = (int32_t)v;
+        if (SIGNED) {
+            if (v > H) {
+                d = (int32_t)v - (int32_t)(2u * H);
+                carry = 1;
+            } else {
+                carry = 0;
+            }
+        }
+        out[(size_t)w * n + i] = d;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2 phase 2: exclusive prefix sum of the W*nb bucket counts (three small launches).
+constexpr int SCAN_BLOCK = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
+
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* total) {
+    __shared__ uint32_t wsum[SCAN_BLOCK / 64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) wsum[wid] = x;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_BLOCK / 64; k++) {
+        if (k < wid) base += wsum[k];
+        tot += wsum[k];
+    }
+    __syncthreads();
+    *total = tot;
+    return base + x - v;
+}
+
+// tile-local exclusive scan; tile totals to block_sums
+__global__ void k_scan_tiles(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t* __restrict__ block_sums,
+                             uint32_t count) {
+    uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS], sum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        v[k] = (base + k < count) ? in[base + k] : 0u;
+        sum += v[k];
+    }
+    uint32_t total;
+    uint32_t ex = block_exclusive_scan(sum, &total);
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        if (base + k < count) out[base + k] = ex;
+        ex += v[k];
+    }
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+// single block: exclusive scan of the tile totals (any number of tiles), grand total to *total_out
+__global__ void k_scan_block_sums(uint32_t* block_sums, uint32_t nblocks, uint32_t* total_out) {
+    uint32_t running = 0;
+    for (uint32_t start = 0; start < nblocks; start += SCAN_BLOCK) {
+        uint32_t idx = start + threadIdx.x;
+        uint32_t v = idx < nblocks ? block_sums[idx] : 0u;
+        uint32_t total;
+        uint32_t ex = block_exclusive_scan(v, &total);
+        if (idx < nblocks) block_sums[idx] = running + ex;
+        running += total;
+    }
+    if (threadIdx.x == 0) *total_out = running;
+}
+__global__ void k_scan_add(uint32_t* __restrict__ out, const uint32_t* __restrict__ block_sums, uint32_t count,
+                           const uint32_t* __restrict__ total) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] += block_sums[i / SCAN_TILE];
+    if (i == 0) out[count] = *total;
+}
+
+// K2 phase 3: place every (point, sign) at offsets[bucket] + rank
+__global__ void k_scatter(const uint32_t* __restrict__ digits, const uint32_t* __restrict__ ranks,
+                          const uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted, uint32_t n, uint32_t nb) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t w = blockIdx.y;
+    if (i >= n) return;
+    size_t o = (size_t)w * n + i;
+    uint32_t d = digits[o];
+    if (d == DIGIT_SKIP) return;
+    uint32_t bkt = d & ~SIGN_BIT;
+    sorted[offsets[(size_t)w * nb + bkt] + ranks[o]] = i | (d & SIGN_BIT);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: bucket accumulation.  One thread per (window, bucket); the bucket's points are a contiguous
+// segment of `sorted`; each is gathered as one 64-byte affine point and folded into an XYZZ
+// accumulator held in registers (8M+2S per point).
+__global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
+                                                    const uint32_t* __restrict__ offsets, uint32_t* __restrict__ buckets,
+                                                    uint32_t total_buckets) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= total_buckets) return;
+    uint32_t beg = offsets[k], end = offsets[k + 1];
+    xyzz acc = xyzz_identity();
+    for (uint32_t j = beg; j < end; j++) {
+        uint32_t e = sorted[j];
+        const uint32_t* bp = bases + (size_t)(e & ~SIGN_BIT) * 16;
+        affine q{load_fp(bp), load_fp(bp + 8)};
+        if (e & SIGN_BIT) q.y = fp_neg(q.y);
+        xyzz_madd(acc, q);
+    }
+    store_xyzz(buckets + (size_t)k * 32, acc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4+K5: running-sum bucket reduction.  Thread j of window w owns buckets [jL, (j+1)L) (magnitudes
+// jL+1 .. (j+1)L), computes S = sum B and T = sum (i+1) B_{jL+i} by the running-sum trick, then adds
+// (jL)*S by double-and-add (pbpr.metal:16-31, 98-148), leaving G_j = sum_k k*B_k over its chunk.
+__device__ __forceinline__ xyzz xyzz_mul_small(xyzz p, uint32_t s) {
+    xyzz r = xyzz_identity();
+    while (s) {
+        if (s & 1u) r = xyzz_add(r, p);
+        s >>= 1;
+        if (s) p = xyzz_dbl(p);
+    }
+    return r;
+}
+__global__ void __launch_bounds__(64) k_reduce_chunks(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ gpoints,
+                                                      uint32_t nb, uint32_t L, uint32_t chunks_per_window,
+                                                      uint32_t total_chunks) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total_chunks) return;
+    uint32_t w = t / chunks_per_window, j = t % chunks_per_window;
+    uint32_t lo = j * L, hi = min(lo + L, nb);
+    const uint32_t* bw = buckets + (size_t)w * nb * 32;
+    xyzz s = xyzz_identity(), tt = xyzz_identity();
+    for (uint32_t b = hi; b-- > lo;) {
+        s = xyzz_add(s, load_xyzz(bw + (size_t)b * 32));
+        tt = xyzz_add(tt, s);
+    }
+    if (lo) tt = xyzz_add(tt, xyzz_mul_small(s, lo));
+    store_xyzz(gpoints + (size_t)t * 32, tt);
+}
+
+// wavefront tree reduction of one XYZZ per lane with __shfl_down (64-wide)
+__device__ __forceinline__ fp shfl_down_fp(const fp& a, int d) {
+    fp r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = __shfl_down(a.v[i], d, 64);
+    return r;
+}
+__device__ __forceinline__ xyzz wave_reduce_xyzz(xyzz v) {
+    for (int d = 32; d >= 1; d >>= 1) {
+        xyzz o{shfl_down_fp(v.x, d), shfl_down_fp(v.y, d), shfl_down_fp(v.zz, d), shfl_down_fp(v.zzz, d)};
+        v = xyzz_add(v, o);
+    }
+    return v;  // lane 0 holds the sum
+}
+// one 256-thread block per window: sum the window's G points, emit a Jacobian window sum
+__global__ void __launch_bounds__(256) k_reduce_windows(const uint32_t* __restrict__ gpoints, uint32_t chunks_per_window,
+                                                        uint32_t* __restrict__ winsums /* W x 24 */) {
+    __shared__ uint32_t lds[4 * 32];
+    uint32_t w = blockIdx.x;
+    const uint32_t* g = gpoints + (size_t)w * chunks_per_window * 32;
+    xyzz acc = xyzz_identity();
+    for (uint32_t j = threadIdx.x; j < chunks_per_window; j += blockDim.x) acc = xyzz_add(acc, load_xyzz(g + (size_t)j * 32));
+    acc = wave_reduce_xyzz(acc);
+    int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) store_xyzz(lds + wid * 32, acc);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        xyzz tot = load_xyzz(lds);
+        for (int k = 1; k < 4; k++) tot = xyzz_add(tot, load_xyzz(lds + k * 32));
+        jacobian jj = xyzz_to_jacobian(tot);
+        uint32_t* o = winsums + (size_t)w * 24;
+        store_fp(o, jj.x);
+        store_fp(o + 8, jj.y);
+        store_fp(o + 16, jj.z);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// synthetic inputs (counterpart of test_utils::generate_random_bases_and_scalars, metal_msm.rs:698-731)
+__host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t& st) {
+    uint64_t z = (st += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+// element i of stream `seed`: 254-bit rejection sampling below r (and != 0 when nonzero)
+__host__ __device__ inline void gen_scalar(uint64_t seed, uint64_t i, bool nonzero, uint32_t out[8]) {
+    const uint64_t R[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+    uint64_t st = seed + i * 0xD1342543DE82EF95ULL;
+    uint64_t v[4];
+    for (;;) {
+        for (int k = 0; k < 4; k++) v[k] = splitmix64(st);
+        v[3] &= 0x3FFFFFFFFFFFFFFFULL;
+        bool lt = false;
+        for (int k = 3; k >= 0; k--) {
+            if (v[k] != R[k]) {
+                lt = v[k] < R[k];
+                break;
+            }
+        }
+        if (!lt) continue;
+        if (nonzero && (v[0] | v[1] | v[2] | v[3]) == 0) continue;
+        break;
+    }
+    for (int k = 0; k < 4; k++) {
+        out[2 * k] = (uint32_t)v[k];
+        out[2 * k + 1] = (uint32_t)(v[k] >> 32);
+    }
+}
+__global__ void k_gen_scalars(uint64_t seed, uint32_t n, uint32_t* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s[8];
+    gen_scalar(seed, i, false, s);
+    uint4* q = reinterpret_cast<uint4*>(out + (size_t)i * 8);
+    q[0] = make_uint4(s[0], s[1], s[2], s[3]);
+    q[1] = make_uint4(s[4], s[5], s[6], s[7]);
+}
+// base i = k_i * G with k_i = nonzero stream element; pow2_table[j] = 2^j * G (affine Montgomery, 254 entries)
+__global__ void __launch_bounds__(128) k_gen_bases(uint64_t seed, uint32_t n, const uint32_t* __restrict__ pow2_table,
+                                                   uint32_t* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t k[8];
+    gen_scalar(seed, i, true, k);
+    xyzz acc = xyzz_identity();
+    for (int j = 0; j < SCALAR_BITS; j++) {
+        if ((k[j >> 5] >> (j & 31)) & 1u) {
+            const uint32_t* tp = pow2_table + (size_t)j * 16;
+            affine q{load_fp(tp), load_fp(tp + 8)};
+            xyzz_madd(acc, q);
+        }
+    }
+    affine a;
+    xyzz_to_affine(acc, a);
+    store_fp(out + (size_t)i * 16, a.x);
+    store_fp(out + (size_t)i * 16 + 8, a.y);
+}
+
+// ---------------------------------------------------------------------------------------------
+// device-math unit-test kernels (counterpart of the reference's test_* kernels)
+__global__ void k_test_fp(uint32_t op, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                          uint32_t* __restrict__ out, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fp x = load_fp(a + (size_t)i * 8), y = b ? load_fp(b + (size_t)i * 8) : fp_zero(), r;
+    switch (op) {
+        case 0: r = fp_add(x, y); break;
+        case 1: r = fp_sub(x, y); break;
+        case 2: r = fp_mul(x, y); break;
+        case 3: r = fp_to_mont(x); break;
+        case 4: r = fp_from_mont(x); break;
+        default: r = fp_inv(x); break;
+    }
+    store_fp(out + (size_t)i * 8, r);
+}
+__global__ void __launch_bounds__(64) k_test_g1(uint32_t op, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                                uint32_t* __restrict__ out, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* ap = a + (size_t)i * 24;
+    xyzz p = xyzz_from_jacobian(jacobian{load_fp(ap), load_fp(ap + 8), load_fp(ap + 16)});
+    xyzz r;
+    if (op == 0) {
+        const uint32_t* bp = b + (size_t)i * 16;
+        affine q{load_fp(bp), load_fp(bp + 8)};
+        r = p;
+        xyzz_madd(r, q);
+    } else if (op == 1) {
+        const uint32_t* bp = b + (size_t)i * 24;
+        r = xyzz_add(p, xyzz_from_jacobian(jacobian{load_fp(bp), load_fp(bp + 8), load_fp(bp + 16)}));
+    } else {
+        r = xyzz_dbl(p);
+    }
+    jacobian jj = xyzz_to_jacobian(r);
+    uint32_t* o = out + (size_t)i * 24;
+    store_fp(o, jj.x);
+    store_fp(o + 8, jj.y);
+    store_fp(o + 16, jj.z);
+}
+
+}  // namespace msmk

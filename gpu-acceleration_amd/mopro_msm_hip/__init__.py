@@ -1,0 +1,288 @@
+"""mopro_msm_hip -- Python host-side mirror of the reference's MSM operator interface, over the
+C ABI of libmsm_hip.so (include/msm_hip.h).
+
+Reference surface mirrored (mopro-msm/src/msm/metal_msm/metal_msm.rs):
+  metal_variable_base_msm(&bases, &scalars) -> Result<G1Projective, Box<dyn Error>>   :642-695
+      * empty input            -> Err("Empty input")                                   :647-649
+      * unequal lengths        -> silently truncated to the shorter one                :652-656
+  test_utils::generate_random_bases_and_scalars(size)                                  :698-731
+The Rust shim a maintainer would add is in rust/mopro-msm-hip; this module is the
+same thin layer for Python callers, tests and bench.py.  It holds no arithmetic: every result comes
+from the HIP library, and importing/using it without the built library or without a GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libmsm_hip.so")
+
+FORM_STD, FORM_MONT = 0, 1
+FLAG_UNSIGNED_DIGITS = 1
+OK, ERR_EMPTY, ERR_BAD_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
+
+# every symbol include/msm_hip.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "msm_abi_version", "msm_ctx_create", "msm_ctx_destroy", "msm_last_error", "msm_bn254_g1",
+    "msm_bn254_g1_upload_bases", "msm_bn254_g1_resident", "msm_bn254_g1_device", "msm_bn254_g1_combine",
+    "msm_plan", "msm_get_timings", "msm_get_accumulate_kernel_stats", "msm_reset_kernel_stats",
+    "msm_bn254_g1_generate_device", "msm_bn254_generate_scalars_host", "msm_test_fp_op", "msm_test_g1_op",
+    "msm_test_decompose",
+]
+
+
+class MsmError(RuntimeError):
+    """Counterpart of the reference's Box<dyn Error>; .code is the C-ABI status."""
+
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("window_bits", C.c_uint32), ("flags", C.c_uint32),
+                ("reserved", C.c_uint32), ("max_points", C.c_uint64)]
+
+
+class Plan(C.Structure):
+    _fields_ = [("window_bits", C.c_uint32), ("num_windows", C.c_uint32), ("num_buckets", C.c_uint32),
+                ("signed_digits", C.c_uint32), ("workspace_bytes", C.c_uint64)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("h2d_ms", C.c_float), ("convert_ms", C.c_float), ("decompose_ms", C.c_float),
+                ("sort_ms", C.c_float), ("accumulate_ms", C.c_float), ("reduce_ms", C.c_float),
+                ("finish_ms", C.c_float), ("total_ms", C.c_float), ("num_points", C.c_uint64),
+                ("num_adds", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_u32p = C.POINTER(C.c_uint32)
+_u8p = C.POINTER(C.c_uint8)
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree libmsm_hip.so; fails loudly if it was not built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MsmError(ERR_NO_DEVICE, f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                      "(make -C gpu-acceleration_amd/csrc); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.msm_abi_version.restype = C.c_uint32
+    L.msm_ctx_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.msm_ctx_destroy.argtypes = [vp]
+    L.msm_ctx_destroy.restype = None
+    L.msm_last_error.argtypes = [vp]
+    L.msm_last_error.restype = C.c_char_p
+    L.msm_bn254_g1.argtypes = [vp, _u32p, C.c_uint32, _u8p, _u32p, C.c_size_t, _u32p, _u32p, _u8p]
+    L.msm_bn254_g1_upload_bases.argtypes = [vp, _u32p, C.c_uint32, _u8p, C.c_size_t]
+    L.msm_bn254_g1_resident.argtypes = [vp, _u32p, C.c_size_t, _u32p, _u32p, _u8p]
+    L.msm_bn254_g1_device.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, _u32p, _u32p, _u8p]
+    L.msm_bn254_g1_combine.argtypes = [_u32p, C.c_size_t, _u32p, _u32p, _u8p]
+    L.msm_plan.argtypes = [C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(Plan)]
+    L.msm_get_timings.argtypes = [vp, C.POINTER(Timings)]
+    L.msm_get_accumulate_kernel_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.msm_reset_kernel_stats.argtypes = [vp]
+    L.msm_reset_kernel_stats.restype = None
+    L.msm_bn254_g1_generate_device.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_size_t, vp, vp]
+    L.msm_bn254_generate_scalars_host.argtypes = [C.c_uint64, C.c_size_t, C.c_int, _u32p]
+    L.msm_test_fp_op.argtypes = [vp, C.c_uint32, _u32p, _u32p, _u32p, C.c_size_t]
+    L.msm_test_g1_op.argtypes = [vp, C.c_uint32, _u32p, _u32p, _u32p, C.c_size_t]
+    L.msm_test_decompose.argtypes = [vp, _u32p, C.c_size_t, C.c_uint32, C.POINTER(C.c_int32)]
+    for name in ABI_SYMBOLS:
+        f = getattr(L, name)
+        if f.restype is C.c_int:  # default
+            f.restype = C.c_int32
+    _lib = L
+    return L
+
+
+def _words(a, width):
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    return a.reshape(-1, width)
+
+
+def _p32(a):
+    return a.ctypes.data_as(_u32p) if a is not None else None
+
+
+class MsmResult:
+    """One G1 result: Jacobian Montgomery words (what the Rust shim turns into G1Projective via
+    Fq::new_unchecked, metal_msm.rs:228-241) and the canonical affine standard-form words."""
+
+    def __init__(self, jac, aff, inf):
+        self.jacobian_mont = jac
+        self.affine_std = aff
+        self.is_infinity = bool(inf)
+
+    def affine_ints(self):
+        if self.is_infinity:
+            return None
+        to_int = lambda ws: sum(int(w) << (32 * i) for i, w in enumerate(ws.tolist()))
+        return to_int(self.affine_std[:8]), to_int(self.affine_std[8:])
+
+
+def plan(n, window_bits=0, flags=0):
+    p = Plan()
+    rc = load_library().msm_plan(n, window_bits, flags, C.byref(p))
+    if rc != OK:
+        raise MsmError(rc, "Empty input" if rc == ERR_EMPTY else f"msm_plan failed ({rc})")
+    return p
+
+
+def combine_partials(partials_jacobian_mont):
+    """Fold per-rank partial sums in fixed rank order (host arithmetic inside the library)."""
+    p = _words(partials_jacobian_mont, 24)
+    jac, aff, inf = np.zeros(24, np.uint32), np.zeros(16, np.uint32), C.c_uint8(0)
+    rc = load_library().msm_bn254_g1_combine(_p32(p), p.shape[0], _p32(jac), _p32(aff), C.byref(inf))
+    if rc != OK:
+        raise MsmError(rc, "Empty input" if rc == ERR_EMPTY else f"combine failed ({rc})")
+    return MsmResult(jac, aff, inf.value)
+
+
+def generate_scalars_host(seed, n, nonzero=False):
+    out = np.zeros((n, 8), np.uint32)
+    load_library().msm_bn254_generate_scalars_host(seed, n, int(nonzero), _p32(out))
+    return out
+
+
+class MsmContext:
+    """Persistent engine context (replaces MetalMSMPipeline, rebuilt per call in the reference)."""
+
+    def __init__(self, device=-1, window_bits=0, flags=0, max_points=0):
+        self._lib = load_library()
+        cfg = Config(device, window_bits, flags, 0, max_points)
+        h = C.c_void_p()
+        rc = self._lib.msm_ctx_create(C.byref(cfg), C.byref(h))
+        if rc != OK:
+            raise MsmError(rc, (self._lib.msm_last_error(None) or b"").decode())
+        self._h = h
+        self.window_bits, self.flags = window_bits, flags
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.msm_ctx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc != OK:
+            raise MsmError(rc, (self._lib.msm_last_error(self._h) or b"").decode() or f"status {rc}")
+
+    def _outs(self):
+        return np.zeros(24, np.uint32), np.zeros(16, np.uint32), C.c_uint8(0)
+
+    # -- the drop-in call ---------------------------------------------------------------------
+    def msm(self, bases, scalars, form=FORM_STD, inf=None):
+        bases, scalars = _words(bases, 16), _words(scalars, 8)
+        if bases.shape[0] == 0 or scalars.shape[0] == 0:
+            raise MsmError(ERR_EMPTY, "Empty input")  # metal_msm.rs:647-649
+        n = min(bases.shape[0], scalars.shape[0])  # metal_msm.rs:652-656
+        infp = None
+        if inf is not None:
+            inf = np.ascontiguousarray(inf, dtype=np.uint8)
+            infp = inf.ctypes.data_as(_u8p)
+        jac, aff, oi = self._outs()
+        self._check(self._lib.msm_bn254_g1(self._h, _p32(bases), form, infp, _p32(scalars), n, _p32(jac), _p32(aff),
+                                           C.byref(oi)))
+        return MsmResult(jac, aff, oi.value)
+
+    def upload_bases(self, bases, form=FORM_STD, inf=None):
+        bases = _words(bases, 16)
+        if bases.shape[0] == 0:
+            raise MsmError(ERR_EMPTY, "Empty input")
+        infp = None
+        if inf is not None:
+            inf = np.ascontiguousarray(inf, dtype=np.uint8)
+            infp = inf.ctypes.data_as(_u8p)
+        self._check(self._lib.msm_bn254_g1_upload_bases(self._h, _p32(bases), form, infp, bases.shape[0]))
+
+    def msm_resident(self, scalars):
+        scalars = _words(scalars, 8)
+        if scalars.shape[0] == 0:
+            raise MsmError(ERR_EMPTY, "Empty input")
+        jac, aff, oi = self._outs()
+        self._check(self._lib.msm_bn254_g1_resident(self._h, _p32(scalars), scalars.shape[0], _p32(jac), _p32(aff),
+                                                    C.byref(oi)))
+        return MsmResult(jac, aff, oi.value)
+
+    def msm_device(self, d_bases_ptr, d_scalars_ptr, n, d_inf_ptr=None, stream=None):
+        """All operands already in HBM (raw device pointers, e.g. torch.Tensor.data_ptr())."""
+        if n == 0:
+            raise MsmError(ERR_EMPTY, "Empty input")
+        jac, aff, oi = self._outs()
+        self._check(self._lib.msm_bn254_g1_device(self._h, d_bases_ptr, d_inf_ptr, d_scalars_ptr, n, stream, _p32(jac),
+                                                  _p32(aff), C.byref(oi)))
+        return MsmResult(jac, aff, oi.value)
+
+    def generate_device(self, base_seed, scalar_seed, n, d_bases_ptr, d_scalars_ptr):
+        self._check(self._lib.msm_bn254_g1_generate_device(self._h, base_seed, scalar_seed, n, d_bases_ptr, d_scalars_ptr))
+
+    def timings(self):
+        t = Timings()
+        self._check(self._lib.msm_get_timings(self._h, C.byref(t)))
+        return t.as_dict()
+
+    def accumulate_kernel_stats(self):
+        avg, cnt = C.c_double(0), C.c_uint64(0)
+        self._check(self._lib.msm_get_accumulate_kernel_stats(self._h, C.byref(avg), C.byref(cnt)))
+        return avg.value, cnt.value
+
+    def reset_kernel_stats(self):
+        self._lib.msm_reset_kernel_stats(self._h)
+
+    # -- device-math unit-test hooks -----------------------------------------------------------
+    def test_fp_op(self, op, a, b=None):
+        a = _words(a, 8)
+        b = _words(b, 8) if b is not None else None
+        out = np.zeros_like(a)
+        self._check(self._lib.msm_test_fp_op(self._h, op, _p32(a), _p32(b), _p32(out), a.shape[0]))
+        return out
+
+    def test_g1_op(self, op, a, b=None):
+        a = _words(a, 24)
+        b = _words(b, 16 if op == 0 else 24) if b is not None else None
+        out = np.zeros_like(a)
+        self._check(self._lib.msm_test_g1_op(self._h, op, _p32(a), _p32(b), _p32(out), a.shape[0]))
+        return out
+
+    def test_decompose(self, scalars, window_bits=0):
+        scalars = _words(scalars, 8)
+        n = scalars.shape[0]
+        p = plan(n, window_bits or self.window_bits, self.flags)
+        out = np.zeros((p.num_windows, n), np.int32)
+        self._check(self._lib.msm_test_decompose(self._h, _p32(scalars), n, window_bits, out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out
+
+
+_default_ctx = None
+
+
+def default_context():
+    """Process-global lazily created context, as the Rust shim keeps."""
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = MsmContext()
+    return _default_ctx
+
+
+def hip_variable_base_msm(bases, scalars, form=FORM_STD, inf=None):
+    """Drop-in for metal_variable_base_msm(&bases, &scalars) (metal_msm.rs:642-695)."""
+    return default_context().msm(bases, scalars, form, inf)
+
+
+metal_variable_base_msm = hip_variable_base_msm  # the reference's own name, kept as an alias

@@ -1,0 +1,158 @@
+/*
+ * msm_hip.h -- C ABI of the MI355X-native BN254 G1 variable-base MSM engine.
+ *
+ * This is the drop-in boundary for ONE path of zkmopro/gpu-acceleration (mopro-msm v0.2.0):
+ *
+ *     pub fn metal_variable_base_msm(bases: &[G1Affine], scalars: &[Fr])
+ *         -> Result<G1Projective, Box<dyn Error>>          mopro-msm/src/msm/metal_msm/metal_msm.rs:642-695
+ *
+ * A Rust shim (rust/mopro-msm-hip) keeps that signature and forwards to
+ * msm_bn254_g1() below.  Everything the reference does between that call and its return value --
+ * MetalMSMPipeline::new / execute_pipeline / final_reduction (metal_msm.rs:48-261), the Metal
+ * dispatch layer (host/metal_wrapper.rs:55-217, host/shader_manager.rs:98-167, host/gpu.rs:3-31) and the
+ * five kernels (shader/cuzk/{convert_point_coords_and_decompose_scalars,transpose,smvp,pbpr}.metal) -- is
+ * replaced by the implementation behind this header.
+ *
+ * Word formats (pinned by the reference's packer, utils/limbs_conversion.rs:311-378):
+ *   field element  = 8 little-endian uint32 words
+ *   affine base    = x[8] || y[8]                         (16 words, 64 bytes)
+ *   scalar         = 8 words, standard (non-Montgomery) form, value < r
+ *   Jacobian point = X[8] || Y[8] || Z[8], Montgomery form (R = 2^256); identity <=> Z == 0
+ * MSM_FORM_MONT coordinates are bit-identical to arkworks' internal `Fq.0.0` limbs, so the shim
+ * can hand them over without the 3N CPU-side Montgomery reductions of pack_affine_and_scalars.
+ *
+ * Threading: a context serialises its own calls with an internal mutex; different contexts are
+ * independent.  No caller pointer is retained after a call returns.  Nothing aborts or panics:
+ * every failure is a negative status plus msm_last_error().
+ */
+#ifndef MSM_HIP_H
+#define MSM_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSM_HIP_ABI_VERSION 1u
+
+/* status codes */
+#define MSM_OK 0
+#define MSM_ERR_EMPTY (-1)      /* n == 0: reference returns Err("Empty input"), metal_msm.rs:647-649 */
+#define MSM_ERR_BAD_ARG (-2)    /* NULL pointer, bad form/flags, scalar >= 2^254, window out of range   */
+#define MSM_ERR_NO_DEVICE (-3)  /* no HIP device / extension unusable: the product never falls back to CPU */
+#define MSM_ERR_HIP (-4)        /* a HIP runtime call failed; see msm_last_error()                      */
+#define MSM_ERR_OOM (-5)
+#define MSM_ERR_STATE (-6)      /* e.g. resident call without uploaded bases                            */
+
+/* coordinate form of the bases handed in */
+#define MSM_FORM_STD 0u  /* plain integers < p   (what pack_affine_and_scalars emits)          */
+#define MSM_FORM_MONT 1u /* x*2^256 mod p        (arkworks Fq.0 as is)                          */
+
+/* msm_config_t.flags */
+#define MSM_FLAG_UNSIGNED_DIGITS 1u /* plain radix-2^c digits, 2^c-1 buckets/window (BASELINE config "fixed 16-bit window") */
+
+typedef struct msm_ctx msm_ctx;
+
+typedef struct {
+    int32_t device;       /* HIP device ordinal; -1 = current device                                   */
+    uint32_t window_bits; /* c; 0 = planner (replaces the N->window table at metal_msm.rs:661-673)     */
+    uint32_t flags;       /* MSM_FLAG_*                                                                */
+    uint32_t reserved;
+    uint64_t max_points;  /* pre-size the HBM workspace for this many points; 0 = grow on demand        */
+} msm_config_t;
+
+typedef struct {
+    uint32_t window_bits;  /* c                                         */
+    uint32_t num_windows;  /* W                                         */
+    uint32_t num_buckets;  /* buckets per window (2^(c-1) signed, 2^c unsigned incl. an unused slot) */
+    uint32_t signed_digits;
+    uint64_t workspace_bytes;
+} msm_plan_t;
+
+/* per-stage device times of the last call on this context, milliseconds (hipEvent) */
+typedef struct {
+    float h2d_ms;        /* host->HBM copies (0 for device-resident calls)      */
+    float convert_ms;    /* bases to Montgomery / internal layout               */
+    float decompose_ms;  /* scalar windowing + signed digits + bucket histogram */
+    float sort_ms;       /* bucket offsets (scan) + scatter of point indices    */
+    float accumulate_ms; /* per-bucket point accumulation -- the graded kernel  */
+    float reduce_ms;     /* running-sum bucket reduction + per-window sums      */
+    float finish_ms;     /* D2H of W window sums + host Horner + normalisation  */
+    float total_ms;      /* wall clock of the whole call                        */
+    uint64_t num_points;
+    uint64_t num_adds;   /* mixed additions executed by accumulate (non-zero digits) */
+} msm_timings_t;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+/* replaces MetalMSMPipeline::with_default_config() (metal_msm.rs:64, rebuilt on EVERY call there) */
+int32_t msm_ctx_create(const msm_config_t *cfg /* NULL = defaults */, msm_ctx **out);
+void msm_ctx_destroy(msm_ctx *ctx);
+/* message of the last failure on ctx (or of the last failed msm_ctx_create when ctx == NULL) */
+const char *msm_last_error(const msm_ctx *ctx);
+uint32_t msm_abi_version(void);
+
+/* ---- the drop-in call: host pointers in, host results out ---------------------------------- */
+/* replaces metal_variable_base_msm (metal_msm.rs:642-695).  bases: n x 16 words; inf_mask: n bytes
+ * (non-zero = point at infinity, arkworks G1Affine.infinity) or NULL; scalars: n x 8 words.
+ * Any of the three outputs may be NULL.  out_affine_std = canonical affine, standard form (0,0 when
+ * the result is the identity and *out_is_inf = 1). */
+int32_t msm_bn254_g1(msm_ctx *ctx, const uint32_t *bases_xy, uint32_t base_form, const uint8_t *inf_mask,
+                     const uint32_t *scalars, size_t n, uint32_t out_jacobian_mont[24],
+                     uint32_t out_affine_std[16], uint8_t *out_is_inf);
+
+/* ---- bases resident in HBM ------------------------------------- */
+int32_t msm_bn254_g1_upload_bases(msm_ctx *ctx, const uint32_t *bases_xy, uint32_t base_form,
+                                  const uint8_t *inf_mask, size_t n);
+int32_t msm_bn254_g1_resident(msm_ctx *ctx, const uint32_t *scalars, size_t n, uint32_t out_jacobian_mont[24],
+                              uint32_t out_affine_std[16], uint8_t *out_is_inf);
+
+/* ---- everything already in HBM (what bench.py times) ---------------------------------------- */
+/* d_bases_mont: n x 16 words, Montgomery form, device memory; d_inf_mask: n bytes device memory or NULL;
+ * d_scalars: n x 8 words device memory.  hip_stream: a hipStream_t (NULL = the context's stream).
+ * Blocks until the result is on the host. */
+int32_t msm_bn254_g1_device(msm_ctx *ctx, const void *d_bases_mont, const void *d_inf_mask, const void *d_scalars,
+                            size_t n, void *hip_stream, uint32_t out_jacobian_mont[24],
+                            uint32_t out_affine_std[16], uint8_t *out_is_inf);
+
+/* ---- multi-GPU: fold per-rank partial results (host arithmetic, like final_reduction
+ *      metal_msm.rs:204-261 runs on the CPU).  partials: k x 24 words Jacobian Montgomery. -------- */
+int32_t msm_bn254_g1_combine(const uint32_t *partials_jacobian_mont, size_t k, uint32_t out_jacobian_mont[24],
+                             uint32_t out_affine_std[16], uint8_t *out_is_inf);
+
+/* ---- introspection --------------------------------------------------------------------------- */
+int32_t msm_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_plan_t *out);
+int32_t msm_get_timings(const msm_ctx *ctx, msm_timings_t *out);
+/* average duration (ms) of the accumulate kernel launches since the last reset, measured with
+ * hipEvents on the stream the kernel runs on; *launches receives the count */
+int32_t msm_get_accumulate_kernel_stats(const msm_ctx *ctx, double *avg_ms, uint64_t *launches);
+void msm_reset_kernel_stats(msm_ctx *ctx);
+
+/* ---- synthetic inputs: counterpart of test_utils::generate_random_bases_and_scalars
+ *      (metal_msm.rs:698-731).  Base i is k_i*G with k_i = SplitMix64 stream (seed, i) reduced below r,
+ *      scalar i likewise from scalar_seed; both written to DEVICE memory (Montgomery bases). ------- */
+int32_t msm_bn254_g1_generate_device(msm_ctx *ctx, uint64_t base_seed, uint64_t scalar_seed, size_t n,
+                                     void *d_bases_mont_out, void *d_scalars_out);
+/* the same k_i / s_i streams on the host (8 words each), for closed-form checks */
+int32_t msm_bn254_generate_scalars_host(uint64_t seed, size_t n, int nonzero, uint32_t *out);
+
+/* ---- device-math unit-test hooks: counterpart of the reference's test_* kernels (SURVEY C10,
+ *      e.g. mont_mul_cios.metal:8-15, jacobian_add_2007_bl.metal:8-40).  Host arrays in/out. ------ */
+#define MSM_OP_FP_ADD 0u
+#define MSM_OP_FP_SUB 1u
+#define MSM_OP_FP_MONT_MUL 2u
+#define MSM_OP_FP_TO_MONT 3u
+#define MSM_OP_FP_FROM_MONT 4u
+#define MSM_OP_FP_INV 5u
+int32_t msm_test_fp_op(msm_ctx *ctx, uint32_t op, const uint32_t *a, const uint32_t *b, uint32_t *out, size_t n);
+#define MSM_OP_G1_MADD 0u /* a: Jacobian(24) + b: affine Montgomery(16) -> Jacobian(24) */
+#define MSM_OP_G1_ADD 1u  /* a: Jacobian(24) + b: Jacobian(24)          -> Jacobian(24) */
+#define MSM_OP_G1_DBL 2u  /* a: Jacobian(24)                            -> Jacobian(24) */
+int32_t msm_test_g1_op(msm_ctx *ctx, uint32_t op, const uint32_t *a, const uint32_t *b, uint32_t *out, size_t n);
+/* signed/unsigned digit decomposition of the planner's choice, digits[w*n + i] as int32 */
+int32_t msm_test_decompose(msm_ctx *ctx, const uint32_t *scalars, size_t n, uint32_t window_bits, int32_t *digits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSM_HIP_H */

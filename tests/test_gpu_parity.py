@@ -1,0 +1,264 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle
+(oracle/bn254_oracle.c), the committed golden vectors, and size-independent properties at
+BASELINE.json's full sizes.  Bit-exact everywhere: this is integer work."""
+import numpy as np
+import pytest
+
+import mopro_msm_hip as mh
+from conftest import golden_cases, load_golden
+from oracle import bn254_oracle as orc
+
+pytestmark = pytest.mark.gpu
+P, R = orc.P, orc.R_ORDER
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = mh.MsmContext()
+    yield c
+    c.close()
+
+
+def rand_fp(rng, n):
+    vals = [0, 1, 2, P - 1, P - 2, (1 << 256) % P, (1 << 255) % P] + [int(rng.integers(0, 2**63)) for _ in range(4)]
+    while len(vals) < n:
+        vals.append(int.from_bytes(rng.bytes(32), "little") % P)
+    return np.stack([orc.int_to_words(v) for v in vals[:n]])
+
+
+# ---- device math library (counterpart of T/field, T/bigint, T/mont_backend tests) -------------
+def test_fp_ops_match_oracle(ctx):
+    rng = np.random.default_rng(1)
+    n = 600
+    a, b = rand_fp(rng, n), rand_fp(rng, n)[::-1].copy()
+    table = [(0, orc.fq_add), (1, orc.fq_sub), (2, orc.fq_mont_mul)]
+    for op, ref in table:
+        out = ctx.test_fp_op(op, a, b)
+        exp = np.stack([ref(a[i], b[i]) for i in range(n)])
+        assert (out == exp).all(), f"fp op {op}"
+    for op, ref in [(3, orc.fq_to_mont), (4, orc.fq_from_mont)]:
+        out = ctx.test_fp_op(op, a)
+        exp = np.stack([ref(a[i]) for i in range(n)])
+        assert (out == exp).all(), f"fp op {op}"
+    m = 40
+    out = ctx.test_fp_op(5, a[:m])
+    exp = np.stack([orc.fq_inv_mont(a[i]) for i in range(m)])
+    assert (out == exp).all()
+    # a * a^-1 == R (Montgomery one), skipping a == 0
+    prod = ctx.test_fp_op(2, a[1:m], out[1:m])
+    assert all(orc.words_to_int(p) == (1 << 256) % P for p in prod)
+
+
+def _jac_points(n, seed):
+    k = orc.gen_scalars(seed, n, nonzero=True)
+    g = np.concatenate([orc.int_to_words(1), orc.int_to_words(2)])
+    return np.stack([orc.g1_scalar_mul(g, k[i]) for i in range(n)])
+
+
+def _affine_of(jacs):
+    return [orc.g1_to_affine_std(j) for j in jacs]
+
+
+def _neg(j):
+    o = j.copy()
+    o[8:16] = orc.int_to_words((P - orc.words_to_int(j[8:16])) % P)
+    return o
+
+
+def _same_affine(x, y):
+    ax, ai = orc.g1_to_affine_std(x)
+    bx, bi = orc.g1_to_affine_std(y)
+    return ai == bi and (ax == bx).all()
+
+
+def test_g1_ops_match_oracle(ctx):
+    """madd / add / dbl incl. 0+Q, P+0, 0+0, P+P, P+P with different Z, P+(-P)
+    (T/curve/jacobian_add_2007_b1.rs:121-180 cases, plus the ones the reference gets wrong)."""
+    n = 40
+    a = _jac_points(n, 11)
+    b = _jac_points(n, 12)
+    ident = np.zeros(24, np.uint32)
+    ident[:8] = orc.fq_to_mont(orc.int_to_words(1))
+    ident[8:16] = ident[:8]
+    a[0] = ident
+    b[1] = ident
+    a[2] = ident
+    b[2] = ident
+    b[3] = a[3]
+    b[4] = orc.g1_add(orc.g1_dbl(a[4]), _neg(a[4]))  # same point as a4, different Z
+    b[5] = _neg(a[5])
+    b[6] = _neg(orc.g1_add(orc.g1_dbl(a[6]), _neg(a[6])))  # -a6 with a different Z
+    assert _same_affine(a[4], b[4]) and not (a[4] == b[4]).all()
+    out = ctx.test_g1_op(1, a, b)
+    for i in range(n):
+        assert _same_affine(out[i], orc.g1_add(a[i], b[i])), ("add", i)
+    assert orc.g1_to_affine_std(out[5])[1] == 1 and orc.g1_to_affine_std(out[6])[1] == 1
+    out = ctx.test_g1_op(2, a)
+    for i in range(n):
+        assert _same_affine(out[i], orc.g1_dbl(a[i])), ("dbl", i)
+    # mixed add: q affine Montgomery (identity cannot be an affine operand: use a fresh point there)
+    spare = _jac_points(2, 13)
+    baff = []
+    for i in range(n):
+        src = b[i] if i not in (1, 2) else spare[i - 1]
+        xy, inf = orc.g1_to_affine_std(src)
+        assert inf == 0
+        baff.append(np.concatenate([orc.fq_to_mont(xy[:8]), orc.fq_to_mont(xy[8:])]))
+    baff = np.stack(baff)
+    out = ctx.test_g1_op(0, a, baff)
+    for i in range(n):
+        assert _same_affine(out[i], orc.g1_madd(a[i], baff[i])), ("madd", i)
+    assert orc.g1_to_affine_std(out[5])[1] == 1  # P + (-P)
+    assert _same_affine(out[3], orc.g1_dbl(a[3])) and _same_affine(out[4], orc.g1_dbl(a[4]))
+
+
+def test_signed_digits_reconstruct_scalar(ctx):
+    g = load_golden("edge_carry_patterns")
+    sc = np.concatenate([g["scalars"], orc.gen_scalars(5, 200), np.stack([orc.int_to_words(v) for v in (0, 1, R - 1, R - 2, (1 << 253) + 12345)])])
+    for wb in (4, 8, 13, 15, 16, 17):
+        d = ctx.test_decompose(sc, wb).astype(object)
+        H = 1 << (wb - 1)
+        assert d.shape[0] == 254 // wb + 1
+        assert d.max() <= H and d.min() >= -(H - 1)
+        for i in range(sc.shape[0]):
+            assert sum(int(d[k, i]) << (wb * k) for k in range(d.shape[0])) == orc.words_to_int(sc[i]), (wb, i)
+
+
+# ---- end to end (counterpart of T/cuzk/e2e.rs:14-63, metal_msm.rs:739-760) ---------------------
+@pytest.mark.parametrize("name", golden_cases())
+def test_msm_golden_default_plan(ctx, name):
+    g = load_golden(name)
+    r = ctx.msm(g["bases"], g["scalars"], mh.FORM_STD, g["inf"])
+    assert r.is_infinity == bool(g["expected_inf"]), name
+    assert (r.affine_std == g["expected"]).all(), name
+    aff, inf = orc.g1_to_affine_std(r.jacobian_mont)
+    assert inf == int(g["expected_inf"]) and (aff == g["expected"]).all()
+
+
+@pytest.mark.parametrize("wb,flags", [(8, 0), (13, 0), (15, 0), (16, 0), (16, mh.FLAG_UNSIGNED_DIGITS), (5, 0), (11, mh.FLAG_UNSIGNED_DIGITS)])
+def test_msm_golden_window_overrides(wb, flags):
+    with mh.MsmContext(window_bits=wb, flags=flags) as c:
+        for name in golden_cases():
+            g = load_golden(name)
+            if g["bases"].shape[0] > 1024 and wb < 8:
+                continue
+            r = c.msm(g["bases"], g["scalars"], mh.FORM_STD, g["inf"])
+            assert r.is_infinity == bool(g["expected_inf"]), (name, wb)
+            assert (r.affine_std == g["expected"]).all(), (name, wb)
+
+
+def test_mont_form_and_resident_bases(ctx):
+    g = load_golden("rand_n1024")
+    bm = np.concatenate([ctx.test_fp_op(3, g["bases"][:, :8]), ctx.test_fp_op(3, g["bases"][:, 8:])], axis=1)
+    r = ctx.msm(bm, g["scalars"], mh.FORM_MONT)
+    assert (r.affine_std == g["expected"]).all()
+    ctx.upload_bases(g["bases"], mh.FORM_STD)
+    r2 = ctx.msm_resident(g["scalars"])
+    assert (r2.affine_std == g["expected"]).all()
+    # second scalar vector against the same resident bases
+    s2 = orc.gen_scalars(77, 1024)
+    r3 = ctx.msm_resident(s2)
+    exp, einf, _ = orc.msm_pippenger(g["bases"], s2, orc.FORM_STD)
+    assert (r3.affine_std == exp).all() and not r3.is_infinity
+    # fewer scalars than resident bases -> truncated to the shorter (metal_msm.rs:652-656)
+    r4 = ctx.msm_resident(s2[:100])
+    exp, _, _ = orc.msm_pippenger(g["bases"][:100], s2[:100], orc.FORM_STD)
+    assert (r4.affine_std == exp).all()
+
+
+def test_reference_error_and_truncation_semantics(ctx):
+    g = load_golden("rand_n17")
+    with pytest.raises(mh.MsmError) as e:
+        ctx.msm(np.zeros((0, 16), np.uint32), np.zeros((0, 8), np.uint32))
+    assert str(e.value) == "Empty input" and e.value.code == mh.ERR_EMPTY
+    with pytest.raises(mh.MsmError):
+        mh.hip_variable_base_msm(g["bases"], np.zeros((0, 8), np.uint32))
+    # unequal lengths -> min (metal_msm.rs:652-656)
+    r = ctx.msm(g["bases"], g["scalars"][:9])
+    exp, _, _ = orc.msm_naive(g["bases"][:9], g["scalars"][:9], orc.FORM_STD)
+    assert (r.affine_std == exp).all()
+    # non-canonical scalar (>= 2^254) is rejected, not silently mis-computed
+    bad = g["scalars"].copy()
+    bad[3, 7] |= 0x40000000
+    with pytest.raises(mh.MsmError) as e:
+        ctx.msm(g["bases"], bad)
+    assert e.value.code == mh.ERR_BAD_ARG
+    # the context stays usable after an error
+    r = ctx.msm(g["bases"], g["scalars"])
+    assert (r.affine_std == g["expected"]).all()
+    assert mh.metal_variable_base_msm is mh.hip_variable_base_msm
+
+
+@pytest.mark.parametrize("logn", [10, 12, 16])
+def test_msm_random_vs_oracle(ctx, logn):
+    n = 1 << logn
+    k = orc.gen_scalars(0xB2540001, n, nonzero=True)
+    s = orc.gen_scalars(0xB2540002 + logn, n)
+    bases = orc.gen_bases_from_logs(k, orc.FORM_MONT)
+    r = ctx.msm(bases, s, mh.FORM_MONT)
+    exp, einf, _ = orc.msm_pippenger(bases, s, orc.FORM_MONT)
+    assert not r.is_infinity and einf == 0 and (r.affine_std == exp).all()
+    cf, _ = orc.closed_form_expected(k, s)
+    assert (r.affine_std == cf).all()
+    # determinism: same bits on a second launch
+    r2 = ctx.msm(bases, s, mh.FORM_MONT)
+    assert (r2.affine_std == r.affine_std).all()
+
+
+def test_adversarial_distributions(ctx):
+    """skewed digits (all-equal scalars), 1% duplicates, infinities, a (P,-P) pair -- SURVEY section 8d."""
+    n = 1 << 12
+    k = orc.gen_scalars(21, n, nonzero=True)
+    k[100:140] = k[7]  # duplicates
+    kneg = orc.int_to_words(R - orc.words_to_int(k[9]))
+    k[10] = kneg
+    bases = orc.gen_bases_from_logs(k, orc.FORM_MONT)
+    inf = np.zeros(n, np.uint8)
+    inf[[3, 500, 4095]] = 1
+    for label, s in [("all-equal", np.tile(orc.gen_scalars(3, 1), (n, 1))), ("uniform", orc.gen_scalars(4, n)),
+                     ("small", np.pad(orc.gen_scalars(5, n)[:, :1], ((0, 0), (0, 7)))), ("zeros", np.zeros((n, 8), np.uint32))]:
+        s = s.copy()
+        s[10] = s[9]
+        r = ctx.msm(bases, s, mh.FORM_MONT, inf)
+        exp, einf, _ = orc.msm_pippenger(bases, s, orc.FORM_MONT, inf)
+        assert r.is_infinity == bool(einf) and (r.affine_std == exp).all(), label
+
+
+# ---- BASELINE.json full sizes: size-independent properties ---------------------------------------
+@pytest.mark.parametrize("logn", [16, 20])
+def test_full_size_closed_form_and_linearity(ctx, logn):
+    import torch
+    n = 1 << logn
+    dev = torch.device("cuda:0")
+    d_bases = torch.empty(n * 16, dtype=torch.int32, device=dev)
+    d_s = torch.empty(n * 8, dtype=torch.int32, device=dev)
+    ctx.generate_device(0xB2540001, 0xB2540002, n, d_bases.data_ptr(), d_s.data_ptr())
+    torch.cuda.synchronize()
+    # generated bases are k_i*G: spot-check against the oracle
+    k = mh.generate_scalars_host(0xB2540001, n, nonzero=True)
+    s = mh.generate_scalars_host(0xB2540002, n)
+    hb = d_bases.cpu().numpy().view(np.uint32).reshape(n, 16)
+    idx = [0, 1, 2, n // 2, n - 1, 12345 % n]
+    assert (hb[idx] == orc.gen_bases_from_logs(k[idx], orc.FORM_MONT)).all()
+    assert (d_s.cpu().numpy().view(np.uint32).reshape(n, 8) == s).all()
+    r = ctx.msm_device(d_bases.data_ptr(), d_s.data_ptr(), n)
+    exp, einf = orc.closed_form_expected(k, s)
+    assert not r.is_infinity and (r.affine_std == exp).all()
+    # linearity: MSM(B, s) + MSM(B, t) == MSM(B, s + t mod r), through the same HIP path
+    t = mh.generate_scalars_host(0xB2540003, n)
+    d_t = torch.from_numpy(t.view(np.int32).reshape(-1)).to(dev)
+    rt = ctx.msm_device(d_bases.data_ptr(), d_t.data_ptr(), n)
+    to_int = lambda a: [sum(int(w) << (32 * j) for j, w in enumerate(row)) for row in a.tolist()]
+    st = np.array([orc.int_to_words((x + y) % R) for x, y in zip(to_int(s), to_int(t))], dtype=np.uint32)
+    d_st = torch.from_numpy(st.view(np.int32).reshape(-1)).to(dev)
+    rst = ctx.msm_device(d_bases.data_ptr(), d_st.data_ptr(), n)
+    comb = mh.combine_partials(np.stack([r.jacobian_mont, rt.jacobian_mont]))
+    assert (comb.affine_std == rst.affine_std).all()
+    # point-range sharding (the multi-GPU decomposition) gives the same group element
+    h = n // 2
+    p0 = ctx.msm_device(d_bases.data_ptr(), d_s.data_ptr(), h)
+    p1 = ctx.msm_device(d_bases.data_ptr() + h * 64, d_s.data_ptr() + h * 32, n - h)
+    comb = mh.combine_partials(np.stack([p0.jacobian_mont, p1.jacobian_mont]))
+    assert (comb.affine_std == exp).all()
+    tm = ctx.timings()
+    assert tm["num_points"] == n - h and tm["accumulate_ms"] > 0
