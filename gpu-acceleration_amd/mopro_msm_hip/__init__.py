@@ -73,6 +73,14 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise MsmError(ERR_NO_DEVICE, f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                       "(make -C gpu-acceleration_amd/csrc); there is no CPU fallback")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64 and the
+    # library links the same soname from /opt/rocm.  Whichever is loaded first serves both, and loading
+    # ours first leaves torch with a mixed runtime ("No HIP GPUs are available").  Python callers use torch
+    # for device memory and torch.distributed, so let torch bring in its runtime before we dlopen.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.msm_abi_version.restype = C.c_uint32
