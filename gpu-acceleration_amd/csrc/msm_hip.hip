@@ -49,10 +49,10 @@ struct msm_ctx {
     std::string err;
     hipEvent_t ev[EV_COUNT]{};
     // HBM workspace
-    DevBuf bases, inf, scalars, digits, ranks, sorted, hist, offsets, blocksums, buckets, gpoints, winsums, flags,
+    DevBuf bases, inf, scalars, digits, ranks, sorted, hist, offsets, blocksums, buckets, heads, tails, chunkmap, rc, qsums, flags,
         pow2;
     bool pow2_ready = false;
-    uint32_t* h_winsums = nullptr;  // pinned
+    uint32_t* h_qsums = nullptr;  // pinned: W x (kb+1) Jacobian bit sums
     uint32_t* h_flags = nullptr;    // pinned
     // resident bases
     size_t resident_n = 0;
@@ -131,11 +131,13 @@ int32_t make_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_plan_t* ou
     out->workspace_bytes = n * (64 + 32 + 1) + pairs * 12 + tb * (8 + 128) + tb * 128 / 4;
     return MSM_OK;
 }
-uint32_t reduce_chunk_len(uint32_t nb) {
-    uint32_t L = nb / 2048;  // aim at >= 2048 chunk threads per window
-    if (L < 1) L = 1;
-    if (L > 16) L = 16;
-    return L;
+constexpr uint32_t ACC_CHUNK_LEN = 32;          // sorted entries folded by one k_accumulate thread
+constexpr size_t MAX_QSUM_POINTS = 128 * 21;  // W <= 128 windows (c >= 2), kb + 1 <= 21 bit sums each
+
+uint32_t ilog2(uint32_t v) {
+    uint32_t l = 0;
+    while ((1u << (l + 1)) <= v) l++;
+    return l;
 }
 
 int32_t ensure_pow2_table(msm_ctx* c) {
@@ -183,9 +185,11 @@ int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, 
     const uint32_t W = pl.num_windows, nb = pl.num_buckets, cbits = pl.window_bits;
     const size_t pairs = (size_t)W * n, tb = (size_t)W * nb;
     if (pairs > 0xFFFFFFFFull) return fail(c, MSM_ERR_BAD_ARG, "n*W = %zu does not fit 32-bit offsets", pairs);
-    const uint32_t L = reduce_chunk_len(nb);
-    const uint32_t cpw = (nb + L - 1) / L;
+    const uint32_t kb = ilog2(nb), kb_lo = kb / 2, kb_hi = kb - kb_lo;  // bucket index = hi * n_lo + lo
+    const uint32_t n_lo = 1u << kb_lo, n_hi = 1u << kb_hi;
     const uint32_t ntiles = (uint32_t)((tb + msmk::SCAN_TILE - 1) / msmk::SCAN_TILE);
+    const uint32_t chunk_len = ACC_CHUNK_LEN;
+    const size_t nchunks_max = (pairs + chunk_len - 1) / chunk_len;
     if ((rc = ensure(c, c->digits, pairs * 4))) return rc;
     if ((rc = ensure(c, c->ranks, pairs * 4))) return rc;
     if ((rc = ensure(c, c->sorted, pairs * 4))) return rc;
@@ -193,8 +197,11 @@ int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, 
     if ((rc = ensure(c, c->offsets, (tb + 1) * 4))) return rc;
     if ((rc = ensure(c, c->blocksums, ((size_t)ntiles + 1) * 4))) return rc;
     if ((rc = ensure(c, c->buckets, tb * 128))) return rc;
-    if ((rc = ensure(c, c->gpoints, (size_t)W * cpw * 128))) return rc;
-    if ((rc = ensure(c, c->winsums, (size_t)W * 96))) return rc;
+    if ((rc = ensure(c, c->heads, nchunks_max * 128))) return rc;
+    if ((rc = ensure(c, c->tails, nchunks_max * 128))) return rc;
+    if ((rc = ensure(c, c->chunkmap, nchunks_max * 4))) return rc;
+    if ((rc = ensure(c, c->rc, (size_t)W * (n_hi + n_lo) * 128))) return rc;
+    if ((rc = ensure(c, c->qsums, (size_t)W * (kb + 1) * 96))) return rc;
     if ((rc = ensure(c, c->flags, 64))) return rc;
 
     uint32_t* hist = (uint32_t*)c->hist.p;
@@ -223,19 +230,29 @@ int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, 
     }
     HIPCHK(c, hipEventRecord(c->ev[EV_SORT], st));
     // K3: bucket accumulation (the graded kernel) -- bracketed by its own events on its own stream
+    msmk::k_chunk_map<<<grid1(tb, 256), 256, 0, st>>>(offsets, (uint32_t*)c->chunkmap.p, (uint32_t)tb, chunk_len);
     HIPCHK(c, hipEventRecord(c->ev[EV_ACC0], st));
-    msmk::k_accumulate<<<grid1(tb, 256), 256, 0, st>>>(d_bases, (uint32_t*)c->sorted.p, offsets, (uint32_t*)c->buckets.p,
-                                                      (uint32_t)tb);
+    msmk::k_accumulate<<<grid1(nchunks_max, 256), 256, 0, st>>>(d_bases, (uint32_t*)c->sorted.p, offsets, (uint32_t*)c->chunkmap.p,
+                                                              (uint32_t*)c->buckets.p, (uint32_t*)c->heads.p, (uint32_t*)c->tails.p,
+                                                              flags + 4, chunk_len);
     HIPCHK(c, hipEventRecord(c->ev[EV_ACC1], st));
-    // K4/K5: bucket reduction
+    msmk::k_combine<<<grid1(tb, 256), 256, 0, st>>>(offsets, (uint32_t*)c->heads.p, (uint32_t*)c->tails.p, (uint32_t*)c->buckets.p,
+                                                    (uint32_t)tb, chunk_len);
+    // K4/K5: bucket reduction -- plain row/column sums, then per-bit sums; the weights are applied on the host
     {
-        uint32_t total_chunks = W * cpw;
-        msmk::k_reduce_chunks<<<grid1(total_chunks, 64), 64, 0, st>>>((uint32_t*)c->buckets.p, (uint32_t*)c->gpoints.p, nb, L,
-                                                                     cpw, total_chunks);
-        msmk::k_reduce_windows<<<W, 256, 0, st>>>((uint32_t*)c->gpoints.p, cpw, (uint32_t*)c->winsums.p);
+        const uint32_t* bk = (const uint32_t*)c->buckets.p;
+        uint32_t* rcp = (uint32_t*)c->rc.p;
+        uint32_t g_rows = n_lo < 16 ? n_lo : 16, g_cols = n_hi < 16 ? n_hi : 16;
+        // rows: R[w][hi] = sum_lo B[w][hi*n_lo + lo]
+        msmk::k_reduce_sums<<<grid1((size_t)W * n_hi * g_rows, 256), 256, 0, st>>>(bk, rcp, n_hi + n_lo, 0, W * n_hi, n_hi, nb, n_lo, 1,
+                                                                             n_lo, g_rows);
+        // columns: C[w][lo] = sum_hi B[w][hi*n_lo + lo]
+        msmk::k_reduce_sums<<<grid1((size_t)W * n_lo * g_cols, 256), 256, 0, st>>>(bk, rcp, n_hi + n_lo, n_hi, W * n_lo, n_lo, nb, 1, n_lo,
+                                                                             n_hi, g_cols);
+        msmk::k_reduce_bits<<<W * (kb + 1), 64, 0, st>>>(rcp, (uint32_t*)c->qsums.p, n_hi, n_lo, kb_lo, kb);
     }
     HIPCHK(c, hipEventRecord(c->ev[EV_REDUCE], st));
-    HIPCHK(c, hipMemcpyAsync(c->h_winsums, c->winsums.p, (size_t)W * 96, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(c->h_qsums, c->qsums.p, (size_t)W * (kb + 1) * 96, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(c->h_flags, flags, 32, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());
@@ -245,8 +262,13 @@ int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, 
     // final_reduction (metal_msm.rs:249-258): Horner over windows, high -> low, on the CPU
     hostg1::Jac total = hostg1::identity();
     for (int w = (int)W - 1; w >= 0; w--) {
+        // window sum S_w = Q_all + sum_u 2^u Q_u  (one Horner chain over the bit sums)
+        const uint32_t* qw = c->h_qsums + (size_t)w * (kb + 1) * 24;
+        hostg1::Jac sw = hostg1::identity();
+        for (int u = (int)kb - 1; u >= 0; u--) sw = hostg1::jadd(hostg1::jdbl(sw), hostg1::load_jac(qw + (size_t)u * 24));
+        sw = hostg1::jadd(sw, hostg1::load_jac(qw + (size_t)kb * 24));
         for (uint32_t k = 0; k < cbits; k++) total = hostg1::jdbl(total);
-        total = hostg1::jadd(total, hostg1::load_jac(c->h_winsums + (size_t)w * 24));
+        total = hostg1::jadd(total, sw);
     }
     finish_outputs(total, out_jac, out_aff, out_inf);
     auto t_fin1 = std::chrono::steady_clock::now();
@@ -332,7 +354,7 @@ int32_t msm_ctx_create(const msm_config_t* cfg, msm_ctx** out) {
     DeviceGuard g(dev);
     hipError_t e = g.ok ? hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) : hipErrorInvalidDevice;
     for (int i = 0; i < EV_COUNT && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_winsums, 256 * 96, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_qsums, MAX_QSUM_POINTS * 96, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_flags, 64, hipHostMallocDefault);
     if (e != hipSuccess) {
         fail(nullptr, MSM_ERR_HIP, "context setup failed: %s", hipGetErrorString(e));
@@ -366,9 +388,10 @@ void msm_ctx_destroy(msm_ctx* c) {
         DeviceGuard g(c->device);
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         DevBuf* bufs[] = {&c->bases,   &c->inf,       &c->scalars, &c->digits,  &c->ranks,  &c->sorted, &c->hist,
-                          &c->offsets, &c->blocksums, &c->buckets, &c->gpoints, &c->winsums, &c->flags,  &c->pow2};
+                          &c->offsets, &c->blocksums, &c->buckets, &c->rc,      &c->qsums,   &c->flags,  &c->pow2,
+                          &c->heads,   &c->tails,     &c->chunkmap};
         for (DevBuf* b : bufs) release(*b);
-        if (c->h_winsums) (void)hipHostFree(c->h_winsums);
+        if (c->h_qsums) (void)hipHostFree(c->h_qsums);
         if (c->h_flags) (void)hipHostFree(c->h_flags);
         for (int i = 0; i < EV_COUNT; i++)
             if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);

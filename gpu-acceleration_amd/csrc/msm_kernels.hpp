@@ -6,7 +6,7 @@
 //   K2 transpose (ONE thread per window, serial 2N+C loop) -> k_decompose's histogram/rank atomics,
 //        k_scan_* (bucket offsets) and k_scatter: a counting sort with N*W-way parallelism
 //   K3 smvp (full 16-mul Jacobian add, one thread per bucket pair) -> k_accumulate (XYZZ mixed add)
-//   K4/K5 bpr_stage_1/2 -> k_reduce_chunks (+ k_reduce_windows: wavefront-shuffle tree)
+//   K4/K5 bpr_stage_1/2 -> k_reduce_sums (row/column plain sums) + k_reduce_bits (wavefront-shuffle trees)
 //   final_reduction (CPU) -> stays on the CPU: host_g1.hpp
 //
 // Data layout in HBM (all little-endian u32 words):
@@ -16,7 +16,7 @@
 //   ranks    W x n    arrival rank inside the bucket (return value of the histogram atomic)
 //   offsets  W*nb + 1 exclusive prefix sum of bucket sizes == CSC column pointer of the reference
 //   sorted   W x n    point index | sign<<31 grouped by bucket        == val_idxs of the reference
-//   buckets  W*nb x 32  XYZZ bucket sums
+//   buckets  W*nb x 32  XYZZ bucket sums;  heads/tails  ceil(n*W/L) x 32  partial sums of buckets cut by chunk borders
 #pragma once
 #include "ec_bn254.hpp"
 
@@ -216,87 +216,142 @@ __global__ void k_scatter(const uint32_t* __restrict__ digits, const uint32_t* _
 }
 
 // ---------------------------------------------------------------------------------------------
-// K3: bucket accumulation.  One thread per (window, bucket); the bucket's points are a contiguous
-// segment of `sorted`; each is gathered as one 64-byte affine point and folded into an XYZZ
-// accumulator held in registers (8M+2S per point).
-__global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
-                                                    const uint32_t* __restrict__ offsets, uint32_t* __restrict__ buckets,
-                                                    uint32_t total_buckets) {
+// K3: bucket accumulation.  The sorted (point, sign) array is cut into fixed-length CHUNKS of L entries and
+// every thread folds exactly one chunk, so all 64 lanes of a wavefront run the same number of mixed adds
+// whatever the bucket-size distribution is (Poisson sizes, the short top window whose buckets are ~5x
+// longer, or adversarial inputs with one huge bucket).  The reference gives one thread a whole bucket pair
+// (smvp.metal:46-71) and serialises on the longest.
+//   * a bucket lying inside one chunk is written straight to buckets[k];
+//   * a bucket cut by chunk borders leaves partial sums: tails[t] (it starts in chunk t and runs on) and
+//     heads[t] (it started before chunk t); k_combine adds them: B_k = tails[t0] + heads[t0+1] + ... + heads[t1].
+// Each point is gathered as one 64-byte affine record and folded into an XYZZ accumulator in registers.
+
+// chunk_bucket[t] = bucket that owns sorted entry t*L  (one thread per bucket writes the chunks it starts)
+__global__ void k_chunk_map(const uint32_t* __restrict__ offsets, uint32_t* __restrict__ chunk_bucket, uint32_t total_buckets,
+                            uint32_t L) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= total_buckets) return;
     uint32_t beg = offsets[k], end = offsets[k + 1];
+    if (beg == end) return;
+    for (uint32_t t = (beg + L - 1) / L; t <= (end - 1) / L; t++) chunk_bucket[t] = k;
+}
+
+__global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
+                                                    const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ chunk_bucket,
+                                                    uint32_t* __restrict__ buckets, uint32_t* __restrict__ heads,
+                                                    uint32_t* __restrict__ tails, const uint32_t* __restrict__ total_pairs_ptr,
+                                                    uint32_t L) {
+    const uint32_t total_pairs = *total_pairs_ptr;  // non-zero digits, known only on the device (k_scan_block_sums)
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t j0 = t * L;
+    if (j0 >= total_pairs) return;
+    uint32_t j1 = min(total_pairs, j0 + L);
+    uint32_t k = chunk_bucket[t];
+    uint32_t seg_end = offsets[k + 1];
+    bool is_head = offsets[k] < j0;  // the first bucket of this chunk began in an earlier chunk
     xyzz acc = xyzz_identity();
-    for (uint32_t j = beg; j < end; j++) {
+    for (uint32_t j = j0; j < j1; j++) {
+        if (j == seg_end) {  // bucket k is finished: flush and move to the bucket that owns entry j
+            store_xyzz((is_head ? heads + (size_t)t * 32 : buckets + (size_t)k * 32), acc);
+            do {
+                k++;
+                seg_end = offsets[k + 1];
+            } while (seg_end <= j);
+            is_head = false;
+            acc = xyzz_identity();
+        }
         uint32_t e = sorted[j];
         const uint32_t* bp = bases + (size_t)(e & ~SIGN_BIT) * 16;
         affine q{load_fp(bp), load_fp(bp + 8)};
         if (e & SIGN_BIT) q.y = fp_neg(q.y);
         xyzz_madd(acc, q);
     }
+    uint32_t* dst = is_head ? heads + (size_t)t * 32 : (seg_end == j1 ? buckets + (size_t)k * 32 : tails + (size_t)t * 32);
+    store_xyzz(dst, acc);
+}
+
+// one thread per bucket: empty buckets become the identity, buckets cut by chunk borders are summed
+__global__ void __launch_bounds__(256) k_combine(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ heads,
+                                                 const uint32_t* __restrict__ tails, uint32_t* __restrict__ buckets,
+                                                 uint32_t total_buckets, uint32_t L) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= total_buckets) return;
+    uint32_t beg = offsets[k], end = offsets[k + 1];
+    if (beg == end) {
+        store_xyzz(buckets + (size_t)k * 32, xyzz_identity());
+        return;
+    }
+    uint32_t t0 = beg / L, t1 = (end - 1) / L;
+    if (t0 == t1) return;  // written by k_accumulate
+    xyzz acc = load_xyzz(tails + (size_t)t0 * 32);
+    for (uint32_t t = t0 + 1; t <= t1; t++) acc = xyzz_add(acc, load_xyzz(heads + (size_t)t * 32));
     store_xyzz(buckets + (size_t)k * 32, acc);
 }
 
 // ---------------------------------------------------------------------------------------------
-// K4+K5: running-sum bucket reduction.  Thread j of window w owns buckets [jL, (j+1)L) (magnitudes
-// jL+1 .. (j+1)L), computes S = sum B and T = sum (i+1) B_{jL+i} by the running-sum trick, then adds
-// (jL)*S by double-and-add (pbpr.metal:16-31, 98-148), leaving G_j = sum_k k*B_k over its chunk.
-__device__ __forceinline__ xyzz xyzz_mul_small(xyzz p, uint32_t s) {
-    xyzz r = xyzz_identity();
-    while (s) {
-        if (s & 1u) r = xyzz_add(r, p);
-        s >>= 1;
-        if (s) p = xyzz_dbl(p);
-    }
-    return r;
-}
-__global__ void __launch_bounds__(64) k_reduce_chunks(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ gpoints,
-                                                      uint32_t nb, uint32_t L, uint32_t chunks_per_window,
-                                                      uint32_t total_chunks) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total_chunks) return;
-    uint32_t w = t / chunks_per_window, j = t % chunks_per_window;
-    uint32_t lo = j * L, hi = min(lo + L, nb);
-    const uint32_t* bw = buckets + (size_t)w * nb * 32;
-    xyzz s = xyzz_identity(), tt = xyzz_identity();
-    for (uint32_t b = hi; b-- > lo;) {
-        s = xyzz_add(s, load_xyzz(bw + (size_t)b * 32));
-        tt = xyzz_add(tt, s);
-    }
-    if (lo) tt = xyzz_add(tt, xyzz_mul_small(s, lo));
-    store_xyzz(gpoints + (size_t)t * 32, tt);
-}
-
-// wavefront tree reduction of one XYZZ per lane with __shfl_down (64-wide)
-__device__ __forceinline__ fp shfl_down_fp(const fp& a, int d) {
+// K4+K5: bucket reduction  S_w = sum_b (b+1) * B[w][b].
+//
+// The reference (pbpr.metal:33-148) gives each thread a run of buckets, forms running sums and then a
+// double-and-add by the run's offset -- ~60 dependent group operations per thread.  One dependent XYZZ add
+// costs a lone gfx950 wavefront ~10 us, so dependency DEPTH, not work, is what this stage pays for.  Here the
+// weights are pushed to the host instead, and the device only forms PLAIN sums, which are trees:
+//   split b = hi * n_lo + lo.  With row sums R_hi = sum_lo B[hi][lo] and column sums C_lo = sum_hi B[hi][lo]
+//       S_w = n_lo * sum_hi hi * R_hi  +  sum_lo (lo + 1) * C_lo
+//   and with bit sums  Q_u = sum over {lo : bit u of lo set} C_lo          (u <  kb_lo)
+//                      Q_u = sum over {hi : bit u-kb_lo of hi set} R_hi    (kb_lo <= u < kb),  Q_all = sum_lo C_lo
+//       S_w = Q_all + sum_u 2^u * Q_u
+// k_reduce_sums forms R and C (2 adds per bucket, depth ~11), k_reduce_bits the kb+1 bit sums per window
+// (wavefront __shfl_down trees), and the host finishes with one Horner chain per window (host_g1.hpp).
+__device__ __forceinline__ fp shfl_down_fp(const fp& a, int d, int width) {
     fp r;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r.v[i] = __shfl_down(a.v[i], d, 64);
+    for (int i = 0; i < 8; i++) r.v[i] = __shfl_down(a.v[i], d, width);
     return r;
 }
-__device__ __forceinline__ xyzz wave_reduce_xyzz(xyzz v) {
-    for (int d = 32; d >= 1; d >>= 1) {
-        xyzz o{shfl_down_fp(v.x, d), shfl_down_fp(v.y, d), shfl_down_fp(v.zz, d), shfl_down_fp(v.zzz, d)};
-        v = xyzz_add(v, o);
-    }
-    return v;  // lane 0 holds the sum
+__device__ __forceinline__ xyzz shfl_down_xyzz(const xyzz& v, int d, int width) {
+    return xyzz{shfl_down_fp(v.x, d, width), shfl_down_fp(v.y, d, width), shfl_down_fp(v.zz, d, width),
+                shfl_down_fp(v.zzz, d, width)};
 }
-// one 256-thread block per window: sum the window's G points, emit a Jacobian window sum
-__global__ void __launch_bounds__(256) k_reduce_windows(const uint32_t* __restrict__ gpoints, uint32_t chunks_per_window,
-                                                        uint32_t* __restrict__ winsums /* W x 24 */) {
-    __shared__ uint32_t lds[4 * 32];
-    uint32_t w = blockIdx.x;
-    const uint32_t* g = gpoints + (size_t)w * chunks_per_window * 32;
+// out[o] = sum_{i<count} in[(o / per_w) * nb + (o % per_w) * mul + i * step], G lanes cooperate on one output
+__global__ void __launch_bounds__(256) k_reduce_sums(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t out_per_w_total,
+                                                     uint32_t out_off, uint32_t n_out, uint32_t per_w, uint32_t nb, uint32_t mul,
+                                                     uint32_t step, uint32_t count, uint32_t G) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t o = t / G, g = t % G;
     xyzz acc = xyzz_identity();
-    for (uint32_t j = threadIdx.x; j < chunks_per_window; j += blockDim.x) acc = xyzz_add(acc, load_xyzz(g + (size_t)j * 32));
-    acc = wave_reduce_xyzz(acc);
-    int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    if (lane == 0) store_xyzz(lds + wid * 32, acc);
-    __syncthreads();
+    if (o < n_out) {
+        uint32_t per = count / G;
+        size_t base = (size_t)(o / per_w) * nb + (size_t)(o % per_w) * mul;
+        for (uint32_t i = g * per; i < (g + 1) * per; i++) acc = xyzz_add(acc, load_xyzz(in + (base + (size_t)i * step) * 32));
+    }
+    for (uint32_t d = G >> 1; d >= 1; d >>= 1) acc = xyzz_add(acc, shfl_down_xyzz(acc, (int)d, (int)G));
+    if (o < n_out && g == 0) store_xyzz(out + ((size_t)(o / per_w) * out_per_w_total + out_off + (o % per_w)) * 32, acc);
+}
+// one wavefront per (window, bit): rc[w] = R[0..n_hi) || C[0..n_lo);  q[w][u] Jacobian
+__global__ void __launch_bounds__(64) k_reduce_bits(const uint32_t* __restrict__ rc, uint32_t* __restrict__ q, uint32_t n_hi,
+                                                    uint32_t n_lo, uint32_t kb_lo, uint32_t kb) {
+    uint32_t w = blockIdx.x / (kb + 1), u = blockIdx.x % (kb + 1);
+    const uint32_t* src = rc + (size_t)w * (n_hi + n_lo) * 32;
+    uint32_t cnt, bit;
+    if (u < kb_lo) {
+        src += (size_t)n_hi * 32;
+        cnt = n_lo;
+        bit = u;
+    } else if (u < kb) {
+        cnt = n_hi;
+        bit = u - kb_lo;
+    } else {
+        src += (size_t)n_hi * 32;
+        cnt = n_lo;
+        bit = 0xFFFFFFFFu;
+    }
+    xyzz acc = xyzz_identity();
+    for (uint32_t j = threadIdx.x; j < cnt; j += 64)
+        if (bit == 0xFFFFFFFFu || ((j >> bit) & 1u)) acc = xyzz_add(acc, load_xyzz(src + (size_t)j * 32));
+    for (int d = 32; d >= 1; d >>= 1) acc = xyzz_add(acc, shfl_down_xyzz(acc, d, 64));
     if (threadIdx.x == 0) {
-        xyzz tot = load_xyzz(lds);
-        for (int k = 1; k < 4; k++) tot = xyzz_add(tot, load_xyzz(lds + k * 32));
-        jacobian jj = xyzz_to_jacobian(tot);
-        uint32_t* o = winsums + (size_t)w * 24;
+        jacobian jj = xyzz_to_jacobian(acc);
+        uint32_t* o = q + (size_t)blockIdx.x * 24;
         store_fp(o, jj.x);
         store_fp(o + 8, jj.y);
         store_fp(o + 16, jj.z);

@@ -1,0 +1,9 @@
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/pmc1
+rocprofv3 -L > gpurun_out/pmc1/counters_list.txt 2>&1
+for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS" "GRBM_GUI_ACTIVE SQ_INSTS_SMEM SQ_THREAD_CYCLES_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_LEVEL_VMEM"; do
+  tag=$(echo $set | cut -d' ' -f1)
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/pmc1/$tag -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/pmc1/$tag.log 2>&1
+done
+ls -R gpurun_out/pmc1 | head -40
