@@ -50,7 +50,7 @@ struct msm_ctx {
     hipEvent_t ev[EV_COUNT]{};
     // HBM workspace
     DevBuf bases, inf, scalars, digits, ranks, sorted, hist, offsets, blocksums, buckets, heads, tails, chunkmap, rc, qsums, flags,
-        pow2;
+        pow2, tilecounts;
     bool pow2_ready = false;
     uint32_t* h_qsums = nullptr;  // pinned: W x (kb+1) Jacobian bit sums
     uint32_t* h_flags = nullptr;    // pinned
@@ -131,6 +131,7 @@ int32_t make_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_plan_t* ou
     out->workspace_bytes = n * (64 + 32 + 1) + pairs * 12 + tb * (8 + 128) + tb * 128 / 4;
     return MSM_OK;
 }
+constexpr size_t LDS_HIST_BYTES = 128 * 1024;   // one window's bucket histogram must fit here for the LDS sort path
 constexpr uint32_t ACC_CHUNK_LEN = 32;          // sorted entries folded by one k_accumulate thread
 constexpr size_t MAX_QSUM_POINTS = 128 * 21;  // W <= 128 windows (c >= 2), kb + 1 <= 21 bit sums each
 
@@ -207,17 +208,36 @@ int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, 
     uint32_t* hist = (uint32_t*)c->hist.p;
     uint32_t* offsets = (uint32_t*)c->offsets.p;
     uint32_t* flags = (uint32_t*)c->flags.p;
-    HIPCHK(c, hipMemsetAsync(hist, 0, tb * 4, st));
+    // Counting-sort plan: when one window's histogram fits LDS (nb <= 32768) the bucket counts and arrival
+    // ranks come from per-tile LDS histograms, otherwise from device-scope atomics in k_decompose.
+    const bool tiled = (size_t)nb * 4 <= LDS_HIST_BYTES;
+    uint32_t T = 1, tile_len = (uint32_t)n;
+    if (tiled) {
+        T = (uint32_t)((n + 65535) / 65536);
+        if (T > 64) T = 64;
+        tile_len = (uint32_t)((n + T - 1) / T);
+        if ((rc = ensure(c, c->tilecounts, (size_t)W * T * nb * 4))) return rc;
+    } else {
+        HIPCHK(c, hipMemsetAsync(hist, 0, tb * 4, st));
+    }
     HIPCHK(c, hipMemsetAsync(flags, 0, 64, st));
     HIPCHK(c, hipEventRecord(c->ev[EV_CONVERT], st));
-    // K1b + K2/1: digits, signed recode, bucket histogram with arrival ranks
-    if (pl.signed_digits)
-        msmk::k_decompose<true><<<grid1(n, 256), 256, 0, st>>>(d_scalars, d_inf, (uint32_t)n, cbits, W, nb, hist,
-                                                               (uint32_t*)c->digits.p, (uint32_t*)c->ranks.p, flags);
-    else
-        msmk::k_decompose<false><<<grid1(n, 256), 256, 0, st>>>(d_scalars, d_inf, (uint32_t)n, cbits, W, nb, hist,
-                                                                (uint32_t*)c->digits.p, (uint32_t*)c->ranks.p, flags);
+    // K1b: digits + signed recode
+    {
+        uint32_t *dg = (uint32_t*)c->digits.p, *rk = (uint32_t*)c->ranks.p;
+        dim3 g = grid1(n, 256);
+        if (pl.signed_digits && tiled) msmk::k_decompose<true, false><<<g, 256, 0, st>>>(d_scalars, d_inf, (uint32_t)n, cbits, W, nb, hist, dg, rk, flags);
+        else if (pl.signed_digits) msmk::k_decompose<true, true><<<g, 256, 0, st>>>(d_scalars, d_inf, (uint32_t)n, cbits, W, nb, hist, dg, rk, flags);
+        else if (tiled) msmk::k_decompose<false, false><<<g, 256, 0, st>>>(d_scalars, d_inf, (uint32_t)n, cbits, W, nb, hist, dg, rk, flags);
+        else msmk::k_decompose<false, true><<<g, 256, 0, st>>>(d_scalars, d_inf, (uint32_t)n, cbits, W, nb, hist, dg, rk, flags);
+    }
     HIPCHK(c, hipEventRecord(c->ev[EV_DECOMP], st));
+    // K2/1: per-tile LDS histograms + ranks, then per-bucket prefix over tiles
+    if (tiled) {
+        msmk::k_tile_hist<<<dim3(T, W), msmk::TILE_BLOCK, (size_t)nb * 4, st>>>((uint32_t*)c->digits.p, (uint32_t*)c->ranks.p,
+                                                                              (uint32_t*)c->tilecounts.p, (uint32_t)n, nb, tile_len, T);
+        msmk::k_tile_prefix<<<grid1(tb, 256), 256, 0, st>>>((uint32_t*)c->tilecounts.p, hist, nb, T, (uint32_t)tb);
+    }
     // K2/2: bucket offsets
     msmk::k_scan_tiles<<<ntiles, msmk::SCAN_BLOCK, 0, st>>>(hist, offsets, (uint32_t*)c->blocksums.p, (uint32_t)tb);
     msmk::k_scan_block_sums<<<1, msmk::SCAN_BLOCK, 0, st>>>((uint32_t*)c->blocksums.p, ntiles, flags + 4);
@@ -225,8 +245,12 @@ int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, 
     // K2/3: scatter
     {
         dim3 g((unsigned)((n + 255) / 256), W);
-        msmk::k_scatter<<<g, 256, 0, st>>>((uint32_t*)c->digits.p, (uint32_t*)c->ranks.p, offsets, (uint32_t*)c->sorted.p,
-                                          (uint32_t)n, nb);
+        if (tiled)
+            msmk::k_scatter<true><<<g, 256, 0, st>>>((uint32_t*)c->digits.p, (uint32_t*)c->ranks.p, offsets, (uint32_t*)c->tilecounts.p,
+                                                    (uint32_t*)c->sorted.p, (uint32_t)n, nb, tile_len, T);
+        else
+            msmk::k_scatter<false><<<g, 256, 0, st>>>((uint32_t*)c->digits.p, (uint32_t*)c->ranks.p, offsets, nullptr,
+                                                     (uint32_t*)c->sorted.p, (uint32_t)n, nb, tile_len, T);
     }
     HIPCHK(c, hipEventRecord(c->ev[EV_SORT], st));
     // K3: bucket accumulation (the graded kernel) -- bracketed by its own events on its own stream
@@ -356,6 +380,8 @@ int32_t msm_ctx_create(const msm_config_t* cfg, msm_ctx** out) {
     for (int i = 0; i < EV_COUNT && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_qsums, MAX_QSUM_POINTS * 96, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_flags, 64, hipHostMallocDefault);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)msmk::k_tile_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_HIST_BYTES);
     if (e != hipSuccess) {
         fail(nullptr, MSM_ERR_HIP, "context setup failed: %s", hipGetErrorString(e));
         msm_ctx_destroy(c);
@@ -389,7 +415,7 @@ void msm_ctx_destroy(msm_ctx* c) {
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         DevBuf* bufs[] = {&c->bases,   &c->inf,       &c->scalars, &c->digits,  &c->ranks,  &c->sorted, &c->hist,
                           &c->offsets, &c->blocksums, &c->buckets, &c->rc,      &c->qsums,   &c->flags,  &c->pow2,
-                          &c->heads,   &c->tails,     &c->chunkmap};
+                          &c->heads,   &c->tails,     &c->chunkmap, &c->tilecounts};
         for (DevBuf* b : bufs) release(*b);
         if (c->h_qsums) (void)hipHostFree(c->h_qsums);
         if (c->h_flags) (void)hipHostFree(c->h_flags);

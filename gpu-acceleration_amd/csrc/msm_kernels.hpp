@@ -73,7 +73,9 @@ __device__ __forceinline__ uint32_t scalar_window(const uint32_t s[8], uint32_t 
     return (uint32_t)v & ((1u << c) - 1u);
 }
 
-template <bool SIGNED>
+// HIST = true also counts buckets with global atomics (fallback when a window's histogram does not fit LDS);
+// HIST = false only writes the digits and leaves counting to k_tile_hist.
+template <bool SIGNED, bool HIST>
 __global__ void k_decompose(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_mask, uint32_t n,
                             uint32_t c, uint32_t W, uint32_t nb, uint32_t* __restrict__ hist,
                             uint32_t* __restrict__ digits, uint32_t* __restrict__ ranks, uint32_t* __restrict__ err) {
@@ -103,7 +105,7 @@ __global__ void k_decompose(const uint32_t* __restrict__ scalars, const uint8_t*
             digits[o] = DIGIT_SKIP;
         } else {
             uint32_t bkt = mag - 1;
-            ranks[o] = atomicAdd(&hist[(size_t)w * nb + bkt], 1u);
+            if (HIST) ranks[o] = atomicAdd(&hist[(size_t)w * nb + bkt], 1u);
             digits[o] = bkt | neg;
         }
     }
@@ -202,9 +204,49 @@ __global__ void k_scan_add(uint32_t* __restrict__ out, const uint32_t* __restric
     if (i == 0) out[count] = *total;
 }
 
-// K2 phase 3: place every (point, sign) at offsets[bucket] + rank
+// K2 phase 1 (LDS path): one 1024-thread workgroup counts one TILE of points of one window in an LDS
+// histogram of all nb buckets (<= 128 KB of the CU's 160 KB).  The LDS atomic returns the arrival rank inside
+// (window, tile, bucket); counts[w][tile][b] go to HBM with coalesced stores.  16.7 M LDS atomics replace
+// 16.7 M scattered device-scope atomics (the reference does this with ONE thread per window, transpose.metal:27-32).
+constexpr int TILE_BLOCK = 1024;
+__global__ void __launch_bounds__(TILE_BLOCK) k_tile_hist(const uint32_t* __restrict__ digits, uint32_t* __restrict__ ranks,
+                                                          uint32_t* __restrict__ counts, uint32_t n, uint32_t nb,
+                                                          uint32_t tile_len, uint32_t T) {
+    extern __shared__ uint32_t s_tile_hist[];
+    const uint32_t tile = blockIdx.x, w = blockIdx.y;
+    for (uint32_t b = threadIdx.x; b < nb; b += TILE_BLOCK) s_tile_hist[b] = 0;
+    __syncthreads();
+    const uint32_t i0 = tile * tile_len, i1 = min(n, i0 + tile_len);
+    const size_t row = (size_t)w * n;
+    for (uint32_t i = i0 + threadIdx.x; i < i1; i += TILE_BLOCK) {
+        uint32_t d = digits[row + i];
+        if (d != DIGIT_SKIP) ranks[row + i] = atomicAdd(&s_tile_hist[d & ~SIGN_BIT], 1u);
+    }
+    __syncthreads();
+    uint32_t* out = counts + ((size_t)w * T + tile) * nb;
+    for (uint32_t b = threadIdx.x; b < nb; b += TILE_BLOCK) out[b] = s_tile_hist[b];
+}
+// per (window, bucket): exclusive prefix over the T tiles in place, bucket total to hist
+__global__ void k_tile_prefix(uint32_t* __restrict__ counts, uint32_t* __restrict__ hist, uint32_t nb, uint32_t T,
+                              uint32_t total_buckets) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= total_buckets) return;
+    uint32_t w = k / nb, b = k % nb;
+    uint32_t* p = counts + (size_t)w * T * nb + b;
+    uint32_t run = 0;
+    for (uint32_t t = 0; t < T; t++) {
+        uint32_t cnt = p[(size_t)t * nb];
+        p[(size_t)t * nb] = run;
+        run += cnt;
+    }
+    hist[k] = run;
+}
+
+// K2 phase 3: place every (point, sign) at offsets[bucket] (+ tile base) + rank
+template <bool TILED>
 __global__ void k_scatter(const uint32_t* __restrict__ digits, const uint32_t* __restrict__ ranks,
-                          const uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted, uint32_t n, uint32_t nb) {
+                          const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ tile_base,
+                          uint32_t* __restrict__ sorted, uint32_t n, uint32_t nb, uint32_t tile_len, uint32_t T) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t w = blockIdx.y;
     if (i >= n) return;
@@ -212,7 +254,9 @@ __global__ void k_scatter(const uint32_t* __restrict__ digits, const uint32_t* _
     uint32_t d = digits[o];
     if (d == DIGIT_SKIP) return;
     uint32_t bkt = d & ~SIGN_BIT;
-    sorted[offsets[(size_t)w * nb + bkt] + ranks[o]] = i | (d & SIGN_BIT);
+    uint32_t pos = offsets[(size_t)w * nb + bkt] + ranks[o];
+    if (TILED) pos += tile_base[((size_t)w * T + i / tile_len) * nb + bkt];
+    sorted[pos] = i | (d & SIGN_BIT);
 }
 
 // ---------------------------------------------------------------------------------------------
