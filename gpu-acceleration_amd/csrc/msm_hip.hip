@@ -192,7 +192,6 @@ int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, 
     const uint32_t chunk_len = ACC_CHUNK_LEN;
     const size_t nchunks_max = (pairs + chunk_len - 1) / chunk_len;
     if ((rc = ensure(c, c->digits, pairs * 4))) return rc;
-    if ((rc = ensure(c, c->ranks, pairs * 4))) return rc;
     if ((rc = ensure(c, c->sorted, pairs * 4))) return rc;
     if ((rc = ensure(c, c->hist, tb * 4))) return rc;
     if ((rc = ensure(c, c->offsets, (tb + 1) * 4))) return rc;
@@ -212,6 +211,7 @@ int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, 
     // ranks come from per-tile LDS histograms, otherwise from device-scope atomics in k_decompose.
     const bool tiled = (size_t)nb * 4 <= LDS_HIST_BYTES;
     uint32_t T = 1, tile_len = (uint32_t)n;
+    if (!tiled && (rc = ensure(c, c->ranks, pairs * 4))) return rc;
     if (tiled) {
         T = (uint32_t)((n + 65535) / 65536);
         if (T > 64) T = 64;
@@ -234,8 +234,8 @@ int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, 
     HIPCHK(c, hipEventRecord(c->ev[EV_DECOMP], st));
     // K2/1: per-tile LDS histograms + ranks, then per-bucket prefix over tiles
     if (tiled) {
-        msmk::k_tile_hist<<<dim3(T, W), msmk::TILE_BLOCK, (size_t)nb * 4, st>>>((uint32_t*)c->digits.p, (uint32_t*)c->ranks.p,
-                                                                              (uint32_t*)c->tilecounts.p, (uint32_t)n, nb, tile_len, T);
+        msmk::k_tile_hist<<<dim3(T, W), msmk::TILE_BLOCK, (size_t)nb * 4, st>>>((uint32_t*)c->digits.p, (uint32_t*)c->tilecounts.p,
+                                                                              (uint32_t)n, nb, tile_len, T);
         msmk::k_tile_prefix<<<grid1(tb, 256), 256, 0, st>>>((uint32_t*)c->tilecounts.p, hist, nb, T, (uint32_t)tb);
     }
     // K2/2: bucket offsets
@@ -243,14 +243,12 @@ int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, 
     msmk::k_scan_block_sums<<<1, msmk::SCAN_BLOCK, 0, st>>>((uint32_t*)c->blocksums.p, ntiles, flags + 4);
     msmk::k_scan_add<<<grid1(tb, 256), 256, 0, st>>>(offsets, (uint32_t*)c->blocksums.p, (uint32_t)tb, flags + 4);
     // K2/3: scatter
-    {
+    if (tiled) {
+        msmk::k_tile_scatter<<<dim3(T, W), msmk::TILE_BLOCK, (size_t)nb * 4, st>>>((uint32_t*)c->digits.p, offsets, (uint32_t*)c->tilecounts.p,
+                                                                                 (uint32_t*)c->sorted.p, (uint32_t)n, nb, tile_len, T);
+    } else {
         dim3 g((unsigned)((n + 255) / 256), W);
-        if (tiled)
-            msmk::k_scatter<true><<<g, 256, 0, st>>>((uint32_t*)c->digits.p, (uint32_t*)c->ranks.p, offsets, (uint32_t*)c->tilecounts.p,
-                                                    (uint32_t*)c->sorted.p, (uint32_t)n, nb, tile_len, T);
-        else
-            msmk::k_scatter<false><<<g, 256, 0, st>>>((uint32_t*)c->digits.p, (uint32_t*)c->ranks.p, offsets, nullptr,
-                                                     (uint32_t*)c->sorted.p, (uint32_t)n, nb, tile_len, T);
+        msmk::k_scatter<<<g, 256, 0, st>>>((uint32_t*)c->digits.p, (uint32_t*)c->ranks.p, offsets, (uint32_t*)c->sorted.p, (uint32_t)n, nb);
     }
     HIPCHK(c, hipEventRecord(c->ev[EV_SORT], st));
     // K3: bucket accumulation (the graded kernel) -- bracketed by its own events on its own stream
@@ -382,6 +380,8 @@ int32_t msm_ctx_create(const msm_config_t* cfg, msm_ctx** out) {
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_flags, 64, hipHostMallocDefault);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)msmk::k_tile_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_HIST_BYTES);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)msmk::k_tile_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_HIST_BYTES);
     if (e != hipSuccess) {
         fail(nullptr, MSM_ERR_HIP, "context setup failed: %s", hipGetErrorString(e));
         msm_ctx_destroy(c);
@@ -395,7 +395,6 @@ int32_t msm_ctx_create(const msm_config_t* cfg, msm_ctx** out) {
         if (!rc) rc = ensure(c, c->bases, c0.max_points * 64);
         if (!rc) rc = ensure(c, c->scalars, c0.max_points * 32);
         if (!rc) rc = ensure(c, c->digits, pairs * 4);
-        if (!rc) rc = ensure(c, c->ranks, pairs * 4);
         if (!rc) rc = ensure(c, c->sorted, pairs * 4);
         if (!rc) rc = ensure(c, c->buckets, tb * 128);
         if (rc) {

@@ -13,7 +13,7 @@
 //   bases    n x 16   affine Montgomery x||y, 64 B per point = one half cache line per gather
 //   scalars  n x 8    standard form
 //   digits   W x n    bucket index (bit 31 = negate, 0xFFFFFFFF = digit 0 / base at infinity), window-major
-//   ranks    W x n    arrival rank inside the bucket (return value of the histogram atomic)
+//   ranks    W x n    arrival rank inside the bucket (fallback path only: nb > 32768)
 //   offsets  W*nb + 1 exclusive prefix sum of bucket sizes == CSC column pointer of the reference
 //   sorted   W x n    point index | sign<<31 grouped by bucket        == val_idxs of the reference
 //   buckets  W*nb x 32  XYZZ bucket sums;  heads/tails  ceil(n*W/L) x 32  partial sums of buckets cut by chunk borders
@@ -206,12 +206,12 @@ __global__ void k_scan_add(uint32_t* __restrict__ out, const uint32_t* __restric
 
 // K2 phase 1 (LDS path): one 1024-thread workgroup counts one TILE of points of one window in an LDS
 // histogram of all nb buckets (<= 128 KB of the CU's 160 KB).  The LDS atomic returns the arrival rank inside
-// (window, tile, bucket); counts[w][tile][b] go to HBM with coalesced stores.  16.7 M LDS atomics replace
+// (window, tile, bucket) -- used by k_tile_scatter, which repeats the same atomics on absolute cursors;
+// counts[w][tile][b] go to HBM with coalesced stores.  16.7 M LDS atomics replace
 // 16.7 M scattered device-scope atomics (the reference does this with ONE thread per window, transpose.metal:27-32).
 constexpr int TILE_BLOCK = 1024;
-__global__ void __launch_bounds__(TILE_BLOCK) k_tile_hist(const uint32_t* __restrict__ digits, uint32_t* __restrict__ ranks,
-                                                          uint32_t* __restrict__ counts, uint32_t n, uint32_t nb,
-                                                          uint32_t tile_len, uint32_t T) {
+__global__ void __launch_bounds__(TILE_BLOCK) k_tile_hist(const uint32_t* __restrict__ digits, uint32_t* __restrict__ counts,
+                                                          uint32_t n, uint32_t nb, uint32_t tile_len, uint32_t T) {
     extern __shared__ uint32_t s_tile_hist[];
     const uint32_t tile = blockIdx.x, w = blockIdx.y;
     for (uint32_t b = threadIdx.x; b < nb; b += TILE_BLOCK) s_tile_hist[b] = 0;
@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_tile_hist(const uint32_t* __rest
     const size_t row = (size_t)w * n;
     for (uint32_t i = i0 + threadIdx.x; i < i1; i += TILE_BLOCK) {
         uint32_t d = digits[row + i];
-        if (d != DIGIT_SKIP) ranks[row + i] = atomicAdd(&s_tile_hist[d & ~SIGN_BIT], 1u);
+        if (d != DIGIT_SKIP) atomicAdd(&s_tile_hist[d & ~SIGN_BIT], 1u);
     }
     __syncthreads();
     uint32_t* out = counts + ((size_t)w * T + tile) * nb;
@@ -242,11 +242,31 @@ __global__ void k_tile_prefix(uint32_t* __restrict__ counts, uint32_t* __restric
     hist[k] = run;
 }
 
-// K2 phase 3: place every (point, sign) at offsets[bucket] (+ tile base) + rank
-template <bool TILED>
+// K2 phase 3 (LDS path): the same (window, tile) workgroup shape as k_tile_hist.  The LDS array now holds the
+// ABSOLUTE write cursor of every bucket for this tile (bucket offset + counts of earlier tiles, both read with
+// coalesced loads), and each element takes its slot with one LDS atomic: no rank array, no random reads.
+__global__ void __launch_bounds__(TILE_BLOCK) k_tile_scatter(const uint32_t* __restrict__ digits, const uint32_t* __restrict__ offsets,
+                                                             const uint32_t* __restrict__ tile_base, uint32_t* __restrict__ sorted,
+                                                             uint32_t n, uint32_t nb, uint32_t tile_len, uint32_t T) {
+    extern __shared__ uint32_t s_tile_hist[];
+    // (measured: an XCD-aware window->XCD mapping of these workgroups changes nothing -- the stores are 4-byte
+    // writes into a 4 MB-per-window region and leave L2 as one partially written line each; profiles/NOTES_r1.md)
+    const uint32_t tile = blockIdx.x, w = blockIdx.y;
+    const uint32_t* ob = offsets + (size_t)w * nb;
+    const uint32_t* tbp = tile_base + ((size_t)w * T + tile) * nb;
+    for (uint32_t b = threadIdx.x; b < nb; b += TILE_BLOCK) s_tile_hist[b] = ob[b] + tbp[b];
+    __syncthreads();
+    const uint32_t i0 = tile * tile_len, i1 = min(n, i0 + tile_len);
+    const size_t row = (size_t)w * n;
+    for (uint32_t i = i0 + threadIdx.x; i < i1; i += TILE_BLOCK) {
+        uint32_t d = digits[row + i];
+        if (d != DIGIT_SKIP) sorted[atomicAdd(&s_tile_hist[d & ~SIGN_BIT], 1u)] = i | (d & SIGN_BIT);
+    }
+}
+
+// K2 phase 3 (fallback path): place every (point, sign) at offsets[bucket] + rank
 __global__ void k_scatter(const uint32_t* __restrict__ digits, const uint32_t* __restrict__ ranks,
-                          const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ tile_base,
-                          uint32_t* __restrict__ sorted, uint32_t n, uint32_t nb, uint32_t tile_len, uint32_t T) {
+                          const uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted, uint32_t n, uint32_t nb) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t w = blockIdx.y;
     if (i >= n) return;
@@ -254,9 +274,7 @@ __global__ void k_scatter(const uint32_t* __restrict__ digits, const uint32_t* _
     uint32_t d = digits[o];
     if (d == DIGIT_SKIP) return;
     uint32_t bkt = d & ~SIGN_BIT;
-    uint32_t pos = offsets[(size_t)w * nb + bkt] + ranks[o];
-    if (TILED) pos += tile_base[((size_t)w * T + i / tile_len) * nb + bkt];
-    sorted[pos] = i | (d & SIGN_BIT);
+    sorted[offsets[(size_t)w * nb + bkt] + ranks[o]] = i | (d & SIGN_BIT);
 }
 
 // ---------------------------------------------------------------------------------------------
