@@ -132,7 +132,6 @@ int32_t make_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_plan_t* ou
     return MSM_OK;
 }
 constexpr size_t LDS_HIST_BYTES = 128 * 1024;   // one window's bucket histogram must fit here for the LDS sort path
-constexpr uint32_t ACC_CHUNK_LEN = 32;          // sorted entries folded by one k_accumulate thread
 constexpr size_t MAX_QSUM_POINTS = 128 * 21;  // W <= 128 windows (c >= 2), kb + 1 <= 21 bit sums each
 
 uint32_t ilog2(uint32_t v) {
@@ -189,7 +188,10 @@ int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, 
     const uint32_t kb = ilog2(nb), kb_lo = kb / 2, kb_hi = kb - kb_lo;  // bucket index = hi * n_lo + lo
     const uint32_t n_lo = 1u << kb_lo, n_hi = 1u << kb_hi;
     const uint32_t ntiles = (uint32_t)((tb + msmk::SCAN_TILE - 1) / msmk::SCAN_TILE);
-    const uint32_t chunk_len = ACC_CHUNK_LEN;
+    // sorted entries folded by one k_accumulate thread: as long as possible (fewer cut buckets for k_combine)
+    // while still giving every SIMD its 4 wavefronts (256 CUs x 4 SIMDs x 4 waves x 64 lanes = 262144 threads)
+    uint32_t chunk_len = 8;
+    while (chunk_len < 32 && pairs / (chunk_len * 2) >= 262144) chunk_len *= 2;
     const size_t nchunks_max = (pairs + chunk_len - 1) / chunk_len;
     if ((rc = ensure(c, c->digits, pairs * 4))) return rc;
     if ((rc = ensure(c, c->sorted, pairs * 4))) return rc;
@@ -200,7 +202,7 @@ int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, 
     if ((rc = ensure(c, c->heads, nchunks_max * 128))) return rc;
     if ((rc = ensure(c, c->tails, nchunks_max * 128))) return rc;
     if ((rc = ensure(c, c->chunkmap, nchunks_max * 4))) return rc;
-    if ((rc = ensure(c, c->rc, (size_t)W * (n_hi + n_lo) * 128))) return rc;
+    if ((rc = ensure(c, c->rc, (tb + tb / 2 + 4) * 128))) return rc;  // two families x (1/2 + 1/4) ping-pong levels
     if ((rc = ensure(c, c->qsums, (size_t)W * (kb + 1) * 96))) return rc;
     if ((rc = ensure(c, c->flags, 64))) return rc;
 
@@ -260,18 +262,31 @@ int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, 
     HIPCHK(c, hipEventRecord(c->ev[EV_ACC1], st));
     msmk::k_combine<<<grid1(tb, 256), 256, 0, st>>>(offsets, (uint32_t*)c->heads.p, (uint32_t*)c->tails.p, (uint32_t*)c->buckets.p,
                                                     (uint32_t)tb, chunk_len);
-    // K4/K5: bucket reduction -- plain row/column sums, then per-bit sums; the weights are applied on the host
+    // K4/K5: bucket reduction -- plain row/column sums by dense pairwise levels, then per-bit sums; the weights
+    // are applied on the host
     {
         const uint32_t* bk = (const uint32_t*)c->buckets.p;
-        uint32_t* rcp = (uint32_t*)c->rc.p;
-        uint32_t g_rows = n_lo < 16 ? n_lo : 16, g_cols = n_hi < 16 ? n_hi : 16;
-        // rows: R[w][hi] = sum_lo B[w][hi*n_lo + lo]
-        msmk::k_reduce_sums<<<grid1((size_t)W * n_hi * g_rows, 256), 256, 0, st>>>(bk, rcp, n_hi + n_lo, 0, W * n_hi, n_hi, nb, n_lo, 1,
-                                                                             n_lo, g_rows);
-        // columns: C[w][lo] = sum_hi B[w][hi*n_lo + lo]
-        msmk::k_reduce_sums<<<grid1((size_t)W * n_lo * g_cols, 256), 256, 0, st>>>(bk, rcp, n_hi + n_lo, n_hi, W * n_lo, n_lo, nb, 1, n_lo,
-                                                                             n_hi, g_cols);
-        msmk::k_reduce_bits<<<W * (kb + 1), 64, 0, st>>>(rcp, (uint32_t*)c->qsums.p, n_hi, n_lo, kb_lo, kb);
+        // ping-pong buffers per family: [0, tb/2) and [tb/2, tb/2 + tb/4) elements
+        uint32_t* rbuf[2] = {(uint32_t*)c->rc.p, (uint32_t*)c->rc.p + (tb / 2) * 32};
+        uint32_t* cbuf[2] = {(uint32_t*)c->rc.p + (tb / 2 + tb / 4 + 1) * 32, (uint32_t*)c->rc.p + (tb + tb / 4 + 1) * 32};
+        const uint32_t *rin = bk, *cin = bk;
+        size_t rn = tb, cn = tb;  // current element counts
+        uint32_t levels = kb_hi > kb_lo ? kb_hi : kb_lo;
+        for (uint32_t l = 0; l < levels; l++) {
+            msmk::pair_job ja{nullptr, nullptr, 0, 1}, jb{nullptr, nullptr, 0, 1};
+            if (l < kb_lo) {
+                rn /= 2;
+                ja = msmk::pair_job{rin, rbuf[l & 1], (uint32_t)rn, 1};
+                rin = rbuf[l & 1];
+            }
+            if (l < kb_hi) {
+                cn /= 2;
+                jb = msmk::pair_job{cin, cbuf[l & 1], (uint32_t)cn, n_lo};
+                cin = cbuf[l & 1];
+            }
+            msmk::k_pair_level<<<grid1((size_t)ja.n_out + jb.n_out, 256), 256, 0, st>>>(ja, jb);
+        }
+        msmk::k_reduce_bits<<<W * (kb + 1), 64, 0, st>>>(rin, cin, (uint32_t*)c->qsums.p, n_hi, n_lo, kb_lo, kb);
     }
     HIPCHK(c, hipEventRecord(c->ev[EV_REDUCE], st));
     HIPCHK(c, hipMemcpyAsync(c->h_qsums, c->qsums.p, (size_t)W * (kb + 1) * 96, hipMemcpyDeviceToHost, st));

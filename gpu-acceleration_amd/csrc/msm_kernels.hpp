@@ -6,7 +6,7 @@
 //   K2 transpose (ONE thread per window, serial 2N+C loop) -> k_decompose's histogram/rank atomics,
 //        k_scan_* (bucket offsets) and k_scatter: a counting sort with N*W-way parallelism
 //   K3 smvp (full 16-mul Jacobian add, one thread per bucket pair) -> k_accumulate (XYZZ mixed add)
-//   K4/K5 bpr_stage_1/2 -> k_reduce_sums (row/column plain sums) + k_reduce_bits (wavefront-shuffle trees)
+//   K4/K5 bpr_stage_1/2 -> k_pair_level (row/column plain sums, dense pairwise levels) + k_reduce_bits (wavefront-shuffle trees)
 //   final_reduction (CPU) -> stays on the CPU: host_g1.hpp
 //
 // Data layout in HBM (all little-endian u32 words):
@@ -312,7 +312,22 @@ __global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__
     uint32_t seg_end = offsets[k + 1];
     bool is_head = offsets[k] < j0;  // the first bucket of this chunk began in an earlier chunk
     xyzz acc = xyzz_identity();
+    // software pipeline: the gather of entry j+1 (and the index of entry j+2) are in flight while entry j is folded
+    uint32_t e_cur = sorted[j0];
+    uint32_t e_nxt = j0 + 1 < j1 ? sorted[j0 + 1] : 0u;
+    affine q_cur;
+    {
+        const uint32_t* bp = bases + (size_t)(e_cur & ~SIGN_BIT) * 16;
+        q_cur = affine{load_fp(bp), load_fp(bp + 8)};
+    }
     for (uint32_t j = j0; j < j1; j++) {
+        affine q_nxt = q_cur;
+        uint32_t e_nn = 0;
+        if (j + 1 < j1) {
+            const uint32_t* bp = bases + (size_t)(e_nxt & ~SIGN_BIT) * 16;
+            q_nxt = affine{load_fp(bp), load_fp(bp + 8)};
+            if (j + 2 < j1) e_nn = sorted[j + 2];
+        }
         if (j == seg_end) {  // bucket k is finished: flush and move to the bucket that owns entry j
             store_xyzz((is_head ? heads + (size_t)t * 32 : buckets + (size_t)k * 32), acc);
             do {
@@ -322,11 +337,12 @@ __global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__
             is_head = false;
             acc = xyzz_identity();
         }
-        uint32_t e = sorted[j];
-        const uint32_t* bp = bases + (size_t)(e & ~SIGN_BIT) * 16;
-        affine q{load_fp(bp), load_fp(bp + 8)};
-        if (e & SIGN_BIT) q.y = fp_neg(q.y);
+        affine q = q_cur;
+        if (e_cur & SIGN_BIT) q.y = fp_neg(q.y);
         xyzz_madd(acc, q);
+        q_cur = q_nxt;
+        e_cur = e_nxt;
+        e_nxt = e_nn;
     }
     uint32_t* dst = is_head ? heads + (size_t)t * 32 : (seg_end == j1 ? buckets + (size_t)k * 32 : tails + (size_t)t * 32);
     store_xyzz(dst, acc);
@@ -362,7 +378,7 @@ __global__ void __launch_bounds__(256) k_combine(const uint32_t* __restrict__ of
 //   and with bit sums  Q_u = sum over {lo : bit u of lo set} C_lo          (u <  kb_lo)
 //                      Q_u = sum over {hi : bit u-kb_lo of hi set} R_hi    (kb_lo <= u < kb),  Q_all = sum_lo C_lo
 //       S_w = Q_all + sum_u 2^u * Q_u
-// k_reduce_sums forms R and C (2 adds per bucket, depth ~11), k_reduce_bits the kb+1 bit sums per window
+// k_pair_level forms R and C by dense pairwise levels (2 adds per bucket), k_reduce_bits the kb+1 bit sums per window
 // (wavefront __shfl_down trees), and the host finishes with one Horner chain per window (host_g1.hpp).
 __device__ __forceinline__ fp shfl_down_fp(const fp& a, int d, int width) {
     fp r;
@@ -374,36 +390,47 @@ __device__ __forceinline__ xyzz shfl_down_xyzz(const xyzz& v, int d, int width) 
     return xyzz{shfl_down_fp(v.x, d, width), shfl_down_fp(v.y, d, width), shfl_down_fp(v.zz, d, width),
                 shfl_down_fp(v.zzz, d, width)};
 }
-// out[o] = sum_{i<count} in[(o / per_w) * nb + (o % per_w) * mul + i * step], G lanes cooperate on one output
-__global__ void __launch_bounds__(256) k_reduce_sums(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t out_per_w_total,
-                                                     uint32_t out_off, uint32_t n_out, uint32_t per_w, uint32_t nb, uint32_t mul,
-                                                     uint32_t step, uint32_t count, uint32_t G) {
+// One pairwise level of both families in one launch:  out[o] = in[i0] + in[i0 + B],  i0 = 2*(o/B)*B + o%B.
+//   rows family (halve the lo dimension): B = 1      -> out[o] = in[2o] + in[2o+1]
+//   cols family (halve the hi dimension): B = n_lo   -> out[w][a][b] = in[w][2a][b] + in[w][2a+1][b]
+// Every lane does exactly one XYZZ add, so each level is dense; kb_hi launches take the 2^kb buckets of every
+// window down to R[w][hi] and C[w][lo].
+struct pair_job {
+    const uint32_t* in;
+    uint32_t* out;
+    uint32_t n_out;
+    uint32_t B;
+};
+__global__ void __launch_bounds__(256) k_pair_level(pair_job ja, pair_job jb) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t o = t / G, g = t % G;
-    xyzz acc = xyzz_identity();
-    if (o < n_out) {
-        uint32_t per = count / G;
-        size_t base = (size_t)(o / per_w) * nb + (size_t)(o % per_w) * mul;
-        for (uint32_t i = g * per; i < (g + 1) * per; i++) acc = xyzz_add(acc, load_xyzz(in + (base + (size_t)i * step) * 32));
+    pair_job j = ja;
+    if (t >= ja.n_out) {
+        t -= ja.n_out;
+        j = jb;
+        if (t >= jb.n_out) return;
     }
-    for (uint32_t d = G >> 1; d >= 1; d >>= 1) acc = xyzz_add(acc, shfl_down_xyzz(acc, (int)d, (int)G));
-    if (o < n_out && g == 0) store_xyzz(out + ((size_t)(o / per_w) * out_per_w_total + out_off + (o % per_w)) * 32, acc);
+    size_t i0 = (size_t)2 * (t / j.B) * j.B + (t % j.B);
+    xyzz r = xyzz_add(load_xyzz(j.in + i0 * 32), load_xyzz(j.in + (i0 + j.B) * 32));
+    store_xyzz(j.out + (size_t)t * 32, r);
 }
-// one wavefront per (window, bit): rc[w] = R[0..n_hi) || C[0..n_lo);  q[w][u] Jacobian
-__global__ void __launch_bounds__(64) k_reduce_bits(const uint32_t* __restrict__ rc, uint32_t* __restrict__ q, uint32_t n_hi,
-                                                    uint32_t n_lo, uint32_t kb_lo, uint32_t kb) {
+
+// one wavefront per (window, bit): R[w][0..n_hi), C[w][0..n_lo);  q[w][u] Jacobian
+__global__ void __launch_bounds__(64) k_reduce_bits(const uint32_t* __restrict__ R, const uint32_t* __restrict__ C,
+                                                    uint32_t* __restrict__ q, uint32_t n_hi, uint32_t n_lo, uint32_t kb_lo,
+                                                    uint32_t kb) {
     uint32_t w = blockIdx.x / (kb + 1), u = blockIdx.x % (kb + 1);
-    const uint32_t* src = rc + (size_t)w * (n_hi + n_lo) * 32;
+    const uint32_t* src;
     uint32_t cnt, bit;
     if (u < kb_lo) {
-        src += (size_t)n_hi * 32;
+        src = C + (size_t)w * n_lo * 32;
         cnt = n_lo;
         bit = u;
     } else if (u < kb) {
+        src = R + (size_t)w * n_hi * 32;
         cnt = n_hi;
         bit = u - kb_lo;
     } else {
-        src += (size_t)n_hi * 32;
+        src = C + (size_t)w * n_lo * 32;
         cnt = n_lo;
         bit = 0xFFFFFFFFu;
     }
