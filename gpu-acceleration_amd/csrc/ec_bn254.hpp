@@ -1,21 +1,26 @@
-// ec_bn254.hpp -- BN254 G1 (y^2 = x^3 + 3) group law for gfx950 and host.
+// ec_bn254.hpp -- BN254 G1 (y^2 = x^3 + 3) group law for gfx950 on the lazily reduced 9 x 29-bit field.
 //
 // Replaces the reference's SH/curve/jacobian.metal:11-226 and curve/utils.metal:9-31.
 // Differences, all deliberate:
 //  * accumulators use extended Jacobian "XYZZ" coordinates (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2):
 //    a mixed add is 8M+2S instead of the reference's 16-multiplication add-2007-bl with Z2 = R
-//    (smvp.metal:61-71), and no field inversion is ever needed on the device;
+//    (smvp.metal:61-71), and no field inversion is ever needed in the pipeline;
 //  * the group law is COMPLETE: P+P, P+(-P), infinity operands are decided projectively
 //    (U2 == X1 etc.), not by limb equality (jacobian.metal:52-53) -- arkworks, the behaviour to
 //    match, is complete; the reference is not (SURVEY.md section 4 "gaps");
 //  * identity is ZZ == 0 (the reference encodes it as Z == 0 with X = Y = R).
 // Formulas: EFD shortw/xyzz  madd-2008-s, add-2008-s, dbl-2008-s-1 / mdbl-2008-s-1 (a = 0).
+//
+// Value bounds (multiples of p; k = p/2^261 = 0.0059; a product of inputs < a*p, b*p is < (a*b*k + 1)*p):
+//   affine operand   x < 1, y < 2 (y may be a negation 2p - y)
+//   XYZZ everywhere  X < 7, Y < 5, ZZ < 2, ZZZ < 2        -- every function below re-establishes these
+// Each fp_sub<K>(a, b) needs b < (K-1)*p; the bound of b is written next to it.
 #pragma once
 #include "fp_bn254.hpp"
 
 namespace bn254 {
 
-struct affine {  // Montgomery coordinates; the point at infinity is carried out of band
+struct affine {  // internal Montgomery domain; the point at infinity is carried out of band
     fp x, y;
 };
 struct xyzz {
@@ -26,34 +31,33 @@ struct jacobian {  // X/Z^2, Y/Z^3; identity <=> Z == 0.  Output format of the C
 };
 
 FP_HD xyzz xyzz_identity() { return xyzz{fp_one(), fp_one(), fp_zero(), fp_zero()}; }
-FP_HD bool xyzz_is_identity(const xyzz& p) { return fp_is_zero(p.zz); }
+FP_HD bool xyzz_is_identity(const xyzz& p) { return fp_is_zero_exact(p.zz); }
 FP_HD xyzz xyzz_from_affine(const affine& a) { return xyzz{a.x, a.y, fp_one(), fp_one()}; }
-FP_HD xyzz xyzz_neg(const xyzz& p) { return xyzz{p.x, fp_neg(p.y), p.zz, p.zzz}; }
-FP_HD affine affine_neg(const affine& a) { return affine{a.x, fp_neg(a.y)}; }
+FP_HD affine affine_neg(const affine& a) { return affine{a.x, fp_neg<2>(a.y)}; }  // y < 1  ->  2p - y < 2
 
 // 2*(x,y) for an affine point: mdbl-2008-s-1 with a = 0.   (y != 0 on BN254: no 2-torsion)
 FP_HD xyzz xyzz_dbl_affine(const affine& a) {
-    fp u = fp_dbl(a.y);
-    fp v = fp_sqr(u);
-    fp w = fp_mul(u, v);
-    fp s = fp_mul(a.x, v);
-    fp xx = fp_sqr(a.x);
-    fp m = fp_add(fp_dbl(xx), xx);
-    fp x3 = fp_sub(fp_sqr(m), fp_dbl(s));
-    fp y3 = fp_sub(fp_mul(m, fp_sub(s, x3)), fp_mul(w, a.y));
+    fp u = fp_dbl(a.y);                        // < 4
+    fp v = fp_sqr(u);                          // < 1.1
+    fp w = fp_mul(u, v);                       // < 1.03
+    fp s = fp_mul(a.x, v);                     // < 1.01
+    fp xx = fp_sqr(a.x);                       // < 1.01
+    fp m = fp_add(fp_dbl(xx), xx);             // < 3.03
+    fp x3 = fp_sub<4>(fp_sqr(m), fp_dbl(s));   // 2s < 2.02;  x3 < 1.06 + 4 = 5.06
+    fp y3 = fp_sub<3>(fp_mul(m, fp_sub<7>(s, x3)), fp_mul(w, a.y));  // (s - x3) < 8.01; m*() < 1.15; w*y < 1.02; y3 < 4.2
     return xyzz{x3, y3, v, w};
 }
 // dbl-2008-s-1, a = 0
 FP_HD xyzz xyzz_dbl(const xyzz& p) {
     if (xyzz_is_identity(p)) return p;
-    fp u = fp_dbl(p.y);
-    fp v = fp_sqr(u);
-    fp w = fp_mul(u, v);
-    fp s = fp_mul(p.x, v);
-    fp xx = fp_sqr(p.x);
-    fp m = fp_add(fp_dbl(xx), xx);
-    fp x3 = fp_sub(fp_sqr(m), fp_dbl(s));
-    fp y3 = fp_sub(fp_mul(m, fp_sub(s, x3)), fp_mul(w, p.y));
+    fp u = fp_dbl(p.y);                        // < 10
+    fp v = fp_sqr(u);                          // < 1.6
+    fp w = fp_mul(u, v);                       // < 1.1
+    fp s = fp_mul(p.x, v);                     // < 1.07
+    fp xx = fp_sqr(p.x);                       // < 1.29
+    fp m = fp_add(fp_dbl(xx), xx);             // < 3.87
+    fp x3 = fp_sub<4>(fp_sqr(m), fp_dbl(s));   // 2s < 2.14;  x3 < 1.09 + 4 = 5.09
+    fp y3 = fp_sub<3>(fp_mul(m, fp_sub<7>(s, x3)), fp_mul(w, p.y));  // (s - x3) < 8.07; m*() < 1.19; w*y < 1.04; y3 < 4.19
     return xyzz{x3, y3, fp_mul(v, p.zz), fp_mul(w, p.zzz)};
 }
 
@@ -63,45 +67,47 @@ FP_HD void xyzz_madd(xyzz& acc, const affine& q) {
         acc = xyzz_from_affine(q);
         return;
     }
-    fp u2 = fp_mul(q.x, acc.zz);
-    fp s2 = fp_mul(q.y, acc.zzz);
-    fp pp_ = fp_sub(u2, acc.x);  // P
-    fp r = fp_sub(s2, acc.y);    // R
-    if (fp_is_zero(pp_)) {
-        if (fp_is_zero(r)) acc = xyzz_dbl_affine(q);  // same point
-        else acc = xyzz_identity();                   // opposite points
+    fp u2 = fp_mul(q.x, acc.zz);       // < 1.02
+    fp s2 = fp_mul(q.y, acc.zzz);      // < 1.03
+    fp pp_ = fp_sub<8>(u2, acc.x);     // P: acc.x < 7;  P < 9.02
+    fp r = fp_sub<6>(s2, acc.y);       // R: acc.y < 5;  R < 7.03
+    fp pp = fp_sqr(pp_);               // < 1.49
+    if (fp_is_zero_lt2p(pp)) {         // P == 0 (mod p): same x
+        if (fp_is_zero_lt2p(fp_sqr(r))) acc = xyzz_dbl_affine(q);  // same point
+        else acc = xyzz_identity();                                // opposite points
         return;
     }
-    fp pp = fp_sqr(pp_);
-    fp ppp = fp_mul(pp_, pp);
-    fp qv = fp_mul(acc.x, pp);
-    fp x3 = fp_sub(fp_sub(fp_sqr(r), ppp), fp_dbl(qv));
-    fp y3 = fp_sub(fp_mul(r, fp_sub(qv, x3)), fp_mul(acc.y, ppp));
+    fp ppp = fp_mul(pp_, pp);          // < 1.08
+    fp qv = fp_mul(acc.x, pp);         // < 1.07
+    fp t = fp_add(ppp, fp_dbl(qv));    // < 3.22
+    fp x3 = fp_sub<5>(fp_sqr(r), t);   // r^2 < 1.3;  x3 < 6.3
+    fp y3 = fp_sub<3>(fp_mul(r, fp_sub<8>(qv, x3)), fp_mul(acc.y, ppp));  // (qv - x3) < 9.07; r*() < 1.38; y*ppp < 1.04; y3 < 4.38
     acc.x = x3;
     acc.y = y3;
-    acc.zz = fp_mul(acc.zz, pp);
-    acc.zzz = fp_mul(acc.zzz, ppp);
+    acc.zz = fp_mul(acc.zz, pp);       // < 1.02
+    acc.zzz = fp_mul(acc.zzz, ppp);    // < 1.02
 }
 
 // a + b, add-2008-s, 12M+2S, complete.
 FP_HD xyzz xyzz_add(const xyzz& a, const xyzz& b) {
     if (xyzz_is_identity(a)) return b;
     if (xyzz_is_identity(b)) return a;
-    fp u1 = fp_mul(a.x, b.zz);
+    fp u1 = fp_mul(a.x, b.zz);         // < 1.09
     fp u2 = fp_mul(b.x, a.zz);
-    fp s1 = fp_mul(a.y, b.zzz);
+    fp s1 = fp_mul(a.y, b.zzz);        // < 1.06
     fp s2 = fp_mul(b.y, a.zzz);
-    fp pp_ = fp_sub(u2, u1);
-    fp r = fp_sub(s2, s1);
-    if (fp_is_zero(pp_)) {
-        if (fp_is_zero(r)) return xyzz_dbl(a);
+    fp pp_ = fp_sub<3>(u2, u1);        // < 4.09
+    fp r = fp_sub<3>(s2, s1);          // < 4.06
+    fp pp = fp_sqr(pp_);               // < 1.1
+    if (fp_is_zero_lt2p(pp)) {
+        if (fp_is_zero_lt2p(fp_sqr(r))) return xyzz_dbl(a);
         return xyzz_identity();
     }
-    fp pp = fp_sqr(pp_);
-    fp ppp = fp_mul(pp_, pp);
-    fp qv = fp_mul(u1, pp);
-    fp x3 = fp_sub(fp_sub(fp_sqr(r), ppp), fp_dbl(qv));
-    fp y3 = fp_sub(fp_mul(r, fp_sub(qv, x3)), fp_mul(s1, ppp));
+    fp ppp = fp_mul(pp_, pp);          // < 1.03
+    fp qv = fp_mul(u1, pp);            // < 1.01
+    fp t = fp_add(ppp, fp_dbl(qv));    // < 3.05
+    fp x3 = fp_sub<5>(fp_sqr(r), t);   // r^2 < 1.1;  x3 < 6.1
+    fp y3 = fp_sub<3>(fp_mul(r, fp_sub<8>(qv, x3)), fp_mul(s1, ppp));  // (qv - x3) < 9.01; r*() < 1.22; s1*ppp < 1.01; y3 < 4.22
     fp zz3 = fp_mul(fp_mul(a.zz, b.zz), pp);
     fp zzz3 = fp_mul(fp_mul(a.zzz, b.zzz), ppp);
     return xyzz{x3, y3, zz3, zzz3};
@@ -115,11 +121,11 @@ FP_HD jacobian xyzz_to_jacobian(const xyzz& p) {
     return jacobian{fp_mul(p.x, fp_sqr(zz2)), fp_mul(p.y, fp_sqr(zzz2)), fp_mul(p.zz, p.zzz)};
 }
 FP_HD xyzz xyzz_from_jacobian(const jacobian& p) {
-    if (fp_is_zero(p.z)) return xyzz_identity();
+    if (fp_is_zero_lt2p(p.z)) return xyzz_identity();  // z comes straight from canonical words: < 1.01p
     fp zz = fp_sqr(p.z);
     return xyzz{p.x, p.y, zz, fp_mul(zz, p.z)};
 }
-// canonical affine (Montgomery); returns true for the identity (x = y = 0 then)
+// affine coordinates (internal domain, < 2p); returns true for the identity (x = y = 0 then)
 __host__ __device__ inline bool xyzz_to_affine(const xyzz& p, affine& out) {
     if (xyzz_is_identity(p)) {
         out.x = fp_zero();

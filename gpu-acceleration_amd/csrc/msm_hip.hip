@@ -49,7 +49,7 @@ struct msm_ctx {
     std::string err;
     hipEvent_t ev[EV_COUNT]{};
     // HBM workspace
-    DevBuf bases, inf, scalars, digits, ranks, sorted, hist, offsets, blocksums, buckets, heads, tails, chunkmap, rc, qsums, flags,
+    DevBuf bases, ibases, inf, scalars, digits, ranks, sorted, hist, offsets, blocksums, buckets, heads, tails, chunkmap, rc, qsums, flags,
         pow2, tilecounts;
     bool pow2_ready = false;
     uint32_t* h_qsums = nullptr;  // pinned: W x (kb+1) Jacobian bit sums
@@ -128,9 +128,10 @@ int32_t make_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_plan_t* ou
     out->num_buckets = is_signed ? (1u << (c - 1)) : (1u << c);
     size_t pairs = (size_t)out->num_windows * n;
     size_t tb = (size_t)out->num_windows * out->num_buckets;
-    out->workspace_bytes = n * (64 + 32 + 1) + pairs * 12 + tb * (8 + 128) + tb * 128 / 4;
+    out->workspace_bytes = n * (64 + 32 + 1) + pairs * 12 + tb * (8 + 144) + tb * 144 * 3 / 2;
     return MSM_OK;
 }
+constexpr size_t XB = msmk::XW * 4;               // bytes per XYZZ record (4 coordinates x 9 x 29-bit limbs)
 constexpr size_t LDS_HIST_BYTES = 128 * 1024;   // one window's bucket histogram must fit here for the LDS sort path
 constexpr size_t MAX_QSUM_POINTS = 128 * 21;  // W <= 128 windows (c >= 2), kb + 1 <= 21 bit sums each
 
@@ -139,6 +140,8 @@ uint32_t ilog2(uint32_t v) {
     while ((1u << (l + 1)) <= v) l++;
     return l;
 }
+
+inline dim3 grid1(size_t n, unsigned block) { return dim3((unsigned)((n + block - 1) / block)); }
 
 int32_t ensure_pow2_table(msm_ctx* c) {
     if (c->pow2_ready) return MSM_OK;
@@ -154,8 +157,13 @@ int32_t ensure_pow2_table(msm_ctx* c) {
     }
     int32_t rc = ensure(c, c->pow2, tab.size() * 4);
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->pow2.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, c->stream));
+    void* raw = nullptr;
+    HIPCHK(c, hipMalloc(&raw, tab.size() * 4));
+    HIPCHK(c, hipMemcpyAsync(raw, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, c->stream));
+    msmk::k_convert_bases<<<grid1(2 * (size_t)msmk::SCALAR_BITS, 64), 64, 0, c->stream>>>((const uint32_t*)raw, (uint32_t*)c->pow2.p,
+                                                                                     (uint32_t)msmk::SCALAR_BITS, 1u);
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(raw));
     c->pow2_ready = true;
     return MSM_OK;
 }
@@ -173,9 +181,8 @@ void finish_outputs(const hostg1::Jac& r, uint32_t* out_jac, uint32_t* out_aff, 
     }
 }
 
-inline dim3 grid1(size_t n, unsigned block) { return dim3((unsigned)((n + block - 1) / block)); }
-
-// The pipeline proper: everything in HBM, one stream.  d_bases Montgomery.
+// The pipeline proper: everything in HBM, one stream.  d_bases: INTERNAL-domain packed coordinates
+// (k_convert_bases output).
 int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, const uint32_t* d_scalars, size_t n,
                      hipStream_t st, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf) {
     if (n > 0x7FFFFFFFull) return fail(c, MSM_ERR_BAD_ARG, "n = %zu exceeds 2^31-1 points per context call", n);
@@ -198,11 +205,11 @@ int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, 
     if ((rc = ensure(c, c->hist, tb * 4))) return rc;
     if ((rc = ensure(c, c->offsets, (tb + 1) * 4))) return rc;
     if ((rc = ensure(c, c->blocksums, ((size_t)ntiles + 1) * 4))) return rc;
-    if ((rc = ensure(c, c->buckets, tb * 128))) return rc;
-    if ((rc = ensure(c, c->heads, nchunks_max * 128))) return rc;
-    if ((rc = ensure(c, c->tails, nchunks_max * 128))) return rc;
+    if ((rc = ensure(c, c->buckets, tb * XB))) return rc;
+    if ((rc = ensure(c, c->heads, nchunks_max * XB))) return rc;
+    if ((rc = ensure(c, c->tails, nchunks_max * XB))) return rc;
     if ((rc = ensure(c, c->chunkmap, nchunks_max * 4))) return rc;
-    if ((rc = ensure(c, c->rc, (tb + tb / 2 + 4) * 128))) return rc;  // two families x (1/2 + 1/4) ping-pong levels
+    if ((rc = ensure(c, c->rc, (tb + tb / 2 + 4) * XB))) return rc;  // two families x (1/2 + 1/4) ping-pong levels
     if ((rc = ensure(c, c->qsums, (size_t)W * (kb + 1) * 96))) return rc;
     if ((rc = ensure(c, c->flags, 64))) return rc;
 
@@ -267,8 +274,8 @@ int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, 
     {
         const uint32_t* bk = (const uint32_t*)c->buckets.p;
         // ping-pong buffers per family: [0, tb/2) and [tb/2, tb/2 + tb/4) elements
-        uint32_t* rbuf[2] = {(uint32_t*)c->rc.p, (uint32_t*)c->rc.p + (tb / 2) * 32};
-        uint32_t* cbuf[2] = {(uint32_t*)c->rc.p + (tb / 2 + tb / 4 + 1) * 32, (uint32_t*)c->rc.p + (tb + tb / 4 + 1) * 32};
+        uint32_t* rbuf[2] = {(uint32_t*)c->rc.p, (uint32_t*)c->rc.p + (tb / 2) * msmk::XW};
+        uint32_t* cbuf[2] = {(uint32_t*)c->rc.p + (tb / 2 + tb / 4 + 1) * msmk::XW, (uint32_t*)c->rc.p + (tb + tb / 4 + 1) * msmk::XW};
         const uint32_t *rin = bk, *cin = bk;
         size_t rn = tb, cn = tb;  // current element counts
         uint32_t levels = kb_hi > kb_lo ? kb_hi : kb_lo;
@@ -347,17 +354,20 @@ int32_t check_common(msm_ctx* c, const void* a, const void* b, size_t n) {
     return MSM_OK;
 }
 
+// raw caller coordinates (host) -> c->bases (staging) -> c->ibases (internal domain)
 int32_t upload_bases_locked(msm_ctx* c, const uint32_t* bases_xy, uint32_t form, const uint8_t* inf_mask, size_t n) {
     if (form != MSM_FORM_STD && form != MSM_FORM_MONT) return fail(c, MSM_ERR_BAD_ARG, "unknown base_form %u", form);
     int32_t rc;
     if ((rc = ensure(c, c->bases, n * 64))) return rc;
+    if ((rc = ensure(c, c->ibases, n * 64))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->bases.p, bases_xy, n * 64, hipMemcpyHostToDevice, c->stream));
     if (inf_mask) {
         if ((rc = ensure(c, c->inf, n))) return rc;
         HIPCHK(c, hipMemcpyAsync(c->inf.p, inf_mask, n, hipMemcpyHostToDevice, c->stream));
     }
     HIPCHK(c, hipEventRecord(c->ev[EV_H2D], c->stream));
-    if (form == MSM_FORM_STD) msmk::k_convert_bases<<<grid1(2 * n, 256), 256, 0, c->stream>>>((uint32_t*)c->bases.p, (uint32_t)n);
+    msmk::k_convert_bases<<<grid1(2 * n, 256), 256, 0, c->stream>>>((const uint32_t*)c->bases.p, (uint32_t*)c->ibases.p, (uint32_t)n,
+                                                                  form == MSM_FORM_MONT ? 1u : 0u);
     return MSM_OK;
 }
 
@@ -411,7 +421,8 @@ int32_t msm_ctx_create(const msm_config_t* cfg, msm_ctx** out) {
         if (!rc) rc = ensure(c, c->scalars, c0.max_points * 32);
         if (!rc) rc = ensure(c, c->digits, pairs * 4);
         if (!rc) rc = ensure(c, c->sorted, pairs * 4);
-        if (!rc) rc = ensure(c, c->buckets, tb * 128);
+        if (!rc) rc = ensure(c, c->ibases, c0.max_points * 64);
+        if (!rc) rc = ensure(c, c->buckets, tb * XB);
         if (rc) {
             g_create_error = c->err;
             msm_ctx_destroy(c);
@@ -429,7 +440,7 @@ void msm_ctx_destroy(msm_ctx* c) {
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         DevBuf* bufs[] = {&c->bases,   &c->inf,       &c->scalars, &c->digits,  &c->ranks,  &c->sorted, &c->hist,
                           &c->offsets, &c->blocksums, &c->buckets, &c->rc,      &c->qsums,   &c->flags,  &c->pow2,
-                          &c->heads,   &c->tails,     &c->chunkmap, &c->tilecounts};
+                          &c->heads,   &c->tails,     &c->chunkmap, &c->tilecounts, &c->ibases};
         for (DevBuf* b : bufs) release(*b);
         if (c->h_qsums) (void)hipHostFree(c->h_qsums);
         if (c->h_flags) (void)hipHostFree(c->h_flags);
@@ -452,7 +463,7 @@ int32_t msm_bn254_g1(msm_ctx* c, const uint32_t* bases_xy, uint32_t base_form, c
     HIPCHK(c, hipMemcpyAsync(c->scalars.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
     if ((rc = upload_bases_locked(c, bases_xy, base_form, inf_mask, n))) return rc;
     c->resident_n = 0;  // the scratch copy is not a resident set
-    rc = run_pipeline(c, (const uint32_t*)c->bases.p, inf_mask ? (const uint8_t*)c->inf.p : nullptr,
+    rc = run_pipeline(c, (const uint32_t*)c->ibases.p, inf_mask ? (const uint8_t*)c->inf.p : nullptr,
                       (const uint32_t*)c->scalars.p, n, c->stream, out_jac, out_aff, out_inf);
     if (rc) return rc;
     float ms = 0;
@@ -492,7 +503,7 @@ int32_t msm_bn254_g1_resident(msm_ctx* c, const uint32_t* scalars, size_t n, uin
     if ((rc = ensure(c, c->scalars, n * 32))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->scalars.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[EV_H2D], c->stream));
-    rc = run_pipeline(c, (const uint32_t*)c->bases.p, c->resident_has_inf ? (const uint8_t*)c->inf.p : nullptr,
+    rc = run_pipeline(c, (const uint32_t*)c->ibases.p, c->resident_has_inf ? (const uint8_t*)c->inf.p : nullptr,
                       (const uint32_t*)c->scalars.p, n, c->stream, out_jac, out_aff, out_inf);
     if (rc) return rc;
     float ms = 0;
@@ -511,11 +522,16 @@ int32_t msm_bn254_g1_device(msm_ctx* c, const void* d_bases_mont, const void* d_
     DeviceGuard g(c->device);
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
     auto t0 = std::chrono::steady_clock::now();
-    rc = run_pipeline(c, (const uint32_t*)d_bases_mont, (const uint8_t*)d_inf_mask, (const uint32_t*)d_scalars, n, st, out_jac,
-                      out_aff, out_inf);
+    if ((rc = ensure(c, c->ibases, n * 64))) return rc;
+    HIPCHK(c, hipEventRecord(c->ev[EV_H2D], st));
+    msmk::k_convert_bases<<<grid1(2 * n, 256), 256, 0, st>>>((const uint32_t*)d_bases_mont, (uint32_t*)c->ibases.p, (uint32_t)n, 1u);
+    rc = run_pipeline(c, (const uint32_t*)c->ibases.p, (const uint8_t*)d_inf_mask, (const uint32_t*)d_scalars, n, st, out_jac, out_aff,
+                      out_inf);
     if (rc) return rc;
+    float cms = 0;
+    (void)hipEventElapsedTime(&cms, c->ev[EV_H2D], c->ev[EV_CONVERT]);
     c->tm.h2d_ms = 0;
-    c->tm.convert_ms = 0;
+    c->tm.convert_ms = cms;
     c->tm.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return MSM_OK;
 }

@@ -10,13 +10,15 @@
 //   final_reduction (CPU) -> stays on the CPU: host_g1.hpp
 //
 // Data layout in HBM (all little-endian u32 words):
-//   bases    n x 16   affine Montgomery x||y, 64 B per point = one half cache line per gather
+//   bases    n x 16   affine x||y, INTERNAL Montgomery domain (x*2^261 mod p, canonical, packed 8 x 32-bit
+//                     words per coordinate by k_convert_bases), 64 B per point = half a cache line per gather
 //   scalars  n x 8    standard form
 //   digits   W x n    bucket index (bit 31 = negate, 0xFFFFFFFF = digit 0 / base at infinity), window-major
 //   ranks    W x n    arrival rank inside the bucket (fallback path only: nb > 32768)
 //   offsets  W*nb + 1 exclusive prefix sum of bucket sizes == CSC column pointer of the reference
 //   sorted   W x n    point index | sign<<31 grouped by bucket        == val_idxs of the reference
-//   buckets  W*nb x 32  XYZZ bucket sums;  heads/tails  ceil(n*W/L) x 32  partial sums of buckets cut by chunk borders
+//   buckets  W*nb x 36  XYZZ bucket sums, 4 coordinates x 9 limbs of 29 bits (144 B);
+//   heads/tails  ceil(n*W/L) x 36  partial sums of buckets cut by chunk borders
 #pragma once
 #include "ec_bn254.hpp"
 
@@ -27,37 +29,91 @@ constexpr uint32_t DIGIT_SKIP = 0xFFFFFFFFu;
 constexpr uint32_t SIGN_BIT = 0x80000000u;
 constexpr int SCALAR_BITS = 254;
 
-struct alignas(16) affine_words {
-    uint32_t w[16];
-};
+constexpr int XW = 36;  // words per XYZZ record in HBM: 4 coordinates x 9 limbs
 
-__device__ __forceinline__ fp load_fp(const uint32_t* p) {
+// packed 8-word field element (canonical value) -> 9 x 29-bit limbs
+__device__ __forceinline__ fp load_fp_packed(const uint32_t* p) {
     const uint4* q = reinterpret_cast<const uint4*>(p);
     uint4 a = q[0], b = q[1];
-    return fp{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+    uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    return fp_unpack(w);
 }
-__device__ __forceinline__ void store_fp(uint32_t* p, const fp& v) {
+__device__ __forceinline__ void store_words8(uint32_t* p, const uint32_t w[8]) {
     uint4* q = reinterpret_cast<uint4*>(p);
-    q[0] = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
-    q[1] = make_uint4(v.v[4], v.v[5], v.v[6], v.v[7]);
+    q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    q[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
+__device__ __forceinline__ affine load_affine(const uint32_t* p) { return affine{load_fp_packed(p), load_fp_packed(p + 8)}; }
+// XYZZ record: 36 words = 9 x 16 bytes
 __device__ __forceinline__ xyzz load_xyzz(const uint32_t* p) {
-    return xyzz{load_fp(p), load_fp(p + 8), load_fp(p + 16), load_fp(p + 24)};
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint32_t w[XW];
+#pragma unroll
+    for (int i = 0; i < XW / 4; i++) {
+        uint4 t = q[i];
+        w[4 * i] = t.x;
+        w[4 * i + 1] = t.y;
+        w[4 * i + 2] = t.z;
+        w[4 * i + 3] = t.w;
+    }
+    xyzz r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        r.x.v[i] = w[i];
+        r.y.v[i] = w[9 + i];
+        r.zz.v[i] = w[18 + i];
+        r.zzz.v[i] = w[27 + i];
+    }
+    return r;
 }
 __device__ __forceinline__ void store_xyzz(uint32_t* p, const xyzz& v) {
-    store_fp(p, v.x);
-    store_fp(p + 8, v.y);
-    store_fp(p + 16, v.zz);
-    store_fp(p + 24, v.zzz);
+    uint32_t w[XW];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        w[i] = v.x.v[i];
+        w[9 + i] = v.y.v[i];
+        w[18 + i] = v.zz.v[i];
+        w[27 + i] = v.zzz.v[i];
+    }
+    uint4* q = reinterpret_cast<uint4*>(p);
+#pragma unroll
+    for (int i = 0; i < XW / 4; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+// Jacobian in the C-ABI format: 24 words, canonical R = 2^256 Montgomery
+__device__ __forceinline__ void store_jacobian_mont256(uint32_t* o, const jacobian& j) {
+    uint32_t w[8];
+    fp_to_mont256(w, j.x);
+    store_words8(o, w);
+    fp_to_mont256(w, j.y);
+    store_words8(o + 8, w);
+    fp_to_mont256(w, j.z);
+    store_words8(o + 16, w);
+}
+__device__ __forceinline__ jacobian load_jacobian_mont256(const uint32_t* p) {
+    uint32_t w[8];
+    jacobian j;
+    for (int c = 0; c < 3; c++) {
+        for (int k = 0; k < 8; k++) w[k] = p[8 * c + k];
+        fp t = fp_from_mont256(w);
+        if (c == 0) j.x = t;
+        else if (c == 1) j.y = t;
+        else j.z = t;
+    }
+    return j;
 }
 
 // ---------------------------------------------------------------------------------------------
-// bases given in standard form -> Montgomery, in place (K1's coordinate half)
-__global__ void k_convert_bases(uint32_t* bases, uint32_t n) {
+// K1's coordinate half: caller coordinates (standard form, or arkworks' R = 2^256 Montgomery words) -> the
+// internal domain x*2^261 mod p, canonical, packed.  One Montgomery product per coordinate (the reference
+// spends two 17x17-limb Barrett multiplications here, barrett_reduction.metal:84-118).
+__global__ void k_convert_bases(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n, uint32_t mont_form) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per coordinate
     if (i >= 2u * n) return;
-    uint32_t* p = bases + (size_t)i * 8;
-    store_fp(p, fp_to_mont(load_fp(p)));
+    fp v = load_fp_packed(in + (size_t)i * 8);
+    v = fp_mul(v, mont_form ? fp_const(FP29_IN_MONT) : fp_const(FP29_IN_STD));  // < 1.01p
+    uint32_t w[8];
+    fp_pack(w, fp_reduce_lt2p(v));
+    store_words8(out + (size_t)i * 8, w);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -315,21 +371,24 @@ __global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__
     // software pipeline: the gather of entry j+1 (and the index of entry j+2) are in flight while entry j is folded
     uint32_t e_cur = sorted[j0];
     uint32_t e_nxt = j0 + 1 < j1 ? sorted[j0 + 1] : 0u;
-    affine q_cur;
+    uint4 g_cur[4], g_nxt[4];  // the raw 64-byte records; unpacked to 29-bit limbs only when folded
     {
-        const uint32_t* bp = bases + (size_t)(e_cur & ~SIGN_BIT) * 16;
-        q_cur = affine{load_fp(bp), load_fp(bp + 8)};
+        const uint4* bp = reinterpret_cast<const uint4*>(bases + (size_t)(e_cur & ~SIGN_BIT) * 16);
+#pragma unroll
+        for (int i = 0; i < 4; i++) g_cur[i] = bp[i];
     }
     for (uint32_t j = j0; j < j1; j++) {
-        affine q_nxt = q_cur;
         uint32_t e_nn = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) g_nxt[i] = g_cur[i];
         if (j + 1 < j1) {
-            const uint32_t* bp = bases + (size_t)(e_nxt & ~SIGN_BIT) * 16;
-            q_nxt = affine{load_fp(bp), load_fp(bp + 8)};
+            const uint4* bp = reinterpret_cast<const uint4*>(bases + (size_t)(e_nxt & ~SIGN_BIT) * 16);
+#pragma unroll
+            for (int i = 0; i < 4; i++) g_nxt[i] = bp[i];
             if (j + 2 < j1) e_nn = sorted[j + 2];
         }
         if (j == seg_end) {  // bucket k is finished: flush and move to the bucket that owns entry j
-            store_xyzz((is_head ? heads + (size_t)t * 32 : buckets + (size_t)k * 32), acc);
+            store_xyzz((is_head ? heads + (size_t)t * XW : buckets + (size_t)k * XW), acc);
             do {
                 k++;
                 seg_end = offsets[k + 1];
@@ -337,14 +396,21 @@ __global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__
             is_head = false;
             acc = xyzz_identity();
         }
-        affine q = q_cur;
-        if (e_cur & SIGN_BIT) q.y = fp_neg(q.y);
+        affine q;
+        {
+            uint32_t wx[8] = {g_cur[0].x, g_cur[0].y, g_cur[0].z, g_cur[0].w, g_cur[1].x, g_cur[1].y, g_cur[1].z, g_cur[1].w};
+            uint32_t wy[8] = {g_cur[2].x, g_cur[2].y, g_cur[2].z, g_cur[2].w, g_cur[3].x, g_cur[3].y, g_cur[3].z, g_cur[3].w};
+            q.x = fp_unpack(wx);
+            q.y = fp_unpack(wy);
+        }
+        if (e_cur & SIGN_BIT) q.y = fp_neg<2>(q.y);
         xyzz_madd(acc, q);
-        q_cur = q_nxt;
+#pragma unroll
+        for (int i = 0; i < 4; i++) g_cur[i] = g_nxt[i];
         e_cur = e_nxt;
         e_nxt = e_nn;
     }
-    uint32_t* dst = is_head ? heads + (size_t)t * 32 : (seg_end == j1 ? buckets + (size_t)k * 32 : tails + (size_t)t * 32);
+    uint32_t* dst = is_head ? heads + (size_t)t * XW : (seg_end == j1 ? buckets + (size_t)k * XW : tails + (size_t)t * XW);
     store_xyzz(dst, acc);
 }
 
@@ -356,14 +422,14 @@ __global__ void __launch_bounds__(256) k_combine(const uint32_t* __restrict__ of
     if (k >= total_buckets) return;
     uint32_t beg = offsets[k], end = offsets[k + 1];
     if (beg == end) {
-        store_xyzz(buckets + (size_t)k * 32, xyzz_identity());
+        store_xyzz(buckets + (size_t)k * XW, xyzz_identity());
         return;
     }
     uint32_t t0 = beg / L, t1 = (end - 1) / L;
     if (t0 == t1) return;  // written by k_accumulate
-    xyzz acc = load_xyzz(tails + (size_t)t0 * 32);
-    for (uint32_t t = t0 + 1; t <= t1; t++) acc = xyzz_add(acc, load_xyzz(heads + (size_t)t * 32));
-    store_xyzz(buckets + (size_t)k * 32, acc);
+    xyzz acc = load_xyzz(tails + (size_t)t0 * XW);
+    for (uint32_t t = t0 + 1; t <= t1; t++) acc = xyzz_add(acc, load_xyzz(heads + (size_t)t * XW));
+    store_xyzz(buckets + (size_t)k * XW, acc);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -383,7 +449,7 @@ __global__ void __launch_bounds__(256) k_combine(const uint32_t* __restrict__ of
 __device__ __forceinline__ fp shfl_down_fp(const fp& a, int d, int width) {
     fp r;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r.v[i] = __shfl_down(a.v[i], d, width);
+    for (int i = 0; i < 9; i++) r.v[i] = __shfl_down(a.v[i], d, width);
     return r;
 }
 __device__ __forceinline__ xyzz shfl_down_xyzz(const xyzz& v, int d, int width) {
@@ -410,8 +476,8 @@ __global__ void __launch_bounds__(256) k_pair_level(pair_job ja, pair_job jb) {
         if (t >= jb.n_out) return;
     }
     size_t i0 = (size_t)2 * (t / j.B) * j.B + (t % j.B);
-    xyzz r = xyzz_add(load_xyzz(j.in + i0 * 32), load_xyzz(j.in + (i0 + j.B) * 32));
-    store_xyzz(j.out + (size_t)t * 32, r);
+    xyzz r = xyzz_add(load_xyzz(j.in + i0 * XW), load_xyzz(j.in + (i0 + j.B) * XW));
+    store_xyzz(j.out + (size_t)t * XW, r);
 }
 
 // one wavefront per (window, bit): R[w][0..n_hi), C[w][0..n_lo);  q[w][u] Jacobian
@@ -422,28 +488,24 @@ __global__ void __launch_bounds__(64) k_reduce_bits(const uint32_t* __restrict__
     const uint32_t* src;
     uint32_t cnt, bit;
     if (u < kb_lo) {
-        src = C + (size_t)w * n_lo * 32;
+        src = C + (size_t)w * n_lo * XW;
         cnt = n_lo;
         bit = u;
     } else if (u < kb) {
-        src = R + (size_t)w * n_hi * 32;
+        src = R + (size_t)w * n_hi * XW;
         cnt = n_hi;
         bit = u - kb_lo;
     } else {
-        src = C + (size_t)w * n_lo * 32;
+        src = C + (size_t)w * n_lo * XW;
         cnt = n_lo;
         bit = 0xFFFFFFFFu;
     }
     xyzz acc = xyzz_identity();
     for (uint32_t j = threadIdx.x; j < cnt; j += 64)
-        if (bit == 0xFFFFFFFFu || ((j >> bit) & 1u)) acc = xyzz_add(acc, load_xyzz(src + (size_t)j * 32));
+        if (bit == 0xFFFFFFFFu || ((j >> bit) & 1u)) acc = xyzz_add(acc, load_xyzz(src + (size_t)j * XW));
     for (int d = 32; d >= 1; d >>= 1) acc = xyzz_add(acc, shfl_down_xyzz(acc, d, 64));
     if (threadIdx.x == 0) {
-        jacobian jj = xyzz_to_jacobian(acc);
-        uint32_t* o = q + (size_t)blockIdx.x * 24;
-        store_fp(o, jj.x);
-        store_fp(o + 8, jj.y);
-        store_fp(o + 16, jj.z);
+        store_jacobian_mont256(q + (size_t)blockIdx.x * 24, xyzz_to_jacobian(acc));
     }
 }
 
@@ -488,7 +550,8 @@ __global__ void k_gen_scalars(uint64_t seed, uint32_t n, uint32_t* __restrict__ 
     q[0] = make_uint4(s[0], s[1], s[2], s[3]);
     q[1] = make_uint4(s[4], s[5], s[6], s[7]);
 }
-// base i = k_i * G with k_i = nonzero stream element; pow2_table[j] = 2^j * G (affine Montgomery, 254 entries)
+// base i = k_i * G with k_i = nonzero stream element; pow2_table[j] = 2^j * G (affine, internal domain, packed,
+// 254 entries); the result is written as canonical R = 2^256 Montgomery words (what arkworks holds)
 __global__ void __launch_bounds__(128) k_gen_bases(uint64_t seed, uint32_t n, const uint32_t* __restrict__ pow2_table,
                                                    uint32_t* __restrict__ out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -497,16 +560,15 @@ __global__ void __launch_bounds__(128) k_gen_bases(uint64_t seed, uint32_t n, co
     gen_scalar(seed, i, true, k);
     xyzz acc = xyzz_identity();
     for (int j = 0; j < SCALAR_BITS; j++) {
-        if ((k[j >> 5] >> (j & 31)) & 1u) {
-            const uint32_t* tp = pow2_table + (size_t)j * 16;
-            affine q{load_fp(tp), load_fp(tp + 8)};
-            xyzz_madd(acc, q);
-        }
+        if ((k[j >> 5] >> (j & 31)) & 1u) xyzz_madd(acc, load_affine(pow2_table + (size_t)j * 16));
     }
     affine a;
     xyzz_to_affine(acc, a);
-    store_fp(out + (size_t)i * 16, a.x);
-    store_fp(out + (size_t)i * 16 + 8, a.y);
+    uint32_t w[8];
+    fp_to_mont256(w, a.x);
+    store_words8(out + (size_t)i * 16, w);
+    fp_to_mont256(w, a.y);
+    store_words8(out + (size_t)i * 16 + 8, w);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -515,40 +577,50 @@ __global__ void k_test_fp(uint32_t op, const uint32_t* __restrict__ a, const uin
                           uint32_t* __restrict__ out, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    fp x = load_fp(a + (size_t)i * 8), y = b ? load_fp(b + (size_t)i * 8) : fp_zero(), r;
-    switch (op) {
-        case 0: r = fp_add(x, y); break;
-        case 1: r = fp_sub(x, y); break;
-        case 2: r = fp_mul(x, y); break;
-        case 3: r = fp_to_mont(x); break;
-        case 4: r = fp_from_mont(x); break;
-        default: r = fp_inv(x); break;
+    // operands and results cross the ABI as canonical R = 2^256 Montgomery words (ops 0,1,2,5) or as the
+    // standard/Montgomery pair of the conversion ops (3: std -> mont, 4: mont -> std)
+    uint32_t wa[8], wb[8], wr[8];
+    for (int k = 0; k < 8; k++) {
+        wa[k] = a[(size_t)i * 8 + k];
+        wb[k] = b ? b[(size_t)i * 8 + k] : 0u;
     }
-    store_fp(out + (size_t)i * 8, r);
+    switch (op) {
+        case 0: fp_to_mont256(wr, fp_add(fp_from_mont256(wa), fp_from_mont256(wb))); break;
+        case 1: fp_to_mont256(wr, fp_sub<3>(fp_from_mont256(wa), fp_from_mont256(wb))); break;
+        case 2: fp_to_mont256(wr, fp_mul(fp_from_mont256(wa), fp_from_mont256(wb))); break;
+        case 3: fp_to_mont256(wr, fp_from_std(wa)); break;
+        case 4: fp_to_std(wr, fp_from_mont256(wa)); break;
+        default: {
+            fp x = fp_from_mont256(wa);
+            if (fp_is_zero_lt2p(x)) fp_to_mont256(wr, fp_zero());
+            else fp_to_mont256(wr, fp_inv(x));
+            break;
+        }
+    }
+    for (int k = 0; k < 8; k++) out[(size_t)i * 8 + k] = wr[k];
 }
 __global__ void __launch_bounds__(64) k_test_g1(uint32_t op, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
                                                 uint32_t* __restrict__ out, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t* ap = a + (size_t)i * 24;
-    xyzz p = xyzz_from_jacobian(jacobian{load_fp(ap), load_fp(ap + 8), load_fp(ap + 16)});
+    xyzz p = xyzz_from_jacobian(load_jacobian_mont256(a + (size_t)i * 24));
     xyzz r;
     if (op == 0) {
         const uint32_t* bp = b + (size_t)i * 16;
-        affine q{load_fp(bp), load_fp(bp + 8)};
+        uint32_t wx[8], wy[8];
+        for (int k = 0; k < 8; k++) {
+            wx[k] = bp[k];
+            wy[k] = bp[8 + k];
+        }
+        affine q{fp_from_mont256(wx), fp_from_mont256(wy)};
         r = p;
         xyzz_madd(r, q);
     } else if (op == 1) {
-        const uint32_t* bp = b + (size_t)i * 24;
-        r = xyzz_add(p, xyzz_from_jacobian(jacobian{load_fp(bp), load_fp(bp + 8), load_fp(bp + 16)}));
+        r = xyzz_add(p, xyzz_from_jacobian(load_jacobian_mont256(b + (size_t)i * 24)));
     } else {
         r = xyzz_dbl(p);
     }
-    jacobian jj = xyzz_to_jacobian(r);
-    uint32_t* o = out + (size_t)i * 24;
-    store_fp(o, jj.x);
-    store_fp(o + 8, jj.y);
-    store_fp(o + 16, jj.z);
+    store_jacobian_mont256(out + (size_t)i * 24, xyzz_to_jacobian(r));
 }
 
 }  // namespace msmk
