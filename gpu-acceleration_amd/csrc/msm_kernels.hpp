@@ -368,23 +368,30 @@ __global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__
     uint32_t seg_end = offsets[k + 1];
     bool is_head = offsets[k] < j0;  // the first bucket of this chunk began in an earlier chunk
     xyzz acc = xyzz_identity();
-    // software pipeline: the gather of entry j+1 (and the index of entry j+2) are in flight while entry j is folded
+    // software pipeline: the 64-byte record of entry j+1 (and the index of entry j+2) are in flight while entry j
+    // is folded.  Only ONE raw record is kept: it is unpacked to 29-bit limbs before the next gather is issued.
     uint32_t e_cur = sorted[j0];
     uint32_t e_nxt = j0 + 1 < j1 ? sorted[j0 + 1] : 0u;
-    uint4 g_cur[4], g_nxt[4];  // the raw 64-byte records; unpacked to 29-bit limbs only when folded
+    uint4 g[4];
     {
         const uint4* bp = reinterpret_cast<const uint4*>(bases + (size_t)(e_cur & ~SIGN_BIT) * 16);
 #pragma unroll
-        for (int i = 0; i < 4; i++) g_cur[i] = bp[i];
+        for (int i = 0; i < 4; i++) g[i] = bp[i];
     }
     for (uint32_t j = j0; j < j1; j++) {
+        affine q;
+        {
+            uint32_t wx[8] = {g[0].x, g[0].y, g[0].z, g[0].w, g[1].x, g[1].y, g[1].z, g[1].w};
+            uint32_t wy[8] = {g[2].x, g[2].y, g[2].z, g[2].w, g[3].x, g[3].y, g[3].z, g[3].w};
+            q.x = fp_unpack(wx);
+            q.y = fp_unpack(wy);
+        }
+        if (e_cur & SIGN_BIT) q.y = fp_neg<2>(q.y);
         uint32_t e_nn = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) g_nxt[i] = g_cur[i];
         if (j + 1 < j1) {
             const uint4* bp = reinterpret_cast<const uint4*>(bases + (size_t)(e_nxt & ~SIGN_BIT) * 16);
 #pragma unroll
-            for (int i = 0; i < 4; i++) g_nxt[i] = bp[i];
+            for (int i = 0; i < 4; i++) g[i] = bp[i];
             if (j + 2 < j1) e_nn = sorted[j + 2];
         }
         if (j == seg_end) {  // bucket k is finished: flush and move to the bucket that owns entry j
@@ -396,17 +403,7 @@ __global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__
             is_head = false;
             acc = xyzz_identity();
         }
-        affine q;
-        {
-            uint32_t wx[8] = {g_cur[0].x, g_cur[0].y, g_cur[0].z, g_cur[0].w, g_cur[1].x, g_cur[1].y, g_cur[1].z, g_cur[1].w};
-            uint32_t wy[8] = {g_cur[2].x, g_cur[2].y, g_cur[2].z, g_cur[2].w, g_cur[3].x, g_cur[3].y, g_cur[3].z, g_cur[3].w};
-            q.x = fp_unpack(wx);
-            q.y = fp_unpack(wy);
-        }
-        if (e_cur & SIGN_BIT) q.y = fp_neg<2>(q.y);
         xyzz_madd(acc, q);
-#pragma unroll
-        for (int i = 0; i < 4; i++) g_cur[i] = g_nxt[i];
         e_cur = e_nxt;
         e_nxt = e_nn;
     }
