@@ -84,19 +84,13 @@ def main():
                         d_bases.data_ptr(), d_scalars.data_ptr())
     torch.cuda.synchronize()
 
-    d_part = torch.empty(24, dtype=torch.int32, device=dev)
-    d_all = torch.empty(24 * world, dtype=torch.int32, device=dev)
+    from mopro_msm_hip import distributed as md
 
     def step():
-        r = ctx.msm_device(d_bases.data_ptr(), d_scalars.data_ptr(), n_local)
-        if world == 1:
-            return r
-        # the exchange step: EC addition is not an RCCL reduction op, so the "all-reduce" of partial group
-        # elements is an all-gather of 96 bytes per rank + a local fold in rank order (identical on all ranks)
-        d_part.copy_(torch.from_numpy(r.jacobian_mont.view(np.int32)))
-        dist.all_gather_into_tensor(d_all, d_part)
-        parts = d_all.cpu().numpy().view(np.uint32).reshape(world, 24)
-        return mh.combine_partials(parts)
+        # HIP pipeline on this rank's shard, then (N > 1) the exchange step: EC addition is not an RCCL
+        # reduction op, so the "all-reduce" of partial group elements is an all-gather of 96 bytes per rank
+        # over RCCL + a local fold in rank order (identical on all ranks)
+        return md.distributed_msm_device(ctx, d_bases.data_ptr(), d_scalars.data_ptr(), n_local, device=dev)
 
     def fence():
         if world > 1:

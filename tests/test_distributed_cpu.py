@@ -1,0 +1,75 @@
+"""CPU test of the N>1 path with the gloo backend, world_size 2 (and 3): point-range sharding, the all-gather
+of 96-byte partials and the rank-ordered fold (product host arithmetic in libmsm_hip.so).  The per-rank partial
+MSMs come from the oracle here because there is no GPU; on the GPU box the same exchange runs behind
+bench.py --gpus N with partials from the HIP pipeline."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, case, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "gpu-acceleration_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    import mopro_msm_hip as mh
+    from mopro_msm_hip import distributed as md
+    from oracle import bn254_oracle as orc
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = np.load(os.path.join(ROOT, "tests", "golden", f"msm_{case}.npz"))
+    n = g["bases"].shape[0]
+    lo, hi = md.shard_range(n, rank, world)
+    if hi > lo:
+        _, _, jac = orc.msm_pippenger(g["bases"][lo:hi], g["scalars"][lo:hi], orc.FORM_STD, g["inf"][lo:hi])
+    else:  # empty shard contributes the identity (Z = 0)
+        jac = np.zeros(24, np.uint32)
+    local = mh.MsmResult(jac, None, False)
+    full = md.all_reduce_msm(local)
+    ok = bool((full.affine_std == g["expected"]).all() and full.is_infinity == bool(g["expected_inf"]))
+    parts = md.all_gather_partials(jac)
+    q.put((rank, ok, parts.tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,case", [(2, "rand_n256"), (2, "edge_p_minus_p"), (3, "rand_n17"), (2, "rand_n1")])
+def test_gloo_point_range_shards_allgather_fold(world, case):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    assert len({blob for _, _, blob in res}) == 1  # every rank saw the same gathered partials
+
+
+def test_shard_ranges_partition_everything():
+    from mopro_msm_hip import distributed as md
+    for n in (1, 7, 1 << 20, (1 << 20) + 3):
+        for world in (1, 2, 3, 8):
+            r = [md.shard_range(n, k, world) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[i][1] == r[i + 1][0] for i in range(world - 1))
+            assert max(h - l for l, h in r) - min(h - l for l, h in r) <= 1
