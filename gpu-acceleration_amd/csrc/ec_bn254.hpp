@@ -14,6 +14,7 @@
 // Value bounds (multiples of p; k = p/2^261 = 0.0059; a product of inputs < a*p, b*p is < (a*b*k + 1)*p):
 //   affine operand   x < 1, y < 2 (y may be a negation 2p - y)
 //   XYZZ everywhere  X < 7, Y < 5, ZZ < 2, ZZZ < 2        -- every function below re-establishes these
+//   (Y is in fact < 2 since Y3 comes out of one fused multiply-add; 5 leaves room for affine inputs 2p - y)
 // Each fp_sub<K>(a, b) needs b < (K-1)*p; the bound of b is written next to it.
 #pragma once
 #include "fp_bn254.hpp"
@@ -44,7 +45,7 @@ FP_HD xyzz xyzz_dbl_affine(const affine& a) {
     fp xx = fp_sqr(a.x);                       // < 1.01
     fp m = fp_add(fp_dbl(xx), xx);             // < 3.03
     fp x3 = fp_sub<4>(fp_sqr(m), fp_dbl(s));   // 2s < 2.02;  x3 < 1.06 + 4 = 5.06
-    fp y3 = fp_sub<3>(fp_mul(m, fp_sub<7>(s, x3)), fp_mul(w, a.y));  // (s - x3) < 8.01; m*() < 1.15; w*y < 1.02; y3 < 4.2
+    fp y3 = fp_mul_add(m, fp_sub<7>(s, x3), w, fp_neg<3>(a.y));  // m*(s - x3) + w*(3p - y): (3.03*8.01 + 1.03*3)k + 1 < 1.17
     return xyzz{x3, y3, v, w};
 }
 // dbl-2008-s-1, a = 0
@@ -57,7 +58,7 @@ FP_HD xyzz xyzz_dbl(const xyzz& p) {
     fp xx = fp_sqr(p.x);                       // < 1.29
     fp m = fp_add(fp_dbl(xx), xx);             // < 3.87
     fp x3 = fp_sub<4>(fp_sqr(m), fp_dbl(s));   // 2s < 2.14;  x3 < 1.09 + 4 = 5.09
-    fp y3 = fp_sub<3>(fp_mul(m, fp_sub<7>(s, x3)), fp_mul(w, p.y));  // (s - x3) < 8.07; m*() < 1.19; w*y < 1.04; y3 < 4.19
+    fp y3 = fp_mul_add(m, fp_sub<7>(s, x3), w, fp_neg<6>(p.y));  // m*(s - x3) + w*(6p - y): (3.87*8.07 + 1.1*6)k + 1 < 1.23
     return xyzz{x3, y3, fp_mul(v, p.zz), fp_mul(w, p.zzz)};
 }
 
@@ -81,7 +82,7 @@ FP_HD void xyzz_madd(xyzz& acc, const affine& q) {
     fp qv = fp_mul(acc.x, pp);         // < 1.07
     fp t = fp_add(ppp, fp_dbl(qv));    // < 3.22
     fp x3 = fp_sub<5>(fp_sqr(r), t);   // r^2 < 1.3;  x3 < 6.3
-    fp y3 = fp_sub<3>(fp_mul(r, fp_sub<8>(qv, x3)), fp_mul(acc.y, ppp));  // (qv - x3) < 9.07; r*() < 1.38; y*ppp < 1.04; y3 < 4.38
+    fp y3 = fp_mul_add(r, fp_sub<8>(qv, x3), fp_neg<6>(acc.y), ppp);  // r*(qv - x3) + (6p - y)*ppp: (7.03*9.07 + 6*1.08)k + 1 < 1.42
     acc.x = x3;
     acc.y = y3;
     acc.zz = fp_mul(acc.zz, pp);       // < 1.02
@@ -107,7 +108,7 @@ FP_HD xyzz xyzz_add(const xyzz& a, const xyzz& b) {
     fp qv = fp_mul(u1, pp);            // < 1.01
     fp t = fp_add(ppp, fp_dbl(qv));    // < 3.05
     fp x3 = fp_sub<5>(fp_sqr(r), t);   // r^2 < 1.1;  x3 < 6.1
-    fp y3 = fp_sub<3>(fp_mul(r, fp_sub<8>(qv, x3)), fp_mul(s1, ppp));  // (qv - x3) < 9.01; r*() < 1.22; s1*ppp < 1.01; y3 < 4.22
+    fp y3 = fp_mul_add(r, fp_sub<8>(qv, x3), fp_neg<3>(s1), ppp);  // r*(qv - x3) + (3p - s1)*ppp: (4.06*9.01 + 3*1.03)k + 1 < 1.24
     fp zz3 = fp_mul(fp_mul(a.zz, b.zz), pp);
     fp zzz3 = fp_mul(fp_mul(a.zzz, b.zzz), ppp);
     return xyzz{x3, y3, zz3, zzz3};

@@ -15,7 +15,12 @@
 // There is NO CPU fallback: without a HIP device every compute entry point returns MSM_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <cstdlib>
+#include <functional>
+#include <thread>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -41,8 +46,73 @@ enum { EV_START, EV_H2D, EV_CONVERT, EV_DECOMP, EV_SORT, EV_ACC0, EV_ACC1, EV_RE
 
 }  // namespace
 
+// Small persistent host thread pool for the CPU finish (per-window Horner chains are independent).  The
+// reference runs its CPU finish under rayon (metal_msm.rs:214-247); std::thread + condition variables here.
+class HostPool {
+public:
+    explicit HostPool(int nthreads) {
+        for (int i = 0; i < nthreads; i++) th_.emplace_back([this] { worker(); });
+    }
+    ~HostPool() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+            gen_++;
+        }
+        cv_work_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    int size() const { return (int)th_.size(); }
+    // run fn(0..njobs-1) on the workers and the calling thread; returns when all are done
+    void run(int njobs, const std::function<void(int)>& fn) {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            job_ = &fn;
+            njobs_ = njobs;
+            next_.store(0);
+            pending_ = (int)th_.size();
+            gen_++;
+        }
+        cv_work_.notify_all();
+        for (int i; (i = next_.fetch_add(1)) < njobs;) fn(i);
+        std::unique_lock<std::mutex> lk(m_);
+        cv_done_.wait(lk, [this] { return pending_ == 0; });
+    }
+
+private:
+    void worker() {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(int)>* job;
+            int njobs;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_work_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+                job = job_;
+                njobs = njobs_;
+            }
+            for (int i; (i = next_.fetch_add(1)) < njobs;) (*job)(i);
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (--pending_ == 0) cv_done_.notify_one();
+            }
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_work_, cv_done_;
+    const std::function<void(int)>* job_ = nullptr;
+    std::atomic<int> next_{0};
+    int njobs_ = 0, pending_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+
 struct msm_ctx {
     std::mutex mu;
+    HostPool* pool = nullptr;
     int device = 0;
     hipStream_t stream = nullptr;
     msm_config_t cfg{};
@@ -304,15 +374,29 @@ int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, 
     if (c->h_flags[0] & 1u) return fail(c, MSM_ERR_BAD_ARG, "a scalar is >= 2^254 (not a canonical Fr element)");
     if (c->h_flags[0] & 2u) return fail(c, MSM_ERR_HIP, "internal: signed-digit carry out of the top window");
     // final_reduction (metal_msm.rs:249-258): Horner over windows, high -> low, on the CPU
-    hostg1::Jac total = hostg1::identity();
-    for (int w = (int)W - 1; w >= 0; w--) {
-        // window sum S_w = Q_all + sum_u 2^u Q_u  (one Horner chain over the bit sums)
+    // window term T_w = 2^(c*w) * S_w with S_w = Q_all + sum_u 2^u Q_u (one Horner chain over the bit sums, then
+    // c*w doublings); the W chains are independent, so they run on the context's host pool, heaviest first
+    std::vector<hostg1::Jac> term(W);
+    auto window_job = [&](int job) {
+        const int w = (int)W - 1 - job;
         const uint32_t* qw = c->h_qsums + (size_t)w * (kb + 1) * 24;
         hostg1::Jac sw = hostg1::identity();
         for (int u = (int)kb - 1; u >= 0; u--) sw = hostg1::jadd(hostg1::jdbl(sw), hostg1::load_jac(qw + (size_t)u * 24));
         sw = hostg1::jadd(sw, hostg1::load_jac(qw + (size_t)kb * 24));
-        for (uint32_t k = 0; k < cbits; k++) total = hostg1::jdbl(total);
-        total = hostg1::jadd(total, sw);
+        if (c->pool)
+            for (uint32_t k = 0; k < cbits * (uint32_t)w; k++) sw = hostg1::jdbl(sw);
+        term[w] = sw;
+    };
+    hostg1::Jac total = hostg1::identity();
+    if (c->pool) {
+        c->pool->run((int)W, window_job);
+        for (uint32_t w = 0; w < W; w++) total = hostg1::jadd(total, term[w]);
+    } else {  // serial: plain Horner over windows, high -> low (metal_msm.rs:249-258)
+        for (int job = 0; job < (int)W; job++) window_job(job);
+        for (int w = (int)W - 1; w >= 0; w--) {
+            for (uint32_t k = 0; k < cbits; k++) total = hostg1::jdbl(total);
+            total = hostg1::jadd(total, term[w]);
+        }
     }
     finish_outputs(total, out_jac, out_aff, out_inf);
     auto t_fin1 = std::chrono::steady_clock::now();
@@ -429,12 +513,21 @@ int32_t msm_ctx_create(const msm_config_t* cfg, msm_ctx** out) {
             return rc;
         }
     }
+    {
+        // host finish threads: MSM_HIP_HOST_THREADS=0 forces the serial path
+        int want = (int)std::thread::hardware_concurrency() - 1;
+        if (want > 15) want = 15;
+        if (const char* e = std::getenv("MSM_HIP_HOST_THREADS")) want = std::atoi(e) - 1;
+        if (want >= 1) c->pool = new (std::nothrow) HostPool(want);
+    }
     *out = c;
     return MSM_OK;
 }
 
 void msm_ctx_destroy(msm_ctx* c) {
     if (!c) return;
+    delete c->pool;
+    c->pool = nullptr;
     {
         DeviceGuard g(c->device);
         if (c->stream) (void)hipStreamSynchronize(c->stream);
