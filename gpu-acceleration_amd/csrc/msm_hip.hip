@@ -120,7 +120,7 @@ struct msm_ctx {
     hipEvent_t ev[EV_COUNT]{};
     // HBM workspace
     DevBuf bases, ibases, inf, scalars, digits, ranks, sorted, hist, offsets, blocksums, buckets, heads, tails, chunkmap, rc, qsums, flags,
-        pow2, tilecounts;
+        pow2, tilecounts, longlist;
     bool pow2_ready = false;
     uint32_t* h_qsums = nullptr;  // pinned: W x (kb+1) Jacobian bit sums
     uint32_t* h_flags = nullptr;    // pinned
@@ -175,7 +175,8 @@ void release(DevBuf& b) {
 uint32_t plan_window_bits(size_t n, bool is_signed) {
     double best = 1e300;
     uint32_t best_c = 8;
-    for (uint32_t c = 4; c <= 18; c++) {
+    // c is capped where one window's histogram still fits the 128 KB LDS sort path (nb <= 32768)
+    for (uint32_t c = 4; c <= (is_signed ? 16u : 15u); c++) {
         double W = is_signed ? (double)(254 / c + 1) : (double)((254 + c - 1) / c);
         double nb = is_signed ? (double)(1u << (c - 1)) : (double)(1u << c);
         double cost = W * ((double)n * 10.0 + nb * 2.0 * 14.0 * 1.5);
@@ -265,10 +266,15 @@ int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, 
     const uint32_t kb = ilog2(nb), kb_lo = kb / 2, kb_hi = kb - kb_lo;  // bucket index = hi * n_lo + lo
     const uint32_t n_lo = 1u << kb_lo, n_hi = 1u << kb_hi;
     const uint32_t ntiles = (uint32_t)((tb + msmk::SCAN_TILE - 1) / msmk::SCAN_TILE);
-    // sorted entries folded by one k_accumulate thread: as long as possible (fewer cut buckets for k_combine)
-    // while still giving every SIMD its 4 wavefronts (256 CUs x 4 SIMDs x 4 waves x 64 lanes = 262144 threads)
+    // sorted entries folded by one k_accumulate thread: ~2^19 chunks per call (2.7 rounds of the 196608 threads that
+    // 3 wavefronts/SIMD hold) keep the tail short, and the chunk grows with N so that buckets (mean n / nb entries)
+    // are cut into few pieces for k_combine.  Measured sweep at N = 2^20: L = 32 (profiles/NOTES_r1.md).
     uint32_t chunk_len = 8;
-    while (chunk_len < 32 && pairs / (chunk_len * 2) >= 262144) chunk_len *= 2;
+    while (chunk_len < 1024 && pairs / (chunk_len * 2) > 262144) chunk_len *= 2;
+    if (const char* e = std::getenv("MSM_HIP_CHUNK_LEN")) {  // tuning knob (any value >= 1 is correct)
+        int v = std::atoi(e);
+        if (v >= 1 && v <= 4096) chunk_len = (uint32_t)v;
+    }
     const size_t nchunks_max = (pairs + chunk_len - 1) / chunk_len;
     if ((rc = ensure(c, c->digits, pairs * 4))) return rc;
     if ((rc = ensure(c, c->sorted, pairs * 4))) return rc;
@@ -279,6 +285,7 @@ int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, 
     if ((rc = ensure(c, c->heads, nchunks_max * XB))) return rc;
     if ((rc = ensure(c, c->tails, nchunks_max * XB))) return rc;
     if ((rc = ensure(c, c->chunkmap, nchunks_max * 4))) return rc;
+    if ((rc = ensure(c, c->longlist, (nchunks_max / msmk::LONG_SPAN + 16) * 4))) return rc;  // a long bucket owns >= LONG_SPAN chunks
     if ((rc = ensure(c, c->rc, (tb + tb / 2 + 4) * XB))) return rc;  // two families x (1/2 + 1/4) ping-pong levels
     if ((rc = ensure(c, c->qsums, (size_t)W * (kb + 1) * 96))) return rc;
     if ((rc = ensure(c, c->flags, 64))) return rc;
@@ -331,7 +338,8 @@ int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, 
     }
     HIPCHK(c, hipEventRecord(c->ev[EV_SORT], st));
     // K3: bucket accumulation (the graded kernel) -- bracketed by its own events on its own stream
-    msmk::k_chunk_map<<<grid1(tb, 256), 256, 0, st>>>(offsets, (uint32_t*)c->chunkmap.p, (uint32_t)tb, chunk_len);
+    msmk::k_chunk_map<<<grid1(tb, 256), 256, 0, st>>>(offsets, (uint32_t*)c->chunkmap.p, (uint32_t)tb, chunk_len, flags + 8,
+                                                      (uint32_t*)c->longlist.p);
     HIPCHK(c, hipEventRecord(c->ev[EV_ACC0], st));
     msmk::k_accumulate<<<grid1(nchunks_max, 256), 256, 0, st>>>(d_bases, (uint32_t*)c->sorted.p, offsets, (uint32_t*)c->chunkmap.p,
                                                               (uint32_t*)c->buckets.p, (uint32_t*)c->heads.p, (uint32_t*)c->tails.p,
@@ -339,6 +347,8 @@ int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, 
     HIPCHK(c, hipEventRecord(c->ev[EV_ACC1], st));
     msmk::k_combine<<<grid1(tb, 256), 256, 0, st>>>(offsets, (uint32_t*)c->heads.p, (uint32_t*)c->tails.p, (uint32_t*)c->buckets.p,
                                                     (uint32_t)tb, chunk_len);
+    msmk::k_combine_long<<<1024, 256, 0, st>>>(offsets, (uint32_t*)c->heads.p, (uint32_t*)c->tails.p, (uint32_t*)c->buckets.p, flags + 8,
+                                               (uint32_t*)c->longlist.p, chunk_len);
     // K4/K5: bucket reduction -- plain row/column sums by dense pairwise levels, then per-bit sums; the weights
     // are applied on the host
     {
@@ -533,7 +543,7 @@ void msm_ctx_destroy(msm_ctx* c) {
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         DevBuf* bufs[] = {&c->bases,   &c->inf,       &c->scalars, &c->digits,  &c->ranks,  &c->sorted, &c->hist,
                           &c->offsets, &c->blocksums, &c->buckets, &c->rc,      &c->qsums,   &c->flags,  &c->pow2,
-                          &c->heads,   &c->tails,     &c->chunkmap, &c->tilecounts, &c->ibases};
+                          &c->heads,   &c->tails,     &c->chunkmap, &c->tilecounts, &c->ibases, &c->longlist};
         for (DevBuf* b : bufs) release(*b);
         if (c->h_qsums) (void)hipHostFree(c->h_qsums);
         if (c->h_flags) (void)hipHostFree(c->h_flags);

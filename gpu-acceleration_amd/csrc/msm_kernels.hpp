@@ -79,6 +79,12 @@ __device__ __forceinline__ void store_xyzz(uint32_t* p, const xyzz& v) {
 #pragma unroll
     for (int i = 0; i < XW / 4; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
+__device__ __forceinline__ fp shfl_down_fp9(const fp& a, int d) {
+    fp r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = __shfl_down(a.v[i], d, 64);
+    return r;
+}
 // Jacobian in the C-ABI format: 24 words, canonical R = 2^256 Montgomery
 __device__ __forceinline__ void store_jacobian_mont256(uint32_t* o, const jacobian& j) {
     uint32_t w[8];
@@ -345,13 +351,17 @@ __global__ void k_scatter(const uint32_t* __restrict__ digits, const uint32_t* _
 // Each point is gathered as one 64-byte affine record and folded into an XYZZ accumulator in registers.
 
 // chunk_bucket[t] = bucket that owns sorted entry t*L  (one thread per bucket writes the chunks it starts)
+// Buckets cut into LONG_SPAN or more chunks (tiny top windows, adversarial scalars) are listed for k_combine_long.
+constexpr uint32_t LONG_SPAN = 8;
 __global__ void k_chunk_map(const uint32_t* __restrict__ offsets, uint32_t* __restrict__ chunk_bucket, uint32_t total_buckets,
-                            uint32_t L) {
+                            uint32_t L, uint32_t* __restrict__ long_count, uint32_t* __restrict__ long_list) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= total_buckets) return;
     uint32_t beg = offsets[k], end = offsets[k + 1];
     if (beg == end) return;
-    for (uint32_t t = (beg + L - 1) / L; t <= (end - 1) / L; t++) chunk_bucket[t] = k;
+    uint32_t tf = (beg + L - 1) / L, tl = (end - 1) / L;
+    if (tl - beg / L >= LONG_SPAN) long_list[atomicAdd(long_count, 1u)] = k;
+    for (uint32_t t = tf; t <= tl; t++) chunk_bucket[t] = k;
 }
 
 __global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
@@ -423,10 +433,40 @@ __global__ void __launch_bounds__(256) k_combine(const uint32_t* __restrict__ of
         return;
     }
     uint32_t t0 = beg / L, t1 = (end - 1) / L;
-    if (t0 == t1) return;  // written by k_accumulate
+    if (t0 == t1) return;             // written by k_accumulate
+    if (t1 - t0 >= LONG_SPAN) return;  // k_combine_long
     xyzz acc = load_xyzz(tails + (size_t)t0 * XW);
     for (uint32_t t = t0 + 1; t <= t1; t++) acc = xyzz_add(acc, load_xyzz(heads + (size_t)t * XW));
     store_xyzz(buckets + (size_t)k * XW, acc);
+}
+
+// one 256-thread workgroup per LONG bucket: strided partial sums of its heads, then a wavefront __shfl_down tree
+// and a 4-way LDS step.  Dependency depth ceil(span/256) + 8 instead of span.
+__global__ void __launch_bounds__(256) k_combine_long(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ heads,
+                                                      const uint32_t* __restrict__ tails, uint32_t* __restrict__ buckets,
+                                                      const uint32_t* __restrict__ long_count, const uint32_t* __restrict__ long_list,
+                                                      uint32_t L) {
+    __shared__ uint32_t lds[4 * XW];
+    const uint32_t nlong = *long_count;
+    for (uint32_t item = blockIdx.x; item < nlong; item += gridDim.x) {
+        const uint32_t k = long_list[item];
+        const uint32_t beg = offsets[k], end = offsets[k + 1];
+        const uint32_t t0 = beg / L, t1 = (end - 1) / L;
+        xyzz acc = xyzz_identity();
+        for (uint32_t t = t0 + 1 + threadIdx.x; t <= t1; t += blockDim.x) acc = xyzz_add(acc, load_xyzz(heads + (size_t)t * XW));
+        for (int d = 32; d >= 1; d >>= 1) {
+            xyzz o{shfl_down_fp9(acc.x, d), shfl_down_fp9(acc.y, d), shfl_down_fp9(acc.zz, d), shfl_down_fp9(acc.zzz, d)};
+            acc = xyzz_add(acc, o);
+        }
+        __syncthreads();  // lds reuse across items
+        if ((threadIdx.x & 63) == 0) store_xyzz(lds + (threadIdx.x >> 6) * XW, acc);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            xyzz tot = load_xyzz(tails + (size_t)t0 * XW);
+            for (int q = 0; q < 4; q++) tot = xyzz_add(tot, load_xyzz(lds + q * XW));
+            store_xyzz(buckets + (size_t)k * XW, tot);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
