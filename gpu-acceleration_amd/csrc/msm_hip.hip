@@ -115,6 +115,11 @@ struct msm_ctx {
     HostPool* pool = nullptr;
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;     // host->HBM chunk uploads of the streamed path
+    hipEvent_t ev_copied[2]{}, ev_free[2]{};
+    DevBuf sbases[2], sscalars[2], sinf[2];  // double-buffered raw inputs of the streamed path
+    uint32_t* h_sq = nullptr;              // pinned: per-chunk bit sums + flags of the streamed path
+    size_t h_sq_cap = 0;
     msm_config_t cfg{};
     std::string err;
     hipEvent_t ev[EV_COUNT]{};
@@ -252,10 +257,14 @@ void finish_outputs(const hostg1::Jac& r, uint32_t* out_jac, uint32_t* out_aff, 
     }
 }
 
-// The pipeline proper: everything in HBM, one stream.  d_bases: INTERNAL-domain packed coordinates
-// (k_convert_bases output).
-int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, const uint32_t* d_scalars, size_t n,
-                     hipStream_t st, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf) {
+struct PipeGeom {
+    uint32_t W, nb, cbits, kb;
+};
+
+// Queue the whole device pipeline for one (chunk of an) MSM on stream st; the W*(kb+1) bit sums and the flag words
+// are copied to h_qsums_dst / h_flags_dst (pinned) at the end.  No host synchronisation here.
+int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, const uint32_t* d_scalars, size_t n,
+                         hipStream_t st, uint32_t* h_qsums_dst, uint32_t* h_flags_dst, PipeGeom* geom) {
     if (n > 0x7FFFFFFFull) return fail(c, MSM_ERR_BAD_ARG, "n = %zu exceeds 2^31-1 points per context call", n);
     msm_plan_t pl;
     int32_t rc = make_plan(n, c->cfg.window_bits, c->cfg.flags, &pl);
@@ -376,20 +385,21 @@ int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, 
         msmk::k_reduce_bits<<<W * (kb + 1), 64, 0, st>>>(rin, cin, (uint32_t*)c->qsums.p, n_hi, n_lo, kb_lo, kb);
     }
     HIPCHK(c, hipEventRecord(c->ev[EV_REDUCE], st));
-    HIPCHK(c, hipMemcpyAsync(c->h_qsums, c->qsums.p, (size_t)W * (kb + 1) * 96, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(c->h_flags, flags, 32, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    HIPCHK(c, hipGetLastError());
-    auto t_fin0 = std::chrono::steady_clock::now();
-    if (c->h_flags[0] & 1u) return fail(c, MSM_ERR_BAD_ARG, "a scalar is >= 2^254 (not a canonical Fr element)");
-    if (c->h_flags[0] & 2u) return fail(c, MSM_ERR_HIP, "internal: signed-digit carry out of the top window");
-    // final_reduction (metal_msm.rs:249-258): Horner over windows, high -> low, on the CPU
-    // window term T_w = 2^(c*w) * S_w with S_w = Q_all + sum_u 2^u Q_u (one Horner chain over the bit sums, then
-    // c*w doublings); the W chains are independent, so they run on the context's host pool, heaviest first
+    HIPCHK(c, hipMemcpyAsync(h_qsums_dst, c->qsums.p, (size_t)W * (kb + 1) * 96, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(h_flags_dst, flags, 32, hipMemcpyDeviceToHost, st));
+    *geom = PipeGeom{W, nb, cbits, kb};
+    return MSM_OK;
+}
+
+// final_reduction (metal_msm.rs:204-261) on the CPU.  Window term T_w = 2^(c*w) * S_w with
+// S_w = Q_all + sum_u 2^u Q_u (one Horner chain over the bit sums, then c*w doublings); the W chains are independent,
+// so they run on the context's host pool, heaviest first.
+hostg1::Jac host_finish(msm_ctx* c, const uint32_t* h_qsums, const PipeGeom& g) {
+    const uint32_t W = g.W, kb = g.kb, cbits = g.cbits;
     std::vector<hostg1::Jac> term(W);
     auto window_job = [&](int job) {
         const int w = (int)W - 1 - job;
-        const uint32_t* qw = c->h_qsums + (size_t)w * (kb + 1) * 24;
+        const uint32_t* qw = h_qsums + (size_t)w * (kb + 1) * 24;
         hostg1::Jac sw = hostg1::identity();
         for (int u = (int)kb - 1; u >= 0; u--) sw = hostg1::jadd(hostg1::jdbl(sw), hostg1::load_jac(qw + (size_t)u * 24));
         sw = hostg1::jadd(sw, hostg1::load_jac(qw + (size_t)kb * 24));
@@ -408,6 +418,26 @@ int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, 
             total = hostg1::jadd(total, term[w]);
         }
     }
+    return total;
+}
+
+int32_t check_flags(msm_ctx* c, const uint32_t* h_flags) {
+    if (h_flags[0] & 1u) return fail(c, MSM_ERR_BAD_ARG, "a scalar is >= 2^254 (not a canonical Fr element)");
+    if (h_flags[0] & 2u) return fail(c, MSM_ERR_HIP, "internal: signed-digit carry out of the top window");
+    return MSM_OK;
+}
+
+// The pipeline proper: everything in HBM, one stream.  d_bases: INTERNAL-domain packed coordinates.
+int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, const uint32_t* d_scalars, size_t n,
+                     hipStream_t st, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf) {
+    PipeGeom g;
+    int32_t rc = enqueue_pipeline(c, d_bases, d_inf, d_scalars, n, st, c->h_qsums, c->h_flags, &g);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    auto t_fin0 = std::chrono::steady_clock::now();
+    if ((rc = check_flags(c, c->h_flags))) return rc;
+    hostg1::Jac total = host_finish(c, c->h_qsums, g);
     finish_outputs(total, out_jac, out_aff, out_inf);
     auto t_fin1 = std::chrono::steady_clock::now();
     // timings
@@ -465,6 +495,65 @@ int32_t upload_bases_locked(msm_ctx* c, const uint32_t* bases_xy, uint32_t form,
     return MSM_OK;
 }
 
+// BASELINE config 5: the instance does not have to be resident.  The point range is cut into chunks of 2^k points;
+// chunk j+1 travels host->HBM on the copy stream while the full pipeline of chunk j runs on the compute stream
+// (MSM is linear, so every chunk is an independent MSM and the partial results are added on the host).  Inputs are
+// double-buffered; nothing but W*(kb+1) bit sums per chunk comes back.
+int32_t run_streamed(msm_ctx* c, const uint32_t* bases_xy, uint32_t form, const uint8_t* inf_mask, const uint32_t* scalars,
+                     size_t n, size_t chunk, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf) {
+    if (form != MSM_FORM_STD && form != MSM_FORM_MONT) return fail(c, MSM_ERR_BAD_ARG, "unknown base_form %u", form);
+    const size_t nchunks = (n + chunk - 1) / chunk;
+    const size_t slot_words = MAX_QSUM_POINTS * 24 + 8;
+    int32_t rc;
+    if (c->h_sq_cap < nchunks * slot_words) {
+        if (c->h_sq) HIPCHK(c, hipHostFree(c->h_sq));
+        c->h_sq = nullptr;
+        c->h_sq_cap = 0;
+        HIPCHK(c, hipHostMalloc((void**)&c->h_sq, nchunks * slot_words * 4, hipHostMallocDefault));
+        c->h_sq_cap = nchunks * slot_words;
+    }
+    for (int s = 0; s < 2; s++) {
+        if ((rc = ensure(c, c->sbases[s], chunk * 64))) return rc;
+        if ((rc = ensure(c, c->sscalars[s], chunk * 32))) return rc;
+        if (inf_mask && (rc = ensure(c, c->sinf[s], chunk))) return rc;
+    }
+    if ((rc = ensure(c, c->ibases, chunk * 64))) return rc;
+    std::vector<PipeGeom> geom(nchunks);
+    hipStream_t st = c->stream, cs = c->copy_stream;
+    for (size_t j = 0; j < nchunks; j++) {
+        const int s = (int)(j & 1);
+        const size_t lo = j * chunk, cnt = (lo + chunk <= n) ? chunk : n - lo;
+        if (j >= 2) HIPCHK(c, hipStreamWaitEvent(cs, c->ev_free[s], 0));  // the pipeline that read this slot is done
+        HIPCHK(c, hipMemcpyAsync(c->sbases[s].p, bases_xy + lo * 16, cnt * 64, hipMemcpyHostToDevice, cs));
+        HIPCHK(c, hipMemcpyAsync(c->sscalars[s].p, scalars + lo * 8, cnt * 32, hipMemcpyHostToDevice, cs));
+        if (inf_mask) HIPCHK(c, hipMemcpyAsync(c->sinf[s].p, inf_mask + lo, cnt, hipMemcpyHostToDevice, cs));
+        HIPCHK(c, hipEventRecord(c->ev_copied[s], cs));
+        HIPCHK(c, hipStreamWaitEvent(st, c->ev_copied[s], 0));
+        msmk::k_convert_bases<<<grid1(2 * cnt, 256), 256, 0, st>>>((const uint32_t*)c->sbases[s].p, (uint32_t*)c->ibases.p, (uint32_t)cnt,
+                                                                 form == MSM_FORM_MONT ? 1u : 0u);
+        uint32_t* slot = c->h_sq + j * slot_words;
+        rc = enqueue_pipeline(c, (const uint32_t*)c->ibases.p, inf_mask ? (const uint8_t*)c->sinf[s].p : nullptr,
+                              (const uint32_t*)c->sscalars[s].p, cnt, st, slot + 8, slot, &geom[j]);
+        if (rc) return rc;
+        HIPCHK(c, hipEventRecord(c->ev_free[s], st));
+    }
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    hostg1::Jac total = hostg1::identity();
+    uint64_t adds = 0;
+    for (size_t j = 0; j < nchunks; j++) {
+        const uint32_t* slot = c->h_sq + j * slot_words;
+        if ((rc = check_flags(c, slot))) return rc;
+        adds += slot[4];
+        total = hostg1::jadd(total, host_finish(c, slot + 8, geom[j]));
+    }
+    finish_outputs(total, out_jac, out_aff, out_inf);
+    c->tm = msm_timings_t{};
+    c->tm.num_points = n;
+    c->tm.num_adds = adds;
+    return MSM_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -485,6 +574,8 @@ int32_t msm_ctx_create(const msm_config_t* cfg, msm_ctx** out) {
     msm_plan_t probe;
     if (make_plan(1, c0.window_bits, c0.flags, &probe) != MSM_OK)
         return fail(nullptr, MSM_ERR_BAD_ARG, "bad window_bits/flags (%u, 0x%x)", c0.window_bits, c0.flags);
+    if (c0.stream_chunk_log2 && (c0.stream_chunk_log2 < 8 || c0.stream_chunk_log2 > 28))
+        return fail(nullptr, MSM_ERR_BAD_ARG, "stream_chunk_log2 = %u out of range [8, 28]", c0.stream_chunk_log2);
     int dev = c0.device;
     if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return fail(nullptr, MSM_ERR_NO_DEVICE, "hipGetDevice failed");
     if (dev >= ndev) return fail(nullptr, MSM_ERR_NO_DEVICE, "device %d out of range (%d visible)", dev, ndev);
@@ -495,6 +586,11 @@ int32_t msm_ctx_create(const msm_config_t* cfg, msm_ctx** out) {
     DeviceGuard g(dev);
     hipError_t e = g.ok ? hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) : hipErrorInvalidDevice;
     for (int i = 0; i < EV_COUNT && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) {
+        e = hipEventCreateWithFlags(&c->ev_copied[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_free[i], hipEventDisableTiming);
+    }
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_qsums, MAX_QSUM_POINTS * 96, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_flags, 64, hipHostMallocDefault);
     if (e == hipSuccess)
@@ -547,6 +643,15 @@ void msm_ctx_destroy(msm_ctx* c) {
         for (DevBuf* b : bufs) release(*b);
         if (c->h_qsums) (void)hipHostFree(c->h_qsums);
         if (c->h_flags) (void)hipHostFree(c->h_flags);
+        if (c->h_sq) (void)hipHostFree(c->h_sq);
+        for (int i = 0; i < 2; i++) {
+            release(c->sbases[i]);
+            release(c->sscalars[i]);
+            release(c->sinf[i]);
+            if (c->ev_copied[i]) (void)hipEventDestroy(c->ev_copied[i]);
+            if (c->ev_free[i]) (void)hipEventDestroy(c->ev_free[i]);
+        }
+        if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
         for (int i = 0; i < EV_COUNT; i++)
             if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
         if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -561,11 +666,33 @@ int32_t msm_bn254_g1(msm_ctx* c, const uint32_t* bases_xy, uint32_t base_form, c
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
     auto t0 = std::chrono::steady_clock::now();
+    c->resident_n = 0;  // the scratch copies below are not a resident set
+    {
+        // Streaming needs copies that really run beside the kernels.  Measured (tools/pin_test.py, N = 2^22): from
+        // PINNED caller memory 10.5 ms streamed vs 15.0 ms single-shot; from pageable memory the runtime's staged
+        // copy does not overlap and chunking only adds its fixed costs (16.0 vs 15.1 ms); hipHostRegister costs as
+        // much as the copy itself (10.9 ms per 256 MB).  So: explicit stream_chunk_log2 => always stream;
+        // default => stream only when both caller buffers are pinned.
+        uint32_t lg = c->cfg.stream_chunk_log2 ? c->cfg.stream_chunk_log2 : 21u;
+        size_t chunk = (size_t)1 << lg;
+        bool want = n >= 2 * chunk;
+        if (want && !c->cfg.stream_chunk_log2) {
+            hipPointerAttribute_t a0{}, a1{};
+            want = hipPointerGetAttributes(&a0, bases_xy) == hipSuccess && a0.type == hipMemoryTypeHost &&
+                   hipPointerGetAttributes(&a1, scalars) == hipSuccess && a1.type == hipMemoryTypeHost;
+            (void)hipGetLastError();  // an unregistered pointer is not an error here
+        }
+        if (want) {
+            rc = run_streamed(c, bases_xy, base_form, inf_mask, scalars, n, chunk, out_jac, out_aff, out_inf);
+            if (rc) return rc;
+            c->tm.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            return MSM_OK;
+        }
+    }
     HIPCHK(c, hipEventRecord(c->ev[EV_START], c->stream));
     if ((rc = ensure(c, c->scalars, n * 32))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->scalars.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
     if ((rc = upload_bases_locked(c, bases_xy, base_form, inf_mask, n))) return rc;
-    c->resident_n = 0;  // the scratch copy is not a resident set
     rc = run_pipeline(c, (const uint32_t*)c->ibases.p, inf_mask ? (const uint8_t*)c->inf.p : nullptr,
                       (const uint32_t*)c->scalars.p, n, c->stream, out_jac, out_aff, out_inf);
     if (rc) return rc;

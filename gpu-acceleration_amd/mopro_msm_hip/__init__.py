@@ -42,7 +42,7 @@ class MsmError(RuntimeError):
 
 class Config(C.Structure):
     _fields_ = [("device", C.c_int32), ("window_bits", C.c_uint32), ("flags", C.c_uint32),
-                ("reserved", C.c_uint32), ("max_points", C.c_uint64)]
+                ("stream_chunk_log2", C.c_uint32), ("max_points", C.c_uint64)]
 
 
 class Plan(C.Structure):
@@ -164,9 +164,9 @@ def generate_scalars_host(seed, n, nonzero=False):
 class MsmContext:
     """Persistent engine context (replaces MetalMSMPipeline, rebuilt per call in the reference)."""
 
-    def __init__(self, device=-1, window_bits=0, flags=0, max_points=0):
+    def __init__(self, device=-1, window_bits=0, flags=0, max_points=0, stream_chunk_log2=0):
         self._lib = load_library()
-        cfg = Config(device, window_bits, flags, 0, max_points)
+        cfg = Config(device, window_bits, flags, stream_chunk_log2, max_points)
         h = C.c_void_p()
         rc = self._lib.msm_ctx_create(C.byref(cfg), C.byref(h))
         if rc != OK:

@@ -58,7 +58,10 @@ typedef struct {
     int32_t device;       /* HIP device ordinal; -1 = current device                                   */
     uint32_t window_bits; /* c; 0 = planner (replaces the N->window table at metal_msm.rs:661-673)     */
     uint32_t flags;       /* MSM_FLAG_*                                                                */
-    uint32_t reserved;
+    uint32_t stream_chunk_log2; /* msm_bn254_g1 with n >= 2 * 2^this points streams host->HBM chunks of 2^this points
+                                   overlapped with the pipeline of the previous chunk (BASELINE config 5).
+                                   0 = automatic: 2^21-point chunks, and only when the caller's buffers are pinned
+                                   (pageable copies do not overlap kernels on this runtime) */
     uint64_t max_points;  /* pre-size the HBM workspace for this many points; 0 = grow on demand        */
 } msm_config_t;
 

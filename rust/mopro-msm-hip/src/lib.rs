@@ -24,7 +24,7 @@ struct MsmConfig {
     device: i32,
     window_bits: u32,
     flags: u32,
-    reserved: u32,
+    stream_chunk_log2: u32,
     max_points: u64,
 }
 #[repr(C)]
@@ -48,7 +48,7 @@ unsafe impl Send for Ctx {}
 /// Process-global context: the reference rebuilds its whole Metal pipeline on every call
 /// (metal_msm.rs:693); here device, stream and HBM workspace persist.
 static CTX: Lazy<Mutex<Result<Ctx, String>>> = Lazy::new(|| {
-    let cfg = MsmConfig { device: -1, window_bits: 0, flags: 0, reserved: 0, max_points: 0 };
+    let cfg = MsmConfig { device: -1, window_bits: 0, flags: 0, stream_chunk_log2: 0, max_points: 0 };
     let mut p: *mut MsmCtx = std::ptr::null_mut();
     let rc = unsafe { msm_ctx_create(&cfg, &mut p) };
     Mutex::new(if rc == 0 { Ok(Ctx(p)) } else { Err(last_error(std::ptr::null())) })

@@ -262,3 +262,53 @@ def test_full_size_closed_form_and_linearity(ctx, logn):
     assert (comb.affine_std == exp).all()
     tm = ctx.timings()
     assert tm["num_points"] == n - h and tm["accumulate_ms"] > 0
+
+
+# ---- BASELINE config 5: streamed host->HBM chunks overlapped with the pipeline ---------------------
+def test_streamed_chunks_match_oracle():
+    """msm_bn254_g1 cuts n >= 2*chunk points into chunks (double-buffered H2D on a copy stream, partials added on
+    the host).  Forced to tiny chunks here so that the golden cases exercise it; ragged last chunk and infinity
+    masks included."""
+    with mh.MsmContext(stream_chunk_log2=8) as c:
+        for name in ("rand_n1024", "rand_n4096"):
+            g = load_golden(name)
+            r = c.msm(g["bases"], g["scalars"], mh.FORM_STD, g["inf"])
+            assert (r.affine_std == g["expected"]).all() and not r.is_infinity, name
+            assert c.timings()["num_points"] == g["bases"].shape[0]
+        g = load_golden("rand_n4096")
+        n = 3000  # 11 full chunks + a ragged one
+        inf = np.zeros(n, np.uint8)
+        inf[[0, 255, 256, 2999]] = 1
+        r = c.msm(g["bases"][:n], g["scalars"][:n], mh.FORM_STD, inf)
+        exp, einf, _ = orc.msm_pippenger(g["bases"][:n], g["scalars"][:n], orc.FORM_STD, inf)
+        assert (r.affine_std == exp).all() and r.is_infinity == bool(einf)
+        # Montgomery-form input through the streamed path
+        bm = np.concatenate([c.test_fp_op(3, g["bases"][:, :8]), c.test_fp_op(3, g["bases"][:, 8:])], axis=1)
+        r = c.msm(bm, g["scalars"], mh.FORM_MONT)
+        assert (r.affine_std == g["expected"]).all()
+        # a non-canonical scalar in a LATER chunk is still rejected
+        bad = g["scalars"].copy()
+        bad[4000, 7] |= 0x40000000
+        with pytest.raises(mh.MsmError) as e:
+            c.msm(g["bases"], bad)
+        assert e.value.code == mh.ERR_BAD_ARG
+        # below the threshold the single-shot path is taken
+        g = load_golden("rand_n256")
+        r = c.msm(g["bases"], g["scalars"])
+        assert (r.affine_std == g["expected"]).all()
+
+
+def test_streamed_equals_single_shot_at_2_pow_18(ctx):
+    n = 1 << 18
+    k = mh.generate_scalars_host(0xB2540001, n, nonzero=True)
+    s = mh.generate_scalars_host(0xB2540009, n)
+    import torch
+    d_b = torch.empty(n * 16, dtype=torch.int32, device="cuda:0")
+    d_s = torch.empty(n * 8, dtype=torch.int32, device="cuda:0")
+    ctx.generate_device(0xB2540001, 0xB2540009, n, d_b.data_ptr(), d_s.data_ptr())
+    hb = d_b.cpu().numpy().view(np.uint32).reshape(n, 16)
+    single = ctx.msm(hb, s, mh.FORM_MONT)
+    with mh.MsmContext(stream_chunk_log2=15) as c:  # 8 chunks of 32768
+        streamed = c.msm(hb, s, mh.FORM_MONT)
+    exp, _ = orc.closed_form_expected(k, s)
+    assert (single.affine_std == exp).all() and (streamed.affine_std == exp).all()
