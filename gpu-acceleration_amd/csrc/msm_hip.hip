@@ -125,7 +125,7 @@ struct msm_ctx {
     hipEvent_t ev[EV_COUNT]{};
     // HBM workspace
     DevBuf bases, ibases, inf, scalars, digits, ranks, sorted, hist, offsets, blocksums, buckets, heads, tails, chunkmap, rc, qsums, flags,
-        pow2, tilecounts, longlist;
+        pow2, tilecounts, longlist, ccounts, cregion;
     bool pow2_ready = false;
     uint32_t* h_qsums = nullptr;  // pinned: W x (kb+1) Jacobian bit sums
     uint32_t* h_flags = nullptr;    // pinned
@@ -291,7 +291,7 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
     if ((rc = ensure(c, c->offsets, (tb + 1) * 4))) return rc;
     if ((rc = ensure(c, c->blocksums, ((size_t)ntiles + 1) * 4))) return rc;
     if ((rc = ensure(c, c->buckets, tb * XB))) return rc;
-    if ((rc = ensure(c, c->heads, nchunks_max * XB))) return rc;
+    if ((rc = ensure(c, c->heads, nchunks_max * XB > pairs * 4 ? nchunks_max * XB : pairs * 4))) return rc;  // also stages the 2-level sort
     if ((rc = ensure(c, c->tails, nchunks_max * XB))) return rc;
     if ((rc = ensure(c, c->chunkmap, nchunks_max * 4))) return rc;
     if ((rc = ensure(c, c->longlist, (nchunks_max / msmk::LONG_SPAN + 16) * 4))) return rc;  // a long bucket owns >= LONG_SPAN chunks
@@ -305,9 +305,17 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
     // Counting-sort plan: when one window's histogram fits LDS (nb <= 32768) the bucket counts and arrival
     // ranks come from per-tile LDS histograms, otherwise from device-scope atomics in k_decompose.
     const bool tiled = (size_t)nb * 4 <= LDS_HIST_BYTES;
+    // two-level LDS sort: coarse = top min(kb, 8) bits of the bucket index, fine = the rest (<= 7 bits)
+    const uint32_t coarse_bits = kb < 8 ? kb : 8, fine_bits = kb - coarse_bits, idx_bits = 31 - fine_bits;
+    const uint32_t ncoarse = 1u << coarse_bits;
+    const bool two_level = tiled && fine_bits <= 7 && n <= ((size_t)1 << idx_bits) && !std::getenv("MSM_HIP_DIRECT_SCATTER");
+    const uint32_t NS = (uint32_t)((n + msmk::SUBTILE - 1) / msmk::SUBTILE);
     uint32_t T = 1, tile_len = (uint32_t)n;
     if (!tiled && (rc = ensure(c, c->ranks, pairs * 4))) return rc;
-    if (tiled) {
+    if (two_level) {
+        if ((rc = ensure(c, c->ccounts, (size_t)W * ncoarse * NS * 4))) return rc;
+        if ((rc = ensure(c, c->cregion, ((size_t)W * ncoarse * 2 + 2) * 4))) return rc;
+    } else if (tiled) {
         T = (uint32_t)((n + 65535) / 65536);
         if (T > 64) T = 64;
         tile_len = (uint32_t)((n + T - 1) / T);
@@ -327,23 +335,39 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
         else msmk::k_decompose<false, true><<<g, 256, 0, st>>>(d_scalars, d_inf, (uint32_t)n, cbits, W, nb, hist, dg, rk, flags);
     }
     HIPCHK(c, hipEventRecord(c->ev[EV_DECOMP], st));
-    // K2/1: per-tile LDS histograms + ranks, then per-bucket prefix over tiles
-    if (tiled) {
-        msmk::k_tile_hist<<<dim3(T, W), msmk::TILE_BLOCK, (size_t)nb * 4, st>>>((uint32_t*)c->digits.p, (uint32_t*)c->tilecounts.p,
-                                                                              (uint32_t)n, nb, tile_len, T);
-        msmk::k_tile_prefix<<<grid1(tb, 256), 256, 0, st>>>((uint32_t*)c->tilecounts.p, hist, nb, T, (uint32_t)tb);
-    }
-    // K2/2: bucket offsets
-    msmk::k_scan_tiles<<<ntiles, msmk::SCAN_BLOCK, 0, st>>>(hist, offsets, (uint32_t*)c->blocksums.p, (uint32_t)tb);
-    msmk::k_scan_block_sums<<<1, msmk::SCAN_BLOCK, 0, st>>>((uint32_t*)c->blocksums.p, ntiles, flags + 4);
-    msmk::k_scan_add<<<grid1(tb, 256), 256, 0, st>>>(offsets, (uint32_t*)c->blocksums.p, (uint32_t)tb, flags + 4);
-    // K2/3: scatter
-    if (tiled) {
-        msmk::k_tile_scatter<<<dim3(T, W), msmk::TILE_BLOCK, (size_t)nb * 4, st>>>((uint32_t*)c->digits.p, offsets, (uint32_t*)c->tilecounts.p,
-                                                                                 (uint32_t*)c->sorted.p, (uint32_t)n, nb, tile_len, T);
+    if (two_level) {
+        const uint32_t nregions = W * ncoarse;
+        uint32_t* counts = (uint32_t*)c->ccounts.p;
+        uint32_t* rtotal = (uint32_t*)c->cregion.p;
+        uint32_t* rstart = rtotal + nregions;
+        uint32_t* tmp = (uint32_t*)c->heads.p;  // staging copy; k_accumulate only writes heads later
+        msmk::k_coarse_hist<<<dim3(NS, W), msmk::TILE_BLOCK, 0, st>>>((uint32_t*)c->digits.p, counts, (uint32_t)n, fine_bits, ncoarse, NS);
+        msmk::k_coarse_prefix<<<grid1(nregions, 256), 256, 0, st>>>(counts, rtotal, NS, nregions);
+        msmk::k_coarse_starts<<<1, msmk::SCAN_BLOCK, 0, st>>>(rtotal, rstart, nregions, flags + 4, offsets + tb);
+        msmk::k_coarse_scatter<<<dim3(NS, W), msmk::TILE_BLOCK, 0, st>>>((uint32_t*)c->digits.p, counts, rstart, tmp, (uint32_t)n, fine_bits,
+                                                                       idx_bits, ncoarse, NS);
+        msmk::k_fine_sort<<<dim3(ncoarse, W), 256, ((size_t)(1u << fine_bits) + msmk::FINE_CAP) * 4, st>>>(tmp, rstart, offsets,
+                                                                                                   (uint32_t*)c->sorted.p, nb, fine_bits,
+                                                                                                   idx_bits, ncoarse);
     } else {
-        dim3 g((unsigned)((n + 255) / 256), W);
-        msmk::k_scatter<<<g, 256, 0, st>>>((uint32_t*)c->digits.p, (uint32_t*)c->ranks.p, offsets, (uint32_t*)c->sorted.p, (uint32_t)n, nb);
+        // K2/1: per-tile LDS histograms, then per-bucket prefix over tiles
+        if (tiled) {
+            msmk::k_tile_hist<<<dim3(T, W), msmk::TILE_BLOCK, (size_t)nb * 4, st>>>((uint32_t*)c->digits.p, (uint32_t*)c->tilecounts.p,
+                                                                                  (uint32_t)n, nb, tile_len, T);
+            msmk::k_tile_prefix<<<grid1(tb, 256), 256, 0, st>>>((uint32_t*)c->tilecounts.p, hist, nb, T, (uint32_t)tb);
+        }
+        // K2/2: bucket offsets
+        msmk::k_scan_tiles<<<ntiles, msmk::SCAN_BLOCK, 0, st>>>(hist, offsets, (uint32_t*)c->blocksums.p, (uint32_t)tb);
+        msmk::k_scan_block_sums<<<1, msmk::SCAN_BLOCK, 0, st>>>((uint32_t*)c->blocksums.p, ntiles, flags + 4);
+        msmk::k_scan_add<<<grid1(tb, 256), 256, 0, st>>>(offsets, (uint32_t*)c->blocksums.p, (uint32_t)tb, flags + 4);
+        // K2/3: scatter
+        if (tiled) {
+            msmk::k_tile_scatter<<<dim3(T, W), msmk::TILE_BLOCK, (size_t)nb * 4, st>>>((uint32_t*)c->digits.p, offsets, (uint32_t*)c->tilecounts.p,
+                                                                                     (uint32_t*)c->sorted.p, (uint32_t)n, nb, tile_len, T);
+        } else {
+            dim3 g((unsigned)((n + 255) / 256), W);
+            msmk::k_scatter<<<g, 256, 0, st>>>((uint32_t*)c->digits.p, (uint32_t*)c->ranks.p, offsets, (uint32_t*)c->sorted.p, (uint32_t)n, nb);
+        }
     }
     HIPCHK(c, hipEventRecord(c->ev[EV_SORT], st));
     // K3: bucket accumulation (the graded kernel) -- bracketed by its own events on its own stream
@@ -597,6 +621,8 @@ int32_t msm_ctx_create(const msm_config_t* cfg, msm_ctx** out) {
         e = hipFuncSetAttribute((const void*)msmk::k_tile_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_HIST_BYTES);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)msmk::k_tile_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_HIST_BYTES);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)msmk::k_fine_sort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((128 + msmk::FINE_CAP) * 4));
     if (e != hipSuccess) {
         fail(nullptr, MSM_ERR_HIP, "context setup failed: %s", hipGetErrorString(e));
         msm_ctx_destroy(c);
@@ -639,7 +665,7 @@ void msm_ctx_destroy(msm_ctx* c) {
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         DevBuf* bufs[] = {&c->bases,   &c->inf,       &c->scalars, &c->digits,  &c->ranks,  &c->sorted, &c->hist,
                           &c->offsets, &c->blocksums, &c->buckets, &c->rc,      &c->qsums,   &c->flags,  &c->pow2,
-                          &c->heads,   &c->tails,     &c->chunkmap, &c->tilecounts, &c->ibases, &c->longlist};
+                          &c->heads,   &c->tails,     &c->chunkmap, &c->tilecounts, &c->ibases, &c->longlist, &c->ccounts, &c->cregion};
         for (DevBuf* b : bufs) release(*b);
         if (c->h_qsums) (void)hipHostFree(c->h_qsums);
         if (c->h_flags) (void)hipHostFree(c->h_flags);

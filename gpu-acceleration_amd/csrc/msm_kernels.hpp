@@ -326,6 +326,158 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_tile_scatter(const uint32_t* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// K2, two-level LDS counting sort (the default when n <= 2^(31 - fine_bits)).
+// Measured (profiles/NOTES_r1.md): stores leave L2 per wave instruction, so a scatter of 4-byte elements costs one
+// memory transaction per element whatever its locality (k_tile_scatter: 216 us at N = 2^20).  Here every store
+// instruction writes a contiguous run:
+//   level 1  bucket index = coarse (top <= 8 bits) | fine.  k_coarse_hist counts the 256 coarse bins of every
+//            (window, 16384-point sub-tile); k_coarse_prefix / k_coarse_starts turn the counts into write positions;
+//            k_coarse_scatter sorts a sub-tile by coarse bin IN LDS and copies each bin's run out contiguously.
+//            An element travels as  point index | fine << idx_bits | sign << 31.
+//   level 2  k_fine_sort: one workgroup per (window, coarse bin) region (~8192 elements): fine histogram in LDS ->
+//            the bucket offsets (this replaces k_tile_hist / k_tile_prefix / k_scan_*), LDS-staged placement,
+//            sequential copy-out.  Regions larger than the LDS staging area (skewed data) place directly.
+constexpr uint32_t SUBTILE = 16384;        // elements sorted in LDS by one level-1 workgroup (64 KB staging)
+constexpr uint32_t FINE_CAP = 16384;       // elements a level-2 workgroup can stage in LDS (64 KB: two workgroups per CU)
+constexpr uint32_t COARSE_BINS_MAX = 256;
+
+__global__ void __launch_bounds__(TILE_BLOCK) k_coarse_hist(const uint32_t* __restrict__ digits, uint32_t* __restrict__ counts,
+                                                            uint32_t n, uint32_t fine_bits, uint32_t ncoarse, uint32_t NS) {
+    __shared__ uint32_t s_h[COARSE_BINS_MAX];
+    const uint32_t st = blockIdx.x, w = blockIdx.y;
+    if (threadIdx.x < COARSE_BINS_MAX) s_h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t i0 = st * SUBTILE, i1 = min(n, i0 + SUBTILE);
+    const size_t row = (size_t)w * n;
+    for (uint32_t i = i0 + threadIdx.x; i < i1; i += TILE_BLOCK) {
+        uint32_t d = digits[row + i];
+        if (d != DIGIT_SKIP) atomicAdd(&s_h[(d & ~SIGN_BIT) >> fine_bits], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < ncoarse) counts[((size_t)w * ncoarse + threadIdx.x) * NS + st] = s_h[threadIdx.x];  // [w][bin][sub-tile]
+}
+// per (window, bin): exclusive prefix over the sub-tiles in place; total of the region
+__global__ void k_coarse_prefix(uint32_t* __restrict__ counts, uint32_t* __restrict__ region_total, uint32_t NS, uint32_t nregions) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nregions) return;
+    uint32_t* p = counts + (size_t)r * NS;
+    uint32_t run = 0;
+    for (uint32_t s = 0; s < NS; s++) {
+        uint32_t v = p[s];
+        p[s] = run;
+        run += v;
+    }
+    region_total[r] = run;
+}
+// single workgroup: exclusive scan of the region totals (any count) -> region_start[0..nregions], grand total
+__global__ void k_coarse_starts(const uint32_t* __restrict__ region_total, uint32_t* __restrict__ region_start, uint32_t nregions,
+                                uint32_t* __restrict__ total_out, uint32_t* __restrict__ offsets_end) {
+    uint32_t running = 0;
+    for (uint32_t start = 0; start < nregions; start += SCAN_BLOCK) {
+        uint32_t idx = start + threadIdx.x;
+        uint32_t v = idx < nregions ? region_total[idx] : 0u;
+        uint32_t total;
+        uint32_t ex = block_exclusive_scan(v, &total);
+        if (idx < nregions) region_start[idx] = running + ex;
+        running += total;
+    }
+    if (threadIdx.x == 0) {
+        region_start[nregions] = running;
+        *total_out = running;    // number of sorted entries (non-zero digits)
+        *offsets_end = running;  // offsets[W * nb]
+    }
+}
+__global__ void __launch_bounds__(TILE_BLOCK) k_coarse_scatter(const uint32_t* __restrict__ digits, const uint32_t* __restrict__ counts,
+                                                               const uint32_t* __restrict__ region_start, uint32_t* __restrict__ tmp,
+                                                               uint32_t n, uint32_t fine_bits, uint32_t idx_bits, uint32_t ncoarse,
+                                                               uint32_t NS) {
+    __shared__ uint32_t s_stage[SUBTILE];
+    __shared__ uint32_t s_lstart[COARSE_BINS_MAX + 1];  // local start of each bin's run in s_stage
+    __shared__ uint32_t s_cur[COARSE_BINS_MAX];
+    __shared__ uint32_t s_gbase[COARSE_BINS_MAX];        // where the run goes in tmp
+    const uint32_t st = blockIdx.x, w = blockIdx.y;
+    const uint32_t i0 = st * SUBTILE, i1 = min(n, i0 + SUBTILE);
+    const size_t row = (size_t)w * n;
+    // this sub-tile's bin counts = differences of the prefixes over sub-tiles (last sub-tile: region total - prefix)
+    uint32_t cnt = 0;
+    if (threadIdx.x < ncoarse) {
+        const size_t r = (size_t)w * ncoarse + threadIdx.x;
+        const uint32_t pre = counts[r * NS + st];
+        const uint32_t nxt = (st + 1 < NS) ? counts[r * NS + st + 1] : (region_start[r + 1] - region_start[r]);
+        cnt = nxt - pre;
+        s_gbase[threadIdx.x] = region_start[r] + pre;
+    }
+    // exclusive prefix of the <= 256 bin counts (Hillis-Steele in LDS; every thread of the workgroup reaches the barriers)
+    if (threadIdx.x < COARSE_BINS_MAX) s_cur[threadIdx.x] = threadIdx.x < ncoarse ? cnt : 0u;
+    __syncthreads();
+    for (uint32_t d = 1; d < COARSE_BINS_MAX; d <<= 1) {
+        uint32_t v = 0;
+        if (threadIdx.x < COARSE_BINS_MAX && threadIdx.x >= d) v = s_cur[threadIdx.x - d];
+        __syncthreads();
+        if (threadIdx.x < COARSE_BINS_MAX) s_cur[threadIdx.x] += v;
+        __syncthreads();
+    }
+    if (threadIdx.x < ncoarse) s_lstart[threadIdx.x + 1] = s_cur[threadIdx.x];  // inclusive -> start of the next bin
+    if (threadIdx.x == 0) s_lstart[0] = 0;
+    __syncthreads();
+    if (threadIdx.x < ncoarse) s_cur[threadIdx.x] = s_lstart[threadIdx.x];
+    __syncthreads();
+    const uint32_t fine_mask = (1u << fine_bits) - 1u;
+    for (uint32_t i = i0 + threadIdx.x; i < i1; i += TILE_BLOCK) {
+        uint32_t d = digits[row + i];
+        if (d == DIGIT_SKIP) continue;
+        uint32_t bkt = d & ~SIGN_BIT;
+        uint32_t pos = atomicAdd(&s_cur[bkt >> fine_bits], 1u);
+        s_stage[pos] = i | ((bkt & fine_mask) << idx_bits) | (d & SIGN_BIT);
+    }
+    __syncthreads();
+    // copy-out: a wavefront takes a bin at a time and writes its run with consecutive lanes on consecutive words
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (uint32_t b = wv; b < ncoarse; b += TILE_BLOCK / 64) {
+        const uint32_t ls = s_lstart[b], le = s_lstart[b + 1], gb = s_gbase[b];
+        for (uint32_t k = ls + lane; k < le; k += 64) tmp[gb + (k - ls)] = s_stage[k];
+    }
+}
+__global__ void __launch_bounds__(256) k_fine_sort(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ region_start,
+                                                   uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted, uint32_t nb,
+                                                   uint32_t fine_bits, uint32_t idx_bits, uint32_t ncoarse) {
+    extern __shared__ uint32_t s_fine[];  // [nfine] cursors | [FINE_CAP] staging
+    const uint32_t cb = blockIdx.x, w = blockIdx.y;
+    const uint32_t nfine = 1u << fine_bits;
+    uint32_t* s_cur = s_fine;
+    uint32_t* s_out = s_fine + nfine;
+    const uint32_t r = w * ncoarse + cb;
+    const uint32_t rs = region_start[r], re = region_start[r + 1], S = re - rs;
+    const uint32_t fine_mask = nfine - 1u, idx_mask = (1u << idx_bits) - 1u;
+    for (uint32_t f = threadIdx.x; f < nfine; f += blockDim.x) s_cur[f] = 0;
+    __syncthreads();
+    for (uint32_t j = rs + threadIdx.x; j < re; j += blockDim.x) atomicAdd(&s_cur[(tmp[j] >> idx_bits) & fine_mask], 1u);
+    __syncthreads();
+    // exclusive prefix of the fine counts (nfine <= 128 here: one pass of the workgroup scan)
+    uint32_t v = threadIdx.x < nfine ? s_cur[threadIdx.x] : 0u;
+    uint32_t tot;
+    uint32_t ex = block_exclusive_scan(v, &tot);
+    __syncthreads();
+    if (threadIdx.x < nfine) {
+        s_cur[threadIdx.x] = ex;                                                            // local cursor
+        offsets[(size_t)w * nb + ((size_t)cb << fine_bits) + threadIdx.x] = rs + ex;       // the bucket's CSC column pointer
+    }
+    __syncthreads();
+    const bool staged = S <= FINE_CAP;
+    for (uint32_t j = rs + threadIdx.x; j < re; j += blockDim.x) {
+        uint32_t e = tmp[j];
+        uint32_t pos = atomicAdd(&s_cur[(e >> idx_bits) & fine_mask], 1u);
+        uint32_t val = (e & idx_mask) | (e & SIGN_BIT);
+        if (staged) s_out[pos] = val;
+        else sorted[rs + pos] = val;  // skewed data: region does not fit LDS, place directly
+    }
+    if (staged) {
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < S; k += blockDim.x) sorted[rs + k] = s_out[k];
+    }
+}
+
 // K2 phase 3 (fallback path): place every (point, sign) at offsets[bucket] + rank
 __global__ void k_scatter(const uint32_t* __restrict__ digits, const uint32_t* __restrict__ ranks,
                           const uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted, uint32_t n, uint32_t nb) {
