@@ -342,13 +342,12 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
         uint32_t* rstart = rtotal + nregions;
         uint32_t* tmp = (uint32_t*)c->heads.p;  // staging copy; k_accumulate only writes heads later
         msmk::k_coarse_hist<<<dim3(NS, W), msmk::TILE_BLOCK, 0, st>>>((uint32_t*)c->digits.p, counts, (uint32_t)n, fine_bits, ncoarse, NS);
-        msmk::k_coarse_prefix<<<grid1(nregions, 256), 256, 0, st>>>(counts, rtotal, NS, nregions);
+        msmk::k_coarse_prefix<<<grid1(nregions, 256), 256, 0, st>>>(counts, rtotal, NS, ncoarse, nregions);
         msmk::k_coarse_starts<<<1, msmk::SCAN_BLOCK, 0, st>>>(rtotal, rstart, nregions, flags + 4, offsets + tb);
         msmk::k_coarse_scatter<<<dim3(NS, W), msmk::TILE_BLOCK, 0, st>>>((uint32_t*)c->digits.p, counts, rstart, tmp, (uint32_t)n, fine_bits,
                                                                        idx_bits, ncoarse, NS);
-        msmk::k_fine_sort<<<dim3(ncoarse, W), 256, ((size_t)(1u << fine_bits) + msmk::FINE_CAP) * 4, st>>>(tmp, rstart, offsets,
-                                                                                                   (uint32_t*)c->sorted.p, nb, fine_bits,
-                                                                                                   idx_bits, ncoarse);
+        msmk::k_fine_sort<<<dim3(ncoarse, W), msmk::FINE_BLOCK, 0, st>>>(tmp, rstart, offsets, (uint32_t*)c->sorted.p, nb, fine_bits, idx_bits,
+                                                                        ncoarse);
     } else {
         // K2/1: per-tile LDS histograms, then per-bucket prefix over tiles
         if (tiled) {
@@ -621,8 +620,7 @@ int32_t msm_ctx_create(const msm_config_t* cfg, msm_ctx** out) {
         e = hipFuncSetAttribute((const void*)msmk::k_tile_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_HIST_BYTES);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)msmk::k_tile_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_HIST_BYTES);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)msmk::k_fine_sort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((128 + msmk::FINE_CAP) * 4));
+
     if (e != hipSuccess) {
         fail(nullptr, MSM_ERR_HIP, "context setup failed: %s", hipGetErrorString(e));
         msm_ctx_destroy(c);

@@ -355,17 +355,20 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_coarse_hist(const uint32_t* __re
         if (d != DIGIT_SKIP) atomicAdd(&s_h[(d & ~SIGN_BIT) >> fine_bits], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < ncoarse) counts[((size_t)w * ncoarse + threadIdx.x) * NS + st] = s_h[threadIdx.x];  // [w][bin][sub-tile]
+    if (threadIdx.x < ncoarse) counts[((size_t)w * NS + st) * ncoarse + threadIdx.x] = s_h[threadIdx.x];  // [w][sub-tile][bin]
 }
-// per (window, bin): exclusive prefix over the sub-tiles in place; total of the region
-__global__ void k_coarse_prefix(uint32_t* __restrict__ counts, uint32_t* __restrict__ region_total, uint32_t NS, uint32_t nregions) {
+// per (window, bin): exclusive prefix over the sub-tiles in place; total of the region.  Threads of a wavefront own
+// consecutive bins, so every step reads one coalesced row of counts[w][sub-tile][*]
+__global__ void k_coarse_prefix(uint32_t* __restrict__ counts, uint32_t* __restrict__ region_total, uint32_t NS, uint32_t ncoarse,
+                                uint32_t nregions) {
     uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nregions) return;
-    uint32_t* p = counts + (size_t)r * NS;
+    const uint32_t w = r / ncoarse, b = r % ncoarse;
+    uint32_t* p = counts + (size_t)w * NS * ncoarse + b;
     uint32_t run = 0;
     for (uint32_t s = 0; s < NS; s++) {
-        uint32_t v = p[s];
-        p[s] = run;
+        uint32_t v = p[(size_t)s * ncoarse];
+        p[(size_t)s * ncoarse] = run;
         run += v;
     }
     region_total[r] = run;
@@ -403,8 +406,9 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_coarse_scatter(const uint32_t* _
     uint32_t cnt = 0;
     if (threadIdx.x < ncoarse) {
         const size_t r = (size_t)w * ncoarse + threadIdx.x;
-        const uint32_t pre = counts[r * NS + st];
-        const uint32_t nxt = (st + 1 < NS) ? counts[r * NS + st + 1] : (region_start[r + 1] - region_start[r]);
+        const uint32_t* cw = counts + (size_t)w * NS * ncoarse + threadIdx.x;
+        const uint32_t pre = cw[(size_t)st * ncoarse];
+        const uint32_t nxt = (st + 1 < NS) ? cw[(size_t)(st + 1) * ncoarse] : (region_start[r + 1] - region_start[r]);
         cnt = nxt - pre;
         s_gbase[threadIdx.x] = region_start[r] + pre;
     }
@@ -439,42 +443,66 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_coarse_scatter(const uint32_t* _
         for (uint32_t k = ls + lane; k < le; k += 64) tmp[gb + (k - ls)] = s_stage[k];
     }
 }
-__global__ void __launch_bounds__(256) k_fine_sort(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ region_start,
-                                                   uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted, uint32_t nb,
-                                                   uint32_t fine_bits, uint32_t idx_bits, uint32_t ncoarse) {
-    extern __shared__ uint32_t s_fine[];  // [nfine] cursors | [FINE_CAP] staging
+constexpr int FINE_BLOCK = 1024;
+constexpr int FINE_PER_THREAD = FINE_CAP / FINE_BLOCK;  // 16 elements live in registers between the two phases
+__global__ void __launch_bounds__(FINE_BLOCK) k_fine_sort(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ region_start,
+                                                          uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted, uint32_t nb,
+                                                          uint32_t fine_bits, uint32_t idx_bits, uint32_t ncoarse) {
+    __shared__ uint32_t s_cur[128];
+    __shared__ uint32_t s_out[FINE_CAP];
     const uint32_t cb = blockIdx.x, w = blockIdx.y;
     const uint32_t nfine = 1u << fine_bits;
-    uint32_t* s_cur = s_fine;
-    uint32_t* s_out = s_fine + nfine;
     const uint32_t r = w * ncoarse + cb;
     const uint32_t rs = region_start[r], re = region_start[r + 1], S = re - rs;
     const uint32_t fine_mask = nfine - 1u, idx_mask = (1u << idx_bits) - 1u;
-    for (uint32_t f = threadIdx.x; f < nfine; f += blockDim.x) s_cur[f] = 0;
+    const bool staged = S <= FINE_CAP;
+    if (threadIdx.x < 128) s_cur[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t j = rs + threadIdx.x; j < re; j += blockDim.x) atomicAdd(&s_cur[(tmp[j] >> idx_bits) & fine_mask], 1u);
+    uint32_t e[FINE_PER_THREAD];
+    if (staged) {  // the whole region in registers: FINE_PER_THREAD independent loads per thread
+#pragma unroll
+        for (int k = 0; k < FINE_PER_THREAD; k++) {
+            uint32_t j = rs + threadIdx.x + k * FINE_BLOCK;
+            e[k] = j < re ? tmp[j] : DIGIT_SKIP;
+        }
+#pragma unroll
+        for (int k = 0; k < FINE_PER_THREAD; k++)
+            if (e[k] != DIGIT_SKIP) atomicAdd(&s_cur[(e[k] >> idx_bits) & fine_mask], 1u);
+    } else {
+        for (uint32_t j = rs + threadIdx.x; j < re; j += FINE_BLOCK) atomicAdd(&s_cur[(tmp[j] >> idx_bits) & fine_mask], 1u);
+    }
     __syncthreads();
-    // exclusive prefix of the fine counts (nfine <= 128 here: one pass of the workgroup scan)
-    uint32_t v = threadIdx.x < nfine ? s_cur[threadIdx.x] : 0u;
-    uint32_t tot;
-    uint32_t ex = block_exclusive_scan(v, &tot);
+    // exclusive prefix of the <= 128 fine counts (Hillis-Steele in LDS)
+    for (uint32_t d = 1; d < 128; d <<= 1) {
+        uint32_t v = 0;
+        if (threadIdx.x < 128 && threadIdx.x >= d) v = s_cur[threadIdx.x - d];
+        __syncthreads();
+        if (threadIdx.x < 128) s_cur[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t ex = 0;
+    if (threadIdx.x < nfine) ex = threadIdx.x ? s_cur[threadIdx.x - 1] : 0u;  // inclusive -> exclusive
     __syncthreads();
     if (threadIdx.x < nfine) {
-        s_cur[threadIdx.x] = ex;                                                            // local cursor
-        offsets[(size_t)w * nb + ((size_t)cb << fine_bits) + threadIdx.x] = rs + ex;       // the bucket's CSC column pointer
+        s_cur[threadIdx.x] = ex;                                                       // local cursor
+        offsets[(size_t)w * nb + ((size_t)cb << fine_bits) + threadIdx.x] = rs + ex;  // the bucket's CSC column pointer
     }
     __syncthreads();
-    const bool staged = S <= FINE_CAP;
-    for (uint32_t j = rs + threadIdx.x; j < re; j += blockDim.x) {
-        uint32_t e = tmp[j];
-        uint32_t pos = atomicAdd(&s_cur[(e >> idx_bits) & fine_mask], 1u);
-        uint32_t val = (e & idx_mask) | (e & SIGN_BIT);
-        if (staged) s_out[pos] = val;
-        else sorted[rs + pos] = val;  // skewed data: region does not fit LDS, place directly
-    }
     if (staged) {
+#pragma unroll
+        for (int k = 0; k < FINE_PER_THREAD; k++) {
+            if (e[k] == DIGIT_SKIP) continue;
+            uint32_t pos = atomicAdd(&s_cur[(e[k] >> idx_bits) & fine_mask], 1u);
+            s_out[pos] = (e[k] & idx_mask) | (e[k] & SIGN_BIT);
+        }
         __syncthreads();
-        for (uint32_t k = threadIdx.x; k < S; k += blockDim.x) sorted[rs + k] = s_out[k];
+        for (uint32_t k = threadIdx.x; k < S; k += FINE_BLOCK) sorted[rs + k] = s_out[k];
+    } else {  // skewed data: the region does not fit LDS, place directly
+        for (uint32_t j = rs + threadIdx.x; j < re; j += FINE_BLOCK) {
+            uint32_t v = tmp[j];
+            uint32_t pos = atomicAdd(&s_cur[(v >> idx_bits) & fine_mask], 1u);
+            sorted[rs + pos] = (v & idx_mask) | (v & SIGN_BIT);
+        }
     }
 }
 
