@@ -305,8 +305,13 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
     // Counting-sort plan: when one window's histogram fits LDS (nb <= 32768) the bucket counts and arrival
     // ranks come from per-tile LDS histograms, otherwise from device-scope atomics in k_decompose.
     const bool tiled = (size_t)nb * 4 <= LDS_HIST_BYTES;
-    // two-level LDS sort: coarse = top min(kb, 8) bits of the bucket index, fine = the rest (<= 7 bits)
-    const uint32_t coarse_bits = kb < 8 ? kb : 8, fine_bits = kb - coarse_bits, idx_bits = 31 - fine_bits;
+    // two-level LDS sort: coarse = top bits of the bucket index, fine = the rest (<= 7 bits)
+    // (8 coarse bits up to n = 2^21, then 9 and 10, so that a (window, coarse bin) region stays ~8192 elements and
+    // fits the fine sort's LDS staging)
+    uint32_t coarse_bits = 8;
+    while (coarse_bits < 10 && (n >> coarse_bits) > 8192) coarse_bits++;
+    if (coarse_bits > kb) coarse_bits = kb;
+    const uint32_t fine_bits = kb - coarse_bits, idx_bits = 31 - fine_bits;
     const uint32_t ncoarse = 1u << coarse_bits;
     const bool two_level = tiled && fine_bits <= 7 && n <= ((size_t)1 << idx_bits) && !std::getenv("MSM_HIP_DIRECT_SCATTER");
     const uint32_t NS = (uint32_t)((n + msmk::SUBTILE - 1) / msmk::SUBTILE);

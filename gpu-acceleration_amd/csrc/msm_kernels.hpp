@@ -331,7 +331,8 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_tile_scatter(const uint32_t* __r
 // Measured (profiles/NOTES_r1.md): stores leave L2 per wave instruction, so a scatter of 4-byte elements costs one
 // memory transaction per element whatever its locality (k_tile_scatter: 216 us at N = 2^20).  Here every store
 // instruction writes a contiguous run:
-//   level 1  bucket index = coarse (top <= 8 bits) | fine.  k_coarse_hist counts the 256 coarse bins of every
+//   level 1  bucket index = coarse (top 8..10 bits, so that a region holds ~8192 elements) | fine.  k_coarse_hist
+//            counts the coarse bins of every
 //            (window, 16384-point sub-tile); k_coarse_prefix / k_coarse_starts turn the counts into write positions;
 //            k_coarse_scatter sorts a sub-tile by coarse bin IN LDS and copies each bin's run out contiguously.
 //            An element travels as  point index | fine << idx_bits | sign << 31.
@@ -340,7 +341,7 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_tile_scatter(const uint32_t* __r
 //            sequential copy-out.  Regions larger than the LDS staging area (skewed data) place directly.
 constexpr uint32_t SUBTILE = 16384;        // elements sorted in LDS by one level-1 workgroup (64 KB staging)
 constexpr uint32_t FINE_CAP = 16384;       // elements a level-2 workgroup can stage in LDS (64 KB: two workgroups per CU)
-constexpr uint32_t COARSE_BINS_MAX = 256;
+constexpr uint32_t COARSE_BINS_MAX = 1024;  // == TILE_BLOCK: one thread per coarse bin
 
 __global__ void __launch_bounds__(TILE_BLOCK) k_coarse_hist(const uint32_t* __restrict__ digits, uint32_t* __restrict__ counts,
                                                             uint32_t n, uint32_t fine_bits, uint32_t ncoarse, uint32_t NS) {
@@ -412,7 +413,7 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_coarse_scatter(const uint32_t* _
         cnt = nxt - pre;
         s_gbase[threadIdx.x] = region_start[r] + pre;
     }
-    // exclusive prefix of the <= 256 bin counts (Hillis-Steele in LDS; every thread of the workgroup reaches the barriers)
+    // exclusive prefix of the bin counts (Hillis-Steele in LDS; every thread of the workgroup reaches the barriers)
     if (threadIdx.x < COARSE_BINS_MAX) s_cur[threadIdx.x] = threadIdx.x < ncoarse ? cnt : 0u;
     __syncthreads();
     for (uint32_t d = 1; d < COARSE_BINS_MAX; d <<= 1) {
