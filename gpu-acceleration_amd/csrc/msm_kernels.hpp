@@ -549,7 +549,7 @@ __global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__
                                                     const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ chunk_bucket,
                                                     uint32_t* __restrict__ buckets, uint32_t* __restrict__ heads,
                                                     uint32_t* __restrict__ tails, const uint32_t* __restrict__ total_pairs_ptr,
-                                                    uint32_t L) {
+                                                    uint32_t L, uint32_t total_buckets) {
     const uint32_t total_pairs = *total_pairs_ptr;  // non-zero digits, known only on the device (k_scan_block_sums)
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t j0 = t * L;
@@ -587,10 +587,19 @@ __global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__
         }
         if (j == seg_end) {  // bucket k is finished: flush and move to the bucket that owns entry j
             store_xyzz((is_head ? heads + (size_t)t * XW : buckets + (size_t)k * XW), acc);
-            do {
-                k++;
+            k++;
+            seg_end = offsets[k + 1];
+            if (seg_end <= j) {  // empty buckets follow: binary-search the bucket that owns entry j (skewed scalars
+                                 // leave thousands of empty buckets between two occupied ones)
+                uint32_t lo = k + 1, hi = total_buckets - 1;
+                while (lo < hi) {
+                    uint32_t mid = (lo + hi) >> 1;
+                    if (offsets[mid + 1] > j) hi = mid;
+                    else lo = mid + 1;
+                }
+                k = lo;
                 seg_end = offsets[k + 1];
-            } while (seg_end <= j);
+            }
             is_head = false;
             acc = xyzz_identity();
         }
