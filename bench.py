@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--log-n", type=int, default=LOG_N, help="total instance size (default 2^20, the BASELINE metric)")
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--debug-same-device", action="store_true",
+                    help="functional check of the N>1 path on a 1-GPU box: every rank uses cuda:0 and the exchange runs over gloo")
     args = ap.parse_args()
 
     import torch
@@ -65,11 +67,17 @@ def main():
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MSM engine has no CPU fallback")
+    if args.debug_same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    xdev = None if args.debug_same_device else dev  # device the 96-byte partials are exchanged on
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL on ROCm
+        if args.debug_same_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # RCCL on ROCm
 
     n_total = 1 << args.log_n
     lo = rank * n_total // world
@@ -90,7 +98,7 @@ def main():
         # HIP pipeline on this rank's shard, then (N > 1) the exchange step: EC addition is not an RCCL
         # reduction op, so the "all-reduce" of partial group elements is an all-gather of 96 bytes per rank
         # over RCCL + a local fold in rank order (identical on all ranks)
-        return md.distributed_msm_device(ctx, d_bases.data_ptr(), d_scalars.data_ptr(), n_local, device=dev)
+        return md.distributed_msm_device(ctx, d_bases.data_ptr(), d_scalars.data_ptr(), n_local, device=xdev)
 
     def fence():
         if world > 1:
@@ -109,7 +117,7 @@ def main():
     acc_avg_ms, acc_launches = ctx.accumulate_kernel_stats()
     tm = ctx.timings()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev if xdev is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed * 1e3 / args.steps
