@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include "../gpu-acceleration_amd/csrc/fp_bn254_8x32.hpp"  // the r1a field these numbers were taken with
 #include "../gpu-acceleration_amd/csrc/ec_bn254.hpp"
 using namespace bn254;
 
@@ -119,16 +120,17 @@ __global__ void k_lshladd64(uint32_t* out, uint32_t a, uint32_t b) {
 constexpr int FP_ITER = 256;
 __global__ void k_fpmul(uint32_t* out, const uint32_t* in) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    fp x, y;
+    bn254_8x32::fp x, y;
     for (int k = 0; k < 8; k++) { x.v[k] = in[k] ^ (i * 2654435761u >> (k + 3)); y.v[k] = in[8 + k]; }
     x.v[7] &= 0x0FFFFFFFu; y.v[7] &= 0x0FFFFFFFu;
-    for (int k = 0; k < FP_ITER; k++) { x = fp_mul(x, y); y = fp_mul(y, x); }
+    for (int k = 0; k < FP_ITER; k++) { x = bn254_8x32::fp_mul(x, y); y = bn254_8x32::fp_mul(y, x); }
     out[i] = x.v[0] ^ y.v[3];
 }
 __global__ void k_madd(uint32_t* out, const uint32_t* in) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     affine q;
-    for (int k = 0; k < 8; k++) { q.x.v[k] = in[k]; q.y.v[k] = in[8 + k]; }
+    for (int k = 0; k < 9; k++) { q.x.v[k] = in[k] & FP_MASK; q.y.v[k] = in[8 + k] & FP_MASK; }
+    q.x.v[8] &= 0xFFFFF; q.y.v[8] &= 0xFFFFF;
     xyzz acc = xyzz_from_affine(q);
     acc.x.v[0] ^= (i & 0xff);  // not on the curve: fine for timing, the formulas are branch-free in the common case
     for (int k = 0; k < FP_ITER / 4; k++) xyzz_madd(acc, q);

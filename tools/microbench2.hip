@@ -1,11 +1,14 @@
 // tools/microbench2.hip -- prototype + timing of the 9 x 29-bit carry-free Montgomery multiplication
+// (mul29 below is the prototype that became bn254::fp_mul in csrc/fp_bn254.hpp)
 // against the 8 x 32-bit CIOS of fp_bn254.hpp (see profiles/NOTES_r1.md: carries cost as much as multiplies
 // on gfx950, so fewer carry instructions beat fewer multiplies).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
-#include "../gpu-acceleration_amd/csrc/fp_bn254.hpp"
-using namespace bn254;
+#include "../gpu-acceleration_amd/csrc/fp_bn254_8x32.hpp"  // A/B baseline: 8 x 32-bit CIOS with carry chains
+#include "../gpu-acceleration_amd/csrc/fp_bn254.hpp"       // the product field (this prototype, productised)
+using bn254_8x32::fp;
+using bn254_8x32::fp_mul;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
 struct fq29 { uint32_t v[9]; };
