@@ -264,7 +264,7 @@ struct PipeGeom {
 // Queue the whole device pipeline for one (chunk of an) MSM on stream st; the W*(kb+1) bit sums and the flag words
 // are copied to h_qsums_dst / h_flags_dst (pinned) at the end.  No host synchronisation here.
 int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, const uint32_t* d_scalars, size_t n,
-                         hipStream_t st, uint32_t* h_qsums_dst, uint32_t* h_flags_dst, PipeGeom* geom) {
+                         hipStream_t st, uint32_t* h_qsums_dst, uint32_t* h_flags_dst, PipeGeom* geom, uint32_t scalars_mont = 0) {
     if (n > 0x7FFFFFFFull) return fail(c, MSM_ERR_BAD_ARG, "n = %zu exceeds 2^31-1 points per context call", n);
     msm_plan_t pl;
     int32_t rc = make_plan(n, c->cfg.window_bits, c->cfg.flags, &pl);
@@ -334,10 +334,10 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
     {
         uint32_t *dg = (uint32_t*)c->digits.p, *rk = (uint32_t*)c->ranks.p;
         dim3 g = grid1(n, 256);
-        if (pl.signed_digits && tiled) msmk::k_decompose<true, false><<<g, 256, 0, st>>>(d_scalars, d_inf, (uint32_t)n, cbits, W, nb, hist, dg, rk, flags);
-        else if (pl.signed_digits) msmk::k_decompose<true, true><<<g, 256, 0, st>>>(d_scalars, d_inf, (uint32_t)n, cbits, W, nb, hist, dg, rk, flags);
-        else if (tiled) msmk::k_decompose<false, false><<<g, 256, 0, st>>>(d_scalars, d_inf, (uint32_t)n, cbits, W, nb, hist, dg, rk, flags);
-        else msmk::k_decompose<false, true><<<g, 256, 0, st>>>(d_scalars, d_inf, (uint32_t)n, cbits, W, nb, hist, dg, rk, flags);
+        if (pl.signed_digits && tiled) msmk::k_decompose<true, false><<<g, 256, 0, st>>>(d_scalars, d_inf, (uint32_t)n, cbits, W, nb, hist, dg, rk, flags, scalars_mont);
+        else if (pl.signed_digits) msmk::k_decompose<true, true><<<g, 256, 0, st>>>(d_scalars, d_inf, (uint32_t)n, cbits, W, nb, hist, dg, rk, flags, scalars_mont);
+        else if (tiled) msmk::k_decompose<false, false><<<g, 256, 0, st>>>(d_scalars, d_inf, (uint32_t)n, cbits, W, nb, hist, dg, rk, flags, scalars_mont);
+        else msmk::k_decompose<false, true><<<g, 256, 0, st>>>(d_scalars, d_inf, (uint32_t)n, cbits, W, nb, hist, dg, rk, flags, scalars_mont);
     }
     HIPCHK(c, hipEventRecord(c->ev[EV_DECOMP], st));
     if (two_level) {
@@ -457,9 +457,9 @@ int32_t check_flags(msm_ctx* c, const uint32_t* h_flags) {
 
 // The pipeline proper: everything in HBM, one stream.  d_bases: INTERNAL-domain packed coordinates.
 int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, const uint32_t* d_scalars, size_t n,
-                     hipStream_t st, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf) {
+                     hipStream_t st, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf, uint32_t scalars_mont = 0) {
     PipeGeom g;
-    int32_t rc = enqueue_pipeline(c, d_bases, d_inf, d_scalars, n, st, c->h_qsums, c->h_flags, &g);
+    int32_t rc = enqueue_pipeline(c, d_bases, d_inf, d_scalars, n, st, c->h_qsums, c->h_flags, &g, scalars_mont);
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());
@@ -724,6 +724,41 @@ int32_t msm_bn254_g1(msm_ctx* c, const uint32_t* bases_xy, uint32_t base_form, c
     if ((rc = upload_bases_locked(c, bases_xy, base_form, inf_mask, n))) return rc;
     rc = run_pipeline(c, (const uint32_t*)c->ibases.p, inf_mask ? (const uint8_t*)c->inf.p : nullptr,
                       (const uint32_t*)c->scalars.p, n, c->stream, out_jac, out_aff, out_inf);
+    if (rc) return rc;
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, c->ev[EV_START], c->ev[EV_H2D]);
+    c->tm.h2d_ms = ms;
+    (void)hipEventElapsedTime(&ms, c->ev[EV_H2D], c->ev[EV_CONVERT]);
+    c->tm.convert_ms = ms;
+    c->tm.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return MSM_OK;
+}
+
+int32_t msm_bn254_g1_arkworks(msm_ctx* c, const void* bases, size_t stride, size_t x_off, size_t y_off, size_t inf_off,
+                              const uint32_t* scalars_mont, size_t n, uint32_t out_jac[24], uint32_t out_aff[16], uint8_t* out_inf) {
+    int32_t rc = check_common(c, bases, scalars_mont, n);
+    if (rc) return rc;
+    const bool has_inf = inf_off != (size_t)-1;
+    if (stride < 64 || (stride & 3) || (x_off & 3) || (y_off & 3) || x_off + 32 > stride || y_off + 32 > stride ||
+        (has_inf && inf_off >= stride) || ((uintptr_t)bases & 3))
+        return fail(c, MSM_ERR_BAD_ARG, "bad G1Affine layout: stride %zu x %zu y %zu inf %zu", stride, x_off, y_off, inf_off);
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    auto t0 = std::chrono::steady_clock::now();
+    c->resident_n = 0;
+    HIPCHK(c, hipEventRecord(c->ev[EV_START], c->stream));
+    if ((rc = ensure(c, c->scalars, n * 32))) return rc;
+    if ((rc = ensure(c, c->bases, n * stride))) return rc;
+    if ((rc = ensure(c, c->ibases, n * 64))) return rc;
+    if ((rc = ensure(c, c->inf, n))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->scalars.p, scalars_mont, n * 32, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->bases.p, bases, n * stride, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[EV_H2D], c->stream));
+    msmk::k_import_ark<<<grid1(2 * n, 256), 256, 0, c->stream>>>((const uint8_t*)c->bases.p, (uint64_t)stride, (uint32_t)x_off, (uint32_t)y_off,
+                                                               has_inf ? (uint32_t)inf_off : 0u, has_inf ? 1u : 0u, (uint32_t)n,
+                                                               (uint32_t*)c->ibases.p, (uint8_t*)c->inf.p);
+    rc = run_pipeline(c, (const uint32_t*)c->ibases.p, (const uint8_t*)c->inf.p, (const uint32_t*)c->scalars.p, n, c->stream, out_jac,
+                      out_aff, out_inf, 1u);
     if (rc) return rc;
     float ms = 0;
     (void)hipEventElapsedTime(&ms, c->ev[EV_START], c->ev[EV_H2D]);

@@ -122,6 +122,25 @@ __global__ void k_convert_bases(const uint32_t* __restrict__ in, uint32_t* __res
     store_words8(out + (size_t)i * 8, w);
 }
 
+// Zero-copy ingestion of an array of arkworks `G1Affine` structs: the struct array is copied to
+// HBM as it is and read here through (stride, x offset, y offset, infinity offset) -- the layout is probed by the
+// Rust shim with addr_of!, never assumed.  Coordinates are Fq Montgomery words (R = 2^256).
+__global__ void k_import_ark(const uint8_t* __restrict__ raw, uint64_t stride, uint32_t x_off, uint32_t y_off, uint32_t inf_off,
+                             uint32_t has_inf, uint32_t n, uint32_t* __restrict__ out, uint8_t* __restrict__ inf_out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per coordinate
+    if (i >= 2u * n) return;
+    const uint32_t pt = i >> 1, which = i & 1u;
+    const uint8_t* rec = raw + (size_t)pt * stride;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(rec + (which ? y_off : x_off));  // 4-byte aligned (checked on the host)
+    uint32_t w[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) w[k] = src[k];
+    fp v = fp_mul(fp_unpack(w), fp_const(FP29_IN_MONT));
+    fp_pack(w, fp_reduce_lt2p(v));
+    store_words8(out + (size_t)i * 8, w);
+    if (which == 0 && inf_out) inf_out[pt] = has_inf ? (rec[inf_off] != 0) : 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // K1 scalar half + K2 phase 1.  One thread per point: slice the scalar into W radix-2^c digits,
 // recode to signed digits d in [-(H-1), H] (v > H  =>  d = v - 2H, carry 1), and count the bucket.
@@ -135,17 +154,54 @@ __device__ __forceinline__ uint32_t scalar_window(const uint32_t s[8], uint32_t 
     return (uint32_t)v & ((1u << c) - 1u);
 }
 
+// arkworks holds Fr in Montgomery form (R = 2^256 mod r); the reference converts every scalar on the CPU
+// (`into_bigint()` inside pack_affine_and_scalars, utils/limbs_conversion.rs:311-378).  Done here on the device instead
+// (SURVEY section 8 row f1): s * 2^-256 mod r by word-serial Montgomery reduction, canonical result.
+__device__ __forceinline__ void fr_from_mont(uint32_t s[8]) {
+    constexpr uint32_t R[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+    constexpr uint32_t INV = 0xefffffffu;  // -r^-1 mod 2^32
+    uint32_t t[9] = {s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], 0};
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t m = t[0] * INV;
+        uint64_t carry = ((uint64_t)m * R[0] + t[0]) >> 32;
+#pragma unroll
+        for (int j = 1; j < 8; j++) {
+            uint64_t v = (uint64_t)m * R[j] + t[j] + carry;
+            t[j - 1] = (uint32_t)v;
+            carry = v >> 32;
+        }
+        uint64_t v = (uint64_t)t[8] + carry;
+        t[7] = (uint32_t)v;
+        t[8] = (uint32_t)(v >> 32);
+    }
+    // t < 2r: subtract r once if needed
+    uint32_t d[8];
+    uint64_t bw = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        uint64_t v = (uint64_t)t[j] - R[j] - bw;
+        d[j] = (uint32_t)v;
+        bw = (v >> 32) & 1u;
+    }
+    const bool ge = t[8] != 0 || bw == 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) s[j] = ge ? d[j] : t[j];
+}
+
 // HIST = true also counts buckets with global atomics (fallback when a window's histogram does not fit LDS);
 // HIST = false only writes the digits and leaves counting to k_tile_hist.
 template <bool SIGNED, bool HIST>
 __global__ void k_decompose(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_mask, uint32_t n,
                             uint32_t c, uint32_t W, uint32_t nb, uint32_t* __restrict__ hist,
-                            uint32_t* __restrict__ digits, uint32_t* __restrict__ ranks, uint32_t* __restrict__ err) {
+                            uint32_t* __restrict__ digits, uint32_t* __restrict__ ranks, uint32_t* __restrict__ err,
+                            uint32_t scalars_mont) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
     uint4 a = sp[0], b = sp[1];
     uint32_t s[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    if (scalars_mont) fr_from_mont(s);
     if (s[7] >> 30) atomicOr(err, 1u);  // scalar >= 2^254 cannot be a canonical Fr
     bool skip = inf_mask != nullptr && inf_mask[i] != 0;
     const uint32_t H = 1u << (c - 1);

@@ -25,7 +25,7 @@ OK, ERR_EMPTY, ERR_BAD_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_STATE = 0, -1, 
 # every symbol include/msm_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "msm_abi_version", "msm_ctx_create", "msm_ctx_destroy", "msm_last_error", "msm_bn254_g1",
-    "msm_bn254_g1_upload_bases", "msm_bn254_g1_resident", "msm_bn254_g1_device", "msm_bn254_g1_combine",
+    "msm_bn254_g1_arkworks", "msm_bn254_g1_upload_bases", "msm_bn254_g1_resident", "msm_bn254_g1_device", "msm_bn254_g1_combine",
     "msm_plan", "msm_get_timings", "msm_get_accumulate_kernel_stats", "msm_reset_kernel_stats",
     "msm_bn254_g1_generate_device", "msm_bn254_generate_scalars_host", "msm_test_fp_op", "msm_test_g1_op",
     "msm_test_decompose",
@@ -90,6 +90,7 @@ def load_library():
     L.msm_last_error.argtypes = [vp]
     L.msm_last_error.restype = C.c_char_p
     L.msm_bn254_g1.argtypes = [vp, _u32p, C.c_uint32, _u8p, _u32p, C.c_size_t, _u32p, _u32p, _u8p]
+    L.msm_bn254_g1_arkworks.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _u32p, C.c_size_t, _u32p, _u32p, _u8p]
     L.msm_bn254_g1_upload_bases.argtypes = [vp, _u32p, C.c_uint32, _u8p, C.c_size_t]
     L.msm_bn254_g1_resident.argtypes = [vp, _u32p, C.c_size_t, _u32p, _u32p, _u8p]
     L.msm_bn254_g1_device.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, _u32p, _u32p, _u8p]
@@ -207,6 +208,20 @@ class MsmContext:
         jac, aff, oi = self._outs()
         self._check(self._lib.msm_bn254_g1(self._h, _p32(bases), form, infp, _p32(scalars), n, _p32(jac), _p32(aff),
                                            C.byref(oi)))
+        return MsmResult(jac, aff, oi.value)
+
+    def msm_arkworks(self, raw_structs, stride, x_off, y_off, inf_off, scalars_mont):
+        """Zero-copy path of the Rust shim: `raw_structs` is the byte image of a [G1Affine] slice, scalars are Fr
+        Montgomery words; both go to the GPU untouched."""
+        raw = np.ascontiguousarray(raw_structs, dtype=np.uint8).reshape(-1)
+        sc = _words(scalars_mont, 8)
+        n = min(raw.size // stride, sc.shape[0])
+        if n == 0:
+            raise MsmError(ERR_EMPTY, "Empty input")
+        jac, aff, oi = self._outs()
+        self._check(self._lib.msm_bn254_g1_arkworks(self._h, raw.ctypes.data_as(C.c_void_p), stride, x_off, y_off,
+                                                    inf_off if inf_off is not None else C.c_size_t(-1).value, _p32(sc), n,
+                                                    _p32(jac), _p32(aff), C.byref(oi)))
         return MsmResult(jac, aff, oi.value)
 
     def upload_bases(self, bases, form=FORM_STD, inf=None):

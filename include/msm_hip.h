@@ -104,6 +104,16 @@ int32_t msm_bn254_g1(msm_ctx *ctx, const uint32_t *bases_xy, uint32_t base_form,
                      const uint32_t *scalars, size_t n, uint32_t out_jacobian_mont[24],
                      uint32_t out_affine_std[16], uint8_t *out_is_inf);
 
+/* ---- zero-copy arkworks ingestion ------------------------------------------
+ * bases: array of n `ark_bn254::G1Affine` structs exactly as they sit in memory, described by (stride, byte offsets of
+ * x, y and the `infinity` bool; inf_off = (size_t)-1 if there is none) -- the Rust shim measures these with
+ * size_of / addr_of!, the struct is not repr(C).  Coordinates and scalars are arkworks' internal Montgomery words
+ * (Fq.0 / Fr.0, R = 2^256): no CPU-side `into_bigint()`, no repacking (replaces pack_affine_and_scalars,
+ * utils/limbs_conversion.rs:311-378: 3 Montgomery reductions + 3 heap allocations per point). */
+int32_t msm_bn254_g1_arkworks(msm_ctx *ctx, const void *bases, size_t stride, size_t x_off, size_t y_off, size_t inf_off,
+                              const uint32_t *scalars_mont, size_t n, uint32_t out_jacobian_mont[24],
+                              uint32_t out_affine_std[16], uint8_t *out_is_inf);
+
 /* ---- bases resident in HBM ------------------------------------- */
 int32_t msm_bn254_g1_upload_bases(msm_ctx *ctx, const uint32_t *bases_xy, uint32_t base_form,
                                   const uint8_t *inf_mask, size_t n);

@@ -40,6 +40,10 @@ extern "C" {
         ctx: *mut MsmCtx, bases_xy: *const u32, base_form: u32, inf_mask: *const u8, scalars: *const u32, n: usize,
         out_jacobian_mont: *mut u32, out_affine_std: *mut u32, out_is_inf: *mut u8,
     ) -> i32;
+    fn msm_bn254_g1_arkworks(
+        ctx: *mut MsmCtx, bases: *const core::ffi::c_void, stride: usize, x_off: usize, y_off: usize, inf_off: usize,
+        scalars_mont: *const u32, n: usize, out_jacobian_mont: *mut u32, out_affine_std: *mut u32, out_is_inf: *mut u8,
+    ) -> i32;
 }
 
 struct Ctx(*mut MsmCtx);
@@ -101,6 +105,36 @@ pub fn metal_variable_base_msm(mut bases: &[G1Affine], mut scalars: &[Fr]) -> Re
         return Err(last_error(ctx.0).into());
     }
     // Jacobian Montgomery limbs -> G1Projective without any conversion (reference: metal_msm.rs:228-241)
+    let f = |w: &[u64]| Fq::new_unchecked(BigInt::<4>([w[0], w[1], w[2], w[3]]));
+    Ok(G1Projective::new_unchecked(f(&jac[0..4]), f(&jac[4..8]), f(&jac[8..12])))
+}
+
+/// Zero-copy variant (include/msm_hip.h `msm_bn254_g1_arkworks`): the `[G1Affine]` and `[Fr]` slices go to the GPU as
+/// they are.  The struct layout is MEASURED here (G1Affine is not repr(C)); Fr is `Fp<MontBackend<_,4>,4>` = [u64;4].
+pub fn hip_variable_base_msm_zero_copy(bases: &[G1Affine], scalars: &[Fr]) -> Result<G1Projective, Box<dyn Error>> {
+    if bases.is_empty() || scalars.is_empty() {
+        return Err("Empty input".into());
+    }
+    let n = bases.len().min(scalars.len());
+    let probe = &bases[0];
+    let base_addr = probe as *const G1Affine as usize;
+    let x_off = core::ptr::addr_of!(probe.x) as usize - base_addr;
+    let y_off = core::ptr::addr_of!(probe.y) as usize - base_addr;
+    let inf_off = core::ptr::addr_of!(probe.infinity) as usize - base_addr;
+    assert_eq!(core::mem::size_of::<Fr>(), 32);
+    let guard = CTX.lock().unwrap();
+    let ctx = guard.as_ref().map_err(|e| e.clone())?;
+    let mut jac = [0u64; 12];
+    let mut is_inf = 0u8;
+    let rc = unsafe {
+        msm_bn254_g1_arkworks(
+            ctx.0, bases.as_ptr() as *const core::ffi::c_void, core::mem::size_of::<G1Affine>(), x_off, y_off, inf_off,
+            scalars.as_ptr() as *const u32, n, jac.as_mut_ptr() as *mut u32, std::ptr::null_mut(), &mut is_inf,
+        )
+    };
+    if rc != 0 {
+        return Err(last_error(ctx.0).into());
+    }
     let f = |w: &[u64]| Fq::new_unchecked(BigInt::<4>([w[0], w[1], w[2], w[3]]));
     Ok(G1Projective::new_unchecked(f(&jac[0..4]), f(&jac[4..8]), f(&jac[8..12])))
 }

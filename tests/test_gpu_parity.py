@@ -312,3 +312,51 @@ def test_streamed_equals_single_shot_at_2_pow_18(ctx):
         streamed = c.msm(hb, s, mh.FORM_MONT)
     exp, _ = orc.closed_form_expected(k, s)
     assert (single.affine_std == exp).all() and (streamed.affine_std == exp).all()
+
+
+# ---- zero-copy arkworks ingestion -------------------------------------------
+def _ark_image(bases_std, inf, stride, x_off, y_off, inf_off, rng):
+    """byte image of a [G1Affine] slice: Fq Montgomery limbs at x_off / y_off, `infinity` bool at inf_off, garbage in
+    the padding (arkworks' identity is x = y = 0, infinity = true)"""
+    n = bases_std.shape[0]
+    img = rng.integers(0, 256, size=(n, stride), dtype=np.uint8)
+    R = 1 << 256
+    for i in range(n):
+        x = orc.words_to_int(bases_std[i, :8]) * R % P
+        y = orc.words_to_int(bases_std[i, 8:]) * R % P
+        if inf is not None and inf[i]:
+            x = y = 0
+        img[i, x_off:x_off + 32] = np.frombuffer(x.to_bytes(32, "little"), np.uint8)
+        img[i, y_off:y_off + 32] = np.frombuffer(y.to_bytes(32, "little"), np.uint8)
+        if inf_off is not None:
+            img[i, inf_off] = 1 if (inf is not None and inf[i]) else 0
+    return img
+
+
+def _fr_mont(scalars):
+    R = 1 << 256
+    return np.stack([orc.int_to_words(orc.words_to_int(s) * R % orc.R_ORDER) for s in scalars])
+
+
+@pytest.mark.parametrize("layout", [(72, 0, 32, 64), (80, 40, 8, 72), (64, 32, 0, None)])
+def test_arkworks_struct_ingestion(ctx, layout):
+    stride, x_off, y_off, inf_off = layout
+    rng = np.random.default_rng(5)
+    for name in ("rand_n17", "rand_n1024", "edge_inf_bases", "edge_scalar_r_minus_1", "edge_zero_scalars", "edge_p_minus_p"):
+        g = load_golden(name)
+        inf = g["inf"] if inf_off is not None else None
+        if inf_off is None and g["inf"].any():
+            continue
+        img = _ark_image(g["bases"], inf, stride, x_off, y_off, inf_off, rng)
+        r = ctx.msm_arkworks(img, stride, x_off, y_off, inf_off, _fr_mont(g["scalars"]))
+        assert r.is_infinity == bool(g["expected_inf"]), (name, layout)
+        assert (r.affine_std == g["expected"]).all(), (name, layout)
+
+
+def test_arkworks_ingestion_rejects_bad_layout(ctx):
+    g = load_golden("rand_n3")
+    img = _ark_image(g["bases"], None, 72, 0, 32, 64, np.random.default_rng(1))
+    for bad in [(72, 2, 32, 64), (72, 0, 48, 64), (60, 0, 28, 56), (72, 0, 32, 72)]:
+        with pytest.raises(mh.MsmError) as e:
+            ctx.msm_arkworks(img, bad[0], bad[1], bad[2], bad[3], _fr_mont(g["scalars"]))
+        assert e.value.code == mh.ERR_BAD_ARG
