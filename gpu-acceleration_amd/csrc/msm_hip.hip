@@ -125,7 +125,7 @@ struct msm_ctx {
     hipEvent_t ev[EV_COUNT]{};
     // HBM workspace
     DevBuf bases, ibases, inf, scalars, digits, ranks, sorted, hist, offsets, blocksums, buckets, heads, tails, chunkmap, rc, qsums, flags,
-        pow2, tilecounts, longlist, ccounts, cregion;
+        pow2, tilecounts, longlist, midlist, ccounts, cregion;
     bool pow2_ready = false;
     uint32_t* h_qsums = nullptr;  // pinned: W x (kb+1) Jacobian bit sums
     uint32_t* h_flags = nullptr;    // pinned
@@ -295,6 +295,7 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
     if ((rc = ensure(c, c->tails, nchunks_max * XB))) return rc;
     if ((rc = ensure(c, c->chunkmap, nchunks_max * 4))) return rc;
     if ((rc = ensure(c, c->longlist, (nchunks_max / msmk::LONG_SPAN + 16) * 4))) return rc;  // a long bucket owns >= LONG_SPAN chunks
+    if ((rc = ensure(c, c->midlist, (nchunks_max / 2 + 16) * 4))) return rc;                  // a listed bucket owns >= 2 chunk borders
     if ((rc = ensure(c, c->rc, (tb + tb / 2 + 4) * XB))) return rc;  // two families x (1/2 + 1/4) ping-pong levels
     if ((rc = ensure(c, c->qsums, (size_t)W * (kb + 1) * 96))) return rc;
     if ((rc = ensure(c, c->flags, 64))) return rc;
@@ -375,15 +376,16 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
     }
     HIPCHK(c, hipEventRecord(c->ev[EV_SORT], st));
     // K3: bucket accumulation (the graded kernel) -- bracketed by its own events on its own stream
-    msmk::k_chunk_map<<<grid1(tb, 256), 256, 0, st>>>(offsets, (uint32_t*)c->chunkmap.p, (uint32_t)tb, chunk_len, flags + 8,
-                                                      (uint32_t*)c->longlist.p);
+    msmk::k_chunk_map<<<grid1(tb, 1024), 1024, 0, st>>>(offsets, (uint32_t*)c->chunkmap.p, (uint32_t)tb, chunk_len, flags + 8,
+                                                      (uint32_t*)c->longlist.p, flags + 9, (uint32_t*)c->midlist.p);
     HIPCHK(c, hipEventRecord(c->ev[EV_ACC0], st));
     msmk::k_accumulate<<<grid1(nchunks_max, 256), 256, 0, st>>>(d_bases, (uint32_t*)c->sorted.p, offsets, (uint32_t*)c->chunkmap.p,
                                                               (uint32_t*)c->buckets.p, (uint32_t*)c->heads.p, (uint32_t*)c->tails.p,
                                                               flags + 4, chunk_len, (uint32_t)tb);
     HIPCHK(c, hipEventRecord(c->ev[EV_ACC1], st));
-    msmk::k_combine<<<grid1(tb, 256), 256, 0, st>>>(offsets, (uint32_t*)c->heads.p, (uint32_t*)c->tails.p, (uint32_t*)c->buckets.p,
-                                                    (uint32_t)tb, chunk_len);
+    msmk::k_combine<<<dim3(msmk::MID_BLOCKS + (unsigned)((tb + 255) / 256)), 256, 0, st>>>(offsets, (uint32_t*)c->heads.p, (uint32_t*)c->tails.p,
+                                                                                         (uint32_t*)c->buckets.p, (uint32_t)tb, chunk_len, flags + 9,
+                                                                                         (uint32_t*)c->midlist.p);
     msmk::k_combine_long<<<1024, 256, 0, st>>>(offsets, (uint32_t*)c->heads.p, (uint32_t*)c->tails.p, (uint32_t*)c->buckets.p, flags + 8,
                                                (uint32_t*)c->longlist.p, chunk_len);
     // K4/K5: bucket reduction -- plain row/column sums by dense pairwise levels, then per-bit sums; the weights
@@ -668,7 +670,7 @@ void msm_ctx_destroy(msm_ctx* c) {
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         DevBuf* bufs[] = {&c->bases,   &c->inf,       &c->scalars, &c->digits,  &c->ranks,  &c->sorted, &c->hist,
                           &c->offsets, &c->blocksums, &c->buckets, &c->rc,      &c->qsums,   &c->flags,  &c->pow2,
-                          &c->heads,   &c->tails,     &c->chunkmap, &c->tilecounts, &c->ibases, &c->longlist, &c->ccounts, &c->cregion};
+                          &c->heads,   &c->tails,     &c->chunkmap, &c->tilecounts, &c->ibases, &c->longlist, &c->midlist, &c->ccounts, &c->cregion};
         for (DevBuf* b : bufs) release(*b);
         if (c->h_qsums) (void)hipHostFree(c->h_qsums);
         if (c->h_flags) (void)hipHostFree(c->h_flags);

@@ -588,17 +588,36 @@ __global__ void k_scatter(const uint32_t* __restrict__ digits, const uint32_t* _
 // Each point is gathered as one 64-byte affine record and folded into an XYZZ accumulator in registers.
 
 // chunk_bucket[t] = bucket that owns sorted entry t*L  (one thread per bucket writes the chunks it starts)
-// Buckets cut into LONG_SPAN or more chunks (tiny top windows, adversarial scalars) are listed for k_combine_long.
+// Buckets cut into LONG_SPAN or more chunks (tiny top windows, adversarial scalars) are listed for k_combine_long,
+// buckets cut into 3..LONG_SPAN-1 chunks for k_combine_mid; k_combine itself only meets buckets cut once, so that
+// every one of its wavefronts runs exactly one XYZZ add (a few 3-chunk buckets per wavefront used to double its time).
 constexpr uint32_t LONG_SPAN = 8;
-__global__ void k_chunk_map(const uint32_t* __restrict__ offsets, uint32_t* __restrict__ chunk_bucket, uint32_t total_buckets,
-                            uint32_t L, uint32_t* __restrict__ long_count, uint32_t* __restrict__ long_list) {
+__global__ void __launch_bounds__(1024) k_chunk_map(const uint32_t* __restrict__ offsets, uint32_t* __restrict__ chunk_bucket,
+                                                   uint32_t total_buckets, uint32_t L, uint32_t* __restrict__ long_count,
+                                                   uint32_t* __restrict__ long_list, uint32_t* __restrict__ mid_count,
+                                                   uint32_t* __restrict__ mid_list) {
+    __shared__ uint32_t s_n[2], s_base[2];  // [0] mid, [1] long: list slots are reserved once per workgroup
+    if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
+    __syncthreads();
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= total_buckets) return;
-    uint32_t beg = offsets[k], end = offsets[k + 1];
-    if (beg == end) return;
-    uint32_t tf = (beg + L - 1) / L, tl = (end - 1) / L;
-    if (tl - beg / L >= LONG_SPAN) long_list[atomicAdd(long_count, 1u)] = k;
-    for (uint32_t t = tf; t <= tl; t++) chunk_bucket[t] = k;
+    uint32_t kindl = 2, slot = 0;  // 0 = mid list, 1 = long list, 2 = neither
+    if (k < total_buckets) {
+        uint32_t beg = offsets[k], end = offsets[k + 1];
+        if (beg != end) {
+            uint32_t tf = (beg + L - 1) / L, tl = (end - 1) / L;
+            const uint32_t span = tl - beg / L;  // chunk borders inside the bucket
+            if (span >= LONG_SPAN) kindl = 1;
+            else if (span >= 2) kindl = 0;
+            for (uint32_t t = tf; t <= tl; t++) chunk_bucket[t] = k;
+        }
+    }
+    if (kindl < 2) slot = atomicAdd(&s_n[kindl], 1u);  // LDS
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n[0]) s_base[0] = atomicAdd(mid_count, s_n[0]);
+    if (threadIdx.x == 1 && s_n[1]) s_base[1] = atomicAdd(long_count, s_n[1]);
+    __syncthreads();
+    if (kindl == 0) mid_list[s_base[0] + slot] = k;
+    else if (kindl == 1) long_list[s_base[1] + slot] = k;
 }
 
 __global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
@@ -667,11 +686,27 @@ __global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__
     store_xyzz(dst, acc);
 }
 
-// one thread per bucket: empty buckets become the identity, buckets cut by chunk borders are summed
+// ONE launch, two kinds of workgroups (the listed buckets take 2..6 dependent adds, so their workgroups come FIRST in
+// the grid and run beside the single-add bulk instead of after it):
+//   blockIdx <  MID_BLOCKS : one thread per LISTED bucket (cut into 3..LONG_SPAN-1 chunks), grid-stride over the list
+//   blockIdx >= MID_BLOCKS : one thread per bucket: empty -> identity; cut once -> tails[t0] + heads[t1]
+constexpr uint32_t MID_BLOCKS = 256;
 __global__ void __launch_bounds__(256) k_combine(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ heads,
                                                  const uint32_t* __restrict__ tails, uint32_t* __restrict__ buckets,
-                                                 uint32_t total_buckets, uint32_t L) {
-    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+                                                 uint32_t total_buckets, uint32_t L, const uint32_t* __restrict__ mid_count,
+                                                 const uint32_t* __restrict__ mid_list) {
+    if (blockIdx.x < MID_BLOCKS) {
+        const uint32_t nmid = *mid_count;
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nmid; i += MID_BLOCKS * blockDim.x) {
+            const uint32_t k = mid_list[i];
+            const uint32_t t0 = offsets[k] / L, t1 = (offsets[k + 1] - 1) / L;
+            xyzz acc = load_xyzz(tails + (size_t)t0 * XW);
+            for (uint32_t t = t0 + 1; t <= t1; t++) acc = xyzz_add(acc, load_xyzz(heads + (size_t)t * XW));
+            store_xyzz(buckets + (size_t)k * XW, acc);
+        }
+        return;
+    }
+    uint32_t k = (blockIdx.x - MID_BLOCKS) * blockDim.x + threadIdx.x;
     if (k >= total_buckets) return;
     uint32_t beg = offsets[k], end = offsets[k + 1];
     if (beg == end) {
@@ -679,11 +714,9 @@ __global__ void __launch_bounds__(256) k_combine(const uint32_t* __restrict__ of
         return;
     }
     uint32_t t0 = beg / L, t1 = (end - 1) / L;
-    if (t0 == t1) return;             // written by k_accumulate
-    if (t1 - t0 >= LONG_SPAN) return;  // k_combine_long
-    xyzz acc = load_xyzz(tails + (size_t)t0 * XW);
-    for (uint32_t t = t0 + 1; t <= t1; t++) acc = xyzz_add(acc, load_xyzz(heads + (size_t)t * XW));
-    store_xyzz(buckets + (size_t)k * XW, acc);
+    if (t0 == t1) return;      // written by k_accumulate
+    if (t1 - t0 >= 2) return;  // listed: the MID workgroups above, or k_combine_long
+    store_xyzz(buckets + (size_t)k * XW, xyzz_add(load_xyzz(tails + (size_t)t0 * XW), load_xyzz(heads + (size_t)t1 * XW)));
 }
 
 // one 256-thread workgroup per LONG bucket: strided partial sums of its heads, then a wavefront __shfl_down tree
