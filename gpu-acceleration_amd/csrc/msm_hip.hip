@@ -133,6 +133,7 @@ struct msm_ctx {
     size_t resident_n = 0;
     bool resident_has_inf = false;
     msm_timings_t tm{};
+    bool stage_timing = false;  // record the per-stage hipEvents (each costs ~6 us of stream time); k_accumulate's pair is always on
     double acc_ms_sum = 0;
     uint64_t acc_launches = 0;
 };
@@ -215,6 +216,13 @@ uint32_t ilog2(uint32_t v) {
     uint32_t l = 0;
     while ((1u << (l + 1)) <= v) l++;
     return l;
+}
+
+// elapsed ms between two stage events, 0 when stage timing is off
+float stage_ms(const msm_ctx* c, int a, int b) {
+    float ms = 0;
+    if (c->stage_timing) (void)hipEventElapsedTime(&ms, c->ev[a], c->ev[b]);
+    return ms;
 }
 
 inline dim3 grid1(size_t n, unsigned block) { return dim3((unsigned)((n + block - 1) / block)); }
@@ -330,7 +338,7 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
         HIPCHK(c, hipMemsetAsync(hist, 0, tb * 4, st));
     }
     HIPCHK(c, hipMemsetAsync(flags, 0, 64, st));
-    HIPCHK(c, hipEventRecord(c->ev[EV_CONVERT], st));
+    if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_CONVERT], st));
     // K1b: digits + signed recode
     {
         uint32_t *dg = (uint32_t*)c->digits.p, *rk = (uint32_t*)c->ranks.p;
@@ -340,7 +348,7 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
         else if (tiled) msmk::k_decompose<false, false><<<g, 256, 0, st>>>(d_scalars, d_inf, (uint32_t)n, cbits, W, nb, hist, dg, rk, flags, scalars_mont);
         else msmk::k_decompose<false, true><<<g, 256, 0, st>>>(d_scalars, d_inf, (uint32_t)n, cbits, W, nb, hist, dg, rk, flags, scalars_mont);
     }
-    HIPCHK(c, hipEventRecord(c->ev[EV_DECOMP], st));
+    if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_DECOMP], st));
     if (two_level) {
         const uint32_t nregions = W * ncoarse;
         uint32_t* counts = (uint32_t*)c->ccounts.p;
@@ -374,7 +382,7 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
             msmk::k_scatter<<<g, 256, 0, st>>>((uint32_t*)c->digits.p, (uint32_t*)c->ranks.p, offsets, (uint32_t*)c->sorted.p, (uint32_t)n, nb);
         }
     }
-    HIPCHK(c, hipEventRecord(c->ev[EV_SORT], st));
+    if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_SORT], st));
     // K3: bucket accumulation (the graded kernel) -- bracketed by its own events on its own stream
     msmk::k_chunk_map<<<grid1(tb, 1024), 1024, 0, st>>>(offsets, (uint32_t*)c->chunkmap.p, (uint32_t)tb, chunk_len, flags + 8,
                                                       (uint32_t*)c->longlist.p, flags + 9, (uint32_t*)c->midlist.p);
@@ -414,7 +422,7 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
         }
         msmk::k_reduce_bits<<<W * (kb + 1), 64, 0, st>>>(rin, cin, (uint32_t*)c->qsums.p, n_hi, n_lo, kb_lo, kb);
     }
-    HIPCHK(c, hipEventRecord(c->ev[EV_REDUCE], st));
+    if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_REDUCE], st));
     HIPCHK(c, hipMemcpyAsync(h_qsums_dst, c->qsums.p, (size_t)W * (kb + 1) * 96, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(h_flags_dst, flags, 32, hipMemcpyDeviceToHost, st));
     *geom = PipeGeom{W, nb, cbits, kb};
@@ -473,16 +481,13 @@ int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, 
     // timings
     float ms = 0;
     msm_timings_t& tm = c->tm;
-    (void)hipEventElapsedTime(&ms, c->ev[EV_CONVERT], c->ev[EV_DECOMP]);
-    tm.decompose_ms = ms;
-    (void)hipEventElapsedTime(&ms, c->ev[EV_DECOMP], c->ev[EV_SORT]);
-    tm.sort_ms = ms;
+    tm.decompose_ms = stage_ms(c, EV_CONVERT, EV_DECOMP);
+    tm.sort_ms = stage_ms(c, EV_DECOMP, EV_SORT);
     (void)hipEventElapsedTime(&ms, c->ev[EV_ACC0], c->ev[EV_ACC1]);
     tm.accumulate_ms = ms;
     c->acc_ms_sum += ms;
     c->acc_launches += 1;
-    (void)hipEventElapsedTime(&ms, c->ev[EV_ACC1], c->ev[EV_REDUCE]);
-    tm.reduce_ms = ms;
+    tm.reduce_ms = stage_ms(c, EV_ACC1, EV_REDUCE);
     tm.finish_ms = std::chrono::duration<float, std::milli>(t_fin1 - t_fin0).count();
     tm.num_points = n;
     tm.num_adds = c->h_flags[4];
@@ -519,7 +524,7 @@ int32_t upload_bases_locked(msm_ctx* c, const uint32_t* bases_xy, uint32_t form,
         if ((rc = ensure(c, c->inf, n))) return rc;
         HIPCHK(c, hipMemcpyAsync(c->inf.p, inf_mask, n, hipMemcpyHostToDevice, c->stream));
     }
-    HIPCHK(c, hipEventRecord(c->ev[EV_H2D], c->stream));
+    if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_H2D], c->stream));
     msmk::k_convert_bases<<<grid1(2 * n, 256), 256, 0, c->stream>>>((const uint32_t*)c->bases.p, (uint32_t*)c->ibases.p, (uint32_t)n,
                                                                   form == MSM_FORM_MONT ? 1u : 0u);
     return MSM_OK;
@@ -720,18 +725,15 @@ int32_t msm_bn254_g1(msm_ctx* c, const uint32_t* bases_xy, uint32_t base_form, c
             return MSM_OK;
         }
     }
-    HIPCHK(c, hipEventRecord(c->ev[EV_START], c->stream));
+    if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_START], c->stream));
     if ((rc = ensure(c, c->scalars, n * 32))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->scalars.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
     if ((rc = upload_bases_locked(c, bases_xy, base_form, inf_mask, n))) return rc;
     rc = run_pipeline(c, (const uint32_t*)c->ibases.p, inf_mask ? (const uint8_t*)c->inf.p : nullptr,
                       (const uint32_t*)c->scalars.p, n, c->stream, out_jac, out_aff, out_inf);
     if (rc) return rc;
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, c->ev[EV_START], c->ev[EV_H2D]);
-    c->tm.h2d_ms = ms;
-    (void)hipEventElapsedTime(&ms, c->ev[EV_H2D], c->ev[EV_CONVERT]);
-    c->tm.convert_ms = ms;
+    c->tm.h2d_ms = stage_ms(c, EV_START, EV_H2D);
+    c->tm.convert_ms = stage_ms(c, EV_H2D, EV_CONVERT);
     c->tm.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return MSM_OK;
 }
@@ -748,25 +750,22 @@ int32_t msm_bn254_g1_arkworks(msm_ctx* c, const void* bases, size_t stride, size
     DeviceGuard g(c->device);
     auto t0 = std::chrono::steady_clock::now();
     c->resident_n = 0;
-    HIPCHK(c, hipEventRecord(c->ev[EV_START], c->stream));
+    if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_START], c->stream));
     if ((rc = ensure(c, c->scalars, n * 32))) return rc;
     if ((rc = ensure(c, c->bases, n * stride))) return rc;
     if ((rc = ensure(c, c->ibases, n * 64))) return rc;
     if ((rc = ensure(c, c->inf, n))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->scalars.p, scalars_mont, n * 32, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->bases.p, bases, n * stride, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipEventRecord(c->ev[EV_H2D], c->stream));
+    if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_H2D], c->stream));
     msmk::k_import_ark<<<grid1(2 * n, 256), 256, 0, c->stream>>>((const uint8_t*)c->bases.p, (uint64_t)stride, (uint32_t)x_off, (uint32_t)y_off,
                                                                has_inf ? (uint32_t)inf_off : 0u, has_inf ? 1u : 0u, (uint32_t)n,
                                                                (uint32_t*)c->ibases.p, (uint8_t*)c->inf.p);
     rc = run_pipeline(c, (const uint32_t*)c->ibases.p, (const uint8_t*)c->inf.p, (const uint32_t*)c->scalars.p, n, c->stream, out_jac,
                       out_aff, out_inf, 1u);
     if (rc) return rc;
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, c->ev[EV_START], c->ev[EV_H2D]);
-    c->tm.h2d_ms = ms;
-    (void)hipEventElapsedTime(&ms, c->ev[EV_H2D], c->ev[EV_CONVERT]);
-    c->tm.convert_ms = ms;
+    c->tm.h2d_ms = stage_ms(c, EV_START, EV_H2D);
+    c->tm.convert_ms = stage_ms(c, EV_H2D, EV_CONVERT);
     c->tm.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return MSM_OK;
 }
@@ -795,16 +794,14 @@ int32_t msm_bn254_g1_resident(msm_ctx* c, const uint32_t* scalars, size_t n, uin
     if (n > c->resident_n) n = c->resident_n;  // unequal lengths truncate to the shorter (metal_msm.rs:652-656)
     DeviceGuard g(c->device);
     auto t0 = std::chrono::steady_clock::now();
-    HIPCHK(c, hipEventRecord(c->ev[EV_START], c->stream));
+    if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_START], c->stream));
     if ((rc = ensure(c, c->scalars, n * 32))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->scalars.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipEventRecord(c->ev[EV_H2D], c->stream));
+    if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_H2D], c->stream));
     rc = run_pipeline(c, (const uint32_t*)c->ibases.p, c->resident_has_inf ? (const uint8_t*)c->inf.p : nullptr,
                       (const uint32_t*)c->scalars.p, n, c->stream, out_jac, out_aff, out_inf);
     if (rc) return rc;
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, c->ev[EV_START], c->ev[EV_H2D]);
-    c->tm.h2d_ms = ms;
+    c->tm.h2d_ms = stage_ms(c, EV_START, EV_H2D);
     c->tm.convert_ms = 0;
     c->tm.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return MSM_OK;
@@ -819,15 +816,13 @@ int32_t msm_bn254_g1_device(msm_ctx* c, const void* d_bases_mont, const void* d_
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
     auto t0 = std::chrono::steady_clock::now();
     if ((rc = ensure(c, c->ibases, n * 64))) return rc;
-    HIPCHK(c, hipEventRecord(c->ev[EV_H2D], st));
+    if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_H2D], st));
     msmk::k_convert_bases<<<grid1(2 * n, 256), 256, 0, st>>>((const uint32_t*)d_bases_mont, (uint32_t*)c->ibases.p, (uint32_t)n, 1u);
     rc = run_pipeline(c, (const uint32_t*)c->ibases.p, (const uint8_t*)d_inf_mask, (const uint32_t*)d_scalars, n, st, out_jac, out_aff,
                       out_inf);
     if (rc) return rc;
-    float cms = 0;
-    (void)hipEventElapsedTime(&cms, c->ev[EV_H2D], c->ev[EV_CONVERT]);
     c->tm.h2d_ms = 0;
-    c->tm.convert_ms = cms;
+    c->tm.convert_ms = stage_ms(c, EV_H2D, EV_CONVERT);
     c->tm.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return MSM_OK;
 }
@@ -857,6 +852,12 @@ int32_t msm_get_accumulate_kernel_stats(const msm_ctx* c, double* avg_ms, uint64
     if (!c) return MSM_ERR_BAD_ARG;
     if (avg_ms) *avg_ms = c->acc_launches ? c->acc_ms_sum / (double)c->acc_launches : 0.0;
     if (launches) *launches = c->acc_launches;
+    return MSM_OK;
+}
+int32_t msm_set_stage_timing(msm_ctx* c, int32_t enabled) {
+    if (!c) return MSM_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->stage_timing = enabled != 0;
     return MSM_OK;
 }
 void msm_reset_kernel_stats(msm_ctx* c) {

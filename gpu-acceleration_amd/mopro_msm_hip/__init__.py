@@ -26,7 +26,7 @@ OK, ERR_EMPTY, ERR_BAD_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_STATE = 0, -1, 
 ABI_SYMBOLS = [
     "msm_abi_version", "msm_ctx_create", "msm_ctx_destroy", "msm_last_error", "msm_bn254_g1",
     "msm_bn254_g1_arkworks", "msm_bn254_g1_upload_bases", "msm_bn254_g1_resident", "msm_bn254_g1_device", "msm_bn254_g1_combine",
-    "msm_plan", "msm_get_timings", "msm_get_accumulate_kernel_stats", "msm_reset_kernel_stats",
+    "msm_plan", "msm_get_timings", "msm_set_stage_timing", "msm_get_accumulate_kernel_stats", "msm_reset_kernel_stats",
     "msm_bn254_g1_generate_device", "msm_bn254_generate_scalars_host", "msm_test_fp_op", "msm_test_g1_op",
     "msm_test_decompose",
 ]
@@ -97,6 +97,7 @@ def load_library():
     L.msm_bn254_g1_combine.argtypes = [_u32p, C.c_size_t, _u32p, _u32p, _u8p]
     L.msm_plan.argtypes = [C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(Plan)]
     L.msm_get_timings.argtypes = [vp, C.POINTER(Timings)]
+    L.msm_set_stage_timing.argtypes = [vp, C.c_int32]
     L.msm_get_accumulate_kernel_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.msm_reset_kernel_stats.argtypes = [vp]
     L.msm_reset_kernel_stats.restype = None
@@ -254,6 +255,9 @@ class MsmContext:
 
     def generate_device(self, base_seed, scalar_seed, n, d_bases_ptr, d_scalars_ptr):
         self._check(self._lib.msm_bn254_g1_generate_device(self._h, base_seed, scalar_seed, n, d_bases_ptr, d_scalars_ptr))
+
+    def set_stage_timing(self, enabled=True):
+        self._check(self._lib.msm_set_stage_timing(self._h, int(bool(enabled))))
 
     def timings(self):
         t = Timings()

@@ -136,6 +136,9 @@ int32_t msm_bn254_g1_combine(const uint32_t *partials_jacobian_mont, size_t k, u
 /* ---- introspection --------------------------------------------------------------------------- */
 int32_t msm_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_plan_t *out);
 int32_t msm_get_timings(const msm_ctx *ctx, msm_timings_t *out);
+/* per-stage hipEvents are OFF by default (every record costs ~6 us of stream time); when off, the stage fields of
+ * msm_timings_t other than accumulate_ms / finish_ms / total_ms read 0 */
+int32_t msm_set_stage_timing(msm_ctx *ctx, int32_t enabled);
 /* average duration (ms) of the accumulate kernel launches since the last reset, measured with
  * hipEvents on the stream the kernel runs on; *launches receives the count */
 int32_t msm_get_accumulate_kernel_stats(const msm_ctx *ctx, double *avg_ms, uint64_t *launches);

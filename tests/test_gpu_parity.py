@@ -261,7 +261,12 @@ def test_full_size_closed_form_and_linearity(ctx, logn):
     comb = mh.combine_partials(np.stack([p0.jacobian_mont, p1.jacobian_mont]))
     assert (comb.affine_std == exp).all()
     tm = ctx.timings()
-    assert tm["num_points"] == n - h and tm["accumulate_ms"] > 0
+    assert tm["num_points"] == n - h and tm["accumulate_ms"] > 0 and tm["sort_ms"] == 0
+    ctx.set_stage_timing(True)
+    ctx.msm_device(d_bases.data_ptr(), d_s.data_ptr(), n)
+    tm = ctx.timings()
+    ctx.set_stage_timing(False)
+    assert tm["sort_ms"] > 0 and tm["reduce_ms"] > 0 and tm["decompose_ms"] > 0
 
 
 # ---- BASELINE config 5: streamed host->HBM chunks overlapped with the pipeline ---------------------

@@ -7,7 +7,7 @@ for n in sizes:
                        capture_output=True, text=True)
     try:
         j = json.loads(p.stdout.strip().splitlines()[-1])
-        st = {k: round(v, 3) for k, v in j["stage_ms_last_step"].items()}
+        st = {k: round(v, 3) for k, v in j["stage_ms_untimed_diagnostic_step"].items()}
         print("logN", n, "ms", j["value"], "exact", j["bit_exact"], "c", j["config"]["window_bits"], "acc_ms",
               j["roofline"]["avg_kernel_ms"], "frac", j["roofline"]["frac"], st, flush=True)
     except Exception as e:

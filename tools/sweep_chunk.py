@@ -8,7 +8,7 @@ for rnd in range(3):
         env = dict(os.environ, MSM_HIP_CHUNK_LEN=str(L))
         p = subprocess.run([sys.executable, "bench.py", "--steps", "20", "--warmup", "3", "--no-cpu-baseline"], capture_output=True, text=True, env=env)
         j = json.loads(p.stdout.strip().splitlines()[-1])
-        res[L].append((j["value"], j["roofline"]["avg_kernel_ms"], j["stage_ms_last_step"]["reduce_ms"]))
+        res[L].append((j["value"], j["roofline"]["avg_kernel_ms"], j["stage_ms_untimed_diagnostic_step"]["reduce_ms"]))
 for L in Ls:
     v = res[L]
     print("L", L, "median ms", statistics.median(x[0] for x in v), "acc", round(statistics.median(x[1] for x in v), 3), "reduce",
