@@ -117,6 +117,7 @@ struct msm_ctx {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;     // host->HBM chunk uploads of the streamed path
     hipEvent_t ev_copied[2]{}, ev_free[2]{};
+    hipEvent_t ev_fork = nullptr, ev_bases = nullptr;  // base conversion runs on copy_stream beside the sort kernels
     DevBuf sbases[2], sscalars[2], sinf[2];  // double-buffered raw inputs of the streamed path
     uint32_t* h_sq = nullptr;              // pinned: per-chunk bit sums + flags of the streamed path
     size_t h_sq_cap = 0;
@@ -272,7 +273,8 @@ struct PipeGeom {
 // Queue the whole device pipeline for one (chunk of an) MSM on stream st; the W*(kb+1) bit sums and the flag words
 // are copied to h_qsums_dst / h_flags_dst (pinned) at the end.  No host synchronisation here.
 int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, const uint32_t* d_scalars, size_t n,
-                         hipStream_t st, uint32_t* h_qsums_dst, uint32_t* h_flags_dst, PipeGeom* geom, uint32_t scalars_mont = 0) {
+                         hipStream_t st, uint32_t* h_qsums_dst, uint32_t* h_flags_dst, PipeGeom* geom, uint32_t scalars_mont = 0,
+                         hipEvent_t bases_ready = nullptr) {
     if (n > 0x7FFFFFFFull) return fail(c, MSM_ERR_BAD_ARG, "n = %zu exceeds 2^31-1 points per context call", n);
     msm_plan_t pl;
     int32_t rc = make_plan(n, c->cfg.window_bits, c->cfg.flags, &pl);
@@ -386,6 +388,7 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
     // K3: bucket accumulation (the graded kernel) -- bracketed by its own events on its own stream
     msmk::k_chunk_map<<<grid1(tb, 1024), 1024, 0, st>>>(offsets, (uint32_t*)c->chunkmap.p, (uint32_t)tb, chunk_len, flags + 8,
                                                       (uint32_t*)c->longlist.p, flags + 9, (uint32_t*)c->midlist.p);
+    if (bases_ready) HIPCHK(c, hipStreamWaitEvent(st, bases_ready, 0));  // d_bases is being converted on another stream
     HIPCHK(c, hipEventRecord(c->ev[EV_ACC0], st));
     msmk::k_accumulate<<<grid1(nchunks_max, 256), 256, 0, st>>>(d_bases, (uint32_t*)c->sorted.p, offsets, (uint32_t*)c->chunkmap.p,
                                                               (uint32_t*)c->buckets.p, (uint32_t*)c->heads.p, (uint32_t*)c->tails.p,
@@ -467,9 +470,10 @@ int32_t check_flags(msm_ctx* c, const uint32_t* h_flags) {
 
 // The pipeline proper: everything in HBM, one stream.  d_bases: INTERNAL-domain packed coordinates.
 int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, const uint32_t* d_scalars, size_t n,
-                     hipStream_t st, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf, uint32_t scalars_mont = 0) {
+                     hipStream_t st, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf, uint32_t scalars_mont = 0,
+                     hipEvent_t bases_ready = nullptr) {
     PipeGeom g;
-    int32_t rc = enqueue_pipeline(c, d_bases, d_inf, d_scalars, n, st, c->h_qsums, c->h_flags, &g, scalars_mont);
+    int32_t rc = enqueue_pipeline(c, d_bases, d_inf, d_scalars, n, st, c->h_qsums, c->h_flags, &g, scalars_mont, bases_ready);
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());
@@ -622,6 +626,8 @@ int32_t msm_ctx_create(const msm_config_t* cfg, msm_ctx** out) {
     hipError_t e = g.ok ? hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) : hipErrorInvalidDevice;
     for (int i = 0; i < EV_COUNT && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_bases, hipEventDisableTiming);
     for (int i = 0; i < 2 && e == hipSuccess; i++) {
         e = hipEventCreateWithFlags(&c->ev_copied[i], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_free[i], hipEventDisableTiming);
@@ -687,6 +693,8 @@ void msm_ctx_destroy(msm_ctx* c) {
             if (c->ev_copied[i]) (void)hipEventDestroy(c->ev_copied[i]);
             if (c->ev_free[i]) (void)hipEventDestroy(c->ev_free[i]);
         }
+        if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+        if (c->ev_bases) (void)hipEventDestroy(c->ev_bases);
         if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
         for (int i = 0; i < EV_COUNT; i++)
             if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -816,10 +824,20 @@ int32_t msm_bn254_g1_device(msm_ctx* c, const void* d_bases_mont, const void* d_
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
     auto t0 = std::chrono::steady_clock::now();
     if ((rc = ensure(c, c->ibases, n * 64))) return rc;
-    if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_H2D], st));
-    msmk::k_convert_bases<<<grid1(2 * n, 256), 256, 0, st>>>((const uint32_t*)d_bases_mont, (uint32_t*)c->ibases.p, (uint32_t)n, 1u);
-    rc = run_pipeline(c, (const uint32_t*)c->ibases.p, (const uint8_t*)d_inf_mask, (const uint32_t*)d_scalars, n, st, out_jac, out_aff,
-                      out_inf);
+    if (c->stage_timing) {  // serialised, so that convert_ms means something
+        HIPCHK(c, hipEventRecord(c->ev[EV_H2D], st));
+        msmk::k_convert_bases<<<grid1(2 * n, 256), 256, 0, st>>>((const uint32_t*)d_bases_mont, (uint32_t*)c->ibases.p, (uint32_t)n, 1u);
+        rc = run_pipeline(c, (const uint32_t*)c->ibases.p, (const uint8_t*)d_inf_mask, (const uint32_t*)d_scalars, n, st, out_jac,
+                          out_aff, out_inf);
+    } else {  // the bases are not needed before k_accumulate: convert them on the second stream beside the sort
+        HIPCHK(c, hipEventRecord(c->ev_fork, st));
+        HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_fork, 0));
+        msmk::k_convert_bases<<<grid1(2 * n, 256), 256, 0, c->copy_stream>>>((const uint32_t*)d_bases_mont, (uint32_t*)c->ibases.p,
+                                                                           (uint32_t)n, 1u);
+        HIPCHK(c, hipEventRecord(c->ev_bases, c->copy_stream));
+        rc = run_pipeline(c, (const uint32_t*)c->ibases.p, (const uint8_t*)d_inf_mask, (const uint32_t*)d_scalars, n, st, out_jac,
+                          out_aff, out_inf, 0, c->ev_bases);
+    }
     if (rc) return rc;
     c->tm.h2d_ms = 0;
     c->tm.convert_ms = stage_ms(c, EV_H2D, EV_CONVERT);
