@@ -365,3 +365,25 @@ def test_arkworks_ingestion_rejects_bad_layout(ctx):
         with pytest.raises(mh.MsmError) as e:
             ctx.msm_arkworks(img, bad[0], bad[1], bad[2], bad[3], _fr_mont(g["scalars"]))
         assert e.value.code == mh.ERR_BAD_ARG
+
+
+@pytest.mark.parametrize("wb,flags", [(2, 0), (3, 0), (4, mh.FLAG_UNSIGNED_DIGITS), (17, 0), (18, 0), (20, 0)])
+def test_extreme_window_sizes(wb, flags):
+    """c = 2 (128 windows of 2 buckets) up to c = 20 (13 windows of 2^19 buckets, global-atomic sort fallback)."""
+    with mh.MsmContext(window_bits=wb, flags=flags) as c:
+        for name in ("rand_n1", "rand_n17", "rand_n256", "edge_inf_bases", "edge_p_minus_p", "edge_carry_patterns", "edge_scalar_r_minus_1"):
+            g = load_golden(name)
+            r = c.msm(g["bases"], g["scalars"], mh.FORM_STD, g["inf"])
+            assert r.is_infinity == bool(g["expected_inf"]), (name, wb)
+            assert (r.affine_std == g["expected"]).all(), (name, wb)
+
+
+def test_repeatability_and_context_isolation():
+    """the sort is not order-stable across launches (LDS atomics), the group element must be; two contexts at once"""
+    g = load_golden("rand_n4096")
+    with mh.MsmContext() as c1, mh.MsmContext(window_bits=11) as c2:
+        outs = set()
+        for _ in range(5):
+            outs.add(c1.msm(g["bases"], g["scalars"]).affine_std.tobytes())
+            outs.add(c2.msm(g["bases"], g["scalars"]).affine_std.tobytes())
+        assert outs == {g["expected"].tobytes()}
