@@ -15,6 +15,7 @@
 // There is NO CPU fallback: without a HIP device every compute entry point returns MSM_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -790,6 +791,94 @@ int32_t msm_bn254_g1_upload_bases(msm_ctx* c, const uint32_t* bases_xy, uint32_t
     HIPCHK(c, hipGetLastError());
     c->resident_n = n;
     c->resident_has_inf = inf_mask != nullptr;
+    return MSM_OK;
+}
+
+// row f3: n x 32-byte arkworks compressed images (host) -> c->ibases (+ c->inf); out_ark picks the word domain written
+static int32_t decompress_locked(msm_ctx* c, const uint8_t* compressed, size_t n, uint32_t out_ark, int64_t* first_invalid) {
+    int32_t rc;
+    if (first_invalid) *first_invalid = -1;
+    if (n > 0xFFFFFFF0ull) return fail(c, MSM_ERR_BAD_ARG, "too many points: %zu", n);
+    if ((rc = ensure(c, c->bases, n * 32 + 16))) return rc;
+    if ((rc = ensure(c, c->ibases, n * 64))) return rc;
+    if ((rc = ensure(c, c->inf, n))) return rc;
+    uint32_t* d_bad = (uint32_t*)((uint8_t*)c->bases.p + n * 32);  // lowest failing index, kept behind the images
+    const uint32_t none = 0xFFFFFFFFu;
+    HIPCHK(c, hipMemcpyAsync(c->bases.p, compressed, n * 32, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_bad, &none, 4, hipMemcpyHostToDevice, c->stream));
+    msmk::k_decompress<<<grid1(n, 256), 256, 0, c->stream>>>((const uint32_t*)c->bases.p, (uint32_t)n, (uint32_t*)c->ibases.p,
+                                                          (uint8_t*)c->inf.p, d_bad, out_ark);
+    uint32_t bad = none;
+    HIPCHK(c, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    if (bad != none) {
+        if (first_invalid) *first_invalid = (int64_t)bad;
+        return fail(c, MSM_ERR_INVALID_DATA, "compressed point %u does not decode (flags, x >= p, or x^3+3 not a square)", bad);
+    }
+    return MSM_OK;
+}
+
+int32_t msm_bn254_g1_decompress(msm_ctx* c, const uint8_t* compressed, size_t n, uint32_t* out_xy_mont, uint8_t* out_inf,
+                                int64_t* first_invalid) {
+    int32_t rc = check_common(c, compressed, out_xy_mont, n);
+    if (rc) return rc;
+    if (!out_inf) return fail(c, MSM_ERR_BAD_ARG, "NULL out_inf");
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    c->resident_n = 0;  // ibases is used as the output staging area
+    if ((rc = decompress_locked(c, compressed, n, 1u, first_invalid))) return rc;
+    HIPCHK(c, hipMemcpyAsync(out_xy_mont, c->ibases.p, n * 64, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out_inf, c->inf.p, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MSM_OK;
+}
+
+int32_t msm_bn254_g1_upload_compressed(msm_ctx* c, const uint8_t* compressed, size_t n, int64_t* first_invalid) {
+    int32_t rc = check_common(c, compressed, compressed, n);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    c->resident_n = 0;
+    if ((rc = decompress_locked(c, compressed, n, 0u, first_invalid))) return rc;
+    c->resident_n = n;
+    c->resident_has_inf = true;
+    return MSM_OK;
+}
+
+// host-side inverse (ark-ec 0.4 serialize_compressed): x standard form LE | bit 255 = y > p - y | bit 254 = infinity
+int32_t msm_bn254_g1_compress(const uint32_t* bases_xy, uint32_t base_form, const uint8_t* inf_mask, size_t n, uint8_t* out) {
+    if (n == 0) return MSM_ERR_EMPTY;
+    if (!bases_xy || !out || (base_form != MSM_FORM_STD && base_form != MSM_FORM_MONT)) return MSM_ERR_BAD_ARG;
+    static constexpr uint64_t HALF[4] = {0x9e10460b6c3e7ea3ULL, 0xcbc0b548b438e546ULL, 0xdc2822db40c0ac2eULL, 0x183227397098d014ULL};  // (p-1)/2
+    auto work = [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++) {
+            uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (inf_mask && inf_mask[i]) {
+                w[7] = 1u << 30;
+            } else {
+                hostg1::Fq x = hostg1::load_words(bases_xy + i * 16), y = hostg1::load_words(bases_xy + i * 16 + 8);
+                if (base_form == MSM_FORM_MONT) x = hostg1::from_mont(x), y = hostg1::from_mont(y);
+                hostg1::store_words(w, x);
+                bool larger = false;
+                for (int k = 3; k >= 0; k--)
+                    if (y.l[k] != HALF[k]) {
+                        larger = y.l[k] > HALF[k];
+                        break;
+                    }
+                if (larger) w[7] |= 1u << 31;
+            }
+            std::memcpy(out + i * 32, w, 32);
+        }
+    };
+    const size_t nt = n < 8192 ? 1 : std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()));
+    if (nt == 1) {
+        work(0, n);
+    } else {
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < nt; t++) th.emplace_back(work, n * t / nt, n * (t + 1) / nt);
+        for (auto& t : th) t.join();
+    }
     return MSM_OK;
 }
 

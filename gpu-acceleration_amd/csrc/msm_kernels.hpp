@@ -38,6 +38,11 @@ __device__ __forceinline__ fp load_fp_packed(const uint32_t* p) {
     uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     return fp_unpack(w);
 }
+__device__ __forceinline__ void load_words8(uint32_t w[8], const uint32_t* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 a = q[0], b = q[1];
+    w[0] = a.x, w[1] = a.y, w[2] = a.z, w[3] = a.w, w[4] = b.x, w[5] = b.y, w[6] = b.z, w[7] = b.w;
+}
 __device__ __forceinline__ void store_words8(uint32_t* p, const uint32_t w[8]) {
     uint4* q = reinterpret_cast<uint4*>(p);
     q[0] = make_uint4(w[0], w[1], w[2], w[3]);
@@ -139,6 +144,83 @@ __global__ void k_import_ark(const uint8_t* __restrict__ raw, uint64_t stride, u
     fp_pack(w, fp_reduce_lt2p(v));
     store_words8(out + (size_t)i * 8, w);
     if (which == 0 && inf_out) inf_out[pt] = has_inf ? (rec[inf_off] != 0) : 0;
+}
+
+// Row f3: arkworks `serialize_compressed` images of G1Affine (reference utils/preprocess.rs:193-223) -> bases.
+// One thread per point: x (standard form, flags in bits 254/255) -> y = (x^3+3)^((p+1)/4)  (p = 3 mod 4), the root
+// is checked (y^2 == x^3+3, else the image is invalid) and the sign picked as ark-ec 0.4 does: flag bit 255 set <=> y is
+// the larger of (y, p-y) as integers.  The exponent is a constant, so the square-and-multiply branch is wave-uniform.
+// out_ark = 0: internal domain, packed (the pipeline's base format);  1: arkworks Montgomery words R = 2^256.
+__global__ void k_decompress(const uint32_t* __restrict__ rec, uint32_t n, uint32_t* __restrict__ out, uint8_t* __restrict__ inf_out,
+                             uint32_t* __restrict__ first_bad, uint32_t out_ark) {
+    constexpr uint32_t PW[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+    constexpr uint32_t EXP[8] = {0xb61f3f52u, 0x4f082305u, 0x5a1c72a3u, 0x65e05aa4u, 0xa0605617u, 0x6e14116du, 0xb84c680au, 0x0c19139cu};   // (p+1)/4, 252 bits
+    constexpr uint32_t HALF[8] = {0x6c3e7ea3u, 0x9e10460bu, 0xb438e546u, 0xcbc0b548u, 0x40c0ac2eu, 0xdc2822dbu, 0x7098d014u, 0x18322739u};  // (p-1)/2
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t w[8];
+    load_words8(w, rec + (size_t)i * 8);
+    const uint32_t f_neg = w[7] >> 31, f_inf = (w[7] >> 30) & 1u;
+    w[7] &= 0x3FFFFFFFu;
+    bool lt = false;  // x < p ?
+#pragma unroll
+    for (int k = 7; k >= 0; k--) {
+        if (w[k] != PW[k]) {
+            lt = w[k] < PW[k];
+            break;
+        }
+    }
+    uint32_t zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (!lt || (f_neg & f_inf)) {
+        atomicMin(first_bad, i);
+        store_words8(out + (size_t)i * 16, zero);
+        store_words8(out + (size_t)i * 16 + 8, zero);
+        inf_out[i] = 0;
+        return;
+    }
+    if (f_inf) {  // identity: coordinates unused downstream
+        store_words8(out + (size_t)i * 16, zero);
+        store_words8(out + (size_t)i * 16 + 8, zero);
+        inf_out[i] = 1;
+        return;
+    }
+    const fp x = fp_from_std(w);                                    // < 1.01p
+    const fp three = fp_add(fp_dbl(fp_one()), fp_one());              // < 3p
+    const fp rhs = fp_add(fp_mul(fp_sqr(x), x), three);              // < 4.01p
+    fp y = rhs;
+    for (int b = 250; b >= 0; b--) {                                  // top bit of the exponent consumed by y = rhs
+        y = fp_sqr(y);                                                // < 1.1p
+        if ((EXP[b >> 5] >> (b & 31)) & 1u) y = fp_mul(y, rhs);       // < 1.03p
+    }
+    const fp y2 = fp_canonical(fp_sqr(y)), r2 = fp_canonical(rhs);
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 9; k++) ok = ok && (y2.v[k] == r2.v[k]);
+    if (!ok) {
+        atomicMin(first_bad, i);
+        store_words8(out + (size_t)i * 16, zero);
+        store_words8(out + (size_t)i * 16 + 8, zero);
+        inf_out[i] = 0;
+        return;
+    }
+    uint32_t ys[8];
+    fp_to_std(ys, y);
+    bool larger = false;  // y > (p-1)/2  <=>  y > p - y
+#pragma unroll
+    for (int k = 7; k >= 0; k--) {
+        if (ys[k] != HALF[k]) {
+            larger = ys[k] > HALF[k];
+            break;
+        }
+    }
+    fp yc = fp_reduce_lt2p(y);  // canonical
+    if ((larger ? 1u : 0u) != f_neg && !fp_is_zero_exact(yc)) yc = fp_reduce_lt2p(fp_neg<2>(yc));  // p - y
+    uint32_t o[8];
+    if (out_ark) fp_to_mont256(o, x); else fp_pack(o, fp_reduce_lt2p(x));
+    store_words8(out + (size_t)i * 16, o);
+    if (out_ark) fp_to_mont256(o, yc); else fp_pack(o, yc);
+    store_words8(out + (size_t)i * 16 + 8, o);
+    inf_out[i] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------

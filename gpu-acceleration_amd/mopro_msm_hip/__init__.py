@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "libmsm_hip.so")
 
 FORM_STD, FORM_MONT = 0, 1
 FLAG_UNSIGNED_DIGITS = 1
-OK, ERR_EMPTY, ERR_BAD_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
+OK, ERR_EMPTY, ERR_BAD_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_STATE, ERR_INVALID_DATA = 0, -1, -2, -3, -4, -5, -6, -7
 
 # every symbol include/msm_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "msm_bn254_g1_arkworks", "msm_bn254_g1_upload_bases", "msm_bn254_g1_resident", "msm_bn254_g1_device", "msm_bn254_g1_combine",
     "msm_plan", "msm_get_timings", "msm_set_stage_timing", "msm_get_accumulate_kernel_stats", "msm_reset_kernel_stats",
     "msm_bn254_g1_generate_device", "msm_bn254_generate_scalars_host", "msm_test_fp_op", "msm_test_g1_op",
-    "msm_test_decompose",
+    "msm_test_decompose", "msm_bn254_g1_decompress", "msm_bn254_g1_upload_compressed", "msm_bn254_g1_compress",
 ]
 
 
@@ -106,6 +106,9 @@ def load_library():
     L.msm_test_fp_op.argtypes = [vp, C.c_uint32, _u32p, _u32p, _u32p, C.c_size_t]
     L.msm_test_g1_op.argtypes = [vp, C.c_uint32, _u32p, _u32p, _u32p, C.c_size_t]
     L.msm_test_decompose.argtypes = [vp, _u32p, C.c_size_t, C.c_uint32, C.POINTER(C.c_int32)]
+    L.msm_bn254_g1_decompress.argtypes = [vp, _u8p, C.c_size_t, _u32p, _u8p, C.POINTER(C.c_int64)]
+    L.msm_bn254_g1_upload_compressed.argtypes = [vp, _u8p, C.c_size_t, C.POINTER(C.c_int64)]
+    L.msm_bn254_g1_compress.argtypes = [_u32p, C.c_uint32, _u8p, C.c_size_t, _u8p]
     for name in ABI_SYMBOLS:
         f = getattr(L, name)
         if f.restype is C.c_int:  # default
@@ -155,6 +158,22 @@ def combine_partials(partials_jacobian_mont):
     if rc != OK:
         raise MsmError(rc, "Empty input" if rc == ERR_EMPTY else f"combine failed ({rc})")
     return MsmResult(jac, aff, inf.value)
+
+
+def compress_points(bases, form=FORM_STD, inf=None):
+    """Host-side inverse of MsmContext.decompress: n x 16 coordinate words -> n x 32 bytes (no GPU needed)."""
+    bases = _words(bases, 16)
+    if bases.shape[0] == 0:
+        raise MsmError(ERR_EMPTY, "Empty input")
+    out = np.zeros(bases.shape[0] * 32, np.uint8)
+    infp = None
+    if inf is not None:
+        inf = np.ascontiguousarray(inf, dtype=np.uint8)
+        infp = inf.ctypes.data_as(_u8p)
+    rc = load_library().msm_bn254_g1_compress(_p32(bases), form, infp, bases.shape[0], out.ctypes.data_as(_u8p))
+    if rc != 0:
+        raise MsmError(rc, "msm_bn254_g1_compress failed (%d)" % rc)
+    return out.tobytes()
 
 
 def generate_scalars_host(seed, n, nonzero=False):
@@ -234,6 +253,43 @@ class MsmContext:
             inf = np.ascontiguousarray(inf, dtype=np.uint8)
             infp = inf.ctypes.data_as(_u8p)
         self._check(self._lib.msm_bn254_g1_upload_bases(self._h, _p32(bases), form, infp, bases.shape[0]))
+
+    @staticmethod
+    def _images(images):
+        buf = np.frombuffer(images, dtype=np.uint8) if isinstance(images, (bytes, bytearray, memoryview)) else \
+            np.ascontiguousarray(images, dtype=np.uint8).reshape(-1)
+        if buf.size == 0:
+            raise MsmError(ERR_EMPTY, "Empty input")
+        if buf.size % 32:
+            raise MsmError(ERR_BAD_ARG, "compressed G1Affine images are 32 bytes each")
+        return np.ascontiguousarray(buf)
+
+    def decompress(self, images):
+        """arkworks-0.4 `serialize_compressed` G1Affine images (n x 32 bytes) -> (xy Montgomery words n x 16, inf n).
+        The square roots run on the GPU.  An image that does not decode raises MsmError(ERR_INVALID_DATA) with
+        .first_invalid set (arkworks: SerializationError::InvalidData)."""
+        buf = self._images(images)
+        n = buf.size // 32
+        xy = np.zeros((n, 16), np.uint32)
+        inf = np.zeros(n, np.uint8)
+        bad = C.c_int64(-1)
+        rc = self._lib.msm_bn254_g1_decompress(self._h, buf.ctypes.data_as(_u8p), n, _p32(xy), inf.ctypes.data_as(_u8p), C.byref(bad))
+        self._check_invalid(rc, bad)
+        return xy, inf
+
+    def upload_compressed(self, images):
+        """Decode compressed images straight into the resident-bases set (then msm_resident)."""
+        buf = self._images(images)
+        bad = C.c_int64(-1)
+        rc = self._lib.msm_bn254_g1_upload_compressed(self._h, buf.ctypes.data_as(_u8p), buf.size // 32, C.byref(bad))
+        self._check_invalid(rc, bad)
+
+    def _check_invalid(self, rc, bad):
+        if rc == ERR_INVALID_DATA:
+            e = MsmError(rc, (self._lib.msm_last_error(self._h) or b"invalid data").decode())
+            e.first_invalid = int(bad.value)
+            raise e
+        self._check(rc)
 
     def msm_resident(self, scalars):
         scalars = _words(scalars, 8)

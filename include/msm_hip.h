@@ -44,6 +44,7 @@ extern "C" {
 #define MSM_ERR_HIP (-4)        /* a HIP runtime call failed; see msm_last_error()                      */
 #define MSM_ERR_OOM (-5)
 #define MSM_ERR_STATE (-6)      /* e.g. resident call without uploaded bases                            */
+#define MSM_ERR_INVALID_DATA (-7) /* a compressed point does not decode (arkworks SerializationError::InvalidData) */
 
 /* coordinate form of the bases handed in */
 #define MSM_FORM_STD 0u  /* plain integers < p   (what pack_affine_and_scalars emits)          */
@@ -119,6 +120,23 @@ int32_t msm_bn254_g1_upload_bases(msm_ctx *ctx, const uint32_t *bases_xy, uint32
                                   const uint8_t *inf_mask, size_t n);
 int32_t msm_bn254_g1_resident(msm_ctx *ctx, const uint32_t *scalars, size_t n, uint32_t out_jacobian_mont[24],
                               uint32_t out_affine_std[16], uint8_t *out_is_inf);
+
+/* ---- arkworks `serialize_compressed` point images ---------------
+ * The reference's benchmark harness keeps its instances on disk as `Vec<G1Affine>::serialize_compressed`
+ * (mopro-msm/src/msm/utils/preprocess.rs:193-223 writes, 101-131 / 225-256 read): per point 32 bytes = x in
+ * standard form, little-endian, with bit 255 = "y is the larger of (y, p-y)" and bit 254 = point at infinity
+ * (ark-ec 0.4 SWFlags).  Reading them back costs arkworks one Fq square root per point on the CPU; here the
+ * square root y = (x^3+3)^((p+1)/4) runs on the GPU, one thread per point.
+ * compressed: n x 32 bytes (host).  An image with both flag bits set, x >= p, or x^3+3 a non-residue fails the
+ * whole call with MSM_ERR_INVALID_DATA and *first_invalid (nullable) = the lowest such index.               */
+/* decode to arkworks Montgomery words (R = 2^256): out_xy_mont n x 16 words, out_inf n bytes (both host)   */
+int32_t msm_bn254_g1_decompress(msm_ctx *ctx, const uint8_t *compressed, size_t n, uint32_t *out_xy_mont,
+                                uint8_t *out_inf, int64_t *first_invalid);
+/* decode straight into the resident-bases set (then msm_bn254_g1_resident); nothing returns to the host   */
+int32_t msm_bn254_g1_upload_compressed(msm_ctx *ctx, const uint8_t *compressed, size_t n, int64_t *first_invalid);
+/* the inverse, on the host (no context, no GPU): bases as for msm_bn254_g1 -> n x 32 bytes                */
+int32_t msm_bn254_g1_compress(const uint32_t *bases_xy, uint32_t base_form, const uint8_t *inf_mask, size_t n,
+                              uint8_t *out_compressed);
 
 /* ---- everything already in HBM (what bench.py times) ---------------------------------------- */
 /* d_bases_mont: n x 16 words, Montgomery form, device memory; d_inf_mask: n bytes device memory or NULL;

@@ -622,3 +622,74 @@ void oracle_gen_bases_from_logs(const uint32_t *k, size_t n, uint32_t form, uint
     }
     free(tab);
 }
+
+/* ------------------------------------------------ arkworks compressed images --- */
+/* sqrt in Fq for p = 3 (mod 4): a^((p+1)/4), checked by squaring.  Montgomery in/out.  Returns 0 if a is a non-residue. */
+static int fq_sqrt(fq *o, const fq *a) {
+    /* (p+1)/4 from the limbs of p: (p+1) has no carry out of limb 0 (p ends in ...47) */
+    uint64_t q[4] = {FQ_P.l[0] + 1, FQ_P.l[1], FQ_P.l[2], FQ_P.l[3]};
+    uint64_t e[4];
+    for (int i = 0; i < 4; i++) e[i] = (q[i] >> 2) | (i < 3 ? q[i + 1] << 62 : 0);
+    fq acc = FQ_R1, base = *a, chk;
+    for (int i = 0; i < 256; i++) {
+        if ((e[i >> 6] >> (i & 63)) & 1) fq_mul(&acc, &acc, &base);
+        fq_sqr(&base, &base);
+    }
+    fq_sqr(&chk, &acc);
+    *o = acc;
+    return fq_eq(&chk, a);
+}
+/* integer comparison a > b of canonical standard-form values */
+static int fq_gt(const fq *a, const fq *b) {
+    for (int i = 3; i >= 0; i--)
+        if (a->l[i] != b->l[i]) return a->l[i] > b->l[i];
+    return 0;
+}
+size_t oracle_g1_decompress(const uint8_t *compressed, size_t n, uint32_t form, uint32_t *out_xy, uint8_t *out_inf) {
+    size_t first_bad = 0;
+    for (size_t i = 0; i < n; i++) {
+        uint32_t w[8];
+        memcpy(w, compressed + 32 * i, 32);
+        const int neg = (int)(w[7] >> 31), inf = (int)((w[7] >> 30) & 1);
+        w[7] &= 0x3FFFFFFFu;
+        fq x, y, ny, t, three, ys, nys;
+        fq_load(&x, w);
+        memset(out_xy + 16 * i, 0, 64);
+        out_inf[i] = 0;
+        if ((neg && inf) || fq_gte_p(&x)) { if (!first_bad) first_bad = i + 1; continue; }
+        if (inf) { out_inf[i] = 1; continue; }
+        fq_to_mont(&x, &x);
+        fq_sqr(&t, &x); fq_mul(&t, &t, &x);
+        fq_add(&three, &FQ_R1, &FQ_R1); fq_add(&three, &three, &FQ_R1);
+        fq_add(&t, &t, &three);
+        if (!fq_sqrt(&y, &t)) { if (!first_bad) first_bad = i + 1; continue; }
+        fq_neg(&ny, &y);
+        fq_from_mont(&ys, &y); fq_from_mont(&nys, &ny);
+        /* get_ys_from_x_unchecked orders (smaller, larger); YIsNegative selects the larger */
+        const int y_is_larger = fq_gt(&ys, &nys);
+        const fq *pick = (y_is_larger == neg) ? &y : &ny;
+        fq ox = x, oy = *pick;
+        if (form == ORACLE_FORM_STD) { fq_from_mont(&ox, &ox); fq_from_mont(&oy, &oy); }
+        fq_store(out_xy + 16 * i, &ox);
+        fq_store(out_xy + 16 * i + 8, &oy);
+    }
+    return first_bad;
+}
+void oracle_g1_compress(const uint32_t *bases_xy, uint32_t form, const uint8_t *inf, size_t n, uint8_t *out) {
+    for (size_t i = 0; i < n; i++) {
+        uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (inf && inf[i]) {
+            w[7] = 1u << 30;
+        } else {
+            fq x, y, ny;
+            fq_load(&x, bases_xy + 16 * i); fq_load(&y, bases_xy + 16 * i + 8);
+            if (form == ORACLE_FORM_MONT) { fq_from_mont(&x, &x); fq_from_mont(&y, &y); }
+            /* standard-form negation: p - y (y != 0 on this curve) */
+            fq zero = {{0, 0, 0, 0}};
+            fq_sub(&ny, &zero, &y);
+            fq_store(w, &x);
+            if (fq_gt(&y, &ny)) w[7] |= 1u << 31;
+        }
+        memcpy(out + 32 * i, w, 32);
+    }
+}

@@ -98,6 +98,15 @@ void oracle_gen_scalars(uint64_t seed, size_t n, int nonzero, uint32_t *out);
 /* P_i = k_i * G as affine Montgomery (form=1) or standard (form=0) words */
 void oracle_gen_bases_from_logs(const uint32_t *k, size_t n, uint32_t form, uint32_t *out_xy);
 
+/* ---- arkworks 0.4 compressed G1Affine images (the reference's instance files: utils/preprocess.rs:193-223 write with
+ * `serialize_compressed`, 101-131 / 225-256 read).  ark-serialize 0.4.x / ark-ec 0.4.x are third-party crates absent from
+ * /root/reference; their published format is restated: 32 bytes = x (standard form, little-endian), bit 255 =
+ * SWFlags::YIsNegative (y > p - y as integers), bit 254 = SWFlags::PointAtInfinity; both set = invalid.
+ * The reference commits no such file, so this format is UNPINNED by fixtures (stated in DESIGN.md). */
+/* returns 0, or 1 + index of the first invalid image; out_xy: n x 16 words in `form`; out_inf: n bytes */
+size_t oracle_g1_decompress(const uint8_t *compressed, size_t n, uint32_t form, uint32_t *out_xy, uint8_t *out_inf);
+void oracle_g1_compress(const uint32_t *bases_xy, uint32_t form, const uint8_t *inf, size_t n, uint8_t *out);
+
 #ifdef __cplusplus
 }
 #endif

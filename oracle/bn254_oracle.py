@@ -46,6 +46,9 @@ def lib():
         L.oracle_gen_scalars.argtypes = [C.c_uint64, C.c_size_t, C.c_int, _u32p]
         L.oracle_gen_bases_from_logs.argtypes = [_u32p, C.c_size_t, C.c_uint32, _u32p]
         L.oracle_g1_to_affine_std.restype = C.c_int
+        L.oracle_g1_decompress.argtypes = [_u8p, C.c_size_t, C.c_uint32, _u32p, _u8p]
+        L.oracle_g1_decompress.restype = C.c_size_t
+        L.oracle_g1_compress.argtypes = [_u32p, C.c_uint32, _u8p, C.c_size_t, _u8p]
         L.oracle_threads_available.restype = C.c_int
         _lib = L
     return _lib
@@ -196,6 +199,27 @@ def gen_bases_from_logs(k, form=FORM_MONT):
     out = np.zeros((k.shape[0], 16), np.uint32)
     lib().oracle_gen_bases_from_logs(_p32(k), k.shape[0], form, _p32(out))
     return out
+
+
+def g1_decompress(compressed, form=FORM_MONT):
+    """arkworks-0.4 compressed images (n x 32 bytes) -> (xy words n x 16, inf n, first_invalid or -1)."""
+    buf = np.ascontiguousarray(np.frombuffer(bytes(compressed), dtype=np.uint8))
+    n = buf.size // 32
+    out = np.zeros((n, 16), np.uint32)
+    inf = np.zeros(n, np.uint8)
+    bad = lib().oracle_g1_decompress(buf.ctypes.data_as(_u8p), n, form, _p32(out), inf.ctypes.data_as(_u8p))
+    return out, inf, int(bad) - 1
+
+
+def g1_compress(bases, form=FORM_MONT, inf=None):
+    b = _w(bases).reshape(-1, 16)
+    out = np.zeros(b.shape[0] * 32, np.uint8)
+    ip = None
+    if inf is not None:
+        inf = np.ascontiguousarray(inf, dtype=np.uint8)
+        ip = inf.ctypes.data_as(_u8p)
+    lib().oracle_g1_compress(_p32(b), form, ip, b.shape[0], out.ctypes.data_as(_u8p))
+    return out.tobytes()
 
 
 def closed_form_expected(k_words, s_words):
