@@ -177,23 +177,20 @@ void release(DevBuf& b) {
     b.cap = 0;
 }
 
-// ---- planner: replaces the N -> window_size / scale_factor tables (metal_msm.rs:661-691) and takes the
-// cuZK cost model (utils/window_size_optimizer.rs:38-51) as its shape: per window N mixed adds (10
-// modmul each) plus 2 full adds per bucket (14 modmul each) for the running-sum reduction.
+// ---- planner: replaces the N -> window_size / scale_factor tables (metal_msm.rs:661-691).  The cuZK cost model
+// (utils/window_size_optimizer.rs:38-51: per window N mixed adds plus ~2 full adds per bucket) gives the shape, but two
+// measured effects decide the table below (tools/sweep_c.py, profiles/NOTES_r1.md "window sweep"):
+//  * r < 2^254, so the top window only holds 254 mod c bits.  For c = 7, 9, 11, 12, 14 that is 1-2 bits: every point
+//    lands in one of <= 3 buckets of that window, which serialises the LDS sort cursors and makes those buckets
+//    thousands of chunks long (c = 12 at N = 2^19: 6.7 ms against 1.2 ms).  Only c in {8, 13, 15, 16} (6, 7, 14, 14
+//    top bits) are used.
+//  * below ~2^17 points the per-window fixed costs (dependent reduction levels, launches) outweigh the bucket count:
+//    fewer, wider windows win earlier than the arithmetic model says.
+// c is capped where one window's histogram still fits the LDS sort path (nb <= 32768: 16 signed, 15 unsigned).
 uint32_t plan_window_bits(size_t n, bool is_signed) {
-    double best = 1e300;
-    uint32_t best_c = 8;
-    // c is capped where one window's histogram still fits the 128 KB LDS sort path (nb <= 32768)
-    for (uint32_t c = 4; c <= (is_signed ? 16u : 15u); c++) {
-        double W = is_signed ? (double)(254 / c + 1) : (double)((254 + c - 1) / c);
-        double nb = is_signed ? (double)(1u << (c - 1)) : (double)(1u << c);
-        double cost = W * ((double)n * 10.0 + nb * 2.0 * 14.0 * 1.5);
-        if (cost < best) {
-            best = cost;
-            best_c = c;
-        }
-    }
-    return best_c;
+    uint32_t c = n < ((size_t)1 << 13) ? 8u : n <= ((size_t)1 << 16) ? 13u : n <= ((size_t)1 << 17) ? 15u : 16u;
+    if (!is_signed && c > 15u) c = 15u;
+    return c;
 }
 int32_t make_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_plan_t* out) {
     if (flags & ~MSM_FLAG_UNSIGNED_DIGITS) return MSM_ERR_BAD_ARG;
