@@ -48,7 +48,10 @@ enum { EV_START, EV_H2D, EV_CONVERT, EV_DECOMP, EV_SORT, EV_ACC0, EV_ACC1, EV_RE
 }  // namespace
 
 // Small persistent host thread pool for the CPU finish (per-window Horner chains are independent).  The
-// reference runs its CPU finish under rayon (metal_msm.rs:214-247); std::thread + condition variables here.
+// reference runs its CPU finish under rayon (metal_msm.rs:214-247); std::thread + a condition variable here.
+// run() returns when every JOB is done, not when every worker has checked in: a worker the OS wakes late (seen as
+// 3-10 ms outliers of the finish stage) simply finds nothing left, because the caller and the punctual workers pull jobs
+// from one ticket counter.  The ticket carries the generation, so a late worker can never take a job of a later run().
 class HostPool {
 public:
     explicit HostPool(int nthreads) {
@@ -64,23 +67,33 @@ public:
         for (auto& t : th_) t.join();
     }
     int size() const { return (int)th_.size(); }
-    // run fn(0..njobs-1) on the workers and the calling thread; returns when all are done
+    // run fn(0..njobs-1) on the workers and the calling thread; returns when all jobs are done
     void run(int njobs, const std::function<void(int)>& fn) {
+        uint64_t gen;
         {
             std::lock_guard<std::mutex> lk(m_);
             job_ = &fn;
             njobs_ = njobs;
-            next_.store(0);
-            pending_ = (int)th_.size();
-            gen_++;
+            gen = ++gen_;
+            done_.store(0, std::memory_order_relaxed);
+            ticket_.store(gen << 32, std::memory_order_release);
         }
         cv_work_.notify_all();
-        for (int i; (i = next_.fetch_add(1)) < njobs;) fn(i);
-        std::unique_lock<std::mutex> lk(m_);
-        cv_done_.wait(lk, [this] { return pending_ == 0; });
+        pull(gen, njobs, fn);
+        for (int spins = 0; done_.load(std::memory_order_acquire) < njobs; spins++)
+            if (spins > 2000) std::this_thread::yield();  // the stragglers are <= one window chain (~40 us) long
     }
 
 private:
+    void pull(uint64_t gen, int njobs, const std::function<void(int)>& fn) {
+        for (;;) {
+            uint64_t v = ticket_.load(std::memory_order_acquire);
+            if ((v >> 32) != gen || (int)(uint32_t)v >= njobs) return;
+            if (!ticket_.compare_exchange_weak(v, v + 1, std::memory_order_acq_rel)) continue;
+            fn((int)(uint32_t)v);  // fn outlives this call: run(gen) cannot return before done_ counts it
+            done_.fetch_add(1, std::memory_order_release);
+        }
+    }
     void worker() {
         uint64_t seen = 0;
         for (;;) {
@@ -94,19 +107,16 @@ private:
                 job = job_;
                 njobs = njobs_;
             }
-            for (int i; (i = next_.fetch_add(1)) < njobs;) (*job)(i);
-            {
-                std::lock_guard<std::mutex> lk(m_);
-                if (--pending_ == 0) cv_done_.notify_one();
-            }
+            pull(seen, njobs, *job);
         }
     }
     std::vector<std::thread> th_;
     std::mutex m_;
-    std::condition_variable cv_work_, cv_done_;
+    std::condition_variable cv_work_;
     const std::function<void(int)>* job_ = nullptr;
-    std::atomic<int> next_{0};
-    int njobs_ = 0, pending_ = 0;
+    std::atomic<uint64_t> ticket_{0};  // generation << 32 | next job index
+    std::atomic<int> done_{0};
+    int njobs_ = 0;
     uint64_t gen_ = 0;
     bool stop_ = false;
 };

@@ -84,12 +84,6 @@ __device__ __forceinline__ void store_xyzz(uint32_t* p, const xyzz& v) {
 #pragma unroll
     for (int i = 0; i < XW / 4; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
-__device__ __forceinline__ fp shfl_down_fp9(const fp& a, int d) {
-    fp r;
-#pragma unroll
-    for (int i = 0; i < 9; i++) r.v[i] = __shfl_down(a.v[i], d, 64);
-    return r;
-}
 // Jacobian in the C-ABI format: 24 words, canonical R = 2^256 Montgomery
 __device__ __forceinline__ void store_jacobian_mont256(uint32_t* o, const jacobian& j) {
     uint32_t w[8];
@@ -801,32 +795,33 @@ __global__ void __launch_bounds__(256) k_combine(const uint32_t* __restrict__ of
     store_xyzz(buckets + (size_t)k * XW, xyzz_add(load_xyzz(tails + (size_t)t0 * XW), load_xyzz(heads + (size_t)t1 * XW)));
 }
 
-// one 256-thread workgroup per LONG bucket: strided partial sums of its heads, then a wavefront __shfl_down tree
-// and a 4-way LDS step.  Dependency depth ceil(span/256) + 8 instead of span.
+// one 256-thread workgroup per LONG bucket: its pieces e(0) = tails[t0], e(i) = heads[t0+i] are folded strided
+// (thread j takes e(j), e(j+256), ...) and then by a pairwise tree through LDS that only runs the levels the piece
+// count needs.  Dependency depth ceil(cnt/256) - 1 + ceil(log2(min(cnt, 256))) adds instead of cnt.
 __global__ void __launch_bounds__(256) k_combine_long(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ heads,
                                                       const uint32_t* __restrict__ tails, uint32_t* __restrict__ buckets,
                                                       const uint32_t* __restrict__ long_count, const uint32_t* __restrict__ long_list,
                                                       uint32_t L) {
-    __shared__ uint32_t lds[4 * XW];
+    __shared__ uint32_t lds[256 * XW];
     const uint32_t nlong = *long_count;
     for (uint32_t item = blockIdx.x; item < nlong; item += gridDim.x) {
         const uint32_t k = long_list[item];
         const uint32_t beg = offsets[k], end = offsets[k + 1];
         const uint32_t t0 = beg / L, t1 = (end - 1) / L;
+        const uint32_t cnt = t1 - t0 + 1;
         xyzz acc = xyzz_identity();
-        for (uint32_t t = t0 + 1 + threadIdx.x; t <= t1; t += blockDim.x) acc = xyzz_add(acc, load_xyzz(heads + (size_t)t * XW));
-        for (int d = 32; d >= 1; d >>= 1) {
-            xyzz o{shfl_down_fp9(acc.x, d), shfl_down_fp9(acc.y, d), shfl_down_fp9(acc.zz, d), shfl_down_fp9(acc.zzz, d)};
-            acc = xyzz_add(acc, o);
+#pragma unroll 1
+        for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x)
+            acc = xyzz_add(acc, load_xyzz(i == 0 ? tails + (size_t)t0 * XW : heads + (size_t)(t0 + i) * XW));
+#pragma unroll 1
+        for (uint32_t d = 128; d >= 1; d >>= 1) {
+            if (d >= cnt) continue;  // threads >= cnt hold the identity: this level would add nothing (uniform)
+            __syncthreads();
+            if (threadIdx.x >= d && threadIdx.x < 2 * d) store_xyzz(lds + (size_t)threadIdx.x * XW, acc);
+            __syncthreads();
+            if (threadIdx.x < d) acc = xyzz_add(acc, load_xyzz(lds + (size_t)(threadIdx.x + d) * XW));
         }
-        __syncthreads();  // lds reuse across items
-        if ((threadIdx.x & 63) == 0) store_xyzz(lds + (threadIdx.x >> 6) * XW, acc);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            xyzz tot = load_xyzz(tails + (size_t)t0 * XW);
-            for (int q = 0; q < 4; q++) tot = xyzz_add(tot, load_xyzz(lds + q * XW));
-            store_xyzz(buckets + (size_t)k * XW, tot);
-        }
+        if (threadIdx.x == 0) store_xyzz(buckets + (size_t)k * XW, acc);
     }
 }
 
@@ -900,13 +895,33 @@ __global__ void __launch_bounds__(64) k_reduce_bits(const uint32_t* __restrict__
     }
     // lane m folds the m-th, (m+64)-th, ... SELECTED element (index = m with a 1 inserted at position `bit`), so the
     // serial part is cnt/128 adds instead of cnt/64 masked ones: dependency depth 1 + 6 for 256 row sums
+    // ONE xyzz_add call site for the strided folds and the six shuffle levels: an inlined complete add is ~40 KB of
+    // code, and a lone wavefront running six unrolled copies streams every one of them through the 64 KB instruction
+    // cache cold (measured: 83 us -> see profiles/NOTES_r1.md)
     xyzz acc = xyzz_identity();
     const uint32_t nsel = bit == 0xFFFFFFFFu ? cnt : cnt >> 1;
-    for (uint32_t m = threadIdx.x; m < nsel; m += 64) {
-        uint32_t j = bit == 0xFFFFFFFFu ? m : (((m >> bit) << (bit + 1)) | (1u << bit) | (m & ((1u << bit) - 1u)));
-        acc = xyzz_add(acc, load_xyzz(src + (size_t)j * XW));
+    const uint32_t nser = (nsel + 63) / 64;
+#pragma unroll 1
+    for (uint32_t step = 0; step < nser + 6; step++) {
+        xyzz other;
+        if (step < nser) {
+            const uint32_t m = threadIdx.x + 64 * step;
+            if (m < nsel) {
+                uint32_t j = bit == 0xFFFFFFFFu ? m : (((m >> bit) << (bit + 1)) | (1u << bit) | (m & ((1u << bit) - 1u)));
+                other = load_xyzz(src + (size_t)j * XW);
+            } else {
+                other = xyzz_identity();
+            }
+        } else {
+            // lanes >= d are spectators: __shfl_down hands them their OWN value, and acc + acc would drag the whole
+            // wavefront through the doubling branch on top of the addition (measured: 82 -> see NOTES); give them the identity
+            const uint32_t d = 32u >> (step - nser);
+            if (d >= nsel) continue;  // lanes >= nsel hold the identity: nothing to fold at this distance (uniform)
+            other = shfl_down_xyzz(acc, d, 64);
+            if (threadIdx.x >= d) other = xyzz_identity();
+        }
+        acc = xyzz_add(acc, other);
     }
-    for (int d = 32; d >= 1; d >>= 1) acc = xyzz_add(acc, shfl_down_xyzz(acc, d, 64));
     if (threadIdx.x == 0) {
         store_jacobian_mont256(q + (size_t)blockIdx.x * 24, xyzz_to_jacobian(acc));
     }
