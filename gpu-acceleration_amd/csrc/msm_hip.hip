@@ -143,6 +143,7 @@ struct msm_ctx {
     uint32_t* h_flags = nullptr;    // pinned
     // resident bases
     size_t resident_n = 0;
+    size_t wide_max = 40960;  // pairwise levels up to this many additions use 8 lanes per addition (MSM_HIP_WIDE_MAX; 0 = never)
     bool resident_has_inf = false;
     msm_timings_t tm{};
     bool stage_timing = false;  // record the per-stage hipEvents (each costs ~6 us of stream time); k_accumulate's pair is always on
@@ -405,7 +406,7 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
     msmk::k_combine<<<dim3(msmk::MID_BLOCKS + (unsigned)((tb + 255) / 256)), 256, 0, st>>>(offsets, (uint32_t*)c->heads.p, (uint32_t*)c->tails.p,
                                                                                          (uint32_t*)c->buckets.p, (uint32_t)tb, chunk_len, flags + 9,
                                                                                          (uint32_t*)c->midlist.p);
-    msmk::k_combine_long<<<1024, 256, 0, st>>>(offsets, (uint32_t*)c->heads.p, (uint32_t*)c->tails.p, (uint32_t*)c->buckets.p, flags + 8,
+    msmk::k_combine_long<<<1024, 512, 0, st>>>(offsets, (uint32_t*)c->heads.p, (uint32_t*)c->tails.p, (uint32_t*)c->buckets.p, flags + 8,
                                                (uint32_t*)c->longlist.p, chunk_len);
     // K4/K5: bucket reduction -- plain row/column sums by dense pairwise levels, then per-bit sums; the weights
     // are applied on the host
@@ -429,9 +430,15 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
                 jb = msmk::pair_job{cin, cbuf[l & 1], (uint32_t)cn, n_lo};
                 cin = cbuf[l & 1];
             }
-            msmk::k_pair_level<<<grid1((size_t)ja.n_out + jb.n_out, 256), 256, 0, st>>>(ja, jb);
+            // levels with fewer additions than an eighth of the lanes the chip keeps resident: eight lanes per addition
+            const size_t nadds = (size_t)ja.n_out + jb.n_out;
+            if (nadds <= c->wide_max) msmk::k_pair_level_wide<<<grid1(nadds * msmk::WIDE_LANES, 256), 256, 0, st>>>(ja, jb);
+            else msmk::k_pair_level<<<grid1(nadds, 256), 256, 0, st>>>(ja, jb);
         }
-        msmk::k_reduce_bits<<<W * (kb + 1), 64, 0, st>>>(rin, cin, (uint32_t*)c->qsums.p, n_hi, n_lo, kb_lo, kb);
+        if (c->wide_max && n_hi / 2 <= msmk::WIDE_TREE_MAX && n_lo <= msmk::WIDE_TREE_MAX)
+            msmk::k_reduce_bits_wide<<<W * (kb + 1), 512, 0, st>>>(rin, cin, (uint32_t*)c->qsums.p, n_hi, n_lo, kb_lo, kb);
+        else
+            msmk::k_reduce_bits<<<W * (kb + 1), 64, 0, st>>>(rin, cin, (uint32_t*)c->qsums.p, n_hi, n_lo, kb_lo, kb);
     }
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_REDUCE], st));
     HIPCHK(c, hipMemcpyAsync(h_qsums_dst, c->qsums.p, (size_t)W * (kb + 1) * 96, hipMemcpyDeviceToHost, st));
@@ -674,6 +681,7 @@ int32_t msm_ctx_create(const msm_config_t* cfg, msm_ctx** out) {
         int want = (int)std::thread::hardware_concurrency() - 1;
         if (want > 15) want = 15;
         if (const char* e = std::getenv("MSM_HIP_HOST_THREADS")) want = std::atoi(e) - 1;
+        if (const char* e = std::getenv("MSM_HIP_WIDE_MAX")) c->wide_max = (size_t)std::max(0, std::atoi(e));
         if (want >= 1) c->pool = new (std::nothrow) HostPool(want);
     }
     *out = c;
@@ -1020,7 +1028,8 @@ static int32_t run_test_kernel(msm_ctx* c, bool g1, uint32_t op, const uint32_t*
         HIPCHK(c, hipMalloc(&db, n * b_words * 4));
         HIPCHK(c, hipMemcpy(db, b, n * b_words * 4, hipMemcpyHostToDevice));
     }
-    if (g1) msmk::k_test_g1<<<grid1(n, 64), 64, 0, c->stream>>>(op, (uint32_t*)da, (uint32_t*)db, (uint32_t*)dout, (uint32_t)n);
+    if (g1 && op == MSM_OP_G1_ADD_WIDE) msmk::k_test_g1_wide<<<grid1(n, 8), 64, 0, c->stream>>>((uint32_t*)da, (uint32_t*)db, (uint32_t*)dout, (uint32_t)n);
+    else if (g1) msmk::k_test_g1<<<grid1(n, 64), 64, 0, c->stream>>>(op, (uint32_t*)da, (uint32_t*)db, (uint32_t*)dout, (uint32_t)n);
     else msmk::k_test_fp<<<grid1(n, 64), 64, 0, c->stream>>>(op, (uint32_t*)da, (uint32_t*)db, (uint32_t*)dout, (uint32_t)n);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
@@ -1036,7 +1045,7 @@ int32_t msm_test_fp_op(msm_ctx* c, uint32_t op, const uint32_t* a, const uint32_
     return run_test_kernel(c, false, op, a, 8, op <= MSM_OP_FP_MONT_MUL ? b : nullptr, 8, out, 8, n);
 }
 int32_t msm_test_g1_op(msm_ctx* c, uint32_t op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n) {
-    if (op > MSM_OP_G1_DBL) return MSM_ERR_BAD_ARG;
+    if (op > MSM_OP_G1_ADD_WIDE) return MSM_ERR_BAD_ARG;
     if (op != MSM_OP_G1_DBL && !b) return MSM_ERR_BAD_ARG;
     return run_test_kernel(c, true, op, a, 24, op == MSM_OP_G1_DBL ? nullptr : b, op == MSM_OP_G1_MADD ? 16 : 24, out, 24, n);
 }

@@ -21,6 +21,7 @@
 //   heads/tails  ceil(n*W/L) x 36  partial sums of buckets cut by chunk borders
 #pragma once
 #include "ec_bn254.hpp"
+#include "ec_wide.hpp"
 
 namespace msmk {
 using namespace bn254;
@@ -83,6 +84,52 @@ __device__ __forceinline__ void store_xyzz(uint32_t* p, const xyzz& v) {
     uint4* q = reinterpret_cast<uint4*>(p);
 #pragma unroll
     for (int i = 0; i < XW / 4; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+// one coordinate (0 = X, 1 = Y, 2 = ZZ, 3 = ZZZ) of an XYZZ record, HBM or LDS
+__device__ __forceinline__ fp load_coord(const uint32_t* rec, uint32_t coord) {
+    fp r;
+    const uint32_t* p = rec + 9 * coord;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = p[i];
+    return r;
+}
+__device__ __forceinline__ void store_coord(uint32_t* rec, uint32_t coord, const fp& v) {
+    uint32_t* p = rec + 9 * coord;
+#pragma unroll
+    for (int i = 0; i < 9; i++) p[i] = v.v[i];
+}
+// out = a + b by the EIGHT lanes of a group (ec_wide.hpp: 4 multiplications in series instead of 14).  Records in HBM or
+// LDS; out may alias a.  Must be reached by whole 8-lane groups.  Special pairs (identity operand, equal or opposite
+// points) fall back to the scalar complete addition on the group's first lane.
+__device__ __forceinline__ void wide_add_records(const uint32_t* a_rec, const uint32_t* b_rec, uint32_t* out_rec) {
+    const uint32_t role = threadIdx.x & (WIDE_LANES - 1);
+    const fp opa = load_coord(wide_opa_rec(role) ? b_rec : a_rec, wide_opa_coord(role));
+    const fp opb = load_coord(wide_opb_rec(role) ? b_rec : a_rec, wide_opb_coord(role));
+    const bool ident = role == 4 && (fp_is_zero_exact(opa) || fp_is_zero_exact(opb));  // role 4 holds ZZ1 and ZZ2
+    fp o0, o1;
+    if (xyzz_add_wide(opa, opb, ident, o0, o1)) {
+        if (role == 0) store_xyzz(out_rec, xyzz_add(load_xyzz(a_rec), load_xyzz(b_rec)));
+        return;
+    }
+    if (role == 1) {
+        store_coord(out_rec, 0, o0);
+        store_coord(out_rec, 1, o1);
+    } else if (role == 4) {
+        store_coord(out_rec, 2, o0);
+    } else if (role == 5) {
+        store_coord(out_rec, 3, o0);
+    }
+}
+// pairwise tree over m XYZZ records in LDS, wide additions, result in e[0].  Whole workgroup; blockDim multiple of 64.
+__device__ __forceinline__ void lds_tree_wide(uint32_t* e, uint32_t m) {
+    const uint32_t g = threadIdx.x / WIDE_LANES, ng = blockDim.x / WIDE_LANES;
+    while (m > 1) {  // uniform
+        const uint32_t h = (m + 1) >> 1;
+        __syncthreads();
+        for (uint32_t i = g; i < m - h; i += ng) wide_add_records(e + (size_t)i * XW, e + (size_t)(i + h) * XW, e + (size_t)i * XW);
+        m = h;
+    }
+    __syncthreads();
 }
 // Jacobian in the C-ABI format: 24 words, canonical R = 2^256 Montgomery
 __device__ __forceinline__ void store_jacobian_mont256(uint32_t* o, const jacobian& j) {
@@ -795,33 +842,37 @@ __global__ void __launch_bounds__(256) k_combine(const uint32_t* __restrict__ of
     store_xyzz(buckets + (size_t)k * XW, xyzz_add(load_xyzz(tails + (size_t)t0 * XW), load_xyzz(heads + (size_t)t1 * XW)));
 }
 
-// one 256-thread workgroup per LONG bucket: its pieces e(0) = tails[t0], e(i) = heads[t0+i] are folded strided
-// (thread j takes e(j), e(j+256), ...) and then by a pairwise tree through LDS that only runs the levels the piece
-// count needs.  Dependency depth ceil(cnt/256) - 1 + ceil(log2(min(cnt, 256))) adds instead of cnt.
-__global__ void __launch_bounds__(256) k_combine_long(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ heads,
+// one 512-thread workgroup per LONG bucket.  Its pieces e(0) = tails[t0], e(i) = heads[t0+i] are staged in LDS (more than
+// 256 pieces: threads 0..255 first fold them strided, scalar) and folded by a pairwise tree of WIDE additions.
+// Dependency depth ceil(cnt/256) - 1 scalar additions + ceil(log2(min(cnt, 256))) wide ones, instead of cnt.
+__global__ void __launch_bounds__(512) k_combine_long(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ heads,
                                                       const uint32_t* __restrict__ tails, uint32_t* __restrict__ buckets,
                                                       const uint32_t* __restrict__ long_count, const uint32_t* __restrict__ long_list,
                                                       uint32_t L) {
-    __shared__ uint32_t lds[256 * XW];
+    constexpr uint32_t CAP = 256;
+    __shared__ uint32_t e[CAP * XW];
     const uint32_t nlong = *long_count;
     for (uint32_t item = blockIdx.x; item < nlong; item += gridDim.x) {
         const uint32_t k = long_list[item];
         const uint32_t beg = offsets[k], end = offsets[k + 1];
         const uint32_t t0 = beg / L, t1 = (end - 1) / L;
         const uint32_t cnt = t1 - t0 + 1;
-        xyzz acc = xyzz_identity();
+        __syncthreads();  // e is reused across items
+        if (cnt <= CAP) {
+            for (uint32_t i = threadIdx.x >> 2; i < cnt; i += blockDim.x >> 2) {
+                const uint32_t* piece = i == 0 ? tails + (size_t)t0 * XW : heads + (size_t)(t0 + i) * XW;
+                const uint32_t co = threadIdx.x & 3u;
+                store_coord(e + (size_t)i * XW, co, load_coord(piece, co));
+            }
+        } else if (threadIdx.x < CAP) {
+            xyzz acc = xyzz_identity();
 #pragma unroll 1
-        for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x)
-            acc = xyzz_add(acc, load_xyzz(i == 0 ? tails + (size_t)t0 * XW : heads + (size_t)(t0 + i) * XW));
-#pragma unroll 1
-        for (uint32_t d = 128; d >= 1; d >>= 1) {
-            if (d >= cnt) continue;  // threads >= cnt hold the identity: this level would add nothing (uniform)
-            __syncthreads();
-            if (threadIdx.x >= d && threadIdx.x < 2 * d) store_xyzz(lds + (size_t)threadIdx.x * XW, acc);
-            __syncthreads();
-            if (threadIdx.x < d) acc = xyzz_add(acc, load_xyzz(lds + (size_t)(threadIdx.x + d) * XW));
+            for (uint32_t i = threadIdx.x; i < cnt; i += CAP)
+                acc = xyzz_add(acc, load_xyzz(i == 0 ? tails + (size_t)t0 * XW : heads + (size_t)(t0 + i) * XW));
+            store_xyzz(e + (size_t)threadIdx.x * XW, acc);
         }
-        if (threadIdx.x == 0) store_xyzz(buckets + (size_t)k * XW, acc);
+        lds_tree_wide(e, cnt < CAP ? cnt : CAP);
+        if (threadIdx.x < 4) store_coord(buckets + (size_t)k * XW, threadIdx.x, load_coord(e, threadIdx.x));
     }
 }
 
@@ -871,6 +922,54 @@ __global__ void __launch_bounds__(256) k_pair_level(pair_job ja, pair_job jb) {
     size_t i0 = (size_t)2 * (t / j.B) * j.B + (t % j.B);
     xyzz r = xyzz_add(load_xyzz(j.in + i0 * XW), load_xyzz(j.in + (i0 + j.B) * XW));
     store_xyzz(j.out + (size_t)t * XW, r);
+}
+
+// k_pair_level for the SMALL levels (fewer additions than the chip has lanes / 8): eight lanes per addition.
+__global__ void __launch_bounds__(256) k_pair_level_wide(pair_job ja, pair_job jb) {
+    uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) / WIDE_LANES;
+    pair_job j = ja;
+    if (t >= ja.n_out) {
+        t -= ja.n_out;
+        j = jb;
+        if (t >= jb.n_out) return;
+    }
+    size_t i0 = (size_t)2 * (t / j.B) * j.B + (t % j.B);
+    wide_add_records(j.in + i0 * XW, j.in + (i0 + j.B) * XW, j.out + (size_t)t * XW);
+}
+
+constexpr uint32_t WIDE_TREE_MAX = 256;  // records one workgroup's LDS tree holds (36 KB)
+// k_reduce_bits with wide additions: one 512-thread workgroup per (window, bit); the selected elements are staged in LDS
+// and folded by a pairwise tree (log2(nsel) levels of 4 multiplications each).  Needs nsel <= WIDE_TREE_MAX.
+__global__ void __launch_bounds__(512) k_reduce_bits_wide(const uint32_t* __restrict__ R, const uint32_t* __restrict__ C,
+                                                          uint32_t* __restrict__ q, uint32_t n_hi, uint32_t n_lo, uint32_t kb_lo,
+                                                          uint32_t kb) {
+    __shared__ uint32_t e[WIDE_TREE_MAX * XW];
+    uint32_t w = blockIdx.x / (kb + 1), u = blockIdx.x % (kb + 1);
+    const uint32_t* src;
+    uint32_t cnt, bit;
+    if (u < kb_lo) {
+        src = C + (size_t)w * n_lo * XW;
+        cnt = n_lo;
+        bit = u;
+    } else if (u < kb) {
+        src = R + (size_t)w * n_hi * XW;
+        cnt = n_hi;
+        bit = u - kb_lo;
+    } else {
+        src = C + (size_t)w * n_lo * XW;
+        cnt = n_lo;
+        bit = 0xFFFFFFFFu;
+    }
+    const uint32_t nsel = bit == 0xFFFFFFFFu ? cnt : cnt >> 1;
+    // thread t stages coordinate t&3 of the (t>>2)-th SELECTED element (index = m with a 1 inserted at position `bit`)
+    for (uint32_t m = threadIdx.x >> 2; m < nsel; m += blockDim.x >> 2) {
+        const uint32_t j = bit == 0xFFFFFFFFu ? m : (((m >> bit) << (bit + 1)) | (1u << bit) | (m & ((1u << bit) - 1u)));
+        const uint32_t co = threadIdx.x & 3u;
+        store_coord(e + (size_t)m * XW, co, load_coord(src + (size_t)j * XW, co));
+    }
+    if (nsel == 0 && threadIdx.x == 0) store_xyzz(e, xyzz_identity());
+    lds_tree_wide(e, nsel);
+    if (threadIdx.x == 0) store_jacobian_mont256(q + (size_t)blockIdx.x * 24, xyzz_to_jacobian(load_xyzz(e)));
 }
 
 // one wavefront per (window, bit): R[w][0..n_hi), C[w][0..n_lo);  q[w][u] Jacobian
@@ -1035,10 +1134,29 @@ __global__ void __launch_bounds__(64) k_test_g1(uint32_t op, const uint32_t* __r
         xyzz_madd(r, q);
     } else if (op == 1) {
         r = xyzz_add(p, xyzz_from_jacobian(load_jacobian_mont256(b + (size_t)i * 24)));
+    } else if (op == 3) {
+        // never reached: op 3 (wide addition) has its own kernel, k_test_g1_wide
+        r = p;
     } else {
         r = xyzz_dbl(p);
     }
     store_jacobian_mont256(out + (size_t)i * 24, xyzz_to_jacobian(r));
+}
+
+// test hook for ec_wide.hpp: pair i is added by the 8 lanes of group i (records staged in LDS by the group's first lane)
+__global__ void __launch_bounds__(64) k_test_g1_wide(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                                     uint32_t* __restrict__ out, uint32_t n) {
+    __shared__ uint32_t e[16 * XW];
+    const uint32_t g = threadIdx.x / WIDE_LANES, role = threadIdx.x % WIDE_LANES;
+    const uint32_t i = blockIdx.x * 8 + g;
+    if (i < n && role == 0) {
+        store_xyzz(e + (size_t)(2 * g) * XW, xyzz_from_jacobian(load_jacobian_mont256(a + (size_t)i * 24)));
+        store_xyzz(e + (size_t)(2 * g + 1) * XW, xyzz_from_jacobian(load_jacobian_mont256(b + (size_t)i * 24)));
+    }
+    __syncthreads();
+    if (i < n) wide_add_records(e + (size_t)(2 * g) * XW, e + (size_t)(2 * g + 1) * XW, e + (size_t)(2 * g) * XW);
+    __syncthreads();
+    if (i < n && role == 0) store_jacobian_mont256(out + (size_t)i * 24, xyzz_to_jacobian(load_xyzz(e + (size_t)(2 * g) * XW)));
 }
 
 }  // namespace msmk

@@ -112,6 +112,34 @@ def test_g1_ops_match_oracle(ctx):
     assert _same_affine(out[3], orc.g1_dbl(a[3])) and _same_affine(out[4], orc.g1_dbl(a[4]))
 
 
+def test_wide_add_matches_scalar_add_and_oracle(ctx):
+    """ec_wide.hpp: the 8-lane addition used by the reduction trees == the scalar complete addition == the oracle,
+    on random pairs and on every special case (identity operands, P + P, P + P with another Z, P + (-P)),
+    at group counts that leave partial wavefronts."""
+    for n in (1, 7, 8, 9, 203):
+        a = _jac_points(n, 21 + n)
+        b = _jac_points(n, 22 + n)
+        ident = np.zeros(24, np.uint32)
+        ident[:8] = orc.fq_to_mont(orc.int_to_words(1))
+        ident[8:16] = ident[:8]
+        if n >= 7:
+            a[0] = ident
+            b[1] = ident
+            a[2] = ident
+            b[2] = ident
+            b[3] = a[3]
+            b[4] = orc.g1_add(orc.g1_dbl(a[4]), _neg(a[4]))
+            b[5] = _neg(a[5])
+            b[6] = _neg(orc.g1_add(orc.g1_dbl(a[6]), _neg(a[6])))
+        wide = ctx.test_g1_op(3, a, b)
+        scalar = ctx.test_g1_op(1, a, b)
+        for i in range(n):
+            assert _same_affine(wide[i], orc.g1_add(a[i], b[i])), ("wide add", n, i)
+            assert _same_affine(wide[i], scalar[i]), ("wide vs scalar", n, i)
+        if n >= 7:
+            assert orc.g1_to_affine_std(wide[5])[1] == 1 and orc.g1_to_affine_std(wide[6])[1] == 1 and orc.g1_to_affine_std(wide[2])[1] == 1
+
+
 def test_signed_digits_reconstruct_scalar(ctx):
     g = load_golden("edge_carry_patterns")
     sc = np.concatenate([g["scalars"], orc.gen_scalars(5, 200), np.stack([orc.int_to_words(v) for v in (0, 1, R - 1, R - 2, (1 << 253) + 12345)])])
