@@ -447,33 +447,46 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
     return MSM_OK;
 }
 
-// final_reduction (metal_msm.rs:204-261) on the CPU.  Window term T_w = 2^(c*w) * S_w with
-// S_w = Q_all + sum_u 2^u Q_u (one Horner chain over the bit sums, then c*w doublings); the W chains are independent,
-// so they run on the context's host pool, heaviest first.
+// final_reduction (metal_msm.rs:204-261) on the CPU.  With S_w = Q_all,w + sum_u 2^u Q_w,u the result is
+//     sum_w 2^(c*w) S_w = sum over bit positions p = c*w + u of 2^p * (Q_w,u  [+ Q_all,w when u == 0]),
+// ONE Horner chain over the ~254 positions (one doubling and about one addition per position) instead of the reference's
+// chain per window plus c doublings between windows (metal_msm.rs:249-258).  The chain is cut into a few segments of
+// geometrically shrinking length (a segment starting at position lo pays lo extra doublings to shift its sum), one per
+// host thread: 3-4 threads reach ~45 % of the serial time, more threads add nothing because the shift of the top
+// segment is serial.  Few threads on purpose: a pool of 15 was ~15 us faster in the median but produced 3-10 ms outliers
+// in 2.5 % of the calls when the OS was late waking workers (tools/step_jitter.py).
 hostg1::Jac host_finish(msm_ctx* c, const uint32_t* h_qsums, const PipeGeom& g) {
     const uint32_t W = g.W, kb = g.kb, cbits = g.cbits;
-    std::vector<hostg1::Jac> term(W);
-    auto window_job = [&](int job) {
-        const int w = (int)W - 1 - job;
-        const uint32_t* qw = h_qsums + (size_t)w * (kb + 1) * 24;
-        hostg1::Jac sw = hostg1::identity();
-        for (int u = (int)kb - 1; u >= 0; u--) sw = hostg1::jadd(hostg1::jdbl(sw), hostg1::load_jac(qw + (size_t)u * 24));
-        sw = hostg1::jadd(sw, hostg1::load_jac(qw + (size_t)kb * 24));
-        if (c->pool)
-            for (uint32_t k = 0; k < cbits * (uint32_t)w; k++) sw = hostg1::jdbl(sw);
-        term[w] = sw;
-    };
-    hostg1::Jac total = hostg1::identity();
-    if (c->pool) {
-        c->pool->run((int)W, window_job);
-        for (uint32_t w = 0; w < W; w++) total = hostg1::jadd(total, term[w]);
-    } else {  // serial: plain Horner over windows, high -> low (metal_msm.rs:249-258)
-        for (int job = 0; job < (int)W; job++) window_job(job);
-        for (int w = (int)W - 1; w >= 0; w--) {
-            for (uint32_t k = 0; k < cbits; k++) total = hostg1::jdbl(total);
-            total = hostg1::jadd(total, term[w]);
+    const uint32_t npos = cbits * (W - 1) + (kb > 0 ? kb : 1);  // positions 0 .. npos-1 carry terms
+    auto segment = [&](uint32_t lo, uint32_t hi) {             // sum over p in [lo, hi) of 2^p * term(p)
+        hostg1::Jac acc = hostg1::identity();
+        for (uint32_t p = hi; p-- > lo;) {
+            acc = hostg1::jdbl(acc);
+            const uint32_t w = p / cbits, u = p % cbits;
+            const uint32_t* qw = h_qsums + (size_t)w * (kb + 1) * 24;
+            if (u < kb) acc = hostg1::jadd(acc, hostg1::load_jac(qw + (size_t)u * 24));
+            if (u == 0) acc = hostg1::jadd(acc, hostg1::load_jac(qw + (size_t)kb * 24));
         }
+        for (uint32_t k = 0; k < lo; k++) acc = hostg1::jdbl(acc);
+        return acc;
+    };
+    const int nseg = c->pool ? std::min<int>(c->pool->size() + 1, 8) : 1;
+    if (nseg == 1 || npos < 32) return segment(0, npos);
+    // segment k has length proportional to 0.7^k (a doubling costs ~0.3 of a position's doubling + addition)
+    uint32_t bound[9];
+    double tot = 0, wgt = 1;
+    for (int k = 0; k < nseg; k++, wgt *= 0.7) tot += wgt;
+    double run = 0;
+    wgt = 1;
+    bound[0] = 0;
+    for (int k = 0; k < nseg; k++, wgt *= 0.7) {
+        run += wgt;
+        bound[k + 1] = k + 1 == nseg ? npos : (uint32_t)(npos * (run / tot) + 0.5);
     }
+    std::vector<hostg1::Jac> part((size_t)nseg);
+    c->pool->run(nseg, [&](int k) { part[(size_t)k] = segment(bound[k], bound[k + 1]); });  // job 0 (the longest) is taken first
+    hostg1::Jac total = part[0];
+    for (int k = 1; k < nseg; k++) total = hostg1::jadd(total, part[(size_t)k]);
     return total;
 }
 
@@ -679,7 +692,7 @@ int32_t msm_ctx_create(const msm_config_t* cfg, msm_ctx** out) {
     {
         // host finish threads: MSM_HIP_HOST_THREADS=0 forces the serial path
         int want = (int)std::thread::hardware_concurrency() - 1;
-        if (want > 15) want = 15;
+        if (want > 3) want = 3;  // the calling thread + 3 workers: see host_finish
         if (const char* e = std::getenv("MSM_HIP_HOST_THREADS")) want = std::atoi(e) - 1;
         if (const char* e = std::getenv("MSM_HIP_WIDE_MAX")) c->wide_max = (size_t)std::max(0, std::atoi(e));
         if (want >= 1) c->pool = new (std::nothrow) HostPool(want);
