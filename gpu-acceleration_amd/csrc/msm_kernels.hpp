@@ -522,6 +522,22 @@ constexpr uint32_t SUBTILE = 16384;        // elements sorted in LDS by one leve
 constexpr uint32_t FINE_CAP = 16384;       // elements a level-2 workgroup can stage in LDS (64 KB: two workgroups per CU)
 constexpr uint32_t COARSE_BINS_MAX = 1024;  // == TILE_BLOCK: one thread per coarse bin
 
+// atomicAdd(&ctr[key], 1u) on an LDS counter for the active lanes of a wavefront.  When ALL of them hit the same counter
+// (skewed scalars: one bucket holds most of a window -- many equal witness values, or the adversarial all-equal case) the
+// wavefront issues ONE atomic for the whole group instead of 64 conflicting ones; the check is two ballots.
+__device__ __forceinline__ uint32_t lds_inc(uint32_t* ctr, uint32_t key) {
+    const unsigned long long act = __ballot(1);
+    const uint32_t k0 = __builtin_amdgcn_readfirstlane(key);
+    if (__ballot(key == k0) == act) {  // wave-uniform
+        const uint32_t lane = threadIdx.x & 63u;
+        uint32_t base = 0;
+        if (lane == (uint32_t)(__ffsll((long long)act) - 1)) base = atomicAdd(&ctr[k0], (uint32_t)__popcll(act));
+        base = __builtin_amdgcn_readfirstlane(base);  // the first active lane is the one that added
+        return base + (uint32_t)__popcll(act & ((1ull << lane) - 1ull));
+    }
+    return atomicAdd(&ctr[key], 1u);
+}
+
 __global__ void __launch_bounds__(TILE_BLOCK) k_coarse_hist(const uint32_t* __restrict__ digits, uint32_t* __restrict__ counts,
                                                             uint32_t n, uint32_t fine_bits, uint32_t ncoarse, uint32_t NS) {
     __shared__ uint32_t s_h[COARSE_BINS_MAX];
@@ -532,7 +548,7 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_coarse_hist(const uint32_t* __re
     const size_t row = (size_t)w * n;
     for (uint32_t i = i0 + threadIdx.x; i < i1; i += TILE_BLOCK) {
         uint32_t d = digits[row + i];
-        if (d != DIGIT_SKIP) atomicAdd(&s_h[(d & ~SIGN_BIT) >> fine_bits], 1u);
+        if (d != DIGIT_SKIP) lds_inc(s_h, (d & ~SIGN_BIT) >> fine_bits);
     }
     __syncthreads();
     if (threadIdx.x < ncoarse) counts[((size_t)w * NS + st) * ncoarse + threadIdx.x] = s_h[threadIdx.x];  // [w][sub-tile][bin]
@@ -612,7 +628,7 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_coarse_scatter(const uint32_t* _
         uint32_t d = digits[row + i];
         if (d == DIGIT_SKIP) continue;
         uint32_t bkt = d & ~SIGN_BIT;
-        uint32_t pos = atomicAdd(&s_cur[bkt >> fine_bits], 1u);
+        uint32_t pos = lds_inc(s_cur, bkt >> fine_bits);
         s_stage[pos] = i | ((bkt & fine_mask) << idx_bits) | (d & SIGN_BIT);
     }
     __syncthreads();
@@ -647,9 +663,9 @@ __global__ void __launch_bounds__(FINE_BLOCK) k_fine_sort(const uint32_t* __rest
         }
 #pragma unroll
         for (int k = 0; k < FINE_PER_THREAD; k++)
-            if (e[k] != DIGIT_SKIP) atomicAdd(&s_cur[(e[k] >> idx_bits) & fine_mask], 1u);
+            if (e[k] != DIGIT_SKIP) lds_inc(s_cur, (e[k] >> idx_bits) & fine_mask);
     } else {
-        for (uint32_t j = rs + threadIdx.x; j < re; j += FINE_BLOCK) atomicAdd(&s_cur[(tmp[j] >> idx_bits) & fine_mask], 1u);
+        for (uint32_t j = rs + threadIdx.x; j < re; j += FINE_BLOCK) lds_inc(s_cur, (tmp[j] >> idx_bits) & fine_mask);
     }
     __syncthreads();
     // exclusive prefix of the <= 128 fine counts (Hillis-Steele in LDS)
@@ -672,7 +688,7 @@ __global__ void __launch_bounds__(FINE_BLOCK) k_fine_sort(const uint32_t* __rest
 #pragma unroll
         for (int k = 0; k < FINE_PER_THREAD; k++) {
             if (e[k] == DIGIT_SKIP) continue;
-            uint32_t pos = atomicAdd(&s_cur[(e[k] >> idx_bits) & fine_mask], 1u);
+            uint32_t pos = lds_inc(s_cur, (e[k] >> idx_bits) & fine_mask);
             s_out[pos] = (e[k] & idx_mask) | (e[k] & SIGN_BIT);
         }
         __syncthreads();
@@ -680,7 +696,7 @@ __global__ void __launch_bounds__(FINE_BLOCK) k_fine_sort(const uint32_t* __rest
     } else {  // skewed data: the region does not fit LDS, place directly
         for (uint32_t j = rs + threadIdx.x; j < re; j += FINE_BLOCK) {
             uint32_t v = tmp[j];
-            uint32_t pos = atomicAdd(&s_cur[(v >> idx_bits) & fine_mask], 1u);
+            uint32_t pos = lds_inc(s_cur, (v >> idx_bits) & fine_mask);
             sorted[rs + pos] = (v & idx_mask) | (v & SIGN_BIT);
         }
     }
