@@ -137,7 +137,7 @@ struct msm_ctx {
     hipEvent_t ev[EV_COUNT]{};
     // HBM workspace
     DevBuf bases, ibases, inf, scalars, digits, ranks, sorted, hist, offsets, blocksums, buckets, heads, tails, chunkmap, rc, qsums, flags,
-        pow2, tilecounts, longlist, midlist, ccounts, cregion;
+        pow2, tilecounts, longlist, longdone, midlist, ccounts, cregion;
     bool pow2_ready = false;
     uint32_t* h_qsums = nullptr;  // pinned: W x (kb+1) Jacobian bit sums
     uint32_t* h_flags = nullptr;    // pinned
@@ -313,7 +313,13 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
     if ((rc = ensure(c, c->heads, nchunks_max * XB > pairs * 4 ? nchunks_max * XB : pairs * 4))) return rc;  // also stages the 2-level sort
     if ((rc = ensure(c, c->tails, nchunks_max * XB))) return rc;
     if ((rc = ensure(c, c->chunkmap, nchunks_max * 4))) return rc;
-    if ((rc = ensure(c, c->longlist, (nchunks_max / msmk::LONG_SPAN + 16) * 4))) return rc;  // a long bucket owns >= LONG_SPAN chunks
+    {   // a long bucket owns >= LONG_SPAN chunks and gets one (bucket, segment) entry per LONG_SEG pieces
+        const size_t entries = nchunks_max / msmk::LONG_SPAN + nchunks_max / msmk::LONG_SEG + 32;
+        if ((rc = ensure(c, c->longlist, entries * 8))) return rc;
+        const size_t had = c->longdone.cap;
+        if ((rc = ensure(c, c->longdone, entries * 4))) return rc;
+        if (c->longdone.cap != had) HIPCHK(c, hipMemsetAsync(c->longdone.p, 0, c->longdone.cap, st));  // self-cleaning afterwards
+    }
     if ((rc = ensure(c, c->midlist, (nchunks_max / 2 + 16) * 4))) return rc;                  // a listed bucket owns >= 2 chunk borders
     if ((rc = ensure(c, c->rc, (tb + tb / 2 + 4) * XB))) return rc;  // two families x (1/2 + 1/4) ping-pong levels
     if ((rc = ensure(c, c->qsums, (size_t)W * (kb + 1) * 96))) return rc;
@@ -407,7 +413,7 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
                                                                                          (uint32_t*)c->buckets.p, (uint32_t)tb, chunk_len, flags + 9,
                                                                                          (uint32_t*)c->midlist.p);
     msmk::k_combine_long<<<1024, 512, 0, st>>>(offsets, (uint32_t*)c->heads.p, (uint32_t*)c->tails.p, (uint32_t*)c->buckets.p, flags + 8,
-                                               (uint32_t*)c->longlist.p, chunk_len);
+                                               (uint32_t*)c->longlist.p, (uint32_t*)c->longdone.p, chunk_len);
     // K4/K5: bucket reduction -- plain row/column sums by dense pairwise levels, then per-bit sums; the weights
     // are applied on the host
     {
@@ -710,7 +716,7 @@ void msm_ctx_destroy(msm_ctx* c) {
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         DevBuf* bufs[] = {&c->bases,   &c->inf,       &c->scalars, &c->digits,  &c->ranks,  &c->sorted, &c->hist,
                           &c->offsets, &c->blocksums, &c->buckets, &c->rc,      &c->qsums,   &c->flags,  &c->pow2,
-                          &c->heads,   &c->tails,     &c->chunkmap, &c->tilecounts, &c->ibases, &c->longlist, &c->midlist, &c->ccounts, &c->cregion};
+                          &c->heads,   &c->tails,     &c->chunkmap, &c->tilecounts, &c->ibases, &c->longlist, &c->longdone, &c->midlist, &c->ccounts, &c->cregion};
         for (DevBuf* b : bufs) release(*b);
         if (c->h_qsums) (void)hipHostFree(c->h_qsums);
         if (c->h_flags) (void)hipHostFree(c->h_flags);

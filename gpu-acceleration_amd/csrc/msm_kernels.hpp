@@ -120,6 +120,7 @@ __device__ __forceinline__ void wide_add_records(const uint32_t* a_rec, const ui
         store_coord(out_rec, 3, o0);
     }
 }
+constexpr uint32_t WIDE_TREE_MAX = 256;  // records one workgroup's LDS tree holds (36 KB)
 // pairwise tree over m XYZZ records in LDS, wide additions, result in e[0].  Whole workgroup; blockDim multiple of 64.
 __device__ __forceinline__ void lds_tree_wide(uint32_t* e, uint32_t m) {
     const uint32_t g = threadIdx.x / WIDE_LANES, ng = blockDim.x / WIDE_LANES;
@@ -731,6 +732,7 @@ __global__ void k_scatter(const uint32_t* __restrict__ digits, const uint32_t* _
 // buckets cut into 3..LONG_SPAN-1 chunks for k_combine_mid; k_combine itself only meets buckets cut once, so that
 // every one of its wavefronts runs exactly one XYZZ add (a few 3-chunk buckets per wavefront used to double its time).
 constexpr uint32_t LONG_SPAN = 8;
+constexpr uint32_t LONG_SEG = 2048;  // pieces of a long bucket folded by one k_combine_long workgroup
 __global__ void __launch_bounds__(1024) k_chunk_map(const uint32_t* __restrict__ offsets, uint32_t* __restrict__ chunk_bucket,
                                                    uint32_t total_buckets, uint32_t L, uint32_t* __restrict__ long_count,
                                                    uint32_t* __restrict__ long_list, uint32_t* __restrict__ mid_count,
@@ -739,24 +741,34 @@ __global__ void __launch_bounds__(1024) k_chunk_map(const uint32_t* __restrict__
     if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
     __syncthreads();
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t kindl = 2, slot = 0;  // 0 = mid list, 1 = long list, 2 = neither
+    uint32_t kindl = 2, slot = 0, nseg = 1;  // 0 = mid list, 1 = long list, 2 = neither
     if (k < total_buckets) {
         uint32_t beg = offsets[k], end = offsets[k + 1];
         if (beg != end) {
             uint32_t tf = (beg + L - 1) / L, tl = (end - 1) / L;
-            const uint32_t span = tl - beg / L;  // chunk borders inside the bucket
-            if (span >= LONG_SPAN) kindl = 1;
-            else if (span >= 2) kindl = 0;
+            const uint32_t span = tl - beg / L;  // chunk borders inside the bucket; the bucket has span + 1 pieces
+            if (span >= LONG_SPAN) {
+                kindl = 1;
+                nseg = (span + 1 + LONG_SEG - 1) / LONG_SEG;
+            } else if (span >= 2) {
+                kindl = 0;
+            }
             for (uint32_t t = tf; t <= tl; t++) chunk_bucket[t] = k;
         }
     }
-    if (kindl < 2) slot = atomicAdd(&s_n[kindl], 1u);  // LDS
+    if (kindl < 2) slot = atomicAdd(&s_n[kindl], nseg);  // LDS
     __syncthreads();
     if (threadIdx.x == 0 && s_n[0]) s_base[0] = atomicAdd(mid_count, s_n[0]);
     if (threadIdx.x == 1 && s_n[1]) s_base[1] = atomicAdd(long_count, s_n[1]);
     __syncthreads();
-    if (kindl == 0) mid_list[s_base[0] + slot] = k;
-    else if (kindl == 1) long_list[s_base[1] + slot] = k;
+    if (kindl == 0) {
+        mid_list[s_base[0] + slot] = k;
+    } else if (kindl == 1) {  // one entry per LONG_SEG pieces: (bucket, segment | first entry of the bucket)
+        for (uint32_t j = 0; j < nseg; j++) {
+            long_list[2 * (size_t)(s_base[1] + slot + j)] = k;
+            long_list[2 * (size_t)(s_base[1] + slot + j) + 1] = j;
+        }
+    }
 }
 
 __global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
@@ -858,37 +870,62 @@ __global__ void __launch_bounds__(256) k_combine(const uint32_t* __restrict__ of
     store_xyzz(buckets + (size_t)k * XW, xyzz_add(load_xyzz(tails + (size_t)t0 * XW), load_xyzz(heads + (size_t)t1 * XW)));
 }
 
-// one 512-thread workgroup per LONG bucket.  Its pieces e(0) = tails[t0], e(i) = heads[t0+i] are staged in LDS (more than
-// 256 pieces: threads 0..255 first fold them strided, scalar) and folded by a pairwise tree of WIDE additions.
-// Dependency depth ceil(cnt/256) - 1 scalar additions + ceil(log2(min(cnt, 256))) wide ones, instead of cnt.
-__global__ void __launch_bounds__(512) k_combine_long(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ heads,
-                                                      const uint32_t* __restrict__ tails, uint32_t* __restrict__ buckets,
+// Long buckets (cut into LONG_SPAN or more pieces: tiny top windows, skewed scalars).  Pieces e(0) = tails[t0],
+// e(i) = heads[t0+i].  One 512-thread workgroup per SEGMENT of LONG_SEG pieces: staged in LDS (more than 256: threads
+// 0..255 first fold strided, scalar) and folded by a pairwise tree of WIDE additions.  A bucket of several segments
+// (one bucket holding most of a window) is finished by whichever of its workgroups arrives last: segment sums are
+// parked in the segment's first piece, a device-scope counter per bucket tells the last one (threadfence reduction).
+__device__ __forceinline__ const uint32_t* long_piece(const uint32_t* heads, const uint32_t* tails, uint32_t t0, uint32_t i) {
+    return i == 0 ? tails + (size_t)t0 * XW : heads + (size_t)(t0 + i) * XW;
+}
+// fold pieces first, first+stride, ... (count of them) into e[0]; whole workgroup
+__device__ __forceinline__ void long_fold(uint32_t* e, const uint32_t* heads, const uint32_t* tails, uint32_t t0, uint32_t first,
+                                          uint32_t stride, uint32_t count) {
+    constexpr uint32_t CAP = WIDE_TREE_MAX;
+    __syncthreads();  // e is reused
+    if (count <= CAP) {
+        for (uint32_t i = threadIdx.x >> 2; i < count; i += blockDim.x >> 2) {
+            const uint32_t co = threadIdx.x & 3u;
+            store_coord(e + (size_t)i * XW, co, load_coord(long_piece(heads, tails, t0, first + i * stride), co));
+        }
+    } else if (threadIdx.x < CAP) {
+        xyzz acc = xyzz_identity();
+#pragma unroll 1
+        for (uint32_t i = threadIdx.x; i < count; i += CAP) acc = xyzz_add(acc, load_xyzz(long_piece(heads, tails, t0, first + i * stride)));
+        store_xyzz(e + (size_t)threadIdx.x * XW, acc);
+    }
+    lds_tree_wide(e, count < CAP ? count : CAP);
+}
+__global__ void __launch_bounds__(512) k_combine_long(const uint32_t* __restrict__ offsets, uint32_t* __restrict__ heads,
+                                                      uint32_t* __restrict__ tails, uint32_t* __restrict__ buckets,
                                                       const uint32_t* __restrict__ long_count, const uint32_t* __restrict__ long_list,
-                                                      uint32_t L) {
-    constexpr uint32_t CAP = 256;
-    __shared__ uint32_t e[CAP * XW];
+                                                      uint32_t* __restrict__ long_done, uint32_t L) {
+    __shared__ uint32_t e[WIDE_TREE_MAX * XW];
+    __shared__ uint32_t s_last;
     const uint32_t nlong = *long_count;
     for (uint32_t item = blockIdx.x; item < nlong; item += gridDim.x) {
-        const uint32_t k = long_list[item];
+        const uint32_t k = long_list[2 * (size_t)item], seg = long_list[2 * (size_t)item + 1];
         const uint32_t beg = offsets[k], end = offsets[k + 1];
         const uint32_t t0 = beg / L, t1 = (end - 1) / L;
-        const uint32_t cnt = t1 - t0 + 1;
-        __syncthreads();  // e is reused across items
-        if (cnt <= CAP) {
-            for (uint32_t i = threadIdx.x >> 2; i < cnt; i += blockDim.x >> 2) {
-                const uint32_t* piece = i == 0 ? tails + (size_t)t0 * XW : heads + (size_t)(t0 + i) * XW;
-                const uint32_t co = threadIdx.x & 3u;
-                store_coord(e + (size_t)i * XW, co, load_coord(piece, co));
-            }
-        } else if (threadIdx.x < CAP) {
-            xyzz acc = xyzz_identity();
-#pragma unroll 1
-            for (uint32_t i = threadIdx.x; i < cnt; i += CAP)
-                acc = xyzz_add(acc, load_xyzz(i == 0 ? tails + (size_t)t0 * XW : heads + (size_t)(t0 + i) * XW));
-            store_xyzz(e + (size_t)threadIdx.x * XW, acc);
+        const uint32_t cnt = t1 - t0 + 1, nseg = (cnt + LONG_SEG - 1) / LONG_SEG;
+        const uint32_t first = seg * LONG_SEG, count = min(LONG_SEG, cnt - first);
+        long_fold(e, heads, tails, t0, first, 1, count);
+        if (nseg == 1) {
+            if (threadIdx.x < 4) store_coord(buckets + (size_t)k * XW, threadIdx.x, load_coord(e, threadIdx.x));
+            continue;
         }
-        lds_tree_wide(e, cnt < CAP ? cnt : CAP);
+        // park the segment sum in the segment's first piece (only this workgroup ever read it), then count in
+        uint32_t* park = const_cast<uint32_t*>(long_piece(heads, tails, t0, first));
+        if (threadIdx.x < 4) store_coord(park, threadIdx.x, load_coord(e, threadIdx.x));
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) s_last = atomicAdd(&long_done[item - seg], 1u) == nseg - 1 ? 1u : 0u;
+        __syncthreads();
+        if (!s_last) continue;  // uniform
+        __threadfence();        // see the other segments' sums
+        long_fold(e, heads, tails, t0, 0, LONG_SEG, nseg);
         if (threadIdx.x < 4) store_coord(buckets + (size_t)k * XW, threadIdx.x, load_coord(e, threadIdx.x));
+        if (threadIdx.x == 0) long_done[item - seg] = 0;  // ready for the next call
     }
 }
 
@@ -953,7 +990,6 @@ __global__ void __launch_bounds__(256) k_pair_level_wide(pair_job ja, pair_job j
     wide_add_records(j.in + i0 * XW, j.in + (i0 + j.B) * XW, j.out + (size_t)t * XW);
 }
 
-constexpr uint32_t WIDE_TREE_MAX = 256;  // records one workgroup's LDS tree holds (36 KB)
 // k_reduce_bits with wide additions: one 512-thread workgroup per (window, bit); the selected elements are staged in LDS
 // and folded by a pairwise tree (log2(nsel) levels of 4 multiplications each).  Needs nsel <= WIDE_TREE_MAX.
 __global__ void __launch_bounds__(512) k_reduce_bits_wide(const uint32_t* __restrict__ R, const uint32_t* __restrict__ C,

@@ -297,6 +297,32 @@ def test_full_size_closed_form_and_linearity(ctx, logn):
     assert tm["sort_ms"] > 0 and tm["reduce_ms"] > 0 and tm["decompose_ms"] > 0
 
 
+@pytest.mark.parametrize("logn", [17, 20])
+def test_skewed_scalars_full_size_closed_form(ctx, logn):
+    """Skewed digit distributions at full size: buckets of up to N entries (thousands of chunks -> the segmented
+    k_combine_long with its last-arriver finish, the direct-placement branch of the fine sort, wave-aggregated LDS
+    counters).  Expected value by the closed form (sum s_i k_i) * G; every case twice (per-bucket counters self-clean)."""
+    import torch
+    n = 1 << logn
+    dev = torch.device("cuda:0")
+    d_bases = torch.empty(n * 16, dtype=torch.int32, device=dev)
+    d_s = torch.empty(n * 8, dtype=torch.int32, device=dev)
+    ctx.generate_device(0xB2540011, 0xB2540012, n, d_bases.data_ptr(), d_s.data_ptr())
+    torch.cuda.synchronize()
+    k = mh.generate_scalars_host(0xB2540011, n, nonzero=True)
+    s = mh.generate_scalars_host(0xB2540012, n)
+    idx = np.arange(n)
+    cases = {"all-equal": np.tile(s[:1], (n, 1)), "2-distinct": s[idx % 2], "3-blocked": s[(idx * 3) // n], "256-distinct": s[idx % 256],
+             "below-2^32": np.pad(s[:, :1], ((0, 0), (0, 7))), "ones-and-zeros": np.pad((idx % 3 != 0).astype(np.uint32)[:, None], ((0, 0), (0, 7)))}
+    for label, arr in cases.items():
+        arr = np.ascontiguousarray(arr, dtype=np.uint32)
+        exp, einf = orc.closed_form_expected(k, arr)
+        d_t = torch.from_numpy(arr.view(np.int32).reshape(-1).copy()).to(dev)
+        for rep in range(2):
+            r = ctx.msm_device(d_bases.data_ptr(), d_t.data_ptr(), n)
+            assert r.is_infinity == bool(einf) and (r.affine_std == exp).all(), (label, rep)
+
+
 # ---- BASELINE config 5: streamed host->HBM chunks overlapped with the pipeline ---------------------
 def test_streamed_chunks_match_oracle():
     """msm_bn254_g1 cuts n >= 2*chunk points into chunks (double-buffered H2D on a copy stream, partials added on
