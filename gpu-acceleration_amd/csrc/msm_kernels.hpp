@@ -665,8 +665,17 @@ __global__ void __launch_bounds__(FINE_BLOCK) k_fine_sort(const uint32_t* __rest
 #pragma unroll
         for (int k = 0; k < FINE_PER_THREAD; k++)
             if (e[k] != DIGIT_SKIP) lds_inc(s_cur, (e[k] >> idx_bits) & fine_mask);
-    } else {
-        for (uint32_t j = rs + threadIdx.x; j < re; j += FINE_BLOCK) lds_inc(s_cur, (tmp[j] >> idx_bits) & fine_mask);
+    } else {  // oversized region (one bucket holds a large share of the window): FINE_PER_THREAD loads in flight per thread
+        for (uint32_t base = rs; base < re; base += FINE_CAP) {
+#pragma unroll
+            for (int k = 0; k < FINE_PER_THREAD; k++) {
+                uint32_t j = base + threadIdx.x + k * FINE_BLOCK;
+                e[k] = j < re ? tmp[j] : DIGIT_SKIP;
+            }
+#pragma unroll
+            for (int k = 0; k < FINE_PER_THREAD; k++)
+                if (e[k] != DIGIT_SKIP) lds_inc(s_cur, (e[k] >> idx_bits) & fine_mask);
+        }
     }
     __syncthreads();
     // exclusive prefix of the <= 128 fine counts (Hillis-Steele in LDS)
@@ -694,11 +703,20 @@ __global__ void __launch_bounds__(FINE_BLOCK) k_fine_sort(const uint32_t* __rest
         }
         __syncthreads();
         for (uint32_t k = threadIdx.x; k < S; k += FINE_BLOCK) sorted[rs + k] = s_out[k];
-    } else {  // skewed data: the region does not fit LDS, place directly
-        for (uint32_t j = rs + threadIdx.x; j < re; j += FINE_BLOCK) {
-            uint32_t v = tmp[j];
-            uint32_t pos = lds_inc(s_cur, (v >> idx_bits) & fine_mask);
-            sorted[rs + pos] = (v & idx_mask) | (v & SIGN_BIT);
+    } else {  // skewed data: the region does not fit LDS, place directly (aggregated cursors hand consecutive lanes
+              // consecutive slots, so the stores of a hot bucket are still coalesced)
+        for (uint32_t base = rs; base < re; base += FINE_CAP) {
+#pragma unroll
+            for (int k = 0; k < FINE_PER_THREAD; k++) {
+                uint32_t j = base + threadIdx.x + k * FINE_BLOCK;
+                e[k] = j < re ? tmp[j] : DIGIT_SKIP;
+            }
+#pragma unroll
+            for (int k = 0; k < FINE_PER_THREAD; k++) {
+                if (e[k] == DIGIT_SKIP) continue;
+                uint32_t pos = lds_inc(s_cur, (e[k] >> idx_bits) & fine_mask);
+                sorted[rs + pos] = (e[k] & idx_mask) | (e[k] & SIGN_BIT);
+            }
         }
     }
 }

@@ -13,6 +13,15 @@ with mh.MsmContext() as c:
     idx = np.arange(n)
     cases = [("uniform", s), ("all-equal", np.tile(s[:1], (n, 1))), ("2-distinct-interleaved", s[idx % 2]), ("3-distinct-interleaved", s[idx % 3]),
              ("3-distinct-blocked", s[(idx * 3) // n]), ("256-distinct", s[idx % 256]), ("small<2^32", np.pad(s[:, :1], ((0, 0), (0, 7))))]
+    # a witness-like mix: 40 % zeros, 30 % ones, 10 % below 2^16, 20 % uniform
+    rng = np.random.default_rng(7)
+    u = rng.random(n)
+    mix = s.copy()
+    mix[u < 0.8] = 0
+    mix[(u >= 0.4) & (u < 0.7), 0] = 1
+    sel = (u >= 0.7) & (u < 0.8)
+    mix[sel, 0] = s[sel, 0] & 0xFFFF
+    cases.append(("witness-like mix", mix))
     for label, arr in cases:
         t = torch.from_numpy(np.ascontiguousarray(arr).view(np.int32).reshape(-1).copy()).cuda()
         for _ in range(2): c.msm_device(d_b.data_ptr(), t.data_ptr(), n)
