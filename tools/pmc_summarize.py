@@ -26,5 +26,15 @@ fs = known["k_stream"] / (f["calib_counter_kib"].get("k_stream", 0) * 1024 or 1)
 ws = known["k_store36"] / (w["calib_counter_kib"].get("k_store36", 0) * 1024 or 1)
 res["correction"] = {"fetch_gather_64B_records": fg, "fetch_stream_16B_per_lane": fs, "write_144B_records": ws}
 res["hbm_bytes_per_launch"] = int(f["k_accumulate_kib_per_launch"] * 1024 * fg + w["k_accumulate_kib_per_launch"] * 1024 * ws)
+try:  # the bench line printed under the profiler names the workload the counters belong to
+    line = [l for l in open(f"{d}/bench_FETCH_SIZE.log") if l.startswith("{")][-1]
+    cfg = json.loads(line)["config"]
+    res["n_local"], res["window_bits"] = cfg["n_per_gpu"], cfg["window_bits"]
+except Exception as e:
+    res["n_local"], res["window_bits"] = None, None
+res["how"] = ("tools/pmc_accumulate.sh on an MI355X gpurun box: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes "
+              "(with --kernel-trace only) around `python3 bench.py --steps 3 --warmup 1`; counters corrected with the factors measured "
+              "by tools/calib_gather on the same box (64-B record gathers count exactly, 16 B/lane streams count 1/2, 144-B record "
+              "stores over-count by ~5.6 %)")
 json.dump(res, open(f"{d}/summary.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
