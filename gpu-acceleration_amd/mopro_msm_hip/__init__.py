@@ -16,7 +16,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libmsm_hip.so")
+# MSM_HIP_LIB overrides the in-tree library (A/B runs of two builds: tools/sweep_env.py MSM_HIP_LIB a.so b.so)
+LIB_PATH = os.environ.get("MSM_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libmsm_hip.so")
 
 FORM_STD, FORM_MONT = 0, 1
 FLAG_UNSIGNED_DIGITS = 1
