@@ -336,13 +336,15 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
     // fits the fine sort's LDS staging)
     uint32_t coarse_bits = 8;
     while (coarse_bits < 10 && (n >> coarse_bits) > 8192) coarse_bits++;
+    if (kb > coarse_bits + 7) coarse_bits = std::min(10u, kb - 7);  // wide windows (up to 2^17 buckets): the fine part stays 7 bits
     if (coarse_bits > kb) coarse_bits = kb;
     const uint32_t fine_bits = kb - coarse_bits, idx_bits = 31 - fine_bits;
     const uint32_t ncoarse = 1u << coarse_bits;
-    const bool two_level = tiled && fine_bits <= 7 && n <= ((size_t)1 << idx_bits) && !std::getenv("MSM_HIP_DIRECT_SCATTER");
+    const bool two_level = fine_bits <= 7 && n <= ((size_t)1 << idx_bits) && !std::getenv("MSM_HIP_DIRECT_SCATTER");
+    const bool lds_counts = two_level || tiled;  // no device-scope histogram / rank atomics in k_decompose
     const uint32_t NS = (uint32_t)((n + msmk::SUBTILE - 1) / msmk::SUBTILE);
     uint32_t T = 1, tile_len = (uint32_t)n;
-    if (!tiled && (rc = ensure(c, c->ranks, pairs * 4))) return rc;
+    if (!lds_counts && (rc = ensure(c, c->ranks, pairs * 4))) return rc;
     if (two_level) {
         if ((rc = ensure(c, c->ccounts, (size_t)W * ncoarse * NS * 4))) return rc;
         if ((rc = ensure(c, c->cregion, ((size_t)W * ncoarse * 2 + 2) * 4))) return rc;
@@ -360,9 +362,9 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
     {
         uint32_t *dg = (uint32_t*)c->digits.p, *rk = (uint32_t*)c->ranks.p;
         dim3 g = grid1(n, 256);
-        if (pl.signed_digits && tiled) msmk::k_decompose<true, false><<<g, 256, 0, st>>>(d_scalars, d_inf, (uint32_t)n, cbits, W, nb, hist, dg, rk, flags, scalars_mont);
+        if (pl.signed_digits && lds_counts) msmk::k_decompose<true, false><<<g, 256, 0, st>>>(d_scalars, d_inf, (uint32_t)n, cbits, W, nb, hist, dg, rk, flags, scalars_mont);
         else if (pl.signed_digits) msmk::k_decompose<true, true><<<g, 256, 0, st>>>(d_scalars, d_inf, (uint32_t)n, cbits, W, nb, hist, dg, rk, flags, scalars_mont);
-        else if (tiled) msmk::k_decompose<false, false><<<g, 256, 0, st>>>(d_scalars, d_inf, (uint32_t)n, cbits, W, nb, hist, dg, rk, flags, scalars_mont);
+        else if (lds_counts) msmk::k_decompose<false, false><<<g, 256, 0, st>>>(d_scalars, d_inf, (uint32_t)n, cbits, W, nb, hist, dg, rk, flags, scalars_mont);
         else msmk::k_decompose<false, true><<<g, 256, 0, st>>>(d_scalars, d_inf, (uint32_t)n, cbits, W, nb, hist, dg, rk, flags, scalars_mont);
     }
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_DECOMP], st));
