@@ -44,6 +44,10 @@ extern "C" {
         ctx: *mut MsmCtx, bases: *const core::ffi::c_void, stride: usize, x_off: usize, y_off: usize, inf_off: usize,
         scalars_mont: *const u32, n: usize, out_jacobian_mont: *mut u32, out_affine_std: *mut u32, out_is_inf: *mut u8,
     ) -> i32;
+    fn msm_bn254_g1_upload_compressed(ctx: *mut MsmCtx, compressed: *const u8, n: usize, first_invalid: *mut i64) -> i32;
+    fn msm_bn254_g1_resident(
+        ctx: *mut MsmCtx, scalars: *const u32, n: usize, out_jacobian_mont: *mut u32, out_affine_std: *mut u32, out_is_inf: *mut u8,
+    ) -> i32;
 }
 
 struct Ctx(*mut MsmCtx);
@@ -139,6 +143,44 @@ pub fn hip_variable_base_msm_zero_copy(bases: &[G1Affine], scalars: &[Fr]) -> Re
     Ok(G1Projective::new_unchecked(f(&jac[0..4]), f(&jac[4..8]), f(&jac[8..12])))
 }
 
+/// The benchmark harness's read path (utils/preprocess.rs:101-131 + arkworks_pippenger.rs:7-43) without the CPU square
+/// roots: `points_file_instance` is ONE instance of the `points` file exactly as `Vec<G1Affine>::serialize_compressed`
+/// wrote it (8-byte little-endian length, then 32 bytes per point); the images are decoded on the GPU
+/// (`msm_bn254_g1_upload_compressed`) and stay resident for the MSM.  `scalars` as in the harness: `BigInt<4>` standard form.
+pub fn hip_msm_from_compressed_instance(
+    points_file_instance: &[u8], scalars: &[BigInt<4>],
+) -> Result<G1Projective, Box<dyn Error>> {
+    if points_file_instance.len() < 8 {
+        return Err("failed to read at least one instance from file".into());
+    }
+    let n_pts = u64::from_le_bytes(points_file_instance[0..8].try_into().unwrap()) as usize;
+    let images = &points_file_instance[8..];
+    if n_pts == 0 || scalars.is_empty() {
+        return Err("Empty input".into());
+    }
+    if images.len() < 32 * n_pts {
+        return Err("could not serialize".into());
+    }
+    let guard = CTX.lock().unwrap();
+    let ctx = guard.as_ref().map_err(|e| e.clone())?;
+    let mut bad: i64 = -1;
+    let rc = unsafe { msm_bn254_g1_upload_compressed(ctx.0, images.as_ptr(), n_pts, &mut bad) };
+    if rc != 0 {
+        return Err(last_error(ctx.0).into()); // SerializationError::InvalidData: `bad` = first image that does not decode
+    }
+    let n = n_pts.min(scalars.len());
+    let mut jac = [0u64; 12];
+    let mut is_inf = 0u8;
+    let rc = unsafe {
+        msm_bn254_g1_resident(ctx.0, scalars.as_ptr() as *const u32, n, jac.as_mut_ptr() as *mut u32, std::ptr::null_mut(), &mut is_inf)
+    };
+    if rc != 0 {
+        return Err(last_error(ctx.0).into());
+    }
+    let f = |w: &[u64]| Fq::new_unchecked(BigInt::<4>([w[0], w[1], w[2], w[3]]));
+    Ok(G1Projective::new_unchecked(f(&jac[0..4]), f(&jac[4..8]), f(&jac[8..12])))
+}
+
 /// Alias under the engine's own name.
 pub fn hip_variable_base_msm(bases: &[G1Affine], scalars: &[Fr]) -> Result<G1Projective, Box<dyn Error>> {
     metal_variable_base_msm(bases, scalars)
@@ -161,5 +203,21 @@ mod tests {
             assert_eq!(metal_variable_base_msm(&bases, &scalars).unwrap(), G1Projective::msm(&bases, &scalars).unwrap());
         }
         assert!(metal_variable_base_msm(&[], &[]).is_err());
+    }
+
+    // the compressed image format is restated from ark-serialize 0.4 on the C side: this is the test that pins it
+    #[test]
+    fn compressed_instance_matches_arkworks() {
+        use ark_ff::PrimeField;
+        use ark_serialize::CanonicalSerialize;
+        let mut rng = test_rng();
+        let n = 1 << 10;
+        let mut bases: Vec<G1Affine> = (0..n).map(|_| G1Projective::rand(&mut rng).into_affine()).collect();
+        bases[7] = G1Affine::identity();
+        let scalars: Vec<Fr> = (0..n).map(|_| Fr::rand(&mut rng)).collect();
+        let mut file = Vec::new();
+        bases.serialize_compressed(&mut file).unwrap();
+        let bigints: Vec<BigInt<4>> = scalars.iter().map(|s| s.into_bigint()).collect();
+        assert_eq!(hip_msm_from_compressed_instance(&file, &bigints).unwrap(), G1Projective::msm(&bases, &scalars).unwrap());
     }
 }
