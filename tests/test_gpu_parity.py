@@ -252,6 +252,45 @@ def test_adversarial_distributions(ctx):
         assert r.is_infinity == bool(einf) and (r.affine_std == exp).all(), label
 
 
+def test_randomised_parity_fuzz():
+    """40 random (size, window size, digit mode, infinity mask, scalar skew) combinations against the oracle
+    (tools/fuzz_parity.py is the long-running version of the same net)."""
+    rng = np.random.default_rng(20261002)
+    nmax = 20000
+    k_all = orc.gen_scalars(4242, nmax, nonzero=True)
+    bases_all = orc.gen_bases_from_logs(k_all, orc.FORM_MONT)
+    s_all = orc.gen_scalars(4343, nmax)
+    for it in range(40):
+        n = int(rng.choice([rng.integers(1, 40), rng.integers(40, 3000), rng.integers(3000, nmax)]))
+        off = int(rng.integers(0, nmax - n + 1))
+        bases = bases_all[off:off + n].copy()
+        s = s_all[off:off + n].copy()
+        mode = int(rng.integers(0, 8))
+        if mode == 1:
+            s[:] = s[0]
+        elif mode == 2:
+            s = s[np.arange(n) % 3]
+        elif mode == 3:
+            s[:, 1:] = 0
+        elif mode == 4:
+            s[rng.random(n) < 0.6] = 0
+        elif mode == 5:
+            u = rng.random(n)
+            s[u < 0.7] = 0
+            s[(u >= 0.3) & (u < 0.7), 0] = 1
+        elif mode == 6:
+            s[:] = orc.int_to_words(R - 1)
+        elif mode == 7 and n > 1:
+            bases[1::2] = bases[0]
+        inf = (rng.random(n) < rng.choice([0.001, 0.05, 0.9])).astype(np.uint8) if rng.random() < 0.4 else None
+        wb = int(rng.choice([0, 0, 0, 2, 3, 5, 8, 11, 12, 13, 14, 15, 16, 17, 18]))
+        flags = mh.FLAG_UNSIGNED_DIGITS if (rng.random() < 0.25 and wb not in (17, 18)) else 0
+        with mh.MsmContext(window_bits=wb, flags=flags) as c:
+            r = c.msm(bases, s, mh.FORM_MONT, inf)
+        exp, einf, _ = orc.msm_pippenger(bases, s, orc.FORM_MONT, inf)
+        assert r.is_infinity == bool(einf) and (r.affine_std == exp).all(), dict(case=it, n=n, mode=mode, wb=wb, flags=flags)
+
+
 # ---- BASELINE.json full sizes: size-independent properties ---------------------------------------
 @pytest.mark.parametrize("logn", [16, 20])
 def test_full_size_closed_form_and_linearity(ctx, logn):

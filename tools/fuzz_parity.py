@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Randomised parity run on the GPU box: random sizes, window sizes, digit modes, infinity masks and scalar skews,
+every result compared bit for bit with the CPU oracle (Pippenger) -- a wider net than the fixed test cases.
+usage: tools/fuzz_parity.py [cases] [seed]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "gpu-acceleration_amd")]
+import numpy as np
+import mopro_msm_hip as mh
+from oracle import bn254_oracle as orc
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20261002)
+NMAX = 60000
+k_all = orc.gen_scalars(4242, NMAX, nonzero=True)
+bases_all = orc.gen_bases_from_logs(k_all, orc.FORM_MONT)
+s_all = orc.gen_scalars(4343, NMAX)
+t0 = time.time()
+bad = 0
+for it in range(cases):
+    n = int(rng.choice([rng.integers(1, 40), rng.integers(40, 3000), rng.integers(3000, NMAX)]))
+    off = int(rng.integers(0, NMAX - n + 1))
+    bases = bases_all[off:off + n].copy()
+    mode = int(rng.integers(0, 8))
+    s = s_all[off:off + n].copy()
+    if mode == 1: s[:] = s[0]                                   # all equal
+    elif mode == 2: s = s[np.arange(n) % 3]                     # 3 distinct
+    elif mode == 3: s[:, 1:] = 0                                # < 2^32
+    elif mode == 4: s[rng.random(n) < 0.6] = 0                  # many zeros
+    elif mode == 5:                                             # witness-like
+        u = rng.random(n); s[u < 0.7] = 0; s[(u >= 0.3) & (u < 0.7), 0] = 1
+    elif mode == 6: s[:] = orc.int_to_words(orc.R_ORDER - 1)    # all r-1
+    elif mode == 7 and n > 1: bases[1::2] = bases[0]            # duplicate bases
+    inf = None
+    if rng.random() < 0.4:
+        inf = (rng.random(n) < rng.choice([0.001, 0.05, 0.9])).astype(np.uint8)
+    wb = int(rng.choice([0, 0, 0, 2, 3, 5, 8, 11, 12, 13, 14, 15, 16, 17, 18]))
+    flags = mh.FLAG_UNSIGNED_DIGITS if (rng.random() < 0.25 and wb not in (17, 18)) else 0
+    with mh.MsmContext(window_bits=wb, flags=flags) as ctx:
+        r = ctx.msm(bases, s, mh.FORM_MONT, inf)
+        r2 = ctx.msm(bases, s, mh.FORM_MONT, inf)
+    exp, einf, _ = orc.msm_pippenger(bases, s, orc.FORM_MONT, inf)
+    ok = r.is_infinity == bool(einf) and (r.affine_std == exp).all() and (r2.affine_std == r.affine_std).all()
+    if not ok:
+        bad += 1
+        print("MISMATCH case", it, dict(n=n, off=off, mode=mode, wb=wb, flags=flags, inf=None if inf is None else int(inf.sum())), flush=True)
+print(f"fuzz_parity: {cases} cases, {bad} mismatches, {time.time() - t0:.1f} s")
+sys.exit(1 if bad else 0)
