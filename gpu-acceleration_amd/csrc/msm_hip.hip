@@ -136,7 +136,7 @@ struct msm_ctx {
     std::string err;
     hipEvent_t ev[EV_COUNT]{};
     // HBM workspace
-    DevBuf bases, ibases, inf, scalars, digits, ranks, sorted, hist, offsets, blocksums, buckets, heads, tails, chunkmap, rc, qsums, flags,
+    DevBuf bases, ibases, inf, scalars, digits, ranks, sorted, hist, offsets, blocksums, buckets, heads, tails, chunkmap, rc, flags,
         pow2, tilecounts, longlist, longdone, midlist, ccounts, cregion;
     bool pow2_ready = false;
     uint32_t* h_qsums = nullptr;  // pinned: W x (kb+1) Jacobian bit sums
@@ -280,7 +280,7 @@ struct PipeGeom {
 };
 
 // Queue the whole device pipeline for one (chunk of an) MSM on stream st; the W*(kb+1) bit sums and the flag words
-// are copied to h_qsums_dst / h_flags_dst (pinned) at the end.  No host synchronisation here.
+// are written by the last kernel straight into h_qsums_dst / h_flags_dst (pinned host memory).  No host synchronisation here.
 int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, const uint32_t* d_scalars, size_t n,
                          hipStream_t st, uint32_t* h_qsums_dst, uint32_t* h_flags_dst, PipeGeom* geom, uint32_t scalars_mont = 0,
                          hipEvent_t bases_ready = nullptr) {
@@ -322,7 +322,6 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
     }
     if ((rc = ensure(c, c->midlist, (nchunks_max / 2 + 16) * 4))) return rc;                  // a listed bucket owns >= 2 chunk borders
     if ((rc = ensure(c, c->rc, (tb + tb / 2 + 4) * XB))) return rc;  // two families x (1/2 + 1/4) ping-pong levels
-    if ((rc = ensure(c, c->qsums, (size_t)W * (kb + 1) * 96))) return rc;
     if ((rc = ensure(c, c->flags, 64))) return rc;
 
     uint32_t* hist = (uint32_t*)c->hist.p;
@@ -443,14 +442,17 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
             if (nadds <= c->wide_max) msmk::k_pair_level_wide<<<grid1(nadds * msmk::WIDE_LANES, 256), 256, 0, st>>>(ja, jb);
             else msmk::k_pair_level<<<grid1(nadds, 256), 256, 0, st>>>(ja, jb);
         }
+        // the bit sums (and the flag words) are written by the kernel straight into the caller's PINNED host buffers:
+        // a D2H copy engine transfer started ~11 us after the kernel and took two launches (24 KB + 32 B)
+        uint32_t *q_dev = nullptr, *f_dev = nullptr;
+        HIPCHK(c, hipHostGetDevicePointer((void**)&q_dev, h_qsums_dst, 0));
+        HIPCHK(c, hipHostGetDevicePointer((void**)&f_dev, h_flags_dst, 0));
         if (c->wide_max && n_hi / 2 <= msmk::WIDE_TREE_MAX && n_lo <= msmk::WIDE_TREE_MAX)
-            msmk::k_reduce_bits_wide<<<W * (kb + 1), 512, 0, st>>>(rin, cin, (uint32_t*)c->qsums.p, n_hi, n_lo, kb_lo, kb);
+            msmk::k_reduce_bits_wide<<<W * (kb + 1), 512, 0, st>>>(rin, cin, q_dev, n_hi, n_lo, kb_lo, kb, flags, f_dev);
         else
-            msmk::k_reduce_bits<<<W * (kb + 1), 64, 0, st>>>(rin, cin, (uint32_t*)c->qsums.p, n_hi, n_lo, kb_lo, kb);
+            msmk::k_reduce_bits<<<W * (kb + 1), 64, 0, st>>>(rin, cin, q_dev, n_hi, n_lo, kb_lo, kb, flags, f_dev);
     }
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_REDUCE], st));
-    HIPCHK(c, hipMemcpyAsync(h_qsums_dst, c->qsums.p, (size_t)W * (kb + 1) * 96, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(h_flags_dst, flags, 32, hipMemcpyDeviceToHost, st));
     *geom = PipeGeom{W, nb, cbits, kb};
     return MSM_OK;
 }
@@ -717,7 +719,7 @@ void msm_ctx_destroy(msm_ctx* c) {
         DeviceGuard g(c->device);
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         DevBuf* bufs[] = {&c->bases,   &c->inf,       &c->scalars, &c->digits,  &c->ranks,  &c->sorted, &c->hist,
-                          &c->offsets, &c->blocksums, &c->buckets, &c->rc,      &c->qsums,   &c->flags,  &c->pow2,
+                          &c->offsets, &c->blocksums, &c->buckets, &c->rc,      &c->flags,  &c->pow2,
                           &c->heads,   &c->tails,     &c->chunkmap, &c->tilecounts, &c->ibases, &c->longlist, &c->longdone, &c->midlist, &c->ccounts, &c->cregion};
         for (DevBuf* b : bufs) release(*b);
         if (c->h_qsums) (void)hipHostFree(c->h_qsums);

@@ -1012,7 +1012,8 @@ __global__ void __launch_bounds__(256) k_pair_level_wide(pair_job ja, pair_job j
 // and folded by a pairwise tree (log2(nsel) levels of 4 multiplications each).  Needs nsel <= WIDE_TREE_MAX.
 __global__ void __launch_bounds__(512) k_reduce_bits_wide(const uint32_t* __restrict__ R, const uint32_t* __restrict__ C,
                                                           uint32_t* __restrict__ q, uint32_t n_hi, uint32_t n_lo, uint32_t kb_lo,
-                                                          uint32_t kb) {
+                                                          uint32_t kb, const uint32_t* __restrict__ flags, uint32_t* __restrict__ flags_out) {
+    if (blockIdx.x == 0 && threadIdx.x < 8) flags_out[threadIdx.x] = flags[threadIdx.x];  // q, flags_out: pinned HOST memory
     __shared__ uint32_t e[WIDE_TREE_MAX * XW];
     uint32_t w = blockIdx.x / (kb + 1), u = blockIdx.x % (kb + 1);
     const uint32_t* src;
@@ -1045,7 +1046,8 @@ __global__ void __launch_bounds__(512) k_reduce_bits_wide(const uint32_t* __rest
 // one wavefront per (window, bit): R[w][0..n_hi), C[w][0..n_lo);  q[w][u] Jacobian
 __global__ void __launch_bounds__(64) k_reduce_bits(const uint32_t* __restrict__ R, const uint32_t* __restrict__ C,
                                                     uint32_t* __restrict__ q, uint32_t n_hi, uint32_t n_lo, uint32_t kb_lo,
-                                                    uint32_t kb) {
+                                                    uint32_t kb, const uint32_t* __restrict__ flags, uint32_t* __restrict__ flags_out) {
+    if (blockIdx.x == 0 && threadIdx.x < 8) flags_out[threadIdx.x] = flags[threadIdx.x];  // q, flags_out: pinned HOST memory
     uint32_t w = blockIdx.x / (kb + 1), u = blockIdx.x % (kb + 1);
     const uint32_t* src;
     uint32_t cnt, bit;
