@@ -264,14 +264,13 @@ int32_t ensure_pow2_table(msm_ctx* c) {
 
 void finish_outputs(const hostg1::Jac& r, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf) {
     if (out_jac) hostg1::store_jac(out_jac, r);
-    if (out_aff || out_inf) {
+    if (out_inf) *out_inf = hostg1::is_identity(r) ? 1 : 0;
+    if (out_aff) {  // the only inversion of the whole call (~10 us): callers that want the reference's result type
+                    // (Jacobian, metal_msm.rs:228-241) pass NULL and skip it
         hostg1::Fq x, y;
-        bool inf = hostg1::to_affine_std(r, x, y);
-        if (out_aff) {
-            hostg1::store_words(out_aff, x);
-            hostg1::store_words(out_aff + 8, y);
-        }
-        if (out_inf) *out_inf = inf ? 1 : 0;
+        (void)hostg1::to_affine_std(r, x, y);
+        hostg1::store_words(out_aff, x);
+        hostg1::store_words(out_aff + 8, y);
     }
 }
 

@@ -133,8 +133,16 @@ class MsmResult:
 
     def __init__(self, jac, aff, inf):
         self.jacobian_mont = jac
-        self.affine_std = aff
+        self._aff = aff
         self.is_infinity = bool(inf)
+
+    @property
+    def affine_std(self):
+        """canonical affine standard-form words; computed on first use (one field inversion on the host) when the call
+        returned only the Jacobian point -- the reference's own result type (metal_msm.rs:228-241)"""
+        if self._aff is None:
+            self._aff = combine_partials(self.jacobian_mont.reshape(1, 24))._aff
+        return self._aff
 
     def affine_ints(self):
         if self.is_infinity:
@@ -151,10 +159,11 @@ def plan(n, window_bits=0, flags=0):
     return p
 
 
-def combine_partials(partials_jacobian_mont):
-    """Fold per-rank partial sums in fixed rank order (host arithmetic inside the library)."""
+def combine_partials(partials_jacobian_mont, want_affine=True):
+    """Fold per-rank partial sums in fixed rank order (host arithmetic inside the library).
+    want_affine=False skips the field inversion; MsmResult.affine_std then computes it on first use."""
     p = _words(partials_jacobian_mont, 24)
-    jac, aff, inf = np.zeros(24, np.uint32), np.zeros(16, np.uint32), C.c_uint8(0)
+    jac, aff, inf = np.zeros(24, np.uint32), (np.zeros(16, np.uint32) if want_affine else None), C.c_uint8(0)
     rc = load_library().msm_bn254_g1_combine(_p32(p), p.shape[0], _p32(jac), _p32(aff), C.byref(inf))
     if rc != OK:
         raise MsmError(rc, "Empty input" if rc == ERR_EMPTY else f"combine failed ({rc})")
@@ -305,10 +314,10 @@ class MsmContext:
         """All operands already in HBM (raw device pointers, e.g. torch.Tensor.data_ptr())."""
         if n == 0:
             raise MsmError(ERR_EMPTY, "Empty input")
-        jac, aff, oi = self._outs()
+        jac, _, oi = self._outs()
         self._check(self._lib.msm_bn254_g1_device(self._h, d_bases_ptr, d_inf_ptr, d_scalars_ptr, n, stream, _p32(jac),
-                                                  _p32(aff), C.byref(oi)))
-        return MsmResult(jac, aff, oi.value)
+                                                  None, C.byref(oi)))
+        return MsmResult(jac, None, oi.value)  # affine words on demand (MsmResult.affine_std)
 
     def generate_device(self, base_seed, scalar_seed, n, d_bases_ptr, d_scalars_ptr):
         self._check(self._lib.msm_bn254_g1_generate_device(self._h, base_seed, scalar_seed, n, d_bases_ptr, d_scalars_ptr))

@@ -68,7 +68,7 @@ def all_reduce_msm(local_result: MsmResult, device=None, group=None) -> MsmResul
 
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local_result
-    return combine_partials(all_gather_partials(local_result.jacobian_mont, device, group))
+    return combine_partials(all_gather_partials(local_result.jacobian_mont, device, group), want_affine=False)
 
 
 def distributed_msm_device(ctx, d_bases_ptr, d_scalars_ptr, n_local, device=None, group=None, d_inf_ptr=None) -> MsmResult:
