@@ -574,12 +574,21 @@ __global__ void k_coarse_prefix(uint32_t* __restrict__ counts, uint32_t* __restr
 __global__ void k_coarse_starts(const uint32_t* __restrict__ region_total, uint32_t* __restrict__ region_start, uint32_t nregions,
                                 uint32_t* __restrict__ total_out, uint32_t* __restrict__ offsets_end) {
     uint32_t running = 0;
-    for (uint32_t start = 0; start < nregions; start += SCAN_BLOCK) {
-        uint32_t idx = start + threadIdx.x;
-        uint32_t v = idx < nregions ? region_total[idx] : 0u;
+    for (uint32_t start = 0; start < nregions; start += SCAN_TILE) {  // SCAN_ITEMS consecutive regions per thread and round
+        const uint32_t base = start + threadIdx.x * SCAN_ITEMS;
+        uint32_t v[SCAN_ITEMS], sum = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; k++) {
+            v[k] = base + k < nregions ? region_total[base + k] : 0u;
+            sum += v[k];
+        }
         uint32_t total;
-        uint32_t ex = block_exclusive_scan(v, &total);
-        if (idx < nregions) region_start[idx] = running + ex;
+        uint32_t ex = running + block_exclusive_scan(sum, &total);
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; k++) {
+            if (base + k < nregions) region_start[base + k] = ex;
+            ex += v[k];
+        }
         running += total;
     }
     if (threadIdx.x == 0) {
