@@ -547,10 +547,16 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_coarse_hist(const uint32_t* __re
     __syncthreads();
     const uint32_t i0 = st * SUBTILE, i1 = min(n, i0 + SUBTILE);
     const size_t row = (size_t)w * n;
-    for (uint32_t i = i0 + threadIdx.x; i < i1; i += TILE_BLOCK) {
-        uint32_t d = digits[row + i];
-        if (d != DIGIT_SKIP) lds_inc(s_h, (d & ~SIGN_BIT) >> fine_bits);
+    // SUBTILE / TILE_BLOCK = 16 digits per thread: all loads in flight before the first LDS atomic
+    uint32_t dg[SUBTILE / TILE_BLOCK];
+#pragma unroll
+    for (int k = 0; k < SUBTILE / TILE_BLOCK; k++) {
+        const uint32_t i = i0 + threadIdx.x + k * TILE_BLOCK;
+        dg[k] = i < i1 ? digits[row + i] : DIGIT_SKIP;
     }
+#pragma unroll
+    for (int k = 0; k < SUBTILE / TILE_BLOCK; k++)
+        if (dg[k] != DIGIT_SKIP) lds_inc(s_h, (dg[k] & ~SIGN_BIT) >> fine_bits);
     __syncthreads();
     if (threadIdx.x < ncoarse) counts[((size_t)w * NS + st) * ncoarse + threadIdx.x] = s_h[threadIdx.x];  // [w][sub-tile][bin]
 }
@@ -608,6 +614,12 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_coarse_scatter(const uint32_t* _
     const uint32_t st = blockIdx.x, w = blockIdx.y;
     const uint32_t i0 = st * SUBTILE, i1 = min(n, i0 + SUBTILE);
     const size_t row = (size_t)w * n;
+    uint32_t dg[SUBTILE / TILE_BLOCK];
+#pragma unroll
+    for (int k = 0; k < SUBTILE / TILE_BLOCK; k++) {
+        const uint32_t i = i0 + threadIdx.x + k * TILE_BLOCK;
+        dg[k] = i < i1 ? digits[row + i] : DIGIT_SKIP;
+    }
     // this sub-tile's bin counts = differences of the prefixes over sub-tiles (last sub-tile: region total - prefix)
     uint32_t cnt = 0;
     if (threadIdx.x < ncoarse) {
@@ -634,9 +646,12 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_coarse_scatter(const uint32_t* _
     if (threadIdx.x < ncoarse) s_cur[threadIdx.x] = s_lstart[threadIdx.x];
     __syncthreads();
     const uint32_t fine_mask = (1u << fine_bits) - 1u;
-    for (uint32_t i = i0 + threadIdx.x; i < i1; i += TILE_BLOCK) {
-        uint32_t d = digits[row + i];
+    // the sub-tile's 16 digits per thread were loaded before the prefix phase (loads in flight across the barriers)
+#pragma unroll
+    for (int k = 0; k < SUBTILE / TILE_BLOCK; k++) {
+        const uint32_t d = dg[k];
         if (d == DIGIT_SKIP) continue;
+        const uint32_t i = i0 + threadIdx.x + k * TILE_BLOCK;
         uint32_t bkt = d & ~SIGN_BIT;
         uint32_t pos = lds_inc(s_cur, bkt >> fine_bits);
         s_stage[pos] = i | ((bkt & fine_mask) << idx_bits) | (d & SIGN_BIT);
