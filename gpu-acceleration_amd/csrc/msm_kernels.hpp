@@ -630,21 +630,29 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_coarse_scatter(const uint32_t* _
         cnt = nxt - pre;
         s_gbase[threadIdx.x] = region_start[r] + pre;
     }
-    // exclusive prefix of the bin counts (Hillis-Steele in LDS; every thread of the workgroup reaches the barriers)
-    if (threadIdx.x < COARSE_BINS_MAX) s_cur[threadIdx.x] = threadIdx.x < ncoarse ? cnt : 0u;
-    __syncthreads();
-    for (uint32_t d = 1; d < COARSE_BINS_MAX; d <<= 1) {
-        uint32_t v = 0;
-        if (threadIdx.x < COARSE_BINS_MAX && threadIdx.x >= d) v = s_cur[threadIdx.x - d];
+    // prefix of the bin counts: every wavefront scans its 64 bins with shuffles, the 16 wavefront totals are joined through
+    // LDS (two barriers; a Hillis-Steele scan over 1024 entries took twenty)
+    __shared__ uint32_t s_wtot[TILE_BLOCK / 64];
+    {
+        const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+        uint32_t x = cnt;  // 0 for threads beyond ncoarse
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t y = __shfl_up(x, d, 64);
+            if (lane >= (uint32_t)d) x += y;
+        }
+        if (lane == 63) s_wtot[wv] = x;
         __syncthreads();
-        if (threadIdx.x < COARSE_BINS_MAX) s_cur[threadIdx.x] += v;
+        uint32_t base = 0;
+        for (uint32_t k = 0; k < wv; k++) base += s_wtot[k];
+        const uint32_t incl = base + x;
+        if (threadIdx.x < ncoarse) {
+            s_lstart[threadIdx.x + 1] = incl;  // start of the next bin's run in s_stage
+            s_cur[threadIdx.x] = incl - cnt;   // this bin's cursor
+        }
+        if (threadIdx.x == 0) s_lstart[0] = 0;
         __syncthreads();
     }
-    if (threadIdx.x < ncoarse) s_lstart[threadIdx.x + 1] = s_cur[threadIdx.x];  // inclusive -> start of the next bin
-    if (threadIdx.x == 0) s_lstart[0] = 0;
-    __syncthreads();
-    if (threadIdx.x < ncoarse) s_cur[threadIdx.x] = s_lstart[threadIdx.x];
-    __syncthreads();
     const uint32_t fine_mask = (1u << fine_bits) - 1u;
     // the sub-tile's 16 digits per thread were loaded before the prefix phase (loads in flight across the barriers)
 #pragma unroll
@@ -702,17 +710,23 @@ __global__ void __launch_bounds__(FINE_BLOCK) k_fine_sort(const uint32_t* __rest
         }
     }
     __syncthreads();
-    // exclusive prefix of the <= 128 fine counts (Hillis-Steele in LDS)
-    for (uint32_t d = 1; d < 128; d <<= 1) {
-        uint32_t v = 0;
-        if (threadIdx.x < 128 && threadIdx.x >= d) v = s_cur[threadIdx.x - d];
-        __syncthreads();
-        if (threadIdx.x < 128) s_cur[threadIdx.x] += v;
-        __syncthreads();
-    }
+    // exclusive prefix of the <= 128 fine counts: the first two wavefronts scan 64 counts each with shuffles, one barrier
+    // joins them (a Hillis-Steele scan in LDS cost this kernel 14 workgroup barriers of 1024 threads)
+    __shared__ uint32_t s_half;
     uint32_t ex = 0;
-    if (threadIdx.x < nfine) ex = threadIdx.x ? s_cur[threadIdx.x - 1] : 0u;  // inclusive -> exclusive
+    if (threadIdx.x < 128) {
+        const uint32_t lane = threadIdx.x & 63u, cnt = s_cur[threadIdx.x];
+        uint32_t x = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t y = __shfl_up(x, d, 64);
+            if (lane >= (uint32_t)d) x += y;
+        }
+        if (threadIdx.x == 63) s_half = x;  // total of the first 64 counts
+        ex = x - cnt;
+    }
     __syncthreads();
+    if (threadIdx.x >= 64 && threadIdx.x < 128) ex += s_half;
     if (threadIdx.x < nfine) {
         s_cur[threadIdx.x] = ex;                                                       // local cursor
         offsets[(size_t)w * nb + ((size_t)cb << fine_bits) + threadIdx.x] = rs + ex;  // the bucket's CSC column pointer
