@@ -377,8 +377,13 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
         msmk::k_coarse_starts<<<1, msmk::SCAN_BLOCK, 0, st>>>(rtotal, rstart, nregions, flags + 4, offsets + tb);
         msmk::k_coarse_scatter<<<dim3(NS, W), msmk::TILE_BLOCK, 0, st>>>((uint32_t*)c->digits.p, counts, rstart, tmp, (uint32_t)n, fine_bits,
                                                                        idx_bits, ncoarse, NS);
-        msmk::k_fine_sort<<<dim3(ncoarse, W), msmk::FINE_BLOCK, 0, st>>>(tmp, rstart, offsets, (uint32_t*)c->sorted.p, nb, fine_bits, idx_bits,
-                                                                        ncoarse);
+        // workgroup size by mean region size (a workgroup stages up to 16 elements per thread; larger regions still sort, slower)
+        if ((n >> coarse_bits) <= 1024)
+            msmk::k_fine_sort<256><<<dim3(ncoarse, W), 256, 0, st>>>(tmp, rstart, offsets, (uint32_t*)c->sorted.p, nb, fine_bits, idx_bits, ncoarse);
+        else if ((n >> coarse_bits) <= 4096)
+            msmk::k_fine_sort<512><<<dim3(ncoarse, W), 512, 0, st>>>(tmp, rstart, offsets, (uint32_t*)c->sorted.p, nb, fine_bits, idx_bits, ncoarse);
+        else
+            msmk::k_fine_sort<1024><<<dim3(ncoarse, W), 1024, 0, st>>>(tmp, rstart, offsets, (uint32_t*)c->sorted.p, nb, fine_bits, idx_bits, ncoarse);
     } else {
         // K2/1: per-tile LDS histograms, then per-bucket prefix over tiles
         if (tiled) {

@@ -672,19 +672,23 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_coarse_scatter(const uint32_t* _
         for (uint32_t k = ls + lane; k < le; k += 64) tmp[gb + (k - ls)] = s_stage[k];
     }
 }
-constexpr int FINE_BLOCK = 1024;
-constexpr int FINE_PER_THREAD = FINE_CAP / FINE_BLOCK;  // 16 elements live in registers between the two phases
+constexpr int FINE_PER_THREAD = 16;  // elements that live in registers between the two phases
+// FINE_BLOCK threads stage up to FINE_BLOCK * 16 elements: 1024 threads (16384 elements, 64 KB of LDS) for the regions of a
+// large instance, 256 threads (4096 elements) when regions only hold a few hundred elements -- a 1024-thread workgroup
+// costs its dispatch and barriers whatever it sorts, and below 2^18 points those were most of this kernel's time
+template <int FINE_BLOCK>
 __global__ void __launch_bounds__(FINE_BLOCK) k_fine_sort(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ region_start,
                                                           uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted, uint32_t nb,
                                                           uint32_t fine_bits, uint32_t idx_bits, uint32_t ncoarse) {
     __shared__ uint32_t s_cur[128];
-    __shared__ uint32_t s_out[FINE_CAP];
+    constexpr uint32_t CAP = (uint32_t)FINE_BLOCK * FINE_PER_THREAD;
+    __shared__ uint32_t s_out[CAP];
     const uint32_t cb = blockIdx.x, w = blockIdx.y;
     const uint32_t nfine = 1u << fine_bits;
     const uint32_t r = w * ncoarse + cb;
     const uint32_t rs = region_start[r], re = region_start[r + 1], S = re - rs;
     const uint32_t fine_mask = nfine - 1u, idx_mask = (1u << idx_bits) - 1u;
-    const bool staged = S <= FINE_CAP;
+    const bool staged = S <= CAP;
     if (threadIdx.x < 128) s_cur[threadIdx.x] = 0;
     __syncthreads();
     uint32_t e[FINE_PER_THREAD];
@@ -698,7 +702,7 @@ __global__ void __launch_bounds__(FINE_BLOCK) k_fine_sort(const uint32_t* __rest
         for (int k = 0; k < FINE_PER_THREAD; k++)
             if (e[k] != DIGIT_SKIP) lds_inc(s_cur, (e[k] >> idx_bits) & fine_mask);
     } else {  // oversized region (one bucket holds a large share of the window): FINE_PER_THREAD loads in flight per thread
-        for (uint32_t base = rs; base < re; base += FINE_CAP) {
+        for (uint32_t base = rs; base < re; base += CAP) {
 #pragma unroll
             for (int k = 0; k < FINE_PER_THREAD; k++) {
                 uint32_t j = base + threadIdx.x + k * FINE_BLOCK;
@@ -743,7 +747,7 @@ __global__ void __launch_bounds__(FINE_BLOCK) k_fine_sort(const uint32_t* __rest
         for (uint32_t k = threadIdx.x; k < S; k += FINE_BLOCK) sorted[rs + k] = s_out[k];
     } else {  // skewed data: the region does not fit LDS, place directly (aggregated cursors hand consecutive lanes
               // consecutive slots, so the stores of a hot bucket are still coalesced)
-        for (uint32_t base = rs; base < re; base += FINE_CAP) {
+        for (uint32_t base = rs; base < re; base += CAP) {
 #pragma unroll
             for (int k = 0; k < FINE_PER_THREAD; k++) {
                 uint32_t j = base + threadIdx.x + k * FINE_BLOCK;
