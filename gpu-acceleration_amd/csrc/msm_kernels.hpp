@@ -1,12 +1,15 @@
 // msm_kernels.hpp -- the gfx950 kernels of the BN254 G1 MSM pipeline.
 //
 // Stage map against the reference (shader/cuzk/*.metal):
-//   K1 convert_point_coords_and_decompose_scalars -> k_convert_bases (only for MSM_FORM_STD input; one
-//        Montgomery product by R^2 instead of two Barrett multiplications) + k_decompose
-//   K2 transpose (ONE thread per window, serial 2N+C loop) -> k_decompose's histogram/rank atomics,
-//        k_scan_* (bucket offsets) and k_scatter: a counting sort with N*W-way parallelism
-//   K3 smvp (full 16-mul Jacobian add, one thread per bucket pair) -> k_accumulate (XYZZ mixed add)
-//   K4/K5 bpr_stage_1/2 -> k_pair_level (row/column plain sums, dense pairwise levels) + k_reduce_bits (wavefront-shuffle trees)
+//   K1 convert_point_coords_and_decompose_scalars -> k_convert_bases (one Montgomery product per coordinate instead of two
+//        Barrett multiplications; k_import_ark / k_decompress for the other input forms) + k_decompose
+//   K2 transpose (ONE thread per window, serial 2N+C loop) -> two-level counting sort in LDS: k_coarse_hist, k_coarse_prefix,
+//        k_coarse_starts, k_coarse_scatter, k_fine_sort (fallbacks: k_tile_* for n > 2^24, device-scope atomics in
+//        k_decompose + k_scan_* + k_scatter for windows of more than 2^17 buckets)
+//   K3 smvp (full 16-mul Jacobian add, one thread per bucket pair) -> k_chunk_map, k_accumulate (XYZZ mixed add over
+//        fixed-length chunks), k_combine / k_combine_long (buckets cut by chunk borders)
+//   K4/K5 bpr_stage_1/2 -> k_pair_level / k_pair_level_wide (row/column plain sums, dense pairwise levels) +
+//        k_reduce_bits_wide (per-bit sums, LDS trees of eight-lane additions; k_reduce_bits = the one-lane fallback)
 //   final_reduction (CPU) -> stays on the CPU: host_g1.hpp
 //
 // Data layout in HBM (all little-endian u32 words):
@@ -14,7 +17,7 @@
 //                     words per coordinate by k_convert_bases), 64 B per point = half a cache line per gather
 //   scalars  n x 8    standard form
 //   digits   W x n    bucket index (bit 31 = negate, 0xFFFFFFFF = digit 0 / base at infinity), window-major
-//   ranks    W x n    arrival rank inside the bucket (fallback path only: nb > 32768)
+//   ranks    W x n    arrival rank inside the bucket (fallback path only: more than 2^17 buckets per window)
 //   offsets  W*nb + 1 exclusive prefix sum of bucket sizes == CSC column pointer of the reference
 //   sorted   W x n    point index | sign<<31 grouped by bucket        == val_idxs of the reference
 //   buckets  W*nb x 36  XYZZ bucket sums, 4 coordinates x 9 limbs of 29 bits (144 B);
