@@ -82,7 +82,7 @@ typedef struct {
     float sort_ms;       /* bucket offsets (scan) + scatter of point indices    */
     float accumulate_ms; /* per-bucket point accumulation -- the graded kernel  */
     float reduce_ms;     /* running-sum bucket reduction + per-window sums      */
-    float finish_ms;     /* D2H of W window sums + host Horner + normalisation  */
+    float finish_ms;     /* host Horner over the bit sums (+ normalisation if asked) */
     float total_ms;      /* wall clock of the whole call                        */
     uint64_t num_points;
     uint64_t num_adds;   /* mixed additions executed by accumulate (non-zero digits) */
@@ -99,8 +99,10 @@ uint32_t msm_abi_version(void);
 /* ---- the drop-in call: host pointers in, host results out ---------------------------------- */
 /* replaces metal_variable_base_msm (metal_msm.rs:642-695).  bases: n x 16 words; inf_mask: n bytes
  * (non-zero = point at infinity, arkworks G1Affine.infinity) or NULL; scalars: n x 8 words.
- * Any of the three outputs may be NULL.  out_affine_std = canonical affine, standard form (0,0 when
- * the result is the identity and *out_is_inf = 1). */
+ * Any of the three outputs may be NULL.  out_jacobian_mont is the reference's own result type (G::new(x, y, z),
+ * metal_msm.rs:228-241).  out_affine_std = canonical affine, standard form (0,0 when the result is the identity and
+ * *out_is_inf = 1); it costs the call's only field inversion (~10 us on the host) -- pass NULL to skip it and normalise
+ * later with msm_bn254_g1_combine(partial, 1, ...) if needed. */
 int32_t msm_bn254_g1(msm_ctx *ctx, const uint32_t *bases_xy, uint32_t base_form, const uint8_t *inf_mask,
                      const uint32_t *scalars, size_t n, uint32_t out_jacobian_mont[24],
                      uint32_t out_affine_std[16], uint8_t *out_is_inf);
