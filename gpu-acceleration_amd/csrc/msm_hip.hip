@@ -62,11 +62,24 @@ public:
             std::lock_guard<std::mutex> lk(m_);
             stop_ = true;
             gen_++;
+            ticket_.store(gen_ << 32, std::memory_order_release);  // releases workers spinning in the armed state
         }
         cv_work_.notify_all();
         for (auto& t : th_) t.join();
     }
     int size() const { return (int)th_.size(); }
+    // Wake the workers NOW and let them spin until the next run() publishes its jobs (or ~20 ms pass): called when a
+    // pipeline is enqueued, so that the condition-variable wake-up (the source of the remaining 2-5 ms outliers: ~1 % of
+    // the calls on a busy host) happens during the GPU's milliseconds instead of on the critical path of the finish.
+    void arm() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            njobs_ = 0;  // "armed": nothing to pull yet
+            const uint64_t gen = ++gen_;
+            ticket_.store(gen << 32, std::memory_order_release);
+        }
+        cv_work_.notify_all();
+    }
     // run fn(0..njobs-1) on the workers and the calling thread; returns when all jobs are done
     void run(int njobs, const std::function<void(int)>& fn) {
         uint64_t gen;
@@ -106,6 +119,14 @@ private:
                 if (stop_) return;
                 job = job_;
                 njobs = njobs_;
+            }
+            if (njobs == 0) {  // armed: spin (bounded) until run() moves the ticket to the next generation
+                const auto t0 = std::chrono::steady_clock::now();
+                for (uint32_t spins = 1; (ticket_.load(std::memory_order_acquire) >> 32) == seen; spins++) {
+                    if ((spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+                    __builtin_ia32_pause();
+                }
+                continue;  // re-read generation and job under the lock (cv wait returns at once if run() has published)
             }
             pull(seen, njobs, *job);
         }
@@ -466,9 +487,9 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
 // ONE Horner chain over the ~254 positions (one doubling and about one addition per position) instead of the reference's
 // chain per window plus c doublings between windows (metal_msm.rs:249-258).  The chain is cut into a few segments of
 // geometrically shrinking length (a segment starting at position lo pays lo extra doublings to shift its sum), one per
-// host thread: 3-4 threads reach ~45 % of the serial time, more threads add nothing because the shift of the top
-// segment is serial.  Few threads on purpose: a pool of 15 was ~15 us faster in the median but produced 3-10 ms outliers
-// in 2.5 % of the calls when the OS was late waking workers (tools/step_jitter.py).
+// host thread: 2 threads reach ~60 % of the serial time, 4 threads ~45 %, more add nothing because the shift of the top
+// segment is serial.  TWO threads by default: every further worker lowers the median by a few microseconds and raises the
+// MEAN through 2-8 ms outliers in ~1.3 % of the calls (busy hosts; a pool of 15: 2.5 %) -- tools/step_jitter.py.
 hostg1::Jac host_finish(msm_ctx* c, const uint32_t* h_qsums, const PipeGeom& g) {
     const uint32_t W = g.W, kb = g.kb, cbits = g.cbits;
     const uint32_t npos = cbits * (W - 1) + (kb > 0 ? kb : 1);  // positions 0 .. npos-1 carry terms
@@ -517,6 +538,7 @@ int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, 
     PipeGeom g;
     int32_t rc = enqueue_pipeline(c, d_bases, d_inf, d_scalars, n, st, c->h_qsums, c->h_flags, &g, scalars_mont, bases_ready);
     if (rc) return rc;
+    if (c->pool && n >= 256) c->pool->arm();  // workers wake up while the GPU works
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());
     auto t_fin0 = std::chrono::steady_clock::now();
@@ -706,7 +728,9 @@ int32_t msm_ctx_create(const msm_config_t* cfg, msm_ctx** out) {
     {
         // host finish threads: MSM_HIP_HOST_THREADS=0 forces the serial path
         int want = (int)std::thread::hardware_concurrency() - 1;
-        if (want > 3) want = 3;  // the calling thread + 3 workers: see host_finish
+        if (want > 1) want = 1;  // the calling thread + ONE worker: measured over 1500 calls at 2^17 (tools/step_jitter.py),
+                                 // mean latency 0.608 / 0.575 / 0.588 / 0.590 ms with 1 / 2 / 3 / 4 threads -- the median keeps
+                                 // falling (0.606 / 0.570 / 0.556 / 0.555) but 3+ threads bring 2-8 ms outliers in ~1.3 % of the calls
         if (const char* e = std::getenv("MSM_HIP_HOST_THREADS")) want = std::atoi(e) - 1;
         if (const char* e = std::getenv("MSM_HIP_WIDE_MAX")) c->wide_max = (size_t)std::max(0, std::atoi(e));
         if (want >= 1) c->pool = new (std::nothrow) HostPool(want);
