@@ -71,34 +71,28 @@ inline Fq sub(const Fq& a, const Fq& b) {
     return r;
 }
 inline Fq dbl(const Fq& a) { return add(a, a); }
-// Montgomery product, operand-scanning with interleaved reduction
+// Montgomery product, CIOS with product and reduction interleaved per limb.  The modulus leaves its top bit free
+// (p < 2^254), so the running value never needs a fifth word ("no-carry" CIOS): t3 = carry_a + carry_m cannot overflow.
 inline Fq mul(const Fq& a, const Fq& b) {
-    uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+    uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     for (int i = 0; i < 4; ++i) {
         const uint64_t bi = b.l[i];
-        u128 acc = (u128)a.l[0] * bi + t0;
-        uint64_t r0 = (uint64_t)acc;
-        acc = (u128)a.l[1] * bi + t1 + (uint64_t)(acc >> 64);
-        uint64_t r1 = (uint64_t)acc;
-        acc = (u128)a.l[2] * bi + t2 + (uint64_t)(acc >> 64);
-        uint64_t r2 = (uint64_t)acc;
-        acc = (u128)a.l[3] * bi + t3 + (uint64_t)(acc >> 64);
-        uint64_t r3 = (uint64_t)acc;
-        u128 top = (u128)t4 + (uint64_t)(acc >> 64);
-        const uint64_t m = r0 * NINV;
-        acc = (u128)m * MOD.l[0] + r0;
-        acc = (u128)m * MOD.l[1] + r1 + (uint64_t)(acc >> 64);
-        t0 = (uint64_t)acc;
-        acc = (u128)m * MOD.l[2] + r2 + (uint64_t)(acc >> 64);
-        t1 = (uint64_t)acc;
-        acc = (u128)m * MOD.l[3] + r3 + (uint64_t)(acc >> 64);
-        t2 = (uint64_t)acc;
-        top += (uint64_t)(acc >> 64);
-        t3 = (uint64_t)top;
-        t4 = (uint64_t)(top >> 64);
+        u128 pa = (u128)a.l[0] * bi + t0;               // product chain
+        const uint64_t m = (uint64_t)pa * NINV;
+        u128 pm = (u128)m * MOD.l[0] + (uint64_t)pa;    // reduction chain (low word becomes 0)
+        pa = (u128)a.l[1] * bi + t1 + (uint64_t)(pa >> 64);
+        pm = (u128)m * MOD.l[1] + (uint64_t)pa + (uint64_t)(pm >> 64);
+        t0 = (uint64_t)pm;
+        pa = (u128)a.l[2] * bi + t2 + (uint64_t)(pa >> 64);
+        pm = (u128)m * MOD.l[2] + (uint64_t)pa + (uint64_t)(pm >> 64);
+        t1 = (uint64_t)pm;
+        pa = (u128)a.l[3] * bi + t3 + (uint64_t)(pa >> 64);
+        pm = (u128)m * MOD.l[3] + (uint64_t)pa + (uint64_t)(pm >> 64);
+        t2 = (uint64_t)pm;
+        t3 = (uint64_t)(pa >> 64) + (uint64_t)(pm >> 64);
     }
     Fq r = {{t0, t1, t2, t3}};
-    if (t4 || geq_mod(r)) sub_mod_inplace(r);
+    if (geq_mod(r)) sub_mod_inplace(r);
     return r;
 }
 inline Fq sqr(const Fq& a) { return mul(a, a); }
