@@ -214,13 +214,16 @@ void release(DevBuf& b) {
 // measured effects decide the table below (tools/sweep_c.py, profiles/NOTES_r1.md "window sweep"):
 //  * r < 2^254, so the top window only holds 254 mod c bits.  For c = 7, 9, 11, 12, 14 that is 1-2 bits: every point
 //    lands in one of <= 3 buckets of that window, which serialises the LDS sort cursors and makes those buckets
-//    thousands of chunks long (c = 12 at N = 2^19: 6.7 ms against 1.2 ms).  Only c in {8, 13, 15, 16} (6, 7, 14, 14
+//    thousands of chunks long (c = 12 at N = 2^19: 6.7 ms against 1.2 ms).  Only c in {8, 10, 13, 15, 16} (6, 4, 7, 14, 14
 //    top bits) are used.
 //  * below ~2^17 points the per-window fixed costs (dependent reduction levels, launches) outweigh the bucket count:
 //    fewer, wider windows win earlier than the arithmetic model says.
 // c is capped where one window's histogram still fits the LDS sort path (nb <= 32768: 16 signed, 15 unsigned).
 uint32_t plan_window_bits(size_t n, bool is_signed) {
-    uint32_t c = n < ((size_t)1 << 13) ? 8u : n <= ((size_t)1 << 16) ? 13u : n <= ((size_t)1 << 17) ? 15u : 16u;
+    // re-measured after the reduction-tree and host-latency work (tools/sweep_c.py): 2^13: c = 8 0.335 ms (13: 0.455);
+    // 2^14: c = 10 0.397 (13: 0.431); 2^15: 10 0.412 (13: 0.440); 2^16: 13 0.489; 2^17: 15 0.587; 2^18: 15 0.769 (16: 0.790);
+    // 2^19: 16 1.125 (15: 1.197).  c = 10 leaves the top window 4 bits (9 buckets of n/16 points): fine for the long-bucket path.
+    uint32_t c = n <= ((size_t)1 << 13) ? 8u : n <= ((size_t)1 << 15) ? 10u : n <= ((size_t)1 << 16) ? 13u : n <= ((size_t)1 << 18) ? 15u : 16u;
     if (!is_signed && c > 15u) c = 15u;
     return c;
 }
