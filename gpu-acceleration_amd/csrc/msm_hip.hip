@@ -320,7 +320,9 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
     // sorted entries folded by one k_accumulate thread: ~2^19 chunks per call (2.7 rounds of the 196608 threads that
     // 3 wavefronts/SIMD hold) keep the tail short, and the chunk grows with N so that buckets (mean n / nb entries)
     // are cut into few pieces for k_combine.  Measured sweep at N = 2^20: L = 32 (profiles/NOTES_r1.md).
-    uint32_t chunk_len = 16;  // (8 loses at every size: more buckets are cut 3+ times than the finer granularity wins back)
+    // 16 from 2^13 points up (8 loses there: more buckets are cut 3+ times than the finer granularity wins back); tiny instances
+    // (<= 2^17 sorted entries: a quarter of the SIMDs would hold a wavefront at 16) take 8: 0.262 vs 0.296 ms at 2^10
+    uint32_t chunk_len = pairs <= ((size_t)1 << 17) ? 8 : 16;
     while (chunk_len < 1024 && pairs / (chunk_len * 2) > 262144) chunk_len *= 2;
     if (const char* e = std::getenv("MSM_HIP_CHUNK_LEN")) {  // tuning knob (any value >= 1 is correct)
         int v = std::atoi(e);
