@@ -43,6 +43,25 @@ def words_to_ints(a):
     return out
 
 
+# one mixed addition (ec_bn254.hpp xyzz_madd): 6 fp_mul + 2 fp_sqr + 1 fused fp_mul_add
+MADS_PER_ADD = 6 * 162 + 2 * 126 + 243           # v_mad_u64_u32 instructions
+FPMUL_EQ_PER_ADD = (6 * 171 + 2 * 135 + 252) / 171.0  # in units of one fp_mul (162 mads + 9 Montgomery-digit multiplications)
+
+
+def valu_roofline(num_adds, acc_ms, mad_peak, fpmul_peak):
+    if not (num_adds and acc_ms > 0 and mad_peak > 0 and fpmul_peak > 0):
+        return None
+    t = acc_ms * 1e-3
+    mads = num_adds * MADS_PER_ADD / t
+    fpm = num_adds * FPMUL_EQ_PER_ADD / t
+    return {"bound": "valu", "kernel": "k_accumulate", "mixed_additions_per_launch": num_adds,
+            "achieved": round(fpm / 1e9, 2), "peak": round(fpmul_peak / 1e9, 2), "unit": "G field-mul/s", "frac": round(fpm / fpmul_peak, 4),
+            "mad_u64_achieved_G_per_s": round(mads / 1e9, 1), "mad_u64_peak_G_per_s": round(mad_peak / 1e9, 1),
+            "mad_u64_frac": round(mads / mad_peak, 4),
+            "note": "peaks measured live by msm_calibrate (csrc k_calibrate); field-mul = 9x29-bit Montgomery multiplication, "
+                    "%.2f multiplication-equivalents per mixed addition" % FPMUL_EQ_PER_ADD}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,6 +134,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     acc_avg_ms, acc_launches = ctx.accumulate_kernel_stats()
+    mad_peak, fpmul_peak = ctx.calibrate() if rank == 0 else (0.0, 0.0)  # two ~1 ms micro-kernels, outside the timed region
     # per-stage hipEvents are off in the timed region (each record costs ~6 us of stream time): one extra, untimed
     # step with them on gives the stage breakdown
     ctx.set_stage_timing(True)
@@ -172,7 +192,11 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_ms": round(acc_avg_ms, 4),
                          "launches_timed": int(acc_launches),
-                         "note": "integer-multiply (VALU) bound kernel; HBM fraction reported because BASELINE.json asks for it"},
+                         "note": "integer-multiply (VALU) bound kernel; HBM fraction reported because BASELINE.json asks for it; "
+                                 "the multiplier roofline is in roofline_valu"},
+            # the bound that actually holds: multiplier work of the launch against what two calibration
+            # micro-kernels sustain on THIS device (dependent chains, 4 wavefronts per SIMD, like k_accumulate)
+            "roofline_valu": valu_roofline(int(tm.get("num_adds", 0)), acc_avg_ms, mad_peak, fpmul_peak),
             "stage_ms_untimed_diagnostic_step": {k: round(v, 4) for k, v in tm.items() if k.endswith("_ms")},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -1109,6 +1109,39 @@ int32_t msm_test_g1_op(msm_ctx* c, uint32_t op, const uint32_t* a, const uint32_
     if (op != MSM_OP_G1_DBL && !b) return MSM_ERR_BAD_ARG;
     return run_test_kernel(c, true, op, a, 24, op == MSM_OP_G1_DBL ? nullptr : b, op == MSM_OP_G1_MADD ? 16 : 24, out, 24, n);
 }
+int32_t msm_calibrate(msm_ctx* c, double* mad_per_s, double* fp_mul_per_s) {
+    if (!c) return MSM_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    int32_t rc;
+    if ((rc = ensure(c, c->flags, 64))) return rc;
+    hipDeviceProp_t prop;
+    HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
+    const unsigned blocks = (unsigned)prop.multiProcessorCount * 4u * 4u;  // 256-thread blocks: 4 wavefronts on each of a CU's 4 SIMDs
+    hipEvent_t e0, e1;
+    HIPCHK(c, hipEventCreate(&e0));
+    HIPCHK(c, hipEventCreate(&e1));
+    double out[2] = {0, 0};
+    for (uint32_t what = 0; what < 2; what++) {
+        const uint32_t iters = what == 0 ? 2000u : 400u;
+        const double ops_per_thread = what == 0 ? 64.0 * iters : 4.0 * iters;
+        msmk::k_calibrate<<<blocks, 256, 0, c->stream>>>(what, iters / 10, (uint32_t*)c->flags.p + 15);  // warm-up
+        HIPCHK(c, hipEventRecord(e0, c->stream));
+        msmk::k_calibrate<<<blocks, 256, 0, c->stream>>>(what, iters, (uint32_t*)c->flags.p + 15);
+        HIPCHK(c, hipEventRecord(e1, c->stream));
+        HIPCHK(c, hipEventSynchronize(e1));
+        float ms = 0;
+        HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+        out[what] = ops_per_thread * (double)blocks * 256.0 / ((double)ms * 1e-3);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    HIPCHK(c, hipGetLastError());
+    if (mad_per_s) *mad_per_s = out[0];
+    if (fp_mul_per_s) *fp_mul_per_s = out[1];
+    return MSM_OK;
+}
+
 int32_t msm_test_decompose(msm_ctx* c, const uint32_t* scalars, size_t n, uint32_t window_bits, int32_t* digits) {
     if (!c || !scalars || !digits) return MSM_ERR_BAD_ARG;
     if (n == 0) return MSM_ERR_EMPTY;

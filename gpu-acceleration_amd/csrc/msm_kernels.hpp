@@ -1260,6 +1260,33 @@ __global__ void __launch_bounds__(64) k_test_g1(uint32_t op, const uint32_t* __r
     store_jacobian_mont256(out + (size_t)i * 24, xyzz_to_jacobian(r));
 }
 
+// Calibration kernels for the integer-multiplier roofline ("against the measured v_mad_u64_u32 peak of
+// a calibration micro-kernel on the same device"): dependent chains at 4 wavefronts per SIMD, as k_accumulate runs them.
+//   what = 0: raw v_mad_u64_u32 (64 per iteration);  1: fp_mul, the 9 x 29-bit Montgomery multiplication (4 per iteration)
+__global__ void __launch_bounds__(256) k_calibrate(uint32_t what, uint32_t iters, uint32_t* __restrict__ sink) {
+    uint32_t acc_out = 0;
+    if (what == 0) {
+        uint64_t a = threadIdx.x * 0x9E3779B97F4A7C15ull + 12345u;
+        const uint32_t y = (uint32_t)(a >> 32) | 1u;
+        for (uint32_t i = 0; i < iters; i++) {
+#pragma unroll
+            for (int k = 0; k < 64; k++) a = (uint64_t)(uint32_t)a * y + a;  // one v_mad_u64_u32, operand and addend from the chain (wraps)
+        }
+        acc_out = (uint32_t)a ^ (uint32_t)(a >> 32);
+    } else {
+        fp v = fp_one(), m = fp_one();
+        v.v[0] += threadIdx.x;
+        m.v[1] += 7 + threadIdx.x;
+        for (uint32_t i = 0; i < iters; i++) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) v = fp_mul(v, m);
+        }
+#pragma unroll
+        for (int k = 0; k < 9; k++) acc_out ^= v.v[k];
+    }
+    if (acc_out == 0x12345u) sink[0] = acc_out;  // never true in practice: keeps the chains alive
+}
+
 // test hook for ec_wide.hpp: pair i is added by the 8 lanes of group i (records staged in LDS by the group's first lane)
 __global__ void __launch_bounds__(64) k_test_g1_wide(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
                                                      uint32_t* __restrict__ out, uint32_t n) {

@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "msm_bn254_g1_arkworks", "msm_bn254_g1_upload_bases", "msm_bn254_g1_resident", "msm_bn254_g1_device", "msm_bn254_g1_combine",
     "msm_plan", "msm_get_timings", "msm_set_stage_timing", "msm_get_accumulate_kernel_stats", "msm_reset_kernel_stats",
     "msm_bn254_g1_generate_device", "msm_bn254_generate_scalars_host", "msm_test_fp_op", "msm_test_g1_op",
-    "msm_test_decompose", "msm_bn254_g1_decompress", "msm_bn254_g1_upload_compressed", "msm_bn254_g1_compress",
+    "msm_test_decompose", "msm_bn254_g1_decompress", "msm_bn254_g1_upload_compressed", "msm_bn254_g1_compress", "msm_calibrate",
 ]
 
 
@@ -110,6 +110,7 @@ def load_library():
     L.msm_bn254_g1_decompress.argtypes = [vp, _u8p, C.c_size_t, _u32p, _u8p, C.POINTER(C.c_int64)]
     L.msm_bn254_g1_upload_compressed.argtypes = [vp, _u8p, C.c_size_t, C.POINTER(C.c_int64)]
     L.msm_bn254_g1_compress.argtypes = [_u32p, C.c_uint32, _u8p, C.c_size_t, _u8p]
+    L.msm_calibrate.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     for name in ABI_SYMBOLS:
         f = getattr(L, name)
         if f.restype is C.c_int:  # default
@@ -352,6 +353,12 @@ class MsmContext:
         out = np.zeros_like(a)
         self._check(self._lib.msm_test_g1_op(self._h, op, _p32(a), _p32(b), _p32(out), a.shape[0]))
         return out
+
+    def calibrate(self):
+        """(v_mad_u64_u32 per second, field multiplications per second) this device sustains -- two ~1 ms micro-kernels."""
+        a, b = C.c_double(0), C.c_double(0)
+        self._check(self._lib.msm_calibrate(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def test_decompose(self, scalars, window_bits=0):
         scalars = _words(scalars, 8)

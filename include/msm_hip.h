@@ -189,6 +189,14 @@ int32_t msm_test_g1_op(msm_ctx *ctx, uint32_t op, const uint32_t *a, const uint3
 /* signed/unsigned digit decomposition of the planner's choice, digits[w*n + i] as int32 */
 int32_t msm_test_decompose(msm_ctx *ctx, const uint32_t *scalars, size_t n, uint32_t window_bits, int32_t *digits);
 
+/* ---- integer-multiplier calibration --------------------------------------------
+ * Runs two saturating micro-kernels on the context's device (4 wavefronts per SIMD, dependent chains, ~1 ms each) and
+ * reports what THIS device sustains, per second over the whole chip, lane level:
+ *   *mad_per_s     v_mad_u64_u32 operations (the instruction the field multiplication is made of)
+ *   *fp_mul_per_s  9 x 29-bit Montgomery multiplications (fp_mul of csrc/fp_bn254.hpp, 171 multiplier instructions each)
+ * bench.py prices k_accumulate against these instead of a datasheet figure. */
+int32_t msm_calibrate(msm_ctx *ctx, double *mad_per_s, double *fp_mul_per_s);
+
 #ifdef __cplusplus
 }
 #endif
