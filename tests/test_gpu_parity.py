@@ -140,6 +140,14 @@ def test_wide_add_matches_scalar_add_and_oracle(ctx):
             assert orc.g1_to_affine_std(wide[5])[1] == 1 and orc.g1_to_affine_std(wide[6])[1] == 1 and orc.g1_to_affine_std(wide[2])[1] == 1
 
 
+def test_calibration_reports_plausible_multiplier_rates(ctx):
+    """msm_calibrate (the live peaks bench.py prices k_accumulate against): MI355X sustains ~3.9e13 v_mad_u64_u32/s and
+    ~1.6e11 field multiplications/s; a field multiplication is 171 multiplier instructions plus bookkeeping."""
+    mad, fpm = ctx.calibrate()
+    assert 5e12 < mad < 2e14 and 2e10 < fpm < 1e12
+    assert 171 < mad / fpm < 400
+
+
 def test_signed_digits_reconstruct_scalar(ctx):
     g = load_golden("edge_carry_patterns")
     sc = np.concatenate([g["scalars"], orc.gen_scalars(5, 200), np.stack([orc.int_to_words(v) for v in (0, 1, R - 1, R - 2, (1 << 253) + 12345)])])
