@@ -166,7 +166,8 @@ def main():
         pl = mh.plan(n_local, args.window_bits)
         W, H = pl.num_windows, pl.num_buckets
         # ALGORITHMIC bytes of one accumulate launch: W*(N*(4 B index + 64 B affine point) + H*96 B)
-        alg_bytes = W * (n_local * 68 + H * 96)
+        # (with the GLV split a window sorts and accumulates 2n virtual points in half as many windows: same point term)
+        alg_bytes = W * (int(pl.virtual_points) * 68 + H * 96)
         achieved = alg_bytes / (acc_avg_ms * 1e-3) / 1e9 if acc_avg_ms > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "accumulate_pmc.json")
@@ -186,7 +187,8 @@ def main():
                                    "(BASELINE.json configs[2]); bases k_i*G and scalars resident in HBM, "
                                    "point-range shards + all-gather of 96-byte partials" % args.log_n,
                        "n_total": n_total, "n_per_gpu": n_local, "window_bits": pl.window_bits, "num_windows": W,
-                       "buckets_per_window": H, "parallelism": "point-range x%d" % world},
+                       "buckets_per_window": H, "glv_split": bool(pl.glv), "points_per_window": int(pl.virtual_points),
+                       "parallelism": "point-range x%d" % world},
             "bit_exact": bit_exact,
             "roofline": {"bound": "hbm", "kernel": "k_accumulate", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,

@@ -166,6 +166,7 @@ struct msm_ctx {
     size_t resident_n = 0;
     size_t wide_max = 40960;  // pairwise levels up to this many additions use 8 lanes per addition (MSM_HIP_WIDE_MAX; 0 = never)
     bool resident_has_inf = false;
+    bool resident_glv = false;  // the resident set holds the phi records too (index resident_n + i)
     msm_timings_t tm{};
     bool stage_timing = false;  // record the per-stage hipEvents (each costs ~6 us of stream time); k_accumulate's pair is always on
     double acc_ms_sum = 0;
@@ -227,20 +228,41 @@ uint32_t plan_window_bits(size_t n, bool is_signed) {
     if (!is_signed && c > 15u) c = 15u;
     return c;
 }
+// GLV (glv_bn254.hpp): 2n virtual points with 127-bit scalars.  Used whenever the 2n indices fit the two-level sort's entry
+// format (2^24) -- the same additions in half the windows: half the buckets to reduce, half the host's Horner chain.
+constexpr size_t GLV_MAX_POINTS = (size_t)1 << 23;
+uint32_t plan_window_bits_glv(size_t n, bool is_signed) {
+    uint32_t c = 16u;  // PLACEHOLDER table, re-measured below
+    if (!is_signed && c > 15u) c = 15u;
+    (void)n;
+    return c;
+}
 int32_t make_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_plan_t* out) {
-    if (flags & ~MSM_FLAG_UNSIGNED_DIGITS) return MSM_ERR_BAD_ARG;
+    if (flags & ~(MSM_FLAG_UNSIGNED_DIGITS | MSM_FLAG_NO_GLV)) return MSM_ERR_BAD_ARG;
     bool is_signed = !(flags & MSM_FLAG_UNSIGNED_DIGITS);
-    uint32_t c = window_bits ? window_bits : plan_window_bits(n, is_signed);
+    bool use_glv = !(flags & MSM_FLAG_NO_GLV) && n <= GLV_MAX_POINTS && !std::getenv("MSM_HIP_NO_GLV");
+    uint32_t c = window_bits ? window_bits : (use_glv ? plan_window_bits_glv(n, is_signed) : plan_window_bits(n, is_signed));
     if (c < 2 || c > 20) return MSM_ERR_BAD_ARG;
+    if ((is_signed ? c - 1 : c) > 17) use_glv = false;  // windows wider than the LDS sort covers (forced c >= 19) run unsplit
+    const uint32_t bits = use_glv ? (uint32_t)glv::SPLIT_BITS : 254u;
     out->window_bits = c;
     out->signed_digits = is_signed;
-    // signed: one spare window position so the top digit never overflows (r < 2^254): W = floor(254/c) + 1
-    out->num_windows = is_signed ? (254 / c + 1) : ((254 + c - 1) / c);
+    out->glv = use_glv ? 1u : 0u;
+    out->scalar_bits = bits;
+    out->virtual_points = use_glv ? 2 * (uint64_t)n : (uint64_t)n;
+    // signed: one spare window position so the top digit never overflows (r < 2^254, |k_j| < 2^127): W = floor(bits/c) + 1
+    out->num_windows = is_signed ? (bits / c + 1) : ((bits + c - 1) / c);
     out->num_buckets = is_signed ? (1u << (c - 1)) : (1u << c);
-    size_t pairs = (size_t)out->num_windows * n;
+    size_t nv = (size_t)out->virtual_points;
+    size_t pairs = (size_t)out->num_windows * nv;
     size_t tb = (size_t)out->num_windows * out->num_buckets;
-    out->workspace_bytes = n * (64 + 32 + 1) + pairs * 12 + tb * (8 + 144) + tb * 144 * 3 / 2;
+    out->workspace_bytes = nv * 64 + n * (32 + 1) + pairs * 12 + tb * (8 + 144) + tb * 144 * 3 / 2;
     return MSM_OK;
+}
+// does a call on n points (context configuration + per-call extra flags) use the GLV split, i.e. 2n base records?
+inline bool plan_glv(const msm_ctx* c, size_t n, uint32_t extra_flags = 0) {
+    msm_plan_t pl;
+    return make_plan(n, c->cfg.window_bits, c->cfg.flags | extra_flags, &pl) == MSM_OK && pl.glv != 0;
 }
 constexpr size_t XB = msmk::XW * 4;               // bytes per XYZZ record (4 coordinates x 9 x 29-bit limbs)
 constexpr size_t LDS_HIST_BYTES = 128 * 1024;   // one window's bucket histogram must fit here for the LDS sort path
@@ -279,7 +301,7 @@ int32_t ensure_pow2_table(msm_ctx* c) {
     HIPCHK(c, hipMalloc(&raw, tab.size() * 4));
     HIPCHK(c, hipMemcpyAsync(raw, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, c->stream));
     msmk::k_convert_bases<<<grid1(2 * (size_t)msmk::SCALAR_BITS, 64), 64, 0, c->stream>>>((const uint32_t*)raw, (uint32_t*)c->pow2.p,
-                                                                                     (uint32_t)msmk::SCALAR_BITS, 1u);
+                                                                                     (uint32_t)msmk::SCALAR_BITS, 1u, 0u);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipFree(raw));
     c->pow2_ready = true;
@@ -304,13 +326,15 @@ struct PipeGeom {
 
 // Queue the whole device pipeline for one (chunk of an) MSM on stream st; the W*(kb+1) bit sums and the flag words
 // are written by the last kernel straight into h_qsums_dst / h_flags_dst (pinned host memory).  No host synchronisation here.
-int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, const uint32_t* d_scalars, size_t n,
+// d_bases: INTERNAL-domain records; with the GLV split (make_plan) 2*n_real of them, phi(P_i) at index n_real + i.
+int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, const uint32_t* d_scalars, size_t n_real,
                          hipStream_t st, uint32_t* h_qsums_dst, uint32_t* h_flags_dst, PipeGeom* geom, uint32_t scalars_mont = 0,
-                         hipEvent_t bases_ready = nullptr) {
-    if (n > 0x7FFFFFFFull) return fail(c, MSM_ERR_BAD_ARG, "n = %zu exceeds 2^31-1 points per context call", n);
+                         hipEvent_t bases_ready = nullptr, uint32_t extra_flags = 0) {
+    if (n_real > 0x3FFFFFFFull) return fail(c, MSM_ERR_BAD_ARG, "n = %zu exceeds 2^30-1 points per context call", n_real);
     msm_plan_t pl;
-    int32_t rc = make_plan(n, c->cfg.window_bits, c->cfg.flags, &pl);
+    int32_t rc = make_plan(n_real, c->cfg.window_bits, c->cfg.flags | extra_flags, &pl);
     if (rc) return fail(c, rc, "bad window_bits/flags (%u, 0x%x)", c->cfg.window_bits, c->cfg.flags);
+    const size_t n = (size_t)pl.virtual_points;  // what the sort, the accumulation and the reduction see
     const uint32_t W = pl.num_windows, nb = pl.num_buckets, cbits = pl.window_bits;
     const size_t pairs = (size_t)W * n, tb = (size_t)W * nb;
     if (pairs > 0xFFFFFFFFull) return fail(c, MSM_ERR_BAD_ARG, "n*W = %zu does not fit 32-bit offsets", pairs);
@@ -382,14 +406,19 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
     }
     HIPCHK(c, hipMemsetAsync(flags, 0, 64, st));
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_CONVERT], st));
-    // K1b: digits + signed recode
+    // K1b: digits + signed recode (with the GLV split: two 127-bit halves per scalar, 2*n_real digit columns)
     {
         uint32_t *dg = (uint32_t*)c->digits.p, *rk = (uint32_t*)c->ranks.p;
-        dim3 g = grid1(n, 256);
-        if (pl.signed_digits && lds_counts) msmk::k_decompose<true, false><<<g, 256, 0, st>>>(d_scalars, d_inf, (uint32_t)n, cbits, W, nb, hist, dg, rk, flags, scalars_mont);
-        else if (pl.signed_digits) msmk::k_decompose<true, true><<<g, 256, 0, st>>>(d_scalars, d_inf, (uint32_t)n, cbits, W, nb, hist, dg, rk, flags, scalars_mont);
-        else if (lds_counts) msmk::k_decompose<false, false><<<g, 256, 0, st>>>(d_scalars, d_inf, (uint32_t)n, cbits, W, nb, hist, dg, rk, flags, scalars_mont);
-        else msmk::k_decompose<false, true><<<g, 256, 0, st>>>(d_scalars, d_inf, (uint32_t)n, cbits, W, nb, hist, dg, rk, flags, scalars_mont);
+        dim3 g = grid1(n_real, 256);
+        const uint32_t nr = (uint32_t)n_real;
+        if (pl.glv) {
+            if (!lds_counts) return fail(c, MSM_ERR_BAD_ARG, "window_bits %u needs the non-GLV path (MSM_FLAG_NO_GLV)", cbits);
+            if (pl.signed_digits) msmk::k_decompose_glv<true><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, dg, flags, scalars_mont);
+            else msmk::k_decompose_glv<false><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, dg, flags, scalars_mont);
+        } else if (pl.signed_digits && lds_counts) msmk::k_decompose<true, false><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, nb, hist, dg, rk, flags, scalars_mont);
+        else if (pl.signed_digits) msmk::k_decompose<true, true><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, nb, hist, dg, rk, flags, scalars_mont);
+        else if (lds_counts) msmk::k_decompose<false, false><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, nb, hist, dg, rk, flags, scalars_mont);
+        else msmk::k_decompose<false, true><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, nb, hist, dg, rk, flags, scalars_mont);
     }
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_DECOMP], st));
     if (two_level) {
@@ -533,15 +562,16 @@ hostg1::Jac host_finish(msm_ctx* c, const uint32_t* h_qsums, const PipeGeom& g) 
 int32_t check_flags(msm_ctx* c, const uint32_t* h_flags) {
     if (h_flags[0] & 1u) return fail(c, MSM_ERR_BAD_ARG, "a scalar is >= 2^254 (not a canonical Fr element)");
     if (h_flags[0] & 2u) return fail(c, MSM_ERR_HIP, "internal: signed-digit carry out of the top window");
+    if (h_flags[0] & 4u) return fail(c, MSM_ERR_HIP, "internal: a GLV half exceeds 127 bits");
     return MSM_OK;
 }
 
 // The pipeline proper: everything in HBM, one stream.  d_bases: INTERNAL-domain packed coordinates.
 int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, const uint32_t* d_scalars, size_t n,
                      hipStream_t st, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf, uint32_t scalars_mont = 0,
-                     hipEvent_t bases_ready = nullptr) {
+                     hipEvent_t bases_ready = nullptr, uint32_t extra_flags = 0) {
     PipeGeom g;
-    int32_t rc = enqueue_pipeline(c, d_bases, d_inf, d_scalars, n, st, c->h_qsums, c->h_flags, &g, scalars_mont, bases_ready);
+    int32_t rc = enqueue_pipeline(c, d_bases, d_inf, d_scalars, n, st, c->h_qsums, c->h_flags, &g, scalars_mont, bases_ready, extra_flags);
     if (rc) return rc;
     if (c->pool && n >= 256) c->pool->arm();  // workers wake up while the GPU works
     HIPCHK(c, hipStreamSynchronize(st));
@@ -590,8 +620,9 @@ int32_t check_common(msm_ctx* c, const void* a, const void* b, size_t n) {
 int32_t upload_bases_locked(msm_ctx* c, const uint32_t* bases_xy, uint32_t form, const uint8_t* inf_mask, size_t n) {
     if (form != MSM_FORM_STD && form != MSM_FORM_MONT) return fail(c, MSM_ERR_BAD_ARG, "unknown base_form %u", form);
     int32_t rc;
+    const bool glv = plan_glv(c, n);
     if ((rc = ensure(c, c->bases, n * 64))) return rc;
-    if ((rc = ensure(c, c->ibases, n * 64))) return rc;
+    if ((rc = ensure(c, c->ibases, (glv ? 2 : 1) * n * 64))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->bases.p, bases_xy, n * 64, hipMemcpyHostToDevice, c->stream));
     if (inf_mask) {
         if ((rc = ensure(c, c->inf, n))) return rc;
@@ -599,7 +630,7 @@ int32_t upload_bases_locked(msm_ctx* c, const uint32_t* bases_xy, uint32_t form,
     }
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_H2D], c->stream));
     msmk::k_convert_bases<<<grid1(2 * n, 256), 256, 0, c->stream>>>((const uint32_t*)c->bases.p, (uint32_t*)c->ibases.p, (uint32_t)n,
-                                                                  form == MSM_FORM_MONT ? 1u : 0u);
+                                                                  form == MSM_FORM_MONT ? 1u : 0u, glv ? 1u : 0u);
     return MSM_OK;
 }
 
@@ -625,7 +656,7 @@ int32_t run_streamed(msm_ctx* c, const uint32_t* bases_xy, uint32_t form, const 
         if ((rc = ensure(c, c->sscalars[s], chunk * 32))) return rc;
         if (inf_mask && (rc = ensure(c, c->sinf[s], chunk))) return rc;
     }
-    if ((rc = ensure(c, c->ibases, chunk * 64))) return rc;
+    if ((rc = ensure(c, c->ibases, 2 * chunk * 64))) return rc;  // room for the phi records of a GLV chunk
     std::vector<PipeGeom> geom(nchunks);
     hipStream_t st = c->stream, cs = c->copy_stream;
     for (size_t j = 0; j < nchunks; j++) {
@@ -638,7 +669,7 @@ int32_t run_streamed(msm_ctx* c, const uint32_t* bases_xy, uint32_t form, const 
         HIPCHK(c, hipEventRecord(c->ev_copied[s], cs));
         HIPCHK(c, hipStreamWaitEvent(st, c->ev_copied[s], 0));
         msmk::k_convert_bases<<<grid1(2 * cnt, 256), 256, 0, st>>>((const uint32_t*)c->sbases[s].p, (uint32_t*)c->ibases.p, (uint32_t)cnt,
-                                                                 form == MSM_FORM_MONT ? 1u : 0u);
+                                                                 form == MSM_FORM_MONT ? 1u : 0u, plan_glv(c, cnt) ? 1u : 0u);
         uint32_t* slot = c->h_sq + j * slot_words;
         rc = enqueue_pipeline(c, (const uint32_t*)c->ibases.p, inf_mask ? (const uint8_t*)c->sinf[s].p : nullptr,
                               (const uint32_t*)c->sscalars[s].p, cnt, st, slot + 8, slot, &geom[j]);
@@ -716,13 +747,13 @@ int32_t msm_ctx_create(const msm_config_t* cfg, msm_ctx** out) {
     if (c0.max_points) {
         msm_plan_t pl;
         make_plan(c0.max_points, c0.window_bits, c0.flags, &pl);
-        size_t pairs = (size_t)pl.num_windows * c0.max_points, tb = (size_t)pl.num_windows * pl.num_buckets;
+        size_t pairs = (size_t)pl.num_windows * (size_t)pl.virtual_points, tb = (size_t)pl.num_windows * pl.num_buckets;
         int32_t rc = MSM_OK;
         if (!rc) rc = ensure(c, c->bases, c0.max_points * 64);
         if (!rc) rc = ensure(c, c->scalars, c0.max_points * 32);
         if (!rc) rc = ensure(c, c->digits, pairs * 4);
         if (!rc) rc = ensure(c, c->sorted, pairs * 4);
-        if (!rc) rc = ensure(c, c->ibases, c0.max_points * 64);
+        if (!rc) rc = ensure(c, c->ibases, (pl.glv ? 2 : 1) * c0.max_points * 64);
         if (!rc) rc = ensure(c, c->buckets, tb * XB);
         if (rc) {
             g_create_error = c->err;
@@ -832,15 +863,16 @@ int32_t msm_bn254_g1_arkworks(msm_ctx* c, const void* bases, size_t stride, size
     c->resident_n = 0;
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_START], c->stream));
     if ((rc = ensure(c, c->scalars, n * 32))) return rc;
+    const bool glv = plan_glv(c, n);
     if ((rc = ensure(c, c->bases, n * stride))) return rc;
-    if ((rc = ensure(c, c->ibases, n * 64))) return rc;
+    if ((rc = ensure(c, c->ibases, (glv ? 2 : 1) * n * 64))) return rc;
     if ((rc = ensure(c, c->inf, n))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->scalars.p, scalars_mont, n * 32, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->bases.p, bases, n * stride, hipMemcpyHostToDevice, c->stream));
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_H2D], c->stream));
     msmk::k_import_ark<<<grid1(2 * n, 256), 256, 0, c->stream>>>((const uint8_t*)c->bases.p, (uint64_t)stride, (uint32_t)x_off, (uint32_t)y_off,
                                                                has_inf ? (uint32_t)inf_off : 0u, has_inf ? 1u : 0u, (uint32_t)n,
-                                                               (uint32_t*)c->ibases.p, (uint8_t*)c->inf.p);
+                                                               (uint32_t*)c->ibases.p, (uint8_t*)c->inf.p, glv ? 1u : 0u);
     rc = run_pipeline(c, (const uint32_t*)c->ibases.p, (const uint8_t*)c->inf.p, (const uint32_t*)c->scalars.p, n, c->stream, out_jac,
                       out_aff, out_inf, 1u);
     if (rc) return rc;
@@ -861,6 +893,7 @@ int32_t msm_bn254_g1_upload_bases(msm_ctx* c, const uint32_t* bases_xy, uint32_t
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
     c->resident_n = n;
+    c->resident_glv = plan_glv(c, n);
     c->resident_has_inf = inf_mask != nullptr;
     return MSM_OK;
 }
@@ -870,15 +903,16 @@ static int32_t decompress_locked(msm_ctx* c, const uint8_t* compressed, size_t n
     int32_t rc;
     if (first_invalid) *first_invalid = -1;
     if (n > 0xFFFFFFF0ull) return fail(c, MSM_ERR_BAD_ARG, "too many points: %zu", n);
+    const bool glv = !out_ark && plan_glv(c, n);
     if ((rc = ensure(c, c->bases, n * 32 + 16))) return rc;
-    if ((rc = ensure(c, c->ibases, n * 64))) return rc;
+    if ((rc = ensure(c, c->ibases, (glv ? 2 : 1) * n * 64))) return rc;
     if ((rc = ensure(c, c->inf, n))) return rc;
     uint32_t* d_bad = (uint32_t*)((uint8_t*)c->bases.p + n * 32);  // lowest failing index, kept behind the images
     const uint32_t none = 0xFFFFFFFFu;
     HIPCHK(c, hipMemcpyAsync(c->bases.p, compressed, n * 32, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d_bad, &none, 4, hipMemcpyHostToDevice, c->stream));
     msmk::k_decompress<<<grid1(n, 256), 256, 0, c->stream>>>((const uint32_t*)c->bases.p, (uint32_t)n, (uint32_t*)c->ibases.p,
-                                                          (uint8_t*)c->inf.p, d_bad, out_ark);
+                                                          (uint8_t*)c->inf.p, d_bad, out_ark, glv ? 1u : 0u);
     uint32_t bad = none;
     HIPCHK(c, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -913,6 +947,7 @@ int32_t msm_bn254_g1_upload_compressed(msm_ctx* c, const uint8_t* compressed, si
     c->resident_n = 0;
     if ((rc = decompress_locked(c, compressed, n, 0u, first_invalid))) return rc;
     c->resident_n = n;
+    c->resident_glv = plan_glv(c, n);
     c->resident_has_inf = true;
     return MSM_OK;
 }
@@ -966,8 +1001,10 @@ int32_t msm_bn254_g1_resident(msm_ctx* c, const uint32_t* scalars, size_t n, uin
     if ((rc = ensure(c, c->scalars, n * 32))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->scalars.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_H2D], c->stream));
+    // the phi records sit at index resident_n + i: a call on fewer scalars (truncation) or a set uploaded without them runs unsplit
+    const uint32_t extra = (c->resident_glv && n == c->resident_n) ? 0u : MSM_FLAG_NO_GLV;
     rc = run_pipeline(c, (const uint32_t*)c->ibases.p, c->resident_has_inf ? (const uint8_t*)c->inf.p : nullptr,
-                      (const uint32_t*)c->scalars.p, n, c->stream, out_jac, out_aff, out_inf);
+                      (const uint32_t*)c->scalars.p, n, c->stream, out_jac, out_aff, out_inf, 0, nullptr, extra);
     if (rc) return rc;
     c->tm.h2d_ms = stage_ms(c, EV_START, EV_H2D);
     c->tm.convert_ms = 0;
@@ -983,12 +1020,13 @@ int32_t msm_bn254_g1_device(msm_ctx* c, const void* d_bases_mont, const void* d_
     DeviceGuard g(c->device);
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
     auto t0 = std::chrono::steady_clock::now();
-    if ((rc = ensure(c, c->ibases, n * 64))) return rc;
+    const uint32_t glv = plan_glv(c, n) ? 1u : 0u;
+    if ((rc = ensure(c, c->ibases, (glv ? 2 : 1) * n * 64))) return rc;
     // Each event record / cross-stream wait costs ~6 us of stream time (measured gaps in the kernel trace), so the
     // conversion only moves to the second stream when it is longer than that (n > 2^18: 32 us at 2^20, 5 us at 2^16).
     if (c->stage_timing || n <= ((size_t)1 << 18)) {  // serialised (also: so that convert_ms means something)
         if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_H2D], st));
-        msmk::k_convert_bases<<<grid1(2 * n, 256), 256, 0, st>>>((const uint32_t*)d_bases_mont, (uint32_t*)c->ibases.p, (uint32_t)n, 1u);
+        msmk::k_convert_bases<<<grid1(2 * n, 256), 256, 0, st>>>((const uint32_t*)d_bases_mont, (uint32_t*)c->ibases.p, (uint32_t)n, 1u, glv);
         rc = run_pipeline(c, (const uint32_t*)c->ibases.p, (const uint8_t*)d_inf_mask, (const uint32_t*)d_scalars, n, st, out_jac,
                           out_aff, out_inf);
     } else {  // the bases are not needed before k_accumulate: convert them on the second stream beside the sort
@@ -997,7 +1035,7 @@ int32_t msm_bn254_g1_device(msm_ctx* c, const void* d_bases_mont, const void* d_
             HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_fork, 0));
         }
         msmk::k_convert_bases<<<grid1(2 * n, 256), 256, 0, c->copy_stream>>>((const uint32_t*)d_bases_mont, (uint32_t*)c->ibases.p,
-                                                                           (uint32_t)n, 1u);
+                                                                           (uint32_t)n, 1u, glv);
         HIPCHK(c, hipEventRecord(c->ev_bases, c->copy_stream));
         rc = run_pipeline(c, (const uint32_t*)c->ibases.p, (const uint8_t*)d_inf_mask, (const uint32_t*)d_scalars, n, st, out_jac,
                           out_aff, out_inf, 0, c->ev_bases);
@@ -1146,7 +1184,7 @@ int32_t msm_test_decompose(msm_ctx* c, const uint32_t* scalars, size_t n, uint32
     if (!c || !scalars || !digits) return MSM_ERR_BAD_ARG;
     if (n == 0) return MSM_ERR_EMPTY;
     msm_plan_t pl;
-    if (make_plan(n, window_bits ? window_bits : c->cfg.window_bits, c->cfg.flags, &pl)) return MSM_ERR_BAD_ARG;
+    if (make_plan(n, window_bits ? window_bits : c->cfg.window_bits, c->cfg.flags | MSM_FLAG_NO_GLV, &pl)) return MSM_ERR_BAD_ARG;  // plain 254-bit digits
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
     void *ds = nullptr, *dd = nullptr;

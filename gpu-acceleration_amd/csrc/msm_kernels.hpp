@@ -25,6 +25,7 @@
 #pragma once
 #include "ec_bn254.hpp"
 #include "ec_wide.hpp"
+#include "glv_bn254.hpp"
 
 namespace msmk {
 using namespace bn254;
@@ -162,21 +163,30 @@ __device__ __forceinline__ jacobian load_jacobian_mont256(const uint32_t* p) {
 // K1's coordinate half: caller coordinates (standard form, or arkworks' R = 2^256 Montgomery words) -> the
 // internal domain x*2^261 mod p, canonical, packed.  One Montgomery product per coordinate (the reference
 // spends two 17x17-limb Barrett multiplications here, barrett_reduction.metal:84-118).
-__global__ void k_convert_bases(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n, uint32_t mont_form) {
+// With glv != 0 the record of phi(P_i) = (beta * x_i, y_i) is written as well, at index n + i (glv_bn254.hpp): one more
+// multiplication per point, and the 2n records are what k_accumulate gathers from.
+__device__ __forceinline__ void store_coord_and_phi(uint32_t* __restrict__ out, uint32_t pt, uint32_t which, uint32_t n, const fp& v, uint32_t glv) {
+    uint32_t w[8];
+    fp_pack(w, fp_reduce_lt2p(v));
+    store_words8(out + ((size_t)pt * 2 + which) * 8, w);
+    if (glv) {
+        if (which == 0) fp_pack(w, fp_reduce_lt2p(fp_mul(v, fp_from_std(glv::BETA_STD))));  // beta * x, < 1.01p
+        store_words8(out + ((size_t)(n + pt) * 2 + which) * 8, w);
+    }
+}
+__global__ void k_convert_bases(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n, uint32_t mont_form, uint32_t glv) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per coordinate
     if (i >= 2u * n) return;
     fp v = load_fp_packed(in + (size_t)i * 8);
     v = fp_mul(v, mont_form ? fp_const(FP29_IN_MONT) : fp_const(FP29_IN_STD));  // < 1.01p
-    uint32_t w[8];
-    fp_pack(w, fp_reduce_lt2p(v));
-    store_words8(out + (size_t)i * 8, w);
+    store_coord_and_phi(out, i >> 1, i & 1u, n, v, glv);
 }
 
 // Zero-copy ingestion of an array of arkworks `G1Affine` structs: the struct array is copied to
 // HBM as it is and read here through (stride, x offset, y offset, infinity offset) -- the layout is probed by the
 // Rust shim with addr_of!, never assumed.  Coordinates are Fq Montgomery words (R = 2^256).
 __global__ void k_import_ark(const uint8_t* __restrict__ raw, uint64_t stride, uint32_t x_off, uint32_t y_off, uint32_t inf_off,
-                             uint32_t has_inf, uint32_t n, uint32_t* __restrict__ out, uint8_t* __restrict__ inf_out) {
+                             uint32_t has_inf, uint32_t n, uint32_t* __restrict__ out, uint8_t* __restrict__ inf_out, uint32_t glv) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per coordinate
     if (i >= 2u * n) return;
     const uint32_t pt = i >> 1, which = i & 1u;
@@ -186,8 +196,7 @@ __global__ void k_import_ark(const uint8_t* __restrict__ raw, uint64_t stride, u
 #pragma unroll
     for (int k = 0; k < 8; k++) w[k] = src[k];
     fp v = fp_mul(fp_unpack(w), fp_const(FP29_IN_MONT));
-    fp_pack(w, fp_reduce_lt2p(v));
-    store_words8(out + (size_t)i * 8, w);
+    store_coord_and_phi(out, pt, which, n, v, glv);
     if (which == 0 && inf_out) inf_out[pt] = has_inf ? (rec[inf_off] != 0) : 0;
 }
 
@@ -197,7 +206,7 @@ __global__ void k_import_ark(const uint8_t* __restrict__ raw, uint64_t stride, u
 // the larger of (y, p-y) as integers.  The exponent is a constant, so the square-and-multiply branch is wave-uniform.
 // out_ark = 0: internal domain, packed (the pipeline's base format);  1: arkworks Montgomery words R = 2^256.
 __global__ void k_decompress(const uint32_t* __restrict__ rec, uint32_t n, uint32_t* __restrict__ out, uint8_t* __restrict__ inf_out,
-                             uint32_t* __restrict__ first_bad, uint32_t out_ark) {
+                             uint32_t* __restrict__ first_bad, uint32_t out_ark, uint32_t glv) {
     constexpr uint32_t PW[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
     constexpr uint32_t EXP[8] = {0xb61f3f52u, 0x4f082305u, 0x5a1c72a3u, 0x65e05aa4u, 0xa0605617u, 0x6e14116du, 0xb84c680au, 0x0c19139cu};   // (p+1)/4, 252 bits
     constexpr uint32_t HALF[8] = {0x6c3e7ea3u, 0x9e10460bu, 0xb438e546u, 0xcbc0b548u, 0x40c0ac2eu, 0xdc2822dbu, 0x7098d014u, 0x18322739u};  // (p-1)/2
@@ -265,6 +274,11 @@ __global__ void k_decompress(const uint32_t* __restrict__ rec, uint32_t n, uint3
     store_words8(out + (size_t)i * 16, o);
     if (out_ark) fp_to_mont256(o, yc); else fp_pack(o, yc);
     store_words8(out + (size_t)i * 16 + 8, o);
+    if (glv && !out_ark) {  // record of phi(P_i) = (beta*x, y) at index n + i
+        store_words8(out + (size_t)(n + i) * 16 + 8, o);
+        fp_pack(o, fp_reduce_lt2p(fp_mul(x, fp_from_std(glv::BETA_STD))));
+        store_words8(out + (size_t)(n + i) * 16, o);
+    }
     inf_out[i] = 0;
 }
 
@@ -355,6 +369,55 @@ __global__ void k_decompose(const uint32_t* __restrict__ scalars, const uint8_t*
         }
     }
     if (SIGNED && carry) atomicOr(err, 2u);  // cannot happen for scalars < 2^254 with W = 254/c + 1
+}
+
+// bits [off, off+c) of a 128-bit little-endian magnitude
+__device__ __forceinline__ uint32_t window128(const uint32_t s[4], uint32_t off, uint32_t c) {
+    uint32_t wi = off >> 5, sh = off & 31;
+    if (wi >= 4) return 0;
+    uint64_t lo = s[wi];
+    uint64_t hi = (wi + 1 < 4) ? s[wi + 1] : 0u;
+    return (uint32_t)(((lo | (hi << 32)) >> sh)) & ((1u << c) - 1u);
+}
+// k_decompose with the GLV split (glv_bn254.hpp): scalar k_i -> (k1, k2), |k_j| < 2^127; the digits of |k1| go to virtual point
+// i, those of |k2| to virtual point n + i (the record of phi(P_i)), the sign of k_j is folded into every digit's negate flag.
+// digits: W x 2n, window-major.
+template <bool SIGNED>
+__global__ void k_decompose_glv(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_mask, uint32_t n, uint32_t c,
+                                uint32_t W, uint32_t* __restrict__ digits, uint32_t* __restrict__ err, uint32_t scalars_mont) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+    uint4 a = sp[0], b = sp[1];
+    uint32_t s[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    if (scalars_mont) fr_from_mont(s);
+    if (s[7] >> 30) atomicOr(err, 1u);  // scalar >= 2^254 cannot be a canonical Fr
+    const bool skip = inf_mask != nullptr && inf_mask[i] != 0;
+    uint32_t k[2][4];
+    bool kneg[2];
+    if (!glv::split(s, k[0], kneg[0], k[1], kneg[1])) atomicOr(err, 4u);  // a half beyond 127 bits: cannot happen below 2^254
+    const uint32_t H = 1u << (c - 1);
+    const size_t row = 2 * (size_t)n;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        uint32_t carry = 0;
+        for (uint32_t w = 0; w < W; w++) {
+            uint32_t v = window128(k[h], w * c, c) + carry;
+            uint32_t mag = v;
+            bool neg = kneg[h];
+            if (SIGNED) {
+                if (v > H) {
+                    mag = (2u * H) - v;
+                    neg = !neg;
+                    carry = 1;
+                } else {
+                    carry = 0;
+                }
+            }
+            digits[(size_t)w * row + (size_t)h * n + i] = (mag == 0 || skip) ? DIGIT_SKIP : ((mag - 1) | (neg ? SIGN_BIT : 0u));
+        }
+        if (SIGNED && carry) atomicOr(err, 2u);
+    }
 }
 
 // test hook: plain signed digits as int32

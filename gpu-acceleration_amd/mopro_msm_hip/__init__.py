@@ -21,6 +21,7 @@ LIB_PATH = os.environ.get("MSM_HIP_LIB") or os.path.join(os.path.dirname(_HERE),
 
 FORM_STD, FORM_MONT = 0, 1
 FLAG_UNSIGNED_DIGITS = 1
+FLAG_NO_GLV = 2
 OK, ERR_EMPTY, ERR_BAD_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_STATE, ERR_INVALID_DATA = 0, -1, -2, -3, -4, -5, -6, -7
 
 # every symbol include/msm_hip.h declares (checked by tests/test_abi.py)
@@ -48,7 +49,8 @@ class Config(C.Structure):
 
 class Plan(C.Structure):
     _fields_ = [("window_bits", C.c_uint32), ("num_windows", C.c_uint32), ("num_buckets", C.c_uint32),
-                ("signed_digits", C.c_uint32), ("workspace_bytes", C.c_uint64)]
+                ("signed_digits", C.c_uint32), ("workspace_bytes", C.c_uint64), ("virtual_points", C.c_uint64),
+                ("glv", C.c_uint32), ("scalar_bits", C.c_uint32)]
 
 
 class Timings(C.Structure):
@@ -363,7 +365,7 @@ class MsmContext:
     def test_decompose(self, scalars, window_bits=0):
         scalars = _words(scalars, 8)
         n = scalars.shape[0]
-        p = plan(n, window_bits or self.window_bits, self.flags)
+        p = plan(n, window_bits or self.window_bits, self.flags | FLAG_NO_GLV)  # the hook returns the plain 254-bit digits
         out = np.zeros((p.num_windows, n), np.int32)
         self._check(self._lib.msm_test_decompose(self._h, _p32(scalars), n, window_bits, out.ctypes.data_as(C.POINTER(C.c_int32))))
         return out

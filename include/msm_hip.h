@@ -52,6 +52,8 @@ extern "C" {
 
 /* msm_config_t.flags */
 #define MSM_FLAG_UNSIGNED_DIGITS 1u /* plain radix-2^c digits, 2^c-1 buckets/window (BASELINE config "fixed 16-bit window") */
+#define MSM_FLAG_NO_GLV 2u          /* do not split scalars with the curve endomorphism (csrc/glv_bn254.hpp); the default splits
+                                       k = k1 + lambda*k2, |k_j| < 2^127: 2N points phi-extended, half the windows        */
 
 typedef struct msm_ctx msm_ctx;
 
@@ -72,6 +74,9 @@ typedef struct {
     uint32_t num_buckets;  /* buckets per window (2^(c-1) signed, 2^c unsigned incl. an unused slot) */
     uint32_t signed_digits;
     uint64_t workspace_bytes;
+    uint64_t virtual_points; /* points each window sorts and accumulates: n, or 2n with the GLV split       */
+    uint32_t glv;            /* 1 = scalars are split with the endomorphism                                  */
+    uint32_t scalar_bits;    /* bits the windows cover: 254, or 127 with GLV                                 */
 } msm_plan_t;
 
 /* per-stage device times of the last call on this context, milliseconds (hipEvent) */

@@ -171,7 +171,9 @@ def test_msm_golden_default_plan(ctx, name):
     assert inf == int(g["expected_inf"]) and (aff == g["expected"]).all()
 
 
-@pytest.mark.parametrize("wb,flags", [(8, 0), (13, 0), (15, 0), (16, 0), (16, mh.FLAG_UNSIGNED_DIGITS), (5, 0), (11, mh.FLAG_UNSIGNED_DIGITS)])
+@pytest.mark.parametrize("wb,flags", [(8, 0), (13, 0), (15, 0), (16, 0), (16, mh.FLAG_UNSIGNED_DIGITS), (5, 0), (11, mh.FLAG_UNSIGNED_DIGITS),
+                                      (0, mh.FLAG_NO_GLV), (8, mh.FLAG_NO_GLV), (13, mh.FLAG_NO_GLV), (16, mh.FLAG_NO_GLV),
+                                      (16, mh.FLAG_UNSIGNED_DIGITS | mh.FLAG_NO_GLV), (11, mh.FLAG_UNSIGNED_DIGITS | mh.FLAG_NO_GLV)])
 def test_msm_golden_window_overrides(wb, flags):
     with mh.MsmContext(window_bits=wb, flags=flags) as c:
         for name in golden_cases():
@@ -293,6 +295,8 @@ def test_randomised_parity_fuzz():
         inf = (rng.random(n) < rng.choice([0.001, 0.05, 0.9])).astype(np.uint8) if rng.random() < 0.4 else None
         wb = int(rng.choice([0, 0, 0, 2, 3, 5, 8, 11, 12, 13, 14, 15, 16, 17, 18]))
         flags = mh.FLAG_UNSIGNED_DIGITS if (rng.random() < 0.25 and wb not in (17, 18)) else 0
+        if rng.random() < 0.35:
+            flags |= mh.FLAG_NO_GLV  # the unsplit (reference-shaped) pipeline
         with mh.MsmContext(window_bits=wb, flags=flags) as c:
             r = c.msm(bases, s, mh.FORM_MONT, inf)
         exp, einf, _ = orc.msm_pippenger(bases, s, orc.FORM_MONT, inf)

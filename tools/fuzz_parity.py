@@ -36,6 +36,8 @@ for it in range(cases):
         inf = (rng.random(n) < rng.choice([0.001, 0.05, 0.9])).astype(np.uint8)
     wb = int(rng.choice([0, 0, 0, 2, 3, 5, 8, 11, 12, 13, 14, 15, 16, 17, 18]))
     flags = mh.FLAG_UNSIGNED_DIGITS if (rng.random() < 0.25 and wb not in (17, 18)) else 0
+    if rng.random() < 0.35:
+        flags |= mh.FLAG_NO_GLV
     with mh.MsmContext(window_bits=wb, flags=flags) as ctx:
         r = ctx.msm(bases, s, mh.FORM_MONT, inf)
         r2 = ctx.msm(bases, s, mh.FORM_MONT, inf)
