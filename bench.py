@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=LOG_N, help="total instance size (default 2^20, the BASELINE metric)")
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-glv", action="store_true", help="A/B: run the unsplit pipeline (MSM_FLAG_NO_GLV)")
     ap.add_argument("--debug-same-device", action="store_true",
                     help="functional check of the N>1 path on a 1-GPU box: every rank uses cuda:0 and the exchange runs over gloo")
     args = ap.parse_args()
@@ -103,7 +104,8 @@ def main():
     hi = (rank + 1) * n_total // world
     n_local = hi - lo
 
-    ctx = mh.MsmContext(device=local_rank, window_bits=args.window_bits, max_points=n_local)
+    ctx_flags = mh.FLAG_NO_GLV if args.no_glv else 0
+    ctx = mh.MsmContext(device=local_rank, window_bits=args.window_bits, flags=ctx_flags, max_points=n_local)
     d_bases = torch.empty(n_local * 16, dtype=torch.int32, device=dev)
     d_scalars = torch.empty(n_local * 8, dtype=torch.int32, device=dev)
     mask = (1 << 64) - 1
@@ -163,7 +165,7 @@ def main():
         exp, exp_inf = orc.g1_to_affine_std(orc.g1_scalar_mul(g, orc.int_to_words(dot)))
         bit_exact = bool((res.affine_std == exp).all() and res.is_infinity == bool(exp_inf))
 
-        pl = mh.plan(n_local, args.window_bits)
+        pl = mh.plan(n_local, args.window_bits, ctx_flags)
         W, H = pl.num_windows, pl.num_buckets
         # ALGORITHMIC bytes of one accumulate launch: W*(N*(4 B index + 64 B affine point) + H*96 B)
         # (with the GLV split a window sorts and accumulates 2n virtual points in half as many windows: same point term)

@@ -228,19 +228,25 @@ uint32_t plan_window_bits(size_t n, bool is_signed) {
     if (!is_signed && c > 15u) c = 15u;
     return c;
 }
-// GLV (glv_bn254.hpp): 2n virtual points with 127-bit scalars.  Used whenever the 2n indices fit the two-level sort's entry
-// format (2^24) -- the same additions in half the windows: half the buckets to reduce, half the host's Horner chain.
-constexpr size_t GLV_MAX_POINTS = (size_t)1 << 23;
+// GLV (glv_bn254.hpp): 2n virtual points with 127-bit scalars -- the same additions in half the windows: half the buckets to
+// reduce, half the host's Horner chain.  Interleaved A/B against the unsplit pipeline (tools/ab_glv.py): 2^10 -12.8 %, 2^14 -11.9 %,
+// 2^16 -12.3 %, 2^17 -12.2 %, 2^18 -9.6 %, 2^19 +1.1 %, 2^20 -0.4 %, 2^21 +9.2 %, 2^22 +6.8 % (twice the base records to gather
+// from, k_accumulate unchanged, and the fixed costs it halves no longer matter) => on by default up to 2^18 points.
+constexpr size_t GLV_MAX_POINTS = (size_t)1 << 18;
 uint32_t plan_window_bits_glv(size_t n, bool is_signed) {
-    uint32_t c = 16u;  // PLACEHOLDER table, re-measured below
+    // measured (tools/sweep_c.py, split on): 2^10 c = 9/10 0.247/0.249 ms; 2^12 10/11 0.286/0.281; 2^13 10 0.308 (16: 0.364);
+    // 2^14 10 0.330 (16: 0.440); 2^15 12 0.365 (16: 0.435); 2^16 16 0.420 (13: 0.439); 2^17 16 0.504 (13: 0.541); 2^18 16 0.671
+    // (15: 1.06); 2^20 16 1.681.  127 = 7*16 + 15: eight windows, the top one 15 bits wide -- no degenerate window.
+    uint32_t c = n <= ((size_t)1 << 14) ? 10u : n <= ((size_t)1 << 15) ? 12u : 16u;
     if (!is_signed && c > 15u) c = 15u;
-    (void)n;
     return c;
 }
 int32_t make_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_plan_t* out) {
     if (flags & ~(MSM_FLAG_UNSIGNED_DIGITS | MSM_FLAG_NO_GLV)) return MSM_ERR_BAD_ARG;
     bool is_signed = !(flags & MSM_FLAG_UNSIGNED_DIGITS);
-    bool use_glv = !(flags & MSM_FLAG_NO_GLV) && n <= GLV_MAX_POINTS && !std::getenv("MSM_HIP_NO_GLV");
+    size_t glv_max = GLV_MAX_POINTS;
+    if (const char* e = std::getenv("MSM_HIP_GLV_MAX_LOG2")) glv_max = (size_t)1 << std::min(23, std::max(0, std::atoi(e)));  // A/B knob
+    bool use_glv = !(flags & MSM_FLAG_NO_GLV) && n <= glv_max;
     uint32_t c = window_bits ? window_bits : (use_glv ? plan_window_bits_glv(n, is_signed) : plan_window_bits(n, is_signed));
     if (c < 2 || c > 20) return MSM_ERR_BAD_ARG;
     if ((is_signed ? c - 1 : c) > 17) use_glv = false;  // windows wider than the LDS sort covers (forced c >= 19) run unsplit

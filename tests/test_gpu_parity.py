@@ -374,6 +374,34 @@ def test_skewed_scalars_full_size_closed_form(ctx, logn):
             assert r.is_infinity == bool(einf) and (r.affine_std == exp).all(), (label, rep)
 
 
+@pytest.mark.parametrize("logn", [18, 20])
+def test_glv_split_full_size_matches_unsplit_and_closed_form(monkeypatch, logn):
+    """The GLV split (default up to 2^18 points, forced here at 2^20 too) against the unsplit pipeline and the closed form."""
+    import torch
+    n = 1 << logn
+    dev = torch.device("cuda:0")
+    d_bases = torch.empty(n * 16, dtype=torch.int32, device=dev)
+    d_s = torch.empty(n * 8, dtype=torch.int32, device=dev)
+    k = mh.generate_scalars_host(0xB2540021, n, nonzero=True)
+    s = mh.generate_scalars_host(0xB2540022, n)
+    exp, einf = orc.closed_form_expected(k, s)
+    monkeypatch.setenv("MSM_HIP_GLV_MAX_LOG2", "23")
+    assert mh.plan(n).glv == 1 and mh.plan(n, 0, mh.FLAG_NO_GLV).glv == 0
+    with mh.MsmContext() as cg, mh.MsmContext(flags=mh.FLAG_NO_GLV) as cp:
+        cg.generate_device(0xB2540021, 0xB2540022, n, d_bases.data_ptr(), d_s.data_ptr())
+        torch.cuda.synchronize()
+        rg = cg.msm_device(d_bases.data_ptr(), d_s.data_ptr(), n)
+        rp = cp.msm_device(d_bases.data_ptr(), d_s.data_ptr(), n)
+        assert (rg.affine_std == exp).all() and (rp.affine_std == exp).all() and not rg.is_infinity
+        # resident bases: the phi records live behind the first n; a call on fewer scalars runs unsplit on the same set
+        hb = d_bases.cpu().numpy().view(np.uint32).reshape(n, 16)
+        cg.upload_bases(hb, mh.FORM_MONT)
+        assert (cg.msm_resident(s).affine_std == exp).all()
+        m = n // 3
+        e2, _ = orc.closed_form_expected(k[:m], s[:m])
+        assert (cg.msm_resident(s[:m]).affine_std == e2).all()
+
+
 # ---- BASELINE config 5: streamed host->HBM chunks overlapped with the pipeline ---------------------
 def test_streamed_chunks_match_oracle():
     """msm_bn254_g1 cuts n >= 2*chunk points into chunks (double-buffered H2D on a copy stream, partials added on

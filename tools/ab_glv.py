@@ -1,0 +1,14 @@
+#!/usr/bin/env python3
+"""Interleaved A/B of the GLV split against the unsplit pipeline: median bench ms per size (3 rounds each)."""
+import json, subprocess, sys, statistics, os
+for n in [int(x) for x in (sys.argv[1:] or "16 17 18 19 20 21 22".split())]:
+    res = {"glv": [], "plain": []}
+    for rnd in range(3):
+        for name, extra in (("glv", []), ("plain", ["--no-glv"])):
+            p = subprocess.run([sys.executable, "bench.py", "--log-n", str(n), "--steps", "20", "--warmup", "3", "--no-cpu-baseline"] + extra,
+                               capture_output=True, text=True)
+            j = json.loads(p.stdout.strip().splitlines()[-1])
+            assert j["bit_exact"]
+            res[name].append(j["value"])
+    g, q = statistics.median(res["glv"]), statistics.median(res["plain"])
+    print(f"logN {n}: GLV {g:.4f} ms  plain {q:.4f} ms  ({100 * (g / q - 1):+.1f} %)  {res}", flush=True)
