@@ -1167,7 +1167,7 @@ int32_t msm_calibrate(msm_ctx* c, double* mad_per_s, double* fp_mul_per_s) {
     HIPCHK(c, hipEventCreate(&e1));
     double out[2] = {0, 0};
     for (uint32_t what = 0; what < 2; what++) {
-        const uint32_t iters = what == 0 ? 2000u : 400u;
+        const uint32_t iters = what == 0 ? 500u : 100u;  // ~1 ms each
         const double ops_per_thread = what == 0 ? 64.0 * iters : 4.0 * iters;
         msmk::k_calibrate<<<blocks, 256, 0, c->stream>>>(what, iters / 10, (uint32_t*)c->flags.p + 15);  // warm-up
         HIPCHK(c, hipEventRecord(e0, c->stream));
