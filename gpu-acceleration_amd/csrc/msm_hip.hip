@@ -158,7 +158,7 @@ struct msm_ctx {
     hipEvent_t ev[EV_COUNT]{};
     // HBM workspace
     DevBuf bases, ibases, inf, scalars, digits, ranks, sorted, hist, offsets, blocksums, buckets, heads, tails, chunkmap, rc, flags,
-        pow2, tilecounts, longlist, longdone, midlist, ccounts, cregion;
+        pow2, tilecounts, longlist, longdone, midlist, ccounts, cregion, bigslot, big;
     bool pow2_ready = false;
     uint32_t* h_qsums = nullptr;  // pinned: W x (kb+1) Jacobian bit sums
     uint32_t* h_flags = nullptr;    // pinned
@@ -400,6 +400,8 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
     uint32_t T = 1, tile_len = (uint32_t)n;
     if (!lds_counts && (rc = ensure(c, c->ranks, pairs * 4))) return rc;
     if (two_level) {
+        if ((rc = ensure(c, c->bigslot, (size_t)W * ncoarse * 4))) return rc;
+        if ((rc = ensure(c, c->big, msmk::BIG_WORDS * 4))) return rc;
         if ((rc = ensure(c, c->ccounts, (size_t)W * ncoarse * NS * 4))) return rc;
         if ((rc = ensure(c, c->cregion, ((size_t)W * ncoarse * 2 + 2) * 4))) return rc;
     } else if (tiled) {
@@ -435,16 +437,28 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
         uint32_t* tmp = (uint32_t*)c->heads.p;  // staging copy; k_accumulate only writes heads later
         msmk::k_coarse_hist<<<dim3(NS, W), msmk::TILE_BLOCK, 0, st>>>((uint32_t*)c->digits.p, counts, (uint32_t)n, fine_bits, ncoarse, NS);
         msmk::k_coarse_prefix<<<grid1(nregions, 256), 256, 0, st>>>(counts, rtotal, NS, ncoarse, nregions);
-        msmk::k_coarse_starts<<<1, msmk::SCAN_BLOCK, 0, st>>>(rtotal, rstart, nregions, flags + 4, offsets + tb);
+        // regions too large for one workgroup's staging area are cut into batches that worker blocks share (skewed scalars)
+        const uint32_t fine_block = (n >> coarse_bits) <= 1024 ? 256u : (n >> coarse_bits) <= 2048 ? 512u : 1024u;
+        const uint32_t fine_cap = fine_block * 16u;
+        uint32_t* bigslot = (uint32_t*)c->bigslot.p;
+        uint32_t* big = (uint32_t*)c->big.p;
+        msmk::k_coarse_starts<<<1, msmk::SCAN_BLOCK, 0, st>>>(rtotal, rstart, nregions, flags + 4, offsets + tb, bigslot, big, fine_cap);
         msmk::k_coarse_scatter<<<dim3(NS, W), msmk::TILE_BLOCK, 0, st>>>((uint32_t*)c->digits.p, counts, rstart, tmp, (uint32_t)n, fine_bits,
                                                                        idx_bits, ncoarse, NS);
-        // workgroup size by mean region size (a workgroup stages up to 16 elements per thread; larger regions still sort, slower)
-        if ((n >> coarse_bits) <= 1024)
-            msmk::k_fine_sort<256><<<dim3(ncoarse, W), 256, 0, st>>>(tmp, rstart, offsets, (uint32_t*)c->sorted.p, nb, fine_bits, idx_bits, ncoarse);
-        else if ((n >> coarse_bits) <= 2048)  // (4096: 1.5 us faster on uniform scalars, but one hot region then has half the threads)
-            msmk::k_fine_sort<512><<<dim3(ncoarse, W), 512, 0, st>>>(tmp, rstart, offsets, (uint32_t*)c->sorted.p, nb, fine_bits, idx_bits, ncoarse);
-        else
-            msmk::k_fine_sort<1024><<<dim3(ncoarse, W), 1024, 0, st>>>(tmp, rstart, offsets, (uint32_t*)c->sorted.p, nb, fine_bits, idx_bits, ncoarse);
+        // workgroup size by mean region size (a workgroup stages up to 16 elements per thread); grid.x = the window's regions +
+        // BIG_WORKERS_X worker blocks for the batches of oversized regions, which k_big_place then places
+        const dim3 gf(ncoarse + msmk::BIG_WORKERS_X, W), gp(msmk::BIG_WORKERS_X, W);
+        uint32_t* srt = (uint32_t*)c->sorted.p;
+        if (fine_block == 256) {
+            msmk::k_fine_sort<256><<<gf, 256, 0, st>>>(tmp, rstart, offsets, srt, nb, fine_bits, idx_bits, ncoarse, bigslot, big);
+            msmk::k_big_place<256><<<gp, 256, 0, st>>>(tmp, rstart, offsets, srt, nb, fine_bits, idx_bits, ncoarse, bigslot, big);
+        } else if (fine_block == 512) {  // (up to a mean of 2048: at 4096 the 512-thread variant is 1.5 us faster on uniform scalars only)
+            msmk::k_fine_sort<512><<<gf, 512, 0, st>>>(tmp, rstart, offsets, srt, nb, fine_bits, idx_bits, ncoarse, bigslot, big);
+            msmk::k_big_place<512><<<gp, 512, 0, st>>>(tmp, rstart, offsets, srt, nb, fine_bits, idx_bits, ncoarse, bigslot, big);
+        } else {
+            msmk::k_fine_sort<1024><<<gf, 1024, 0, st>>>(tmp, rstart, offsets, srt, nb, fine_bits, idx_bits, ncoarse, bigslot, big);
+            msmk::k_big_place<1024><<<gp, 1024, 0, st>>>(tmp, rstart, offsets, srt, nb, fine_bits, idx_bits, ncoarse, bigslot, big);
+        }
     } else {
         // K2/1: per-tile LDS histograms, then per-bucket prefix over tiles
         if (tiled) {
@@ -790,7 +804,7 @@ void msm_ctx_destroy(msm_ctx* c) {
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         DevBuf* bufs[] = {&c->bases,   &c->inf,       &c->scalars, &c->digits,  &c->ranks,  &c->sorted, &c->hist,
                           &c->offsets, &c->blocksums, &c->buckets, &c->rc,      &c->flags,  &c->pow2,
-                          &c->heads,   &c->tails,     &c->chunkmap, &c->tilecounts, &c->ibases, &c->longlist, &c->longdone, &c->midlist, &c->ccounts, &c->cregion};
+                          &c->heads,   &c->tails,     &c->chunkmap, &c->tilecounts, &c->ibases, &c->longlist, &c->longdone, &c->midlist, &c->ccounts, &c->cregion, &c->bigslot, &c->big};
         for (DevBuf* b : bufs) release(*b);
         if (c->h_qsums) (void)hipHostFree(c->h_qsums);
         if (c->h_flags) (void)hipHostFree(c->h_flags);

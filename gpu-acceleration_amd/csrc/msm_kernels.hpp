@@ -643,8 +643,24 @@ __global__ void k_coarse_prefix(uint32_t* __restrict__ counts, uint32_t* __restr
     region_total[r] = run;
 }
 // single workgroup: exclusive scan of the region totals (any count) -> region_start[0..nregions], grand total
+// OVERSIZED regions (skewed scalars: one bucket holds a large share of a window, e.g. the ones of a witness vector) used to be
+// sorted by their single owner workgroup, element batch after element batch.  They are now cut into (region, batch) work items
+// that extra workgroups share: k_coarse_starts lists them, the worker blocks of k_fine_sort count every batch into the region's
+// global fine histogram, k_big_place turns the histogram into bucket offsets and places every batch (one global cursor add per
+// bucket and batch).  `big` layout (u32): [0] items listed (may exceed BIG_MAX_ITEMS: regions that did not fit keep their owner),
+// [1] table slots used, [16 ..) BIG_MAX_ITEMS x (region, batch), then per slot 128 counts + 128 cursors.
+constexpr uint32_t BIG_NONE = 0xFFFFFFFFu;
+constexpr uint32_t BIG_MAX_ITEMS = 4096;
+constexpr uint32_t BIG_WORKERS_X = 16;  // worker blocks per window row (grid.y = W)
+constexpr uint32_t BIG_ITEMS_OFF = 16, BIG_TAB_OFF = BIG_ITEMS_OFF + 2 * BIG_MAX_ITEMS;
+constexpr size_t BIG_WORDS = (size_t)BIG_TAB_OFF + (size_t)BIG_MAX_ITEMS * 256;
+
 __global__ void k_coarse_starts(const uint32_t* __restrict__ region_total, uint32_t* __restrict__ region_start, uint32_t nregions,
-                                uint32_t* __restrict__ total_out, uint32_t* __restrict__ offsets_end) {
+                                uint32_t* __restrict__ total_out, uint32_t* __restrict__ offsets_end, uint32_t* __restrict__ bigslot,
+                                uint32_t* __restrict__ big, uint32_t big_threshold) {
+    if (threadIdx.x < 2) big[threadIdx.x] = 0;
+    for (uint32_t k = threadIdx.x; k < 2 * BIG_MAX_ITEMS; k += blockDim.x) big[BIG_ITEMS_OFF + k] = BIG_NONE;
+    __syncthreads();
     uint32_t running = 0;
     for (uint32_t start = 0; start < nregions; start += SCAN_TILE) {  // SCAN_ITEMS consecutive regions per thread and round
         const uint32_t base = start + threadIdx.x * SCAN_ITEMS;
@@ -658,7 +674,22 @@ __global__ void k_coarse_starts(const uint32_t* __restrict__ region_total, uint3
         uint32_t ex = running + block_exclusive_scan(sum, &total);
 #pragma unroll
         for (int k = 0; k < SCAN_ITEMS; k++) {
-            if (base + k < nregions) region_start[base + k] = ex;
+            if (base + k < nregions) {
+                region_start[base + k] = ex;
+                uint32_t slot = BIG_NONE;
+                if (v[k] > big_threshold) {  // rare: list the region's batches for the worker blocks
+                    const uint32_t nit = (v[k] + big_threshold - 1) / big_threshold, ib = atomicAdd(&big[0], nit);
+                    if (ib + nit <= BIG_MAX_ITEMS) {
+                        slot = atomicAdd(&big[1], 1u);
+                        for (uint32_t z = 0; z < nit; z++) {
+                            big[BIG_ITEMS_OFF + 2 * (ib + z)] = base + k;
+                            big[BIG_ITEMS_OFF + 2 * (ib + z) + 1] = z;
+                        }
+                        for (uint32_t q = 0; q < 256; q++) big[BIG_TAB_OFF + (size_t)slot * 256 + q] = 0;
+                    }
+                }
+                bigslot[base + k] = slot;
+            }
             ex += v[k];
         }
         running += total;
@@ -745,13 +776,38 @@ constexpr int FINE_PER_THREAD = 16;  // elements that live in registers between 
 template <int FINE_BLOCK>
 __global__ void __launch_bounds__(FINE_BLOCK) k_fine_sort(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ region_start,
                                                           uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted, uint32_t nb,
-                                                          uint32_t fine_bits, uint32_t idx_bits, uint32_t ncoarse) {
+                                                          uint32_t fine_bits, uint32_t idx_bits, uint32_t ncoarse,
+                                                          const uint32_t* __restrict__ bigslot, uint32_t* __restrict__ big) {
     __shared__ uint32_t s_cur[128];
     constexpr uint32_t CAP = (uint32_t)FINE_BLOCK * FINE_PER_THREAD;
     __shared__ uint32_t s_out[CAP];
+    if (blockIdx.x >= ncoarse) {  // worker block: count the batches of oversized regions into their global fine histograms
+        const uint32_t nitems = min(big[0], BIG_MAX_ITEMS), fmask = (1u << fine_bits) - 1u;
+        for (uint32_t it = (blockIdx.x - ncoarse) + BIG_WORKERS_X * blockIdx.y; it < nitems; it += BIG_WORKERS_X * gridDim.y) {
+            const uint32_t rr = big[BIG_ITEMS_OFF + 2 * it], z = big[BIG_ITEMS_OFF + 2 * it + 1];
+            if (rr == BIG_NONE) continue;  // uniform
+            const uint32_t b0 = region_start[rr] + z * CAP, b1 = min(region_start[rr + 1], b0 + CAP);
+            __syncthreads();
+            if (threadIdx.x < 128) s_cur[threadIdx.x] = 0;
+            __syncthreads();
+            uint32_t eb[FINE_PER_THREAD];
+#pragma unroll
+            for (int k = 0; k < FINE_PER_THREAD; k++) {
+                uint32_t j = b0 + threadIdx.x + k * FINE_BLOCK;
+                eb[k] = j < b1 ? tmp[j] : DIGIT_SKIP;
+            }
+#pragma unroll
+            for (int k = 0; k < FINE_PER_THREAD; k++)
+                if (eb[k] != DIGIT_SKIP) lds_inc(s_cur, (eb[k] >> idx_bits) & fmask);
+            __syncthreads();
+            if (threadIdx.x < 128 && s_cur[threadIdx.x]) atomicAdd(&big[BIG_TAB_OFF + (size_t)bigslot[rr] * 256 + threadIdx.x], s_cur[threadIdx.x]);
+        }
+        return;
+    }
     const uint32_t cb = blockIdx.x, w = blockIdx.y;
     const uint32_t nfine = 1u << fine_bits;
     const uint32_t r = w * ncoarse + cb;
+    if (bigslot[r] != BIG_NONE) return;  // oversized region: its batches are shared out to the worker blocks (uniform per workgroup)
     const uint32_t rs = region_start[r], re = region_start[r + 1], S = re - rs;
     const uint32_t fine_mask = nfine - 1u, idx_mask = (1u << idx_bits) - 1u;
     const bool staged = S <= CAP;
@@ -825,6 +881,66 @@ __global__ void __launch_bounds__(FINE_BLOCK) k_fine_sort(const uint32_t* __rest
                 uint32_t pos = lds_inc(s_cur, (e[k] >> idx_bits) & fine_mask);
                 sorted[rs + pos] = (e[k] & idx_mask) | (e[k] & SIGN_BIT);
             }
+        }
+    }
+}
+
+// second half of the oversized-region path: bucket offsets from the region's global fine histogram, then every batch is placed;
+// a batch reserves its share of each bucket with ONE global cursor add per bucket.  grid = (BIG_WORKERS_X, W).
+template <int FINE_BLOCK>
+__global__ void __launch_bounds__(FINE_BLOCK) k_big_place(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ region_start,
+                                                          uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted, uint32_t nb,
+                                                          uint32_t fine_bits, uint32_t idx_bits, uint32_t ncoarse,
+                                                          const uint32_t* __restrict__ bigslot, uint32_t* __restrict__ big) {
+    constexpr uint32_t CAP = (uint32_t)FINE_BLOCK * FINE_PER_THREAD;
+    __shared__ uint32_t s_ex[128], s_cnt[128], s_base[128], s_half;
+    const uint32_t nitems = min(big[0], BIG_MAX_ITEMS);
+    const uint32_t nfine = 1u << fine_bits, fmask = nfine - 1u, idx_mask = (1u << idx_bits) - 1u;
+    for (uint32_t it = blockIdx.x + BIG_WORKERS_X * blockIdx.y; it < nitems; it += BIG_WORKERS_X * gridDim.y) {
+        const uint32_t rr = big[BIG_ITEMS_OFF + 2 * it], z = big[BIG_ITEMS_OFF + 2 * it + 1];
+        if (rr == BIG_NONE) continue;  // uniform
+        uint32_t* tab = big + BIG_TAB_OFF + (size_t)bigslot[rr] * 256;
+        const uint32_t r0 = region_start[rr], b0 = r0 + z * CAP, b1 = min(region_start[rr + 1], b0 + CAP);
+        __syncthreads();
+        if (threadIdx.x < 128) {  // exclusive prefix of the region's 128 bucket counts (two wavefronts, shuffle scans)
+            const uint32_t lane = threadIdx.x & 63u, cnt = tab[threadIdx.x];
+            uint32_t x = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                uint32_t y = __shfl_up(x, d, 64);
+                if (lane >= (uint32_t)d) x += y;
+            }
+            if (threadIdx.x == 63) s_half = x;
+            s_ex[threadIdx.x] = x - cnt;
+            s_cnt[threadIdx.x] = 0;
+        }
+        __syncthreads();
+        if (threadIdx.x >= 64 && threadIdx.x < 128) s_ex[threadIdx.x] += s_half;
+        __syncthreads();
+        if (z == 0 && threadIdx.x < nfine)  // the first batch publishes the buckets' CSC column pointers
+            offsets[(size_t)(rr / ncoarse) * nb + ((size_t)(rr % ncoarse) << fine_bits) + threadIdx.x] = r0 + s_ex[threadIdx.x];
+        uint32_t eb[FINE_PER_THREAD];
+#pragma unroll
+        for (int k = 0; k < FINE_PER_THREAD; k++) {
+            uint32_t j = b0 + threadIdx.x + k * FINE_BLOCK;
+            eb[k] = j < b1 ? tmp[j] : DIGIT_SKIP;
+        }
+#pragma unroll
+        for (int k = 0; k < FINE_PER_THREAD; k++)
+            if (eb[k] != DIGIT_SKIP) lds_inc(s_cnt, (eb[k] >> idx_bits) & fmask);
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const uint32_t cn = s_cnt[threadIdx.x];
+            s_base[threadIdx.x] = cn ? atomicAdd(&tab[128 + threadIdx.x], cn) : 0u;  // this batch's slice of every bucket
+            s_cnt[threadIdx.x] = 0;                                                   // becomes the local cursor
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < FINE_PER_THREAD; k++) {
+            if (eb[k] == DIGIT_SKIP) continue;
+            const uint32_t f = (eb[k] >> idx_bits) & fmask;
+            const uint32_t pos = r0 + s_ex[f] + s_base[f] + lds_inc(s_cnt, f);
+            sorted[pos] = (eb[k] & idx_mask) | (eb[k] & SIGN_BIT);
         }
     }
 }
