@@ -231,8 +231,9 @@ uint32_t plan_window_bits(size_t n, bool is_signed) {
 // GLV (glv_bn254.hpp): 2n virtual points with 127-bit scalars -- the same additions in half the windows: half the buckets to
 // reduce, half the host's Horner chain.  Interleaved A/B against the unsplit pipeline (tools/ab_glv.py): 2^10 -12.8 %, 2^14 -11.9 %,
 // 2^16 -12.3 %, 2^17 -12.2 %, 2^18 -9.6 %, 2^19 +1.1 %, 2^20 -0.4 %, 2^21 +9.2 %, 2^22 +6.8 % (twice the base records to gather
-// from, k_accumulate unchanged, and the fixed costs it halves no longer matter) => on by default up to 2^18 points.
-constexpr size_t GLV_MAX_POINTS = (size_t)1 << 18;
+// from, k_accumulate unchanged, and the fixed costs it halves no longer matter).  With the chunk length following the bucket
+// occupancy: 2^18 -10.4 %, 2^19 -3.4 %, 2^20 -0.3 %, 2^21 +3.6 %, 2^22 +9.9 %  => on by default up to 2^19 points.
+constexpr size_t GLV_MAX_POINTS = (size_t)1 << 19;
 uint32_t plan_window_bits_glv(size_t n, bool is_signed) {
     // measured (tools/sweep_c.py, split on): 2^10 c = 9/10 0.247/0.249 ms; 2^12 10/11 0.286/0.281; 2^13 10 0.308 (16: 0.364);
     // 2^14 10 0.330 (16: 0.440); 2^15 12 0.365 (16: 0.435); 2^16 16 0.420 (13: 0.439); 2^17 16 0.504 (13: 0.541); 2^18 16 0.671
@@ -353,7 +354,9 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
     // 16 from 2^13 points up (8 loses there: more buckets are cut 3+ times than the finer granularity wins back); tiny instances
     // (<= 2^17 sorted entries: a quarter of the SIMDs would hold a wavefront at 16) take 8: 0.262 vs 0.296 ms at 2^10
     uint32_t chunk_len = pairs <= ((size_t)1 << 17) ? 8 : 16;
-    while (chunk_len < 1024 && pairs / (chunk_len * 2) > 262144) chunk_len *= 2;
+    // ... and from there the chunk follows the mean bucket occupancy n/nb (32 at 2^20 unsplit, 64 with the GLV split: measured
+    // 1.728 ms at L = 32 against 1.698 at 64), as long as ~2^17 chunks remain to fill the chip
+    while (chunk_len < 1024 && chunk_len < n / nb && pairs / (chunk_len * 2) >= 131072) chunk_len *= 2;
     if (const char* e = std::getenv("MSM_HIP_CHUNK_LEN")) {  // tuning knob (any value >= 1 is correct)
         int v = std::atoi(e);
         if (v >= 1 && v <= 4096) chunk_len = (uint32_t)v;
