@@ -8,8 +8,12 @@ Total work is fixed as the GPU count grows => "scaling": "strong".  value = ms p
 
 Launch: python bench.py [--gpus N --steps K --warmup W]
         python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
-Prints ONE JSON line on rank 0.  The oracle (oracle/) is used only for the cpu_baseline leg and as a
-checker outside the timed region.
+        python bench.py --gpus N --in-process      (one process, msm_multi: a context + host thread per device, in-library RCCL)
+        ... --log-n 24            BASELINE config 4 (2^21 points per GPU on 8 GPUs)
+        ... --log-n 26 --streamed BASELINE config 5 (host->HBM chunks overlapped with the accumulation; 2^23 points per GPU on 8)
+Prints ONE JSON line on rank 0 and exits non-zero if the result of the last timed step is not bit-exact.  The oracle
+(oracle/) is used only for the cpu_baseline leg and as a checker outside the timed region; inputs come from the hooks build
+(libmsm_hip_hooks.so: generator, calibration), the timed path is the product library (libmsm_hip.so).
 """
 import argparse
 import json
@@ -29,6 +33,7 @@ BASE_SEED, SCALAR_SEED = 0xB2540001, 0xB2540002
 STREAM_MUL = 0xD1342543DE82EF95  # element i of a stream = SplitMix64 seeded with seed + i*STREAM_MUL
 HBM_PEAK_GBPS = 8000.0           # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 R_ORDER = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+MASK64 = (1 << 64) - 1
 
 
 def words_to_ints(a):
@@ -54,12 +59,33 @@ def valu_roofline(num_adds, acc_ms, mad_peak, fpmul_peak):
     t = acc_ms * 1e-3
     mads = num_adds * MADS_PER_ADD / t
     fpm = num_adds * FPMUL_EQ_PER_ADD / t
-    return {"bound": "valu", "kernel": "k_accumulate", "mixed_additions_per_launch": num_adds,
-            "achieved": round(fpm / 1e9, 2), "peak": round(fpmul_peak / 1e9, 2), "unit": "G field-mul/s", "frac": round(fpm / fpmul_peak, 4),
-            "mad_u64_achieved_G_per_s": round(mads / 1e9, 1), "mad_u64_peak_G_per_s": round(mad_peak / 1e9, 1),
-            "mad_u64_frac": round(mads / mad_peak, 4),
-            "note": "peaks measured live by msm_calibrate (csrc k_calibrate); field-mul = 9x29-bit Montgomery multiplication, "
-                    "%.2f multiplication-equivalents per mixed addition" % FPMUL_EQ_PER_ADD}
+    out = {"bound": "valu", "kernel": "k_accumulate", "mixed_additions_per_launch": num_adds,
+           "achieved": round(fpm / 1e9, 2), "peak": round(fpmul_peak / 1e9, 2), "unit": "G field-mul/s", "frac": round(fpm / fpmul_peak, 4),
+           "mad_u64_achieved_G_per_s": round(mads / 1e9, 1), "mad_u64_peak_G_per_s": round(mad_peak / 1e9, 1),
+           "mad_u64_frac": round(mads / mad_peak, 4),
+           "note": "peaks measured live by msm_calibrate (hooks build, k_calibrate); field-mul = 9x29-bit Montgomery multiplication, "
+                   "%.2f multiplication-equivalents per mixed addition" % FPMUL_EQ_PER_ADD}
+    vb = os.path.join(ROOT, "profiles", "accumulate_valu_pmc.json")
+    if os.path.exists(vb):  # hardware VALU-busy counters of the same kernel, collected offline (tools/pmc_valu.sh)
+        try:
+            j = json.load(open(vb))
+            out["valu_busy_counters"] = {k: j[k] for k in ("valu_busy_frac", "valu_util_frac", "source") if k in j}
+        except Exception:
+            pass
+    return out
+
+
+def timed_calls(fn, reps, warm=1):
+    for _ in range(warm):
+        r = fn()
+    best, tot = 1e30, 0.0
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        r = fn()
+        dt = time.perf_counter() - t0
+        tot += dt
+        best = min(best, dt)
+    return r, tot * 1e3 / reps, best * 1e3
 
 
 def main():
@@ -67,24 +93,31 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--log-n", type=int, default=LOG_N, help="total instance size (default 2^20, the BASELINE metric)")
+    ap.add_argument("--log-n", type=int, default=LOG_N, help="total instance size (default 2^20, the BASELINE metric; 24 = config 4, 26 --streamed = config 5)")
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-legs", action="store_true", help="skip the untimed host-pointer legs (pinned / pageable / arkworks zero-copy)")
     ap.add_argument("--no-glv", action="store_true", help="A/B: run the unsplit pipeline (MSM_FLAG_NO_GLV)")
+    ap.add_argument("--streamed", action="store_true",
+                    help="BASELINE config 5: the timed step is the HOST-pointer call on pinned caller memory (host->HBM chunks overlapped "
+                         "with the accumulation) instead of the resident call; value then includes PCIe")
+    ap.add_argument("--in-process", action="store_true",
+                    help="N GPUs driven by ONE process through msm_multi (context + host thread per device, in-library RCCL exchange)")
     ap.add_argument("--debug-same-device", action="store_true",
-                    help="functional check of the N>1 path on a 1-GPU box: every rank uses cuda:0 and the exchange runs over gloo")
+                    help="functional check of the N>1 path on a 1-GPU box: every rank uses cuda:0 and the exchange runs over gloo / the host fold")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     import mopro_msm_hip as mh
+    from mopro_msm_hip import testhooks as th
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
+    if world != args.gpus and not (world == 1 and args.in_process):
         if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N (or with --in-process)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MSM engine has no CPU fallback")
     if args.debug_same_device:
@@ -100,26 +133,54 @@ def main():
             dist.init_process_group("nccl", device_id=dev)  # RCCL on ROCm
 
     n_total = 1 << args.log_n
-    lo = rank * n_total // world
-    hi = (rank + 1) * n_total // world
+    ctx_flags = mh.FLAG_NO_GLV if args.no_glv else 0
+    in_proc = args.in_process and world == 1 and args.gpus >= 1
+    nshards = args.gpus if in_proc else world
+
+    # ---- inputs: shard g = points [g*N/G, (g+1)*N/G) generated on the device that owns it -------------------------------
+    def shard(g):
+        return g * n_total // nshards, (g + 1) * n_total // nshards
+
+    my_shards = list(range(nshards)) if in_proc else [rank]
+    devs = {g: (torch.device("cuda", 0 if args.debug_same_device else g) if in_proc else dev) for g in my_shards}
+    d_bases, d_scalars = {}, {}
+    for g in my_shards:
+        lo, hi = shard(g)
+        with th.HooksContext(device=devs[g].index) as gen:
+            d_bases[g] = torch.empty((hi - lo) * 16, dtype=torch.int32, device=devs[g])
+            d_scalars[g] = torch.empty((hi - lo) * 8, dtype=torch.int32, device=devs[g])
+            gen.generate_device((BASE_SEED + lo * STREAM_MUL) & MASK64, (SCALAR_SEED + lo * STREAM_MUL) & MASK64, hi - lo,
+                                d_bases[g].data_ptr(), d_scalars[g].data_ptr())
+    torch.cuda.synchronize()
+    lo, hi = shard(my_shards[0])
     n_local = hi - lo
 
-    ctx_flags = mh.FLAG_NO_GLV if args.no_glv else 0
-    ctx = mh.MsmContext(device=local_rank, window_bits=args.window_bits, flags=ctx_flags, max_points=n_local)
-    d_bases = torch.empty(n_local * 16, dtype=torch.int32, device=dev)
-    d_scalars = torch.empty(n_local * 8, dtype=torch.int32, device=dev)
-    mask = (1 << 64) - 1
-    ctx.generate_device((BASE_SEED + lo * STREAM_MUL) & mask, (SCALAR_SEED + lo * STREAM_MUL) & mask, n_local,
-                        d_bases.data_ptr(), d_scalars.data_ptr())
-    torch.cuda.synchronize()
-
     from mopro_msm_hip import distributed as md
+
+    multi = None
+    if in_proc:
+        multi = mh.MsmMulti(devices=[devs[g].index for g in my_shards], window_bits=args.window_bits, flags=ctx_flags)
+        ctx = None
+    else:
+        ctx = mh.MsmContext(device=local_rank, window_bits=args.window_bits, flags=ctx_flags, max_points=n_local)
+
+    hb_pin = hs_pin = None
+    if args.streamed:  # config 5: the instance lives in (pinned) host memory
+        hb_pin = d_bases[rank if not in_proc else 0].cpu().pin_memory()
+        hs_pin = d_scalars[rank if not in_proc else 0].cpu().pin_memory()
+        hbn = hb_pin.numpy().view(np.uint32).reshape(-1, 16)
+        hsn = hs_pin.numpy().view(np.uint32).reshape(-1, 8)
 
     def step():
         # HIP pipeline on this rank's shard, then (N > 1) the exchange step: EC addition is not an RCCL
         # reduction op, so the "all-reduce" of partial group elements is an all-gather of 96 bytes per rank
         # over RCCL + a local fold in rank order (identical on all ranks)
-        return md.distributed_msm_device(ctx, d_bases.data_ptr(), d_scalars.data_ptr(), n_local, device=xdev)
+        if in_proc:
+            return multi.msm_device([d_bases[g].data_ptr() for g in my_shards], [d_scalars[g].data_ptr() for g in my_shards],
+                                    [shard(g)[1] - shard(g)[0] for g in my_shards])
+        if args.streamed:
+            return md.all_reduce_msm(ctx.msm(hbn, hsn, mh.FORM_MONT), xdev)
+        return md.distributed_msm_device(ctx, d_bases[rank].data_ptr(), d_scalars[rank].data_ptr(), n_local, device=xdev)
 
     def fence():
         if world > 1:
@@ -128,21 +189,34 @@ def main():
 
     for _ in range(args.warmup):
         res = step()
-    ctx.reset_kernel_stats()
+    if ctx is not None:
+        ctx.reset_kernel_stats()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
     fence()
     elapsed = time.perf_counter() - t0
-    acc_avg_ms, acc_launches = ctx.accumulate_kernel_stats()
-    mad_peak, fpmul_peak = ctx.calibrate() if rank == 0 else (0.0, 0.0)  # two ~1 ms micro-kernels, outside the timed region
+    if ctx is not None:
+        acc_avg_ms, acc_launches = ctx.accumulate_kernel_stats()
+    else:
+        acc_avg_ms, acc_launches = multi.timings(0)["accumulate_ms"], 1
+    mad_peak, fpmul_peak = (0.0, 0.0)
+    if rank == 0:  # two ~1 ms micro-kernels, outside the timed region
+        with th.HooksContext(device=devs[my_shards[0]].index) as cal:
+            mad_peak, fpmul_peak = cal.calibrate()
     # per-stage hipEvents are off in the timed region (each record costs ~6 us of stream time): one extra, untimed
     # step with them on gives the stage breakdown
-    ctx.set_stage_timing(True)
-    step()
-    tm = ctx.timings()
-    ctx.set_stage_timing(False)
+    tm = {}
+    if ctx is not None and not args.streamed:
+        ctx.set_stage_timing(True)
+        step()
+        tm = ctx.timings()
+        ctx.set_stage_timing(False)
+    elif ctx is not None:
+        tm = ctx.timings()
+    else:
+        tm = multi.timings(0)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=xdev if xdev is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -150,19 +224,29 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
 
     # ---- correctness gate (outside the timed region): closed form (sum s_i k_i mod r) * G ----------
-    k_loc = mh.generate_scalars_host((BASE_SEED + lo * STREAM_MUL) & mask, n_local, nonzero=True)
-    s_loc = mh.generate_scalars_host((SCALAR_SEED + lo * STREAM_MUL) & mask, n_local)
-    dot = sum(a * b for a, b in zip(words_to_ints(k_loc), words_to_ints(s_loc))) % R_ORDER
+    dot = 0
+    for g in my_shards:
+        glo, ghi = shard(g)
+        k_loc = th.generate_scalars_host((BASE_SEED + glo * STREAM_MUL) & MASK64, ghi - glo, nonzero=True)
+        s_loc = th.generate_scalars_host((SCALAR_SEED + glo * STREAM_MUL) & MASK64, ghi - glo)
+        dot += sum(a * b for a, b in zip(words_to_ints(k_loc), words_to_ints(s_loc)))
+    dot %= R_ORDER
+    dot_local = dot
     if world > 1:
         dots = [None] * world
         dist.all_gather_object(dots, dot)
         dot = sum(dots) % R_ORDER
 
+    bit_exact = True
     if rank == 0:
         from oracle import bn254_oracle as orc  # checker + cpu_baseline leg only
-        g = np.zeros(16, np.uint32)
-        g[0], g[8] = 1, 2
-        exp, exp_inf = orc.g1_to_affine_std(orc.g1_scalar_mul(g, orc.int_to_words(dot)))
+        gpt = np.zeros(16, np.uint32)
+        gpt[0], gpt[8] = 1, 2
+
+        def expect(d):
+            return orc.g1_to_affine_std(orc.g1_scalar_mul(gpt, orc.int_to_words(d % R_ORDER)))
+
+        exp, exp_inf = expect(dot)
         bit_exact = bool((res.affine_std == exp).all() and res.is_infinity == bool(exp_inf))
 
         pl = mh.plan(n_local, args.window_bits, ctx_flags)
@@ -170,53 +254,102 @@ def main():
         # ALGORITHMIC bytes of one accumulate launch: W*(N*(4 B index + 64 B affine point) + H*96 B)
         # (with the GLV split a window sorts and accumulates 2n virtual points in half as many windows: same point term)
         alg_bytes = W * (int(pl.virtual_points) * 68 + H * 96)
-        achieved = alg_bytes / (acc_avg_ms * 1e-3) / 1e9 if acc_avg_ms > 0 else 0.0
-        traffic = None
+        achieved = alg_bytes / (acc_avg_ms * 1e-3) / 1e9 if acc_avg_ms > 0 and not args.streamed else 0.0
+        traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "accumulate_pmc.json")
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
                 if j.get("n_local") == n_local and j.get("window_bits") == pl.window_bits:
                     traffic = j.get("hbm_bytes_per_launch")
+                    traffic_src = "profiles/accumulate_pmc.json (offline rocprofv3 --pmc passes on the same box class, tools/pmc_accumulate.sh; not measured in this run)"
+                else:
+                    traffic_src = "null: profiles/accumulate_pmc.json holds another shape (n_local %s, c %s)" % (j.get("n_local"), j.get("window_bits"))
             except Exception:
                 traffic = None
+        sort_ms = float(tm.get("sort_ms", 0.0) or 0.0)
+        sort_bytes = 8 * int(pl.virtual_points) * W  # per window N*(2 read + 2 read + 4 write)
         out = {
             "metric": "BN254 G1 MSM latency (ms) at N=2^%d, bit-exact vs arkworks-equivalent oracle" % args.log_n,
-            "value": round(ms_per_step, 4), "unit": "ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(ms_per_step, 4), "unit": "ms", "n_gpus": nshards, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": "BN254 G1 variable-base MSM, N=2^%d, dynamic window + signed-digit buckets "
-                                   "(BASELINE.json configs[2]); bases k_i*G and scalars resident in HBM, "
-                                   "point-range shards + all-gather of 96-byte partials" % args.log_n,
+                                   "(BASELINE.json configs[%d]); bases k_i*G and scalars %s, "
+                                   "point-range shards + all-gather of 96-byte partials"
+                                   % (args.log_n, 4 if args.streamed else 3 if args.log_n >= 24 else 2,
+                                      "in PINNED HOST memory, streamed host->HBM in chunks overlapped with the accumulation" if args.streamed
+                                      else "resident in HBM"),
                        "n_total": n_total, "n_per_gpu": n_local, "window_bits": pl.window_bits, "num_windows": W,
                        "buckets_per_window": H, "glv_split": bool(pl.glv), "points_per_window": int(pl.virtual_points),
-                       "parallelism": "point-range x%d" % world},
+                       "parallelism": "point-range x%d%s" % (nshards, " (one process, msm_multi, exchange=%s)" %
+                                                             {1: "rccl", 2: "host-fold"}.get(multi.exchange, "?") if in_proc else ""),
+                       "timed_call": "msm_multi_device" if in_proc else "msm_bn254_g1 (host pointers, pinned)" if args.streamed else "msm_bn254_g1_device"},
             "bit_exact": bit_exact,
             "roofline": {"bound": "hbm", "kernel": "k_accumulate", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_ms": round(acc_avg_ms, 4),
                          "launches_timed": int(acc_launches),
                          "note": "integer-multiply (VALU) bound kernel; HBM fraction reported because BASELINE.json asks for it; "
                                  "the multiplier roofline is in roofline_valu"},
+            # the sort/scatter stages (north_star: "achieved HBM GB/s on the sort/scatter stages"): SURVEY section 8d algorithmic bytes
+            # 8*N*W over the hipEvent time of k_coarse_hist .. k_fine_sort in the diagnostic step
+            "roofline_sort": ({"bound": "hbm", "kernels": "k_coarse_hist+k_coarse_prefix+k_coarse_starts+k_coarse_scatter+k_fine_sort+k_big_place",
+                               "algorithmic_bytes": sort_bytes, "ms": round(sort_ms, 4), "achieved": round(sort_bytes / (sort_ms * 1e-3) / 1e9, 1),
+                               "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(sort_bytes / (sort_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+                               "note": "latency/LDS-atomic bound at this size (6 dependent launches over 64 MB of digits)"} if sort_ms > 0 else None),
             # the bound that actually holds: multiplier work of the launch against what two calibration
             # micro-kernels sustain on THIS device (dependent chains, 4 wavefronts per SIMD, like k_accumulate)
-            "roofline_valu": valu_roofline(int(tm.get("num_adds", 0)), acc_avg_ms, mad_peak, fpmul_peak),
+            "roofline_valu": valu_roofline(int(tm.get("num_adds", 0)), acc_avg_ms, mad_peak, fpmul_peak) if not args.streamed else None,
             "stage_ms_untimed_diagnostic_step": {k: round(v, 4) for k, v in tm.items() if k.endswith("_ms")},
         }
-        if not args.no_cpu_baseline and world == 1:
+
+        # ---- host-pointer legs (the reference's own measurement shape: benches/e2e.rs:46-60 times the call from HOST slices);
+        #      same instance, copied to the host once outside every timed region; never `value`
+        if world == 1 and not in_proc and not args.no_host_legs and not args.streamed:
+            hb_t, hs_t = d_bases[0].cpu(), d_scalars[0].cpu()
+            hb = hb_t.numpy().view(np.uint32).reshape(n_local, 16)
+            hs = hs_t.numpy().view(np.uint32).reshape(n_local, 8)
+            reps = 5 if n_local <= (1 << 22) else 2
+            legs = {}
+            r, avg, best = timed_calls(lambda: ctx.msm(hb, hs, mh.FORM_MONT), reps)
+            legs["e2e_host_pageable_ms"], legs["e2e_host_pageable_min_ms"] = round(avg, 4), round(best, 4)
+            legs["pageable_path"] = {k: ctx.timings()[k] for k in ("stream_chunks", "staged")}
+            ok = bool((r.affine_std == exp).all())
+            hbp, hsp = hb_t.pin_memory(), hs_t.pin_memory()
+            hbpn, hspn = hbp.numpy().view(np.uint32).reshape(n_local, 16), hsp.numpy().view(np.uint32).reshape(n_local, 8)
+            r, avg, best = timed_calls(lambda: ctx.msm(hbpn, hspn, mh.FORM_MONT), reps)
+            legs["e2e_host_pinned_ms"], legs["e2e_host_pinned_min_ms"] = round(avg, 4), round(best, 4)
+            legs["pinned_path"] = {k: ctx.timings()[k] for k in ("stream_chunks", "staged")}
+            ok = ok and bool((r.affine_std == exp).all())
+            # arkworks zero-copy: a [G1Affine] image (72-byte structs: x at 0, y at 32, `infinity` at 64) and Fr words taken as
+            # Montgomery form, i.e. the scalars are s_i * R^-1 -- the expected point follows by linearity
+            img = np.zeros((n_local, 72), np.uint8)
+            img[:, :64] = hb.view(np.uint8).reshape(n_local, 64)
+            r, avg, best = timed_calls(lambda: ctx.msm_arkworks(img, 72, 0, 32, 64, hs), reps)
+            legs["e2e_arkworks_zero_copy_ms"], legs["e2e_arkworks_zero_copy_min_ms"] = round(avg, 4), round(best, 4)
+            e2, e2i = expect(dot * pow(1 << 256, -1, R_ORDER))
+            ok = ok and bool((r.affine_std == e2).all()) and r.is_infinity == bool(e2i)
+            legs["bit_exact"] = ok
+            legs["note"] = ("host-pointer calls on the same instance (PCIe-inclusive, 96-104 B per point); pageable = numpy arrays, "
+                            "pinned = torch pin_memory; avg and min of %d calls" % reps)
+            out["host_pointer_legs"] = legs
+            bit_exact = bit_exact and ok
+
+        if not args.no_cpu_baseline and world == 1 and not in_proc:
             # CPU baseline: the arkworks-0.4-algorithm restatement (oracle_msm_pippenger) on this host's cores,
             # on the SAME bases/scalars (whole instance when it fits ~30 s of CPU work, else a prefix)
             threads = orc.threads_available()
             n_cpu = min(n_local, (1 << 20) if threads >= 8 else (1 << 18))
-            hb = d_bases[: n_cpu * 16].cpu().numpy().view(np.uint32).reshape(n_cpu, 16)
-            hs = d_scalars[: n_cpu * 8].cpu().numpy().view(np.uint32).reshape(n_cpu, 8)
+            hbc = d_bases[0][: n_cpu * 16].cpu().numpy().view(np.uint32).reshape(n_cpu, 16)
+            hsc = d_scalars[0][: n_cpu * 8].cpu().numpy().view(np.uint32).reshape(n_cpu, 8)
             t0 = time.perf_counter()
-            cpu_aff, cpu_inf, _ = orc.msm_pippenger(hb, hs, orc.FORM_MONT, None, threads)
+            cpu_aff, cpu_inf, _ = orc.msm_pippenger(hbc, hsc, orc.FORM_MONT, None, threads)
             cpu_ms = (time.perf_counter() - t0) * 1e3
             if n_cpu == n_local:
                 cpu_ok = bool((cpu_aff == res.affine_std).all())
             else:
-                chk = ctx.msm_device(d_bases.data_ptr(), d_scalars.data_ptr(), n_cpu)
+                chk = ctx.msm_device(d_bases[0].data_ptr(), d_scalars[0].data_ptr(), n_cpu)
                 cpu_ok = bool((cpu_aff == chk.affine_std).all())
             # arkworks parallelises over windows only (c = ln(n)*0.69 + 2 bits => 17 windows at 2^20): that many threads do work
             lg = int(np.log2(n_cpu))
@@ -227,12 +360,22 @@ def main():
                                              "(not arkworks itself): one thread per window, %d windows of %d bits, %d host threads available"
                                              % (lg, -(-254 // c_ark), c_ark, threads),
                                    "agrees_with_gpu": cpu_ok}
+            bit_exact = bit_exact and cpu_ok
+        out["bit_exact"] = bit_exact
         print(json.dumps(out))
         sys.stdout.flush()
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
+    if multi is not None:
+        multi.close()
     if world > 1:
+        ok_t = torch.tensor([1 if bit_exact else 0], dtype=torch.int32, device=xdev if xdev is not None else "cpu")
+        dist.broadcast(ok_t, src=0)
+        bit_exact = bool(ok_t.item())
         dist.barrier()
         dist.destroy_process_group()
+    if not bit_exact:
+        sys.exit(1)  # a wrong answer must not look like a timing
 
 
 if __name__ == "__main__":

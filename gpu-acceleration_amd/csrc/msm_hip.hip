@@ -5,33 +5,39 @@
 //   ShaderManager / MetalHelper / gpu::{create_buffer,read_buffer} host/shader_manager.rs:98-167,
 //                                                                 host/metal_wrapper.rs:55-217, host/gpu.rs:3-31
 // Design differences (MI355X-first):
-//   * a persistent context owns the device, one HIP stream, the HBM workspace and the hipEvents; the
+//   * a persistent context owns the device, two HIP streams, the HBM workspace and the hipEvents; the
 //     reference re-opens the device, reloads the metallib twice and builds six pipeline states on
 //     EVERY call (metal_msm.rs:693 -> 64 -> 48, window_size_optimizer.rs:79-92);
 //   * all intermediates stay in HBM -- the reference round-trips every stage through a host Vec<u32>
 //     (metal_msm.rs:331-339, 403-407, 505-507, 630-632);
-//   * launches are queued back to back on one stream; the only host synchronisation is the final
-//     copy of W window sums (W*96 bytes).  The reference blocks after each of its 9 submits.
+//   * launches are queued back to back; the only host synchronisation is the final wait for W*(kb+1) bit sums that
+//     the last kernel writes into pinned host memory.  The reference blocks after each of its 9 submits;
+//   * host inputs are pipelined: the bases travel on the copy stream while the scalars are already being sorted, and
+//     from 2^19 points on the point range is cut into chunks that are copied (pageable memory: staged through a
+//     pinned ring by host threads) while the previous chunk is accumulated INTO the shared bucket array.
 // There is NO CPU fallback: without a HIP device every compute entry point returns MSM_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <atomic>
 #include <chrono>
-#include <condition_variable>
-#include <cstdlib>
-#include <functional>
-#include <thread>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/msm_hip.h"
 #include "host_g1.hpp"
+#include "msm_host_pool.hpp"
+#include "msm_planner.hpp"
 #include "msm_kernels.hpp"
 
 namespace {
@@ -45,120 +51,71 @@ struct DevBuf {
 
 enum { EV_START, EV_H2D, EV_CONVERT, EV_DECOMP, EV_SORT, EV_ACC0, EV_ACC1, EV_REDUCE, EV_COUNT };
 
-}  // namespace
-
-// Small persistent host thread pool for the CPU finish (per-window Horner chains are independent).  The
-// reference runs its CPU finish under rayon (metal_msm.rs:214-247); std::thread + a condition variable here.
-// run() returns when every JOB is done, not when every worker has checked in: a worker the OS wakes late (seen as
-// 3-10 ms outliers of the finish stage) simply finds nothing left, because the caller and the punctual workers pull jobs
-// from one ticket counter.  The ticket carries the generation, so a late worker can never take a job of a later run().
-class HostPool {
-public:
-    explicit HostPool(int nthreads) {
-        for (int i = 0; i < nthreads; i++) th_.emplace_back([this] { worker(); });
-    }
-    ~HostPool() {
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            stop_ = true;
-            gen_++;
-            ticket_.store(gen_ << 32, std::memory_order_release);  // releases workers spinning in the armed state
-        }
-        cv_work_.notify_all();
-        for (auto& t : th_) t.join();
-    }
-    int size() const { return (int)th_.size(); }
-    // Wake the workers NOW and let them spin until the next run() publishes its jobs (or ~20 ms pass): called when a
-    // pipeline is enqueued, so that the condition-variable wake-up (the source of the remaining 2-5 ms outliers: ~1 % of
-    // the calls on a busy host) happens during the GPU's milliseconds instead of on the critical path of the finish.
-    void arm() {
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            njobs_ = 0;  // "armed": nothing to pull yet
-            const uint64_t gen = ++gen_;
-            ticket_.store(gen << 32, std::memory_order_release);
-        }
-        cv_work_.notify_all();
-    }
-    // run fn(0..njobs-1) on the workers and the calling thread; returns when all jobs are done
-    void run(int njobs, const std::function<void(int)>& fn) {
-        uint64_t gen;
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            job_ = &fn;
-            njobs_ = njobs;
-            gen = ++gen_;
-            done_.store(0, std::memory_order_relaxed);
-            ticket_.store(gen << 32, std::memory_order_release);
-        }
-        cv_work_.notify_all();
-        pull(gen, njobs, fn);
-        for (int spins = 0; done_.load(std::memory_order_acquire) < njobs; spins++)
-            if (spins > 2000) std::this_thread::yield();  // the stragglers are <= one window chain (~40 us) long
-    }
-
-private:
-    void pull(uint64_t gen, int njobs, const std::function<void(int)>& fn) {
-        for (;;) {
-            uint64_t v = ticket_.load(std::memory_order_acquire);
-            if ((v >> 32) != gen || (int)(uint32_t)v >= njobs) return;
-            if (!ticket_.compare_exchange_weak(v, v + 1, std::memory_order_acq_rel)) continue;
-            fn((int)(uint32_t)v);  // fn outlives this call: run(gen) cannot return before done_ counts it
-            done_.fetch_add(1, std::memory_order_release);
-        }
-    }
-    void worker() {
-        uint64_t seen = 0;
-        for (;;) {
-            const std::function<void(int)>* job;
-            int njobs;
-            {
-                std::unique_lock<std::mutex> lk(m_);
-                cv_work_.wait(lk, [&] { return gen_ != seen; });
-                seen = gen_;
-                if (stop_) return;
-                job = job_;
-                njobs = njobs_;
+// ---- observability (reference counterpart: LOG_DEBUG in build.rs:134-138 and the Metal capture scopes of
+// host/gpu.rs:34-114).  MSM_HIP_ROCTX=1: every stage is bracketed by a roctx range (librocprofiler-sdk-roctx / libroctx64 is
+// dlopen'ed, nothing is linked), so `rocprofv3 --marker-trace` shows the pipeline structure.  MSM_HIP_TRACE=1: one line per
+// call on stderr (plan, path taken, per-stage device times -- turns the per-stage events on).
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        const char* e = std::getenv("MSM_HIP_ROCTX");
+        if (!e || !*e || *e == '0') return;
+        for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+                push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+                pop = (int (*)())dlsym(h, "roctxRangePop");
+                if (push && pop) return;
+                push = nullptr, pop = nullptr;
             }
-            if (njobs == 0) {  // armed: spin (bounded) until run() moves the ticket to the next generation
-                const auto t0 = std::chrono::steady_clock::now();
-                for (uint32_t spins = 1; (ticket_.load(std::memory_order_acquire) >> 32) == seen; spins++) {
-                    if ((spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
-                    __builtin_ia32_pause();
-                }
-                continue;  // re-read generation and job under the lock (cv wait returns at once if run() has published)
-            }
-            pull(seen, njobs, *job);
         }
     }
-    std::vector<std::thread> th_;
-    std::mutex m_;
-    std::condition_variable cv_work_;
-    const std::function<void(int)>* job_ = nullptr;
-    std::atomic<uint64_t> ticket_{0};  // generation << 32 | next job index
-    std::atomic<int> done_{0};
-    int njobs_ = 0;
-    uint64_t gen_ = 0;
-    bool stop_ = false;
 };
+const Roctx& roctx() {
+    static Roctx r;
+    return r;
+}
+struct Range {  // RAII roctx range; free when MSM_HIP_ROCTX is unset
+    bool on;
+    explicit Range(const char* name) : on(roctx().push != nullptr) {
+        if (on) roctx().push(name);
+    }
+    ~Range() {
+        if (on) roctx().pop();
+    }
+};
+bool trace_enabled() {
+    static const bool on = [] {
+        const char* e = std::getenv("MSM_HIP_TRACE");
+        return e && *e && *e != '0';
+    }();
+    return on;
+}
+
+}  // namespace
 
 struct msm_ctx {
     std::mutex mu;
-    HostPool* pool = nullptr;
+    HostPool* pool = nullptr;        // CPU finish: the caller + one worker
+    HostPool* stage_pool = nullptr;  // staging copies of pageable inputs (created on first use)
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t copy_stream = nullptr;     // host->HBM chunk uploads of the streamed path
+    hipStream_t copy_stream = nullptr;     // host->HBM uploads and base conversion beside the sort
     hipEvent_t ev_copied[2]{}, ev_free[2]{};
     hipEvent_t ev_fork = nullptr, ev_bases = nullptr;  // base conversion runs on copy_stream beside the sort kernels
     DevBuf sbases[2], sscalars[2], sinf[2];  // double-buffered raw inputs of the streamed path
-    uint32_t* h_sq = nullptr;              // pinned: per-chunk bit sums + flags of the streamed path
-    size_t h_sq_cap = 0;
+    // pinned staging ring for pageable caller memory: stage threads x 2 slots x STAGE_PIECE bytes, one event per slot
+    uint8_t* h_stage = nullptr;
+    int stage_threads = 0;
+    hipEvent_t ev_stage[32]{};
+    bool stage_used[32]{};
     msm_config_t cfg{};
     std::string err;
     hipEvent_t ev[EV_COUNT]{};
     // HBM workspace
     DevBuf bases, ibases, inf, scalars, digits, ranks, sorted, hist, offsets, blocksums, buckets, heads, tails, chunkmap, rc, flags,
         pow2, tilecounts, longlist, longdone, midlist, ccounts, cregion, bigslot, big;
+    DevBuf rbases, rinf;  // the RESIDENT base set (msm_bn254_g1_upload_bases / _upload_compressed): never used as scratch
     bool pow2_ready = false;
     uint32_t* h_qsums = nullptr;  // pinned: W x (kb+1) Jacobian bit sums
     uint32_t* h_flags = nullptr;    // pinned
@@ -171,6 +128,7 @@ struct msm_ctx {
     bool stage_timing = false;  // record the per-stage hipEvents (each costs ~6 us of stream time); k_accumulate's pair is always on
     double acc_ms_sum = 0;
     uint64_t acc_launches = 0;
+    uint32_t last_sort_path = 0;  // 2 = two-level LDS sort, 1 = tiled LDS histogram, 0 = global atomics (stage tests, trace)
 };
 
 namespace {
@@ -209,63 +167,16 @@ void release(DevBuf& b) {
     b.p = nullptr;
     b.cap = 0;
 }
+// scratch device allocation that is freed on every exit path
+struct DevTmp {
+    void* p = nullptr;
+    ~DevTmp() {
+        if (p) (void)hipFree(p);
+    }
+};
 
-// ---- planner: replaces the N -> window_size / scale_factor tables (metal_msm.rs:661-691).  The cuZK cost model
-// (utils/window_size_optimizer.rs:38-51: per window N mixed adds plus ~2 full adds per bucket) gives the shape, but two
-// measured effects decide the table below (tools/sweep_c.py, profiles/NOTES_r1.md "window sweep"):
-//  * r < 2^254, so the top window only holds 254 mod c bits.  For c = 7, 9, 11, 12, 14 that is 1-2 bits: every point
-//    lands in one of <= 3 buckets of that window, which serialises the LDS sort cursors and makes those buckets
-//    thousands of chunks long (c = 12 at N = 2^19: 6.7 ms against 1.2 ms).  Only c in {8, 10, 13, 15, 16} (6, 4, 7, 14, 14
-//    top bits) are used.
-//  * below ~2^17 points the per-window fixed costs (dependent reduction levels, launches) outweigh the bucket count:
-//    fewer, wider windows win earlier than the arithmetic model says.
-// c is capped where one window's histogram still fits the LDS sort path (nb <= 32768: 16 signed, 15 unsigned).
-uint32_t plan_window_bits(size_t n, bool is_signed) {
-    // re-measured after the reduction-tree and host-latency work (tools/sweep_c.py): 2^13: c = 8 0.335 ms (13: 0.455);
-    // 2^14: c = 10 0.397 (13: 0.431); 2^15: 10 0.412 (13: 0.440); 2^16: 13 0.489; 2^17: 15 0.587; 2^18: 15 0.769 (16: 0.790);
-    // 2^19: 16 1.125 (15: 1.197).  c = 10 leaves the top window 4 bits (9 buckets of n/16 points): fine for the long-bucket path.
-    uint32_t c = n <= ((size_t)1 << 13) ? 8u : n <= ((size_t)1 << 15) ? 10u : n <= ((size_t)1 << 16) ? 13u : n <= ((size_t)1 << 18) ? 15u : 16u;
-    if (!is_signed && c > 15u) c = 15u;
-    return c;
-}
-// GLV (glv_bn254.hpp): 2n virtual points with 127-bit scalars -- the same additions in half the windows: half the buckets to
-// reduce, half the host's Horner chain.  Interleaved A/B against the unsplit pipeline (tools/ab_glv.py): 2^10 -12.8 %, 2^14 -11.9 %,
-// 2^16 -12.3 %, 2^17 -12.2 %, 2^18 -9.6 %, 2^19 +1.1 %, 2^20 -0.4 %, 2^21 +9.2 %, 2^22 +6.8 % (twice the base records to gather
-// from, k_accumulate unchanged, and the fixed costs it halves no longer matter).  With the chunk length following the bucket
-// occupancy: 2^18 -10.4 %, 2^19 -3.4 %, 2^20 -0.3 %, 2^21 +3.6 %, 2^22 +9.9 %  => on by default up to 2^19 points.
-constexpr size_t GLV_MAX_POINTS = (size_t)1 << 19;
-uint32_t plan_window_bits_glv(size_t n, bool is_signed) {
-    // measured (tools/sweep_c.py, split on): 2^10 c = 9/10 0.247/0.249 ms; 2^12 10/11 0.286/0.281; 2^13 10 0.308 (16: 0.364);
-    // 2^14 10 0.330 (16: 0.440); 2^15 12 0.365 (16: 0.435); 2^16 16 0.420 (13: 0.439); 2^17 16 0.504 (13: 0.541); 2^18 16 0.671
-    // (15: 1.06); 2^20 16 1.681.  127 = 7*16 + 15: eight windows, the top one 15 bits wide -- no degenerate window.
-    uint32_t c = n <= ((size_t)1 << 14) ? 10u : n <= ((size_t)1 << 15) ? 12u : 16u;
-    if (!is_signed && c > 15u) c = 15u;
-    return c;
-}
-int32_t make_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_plan_t* out) {
-    if (flags & ~(MSM_FLAG_UNSIGNED_DIGITS | MSM_FLAG_NO_GLV)) return MSM_ERR_BAD_ARG;
-    bool is_signed = !(flags & MSM_FLAG_UNSIGNED_DIGITS);
-    size_t glv_max = GLV_MAX_POINTS;
-    if (const char* e = std::getenv("MSM_HIP_GLV_MAX_LOG2")) glv_max = (size_t)1 << std::min(23, std::max(0, std::atoi(e)));  // A/B knob
-    bool use_glv = !(flags & MSM_FLAG_NO_GLV) && n <= glv_max;
-    uint32_t c = window_bits ? window_bits : (use_glv ? plan_window_bits_glv(n, is_signed) : plan_window_bits(n, is_signed));
-    if (c < 2 || c > 20) return MSM_ERR_BAD_ARG;
-    if ((is_signed ? c - 1 : c) > 17) use_glv = false;  // windows wider than the LDS sort covers (forced c >= 19) run unsplit
-    const uint32_t bits = use_glv ? (uint32_t)glv::SPLIT_BITS : 254u;
-    out->window_bits = c;
-    out->signed_digits = is_signed;
-    out->glv = use_glv ? 1u : 0u;
-    out->scalar_bits = bits;
-    out->virtual_points = use_glv ? 2 * (uint64_t)n : (uint64_t)n;
-    // signed: one spare window position so the top digit never overflows (r < 2^254, |k_j| < 2^127): W = floor(bits/c) + 1
-    out->num_windows = is_signed ? (bits / c + 1) : ((bits + c - 1) / c);
-    out->num_buckets = is_signed ? (1u << (c - 1)) : (1u << c);
-    size_t nv = (size_t)out->virtual_points;
-    size_t pairs = (size_t)out->num_windows * nv;
-    size_t tb = (size_t)out->num_windows * out->num_buckets;
-    out->workspace_bytes = nv * 64 + n * (32 + 1) + pairs * 12 + tb * (8 + 144) + tb * 144 * 3 / 2;
-    return MSM_OK;
-}
+static_assert(msmplan::GLV_SPLIT_BITS == (uint32_t)glv::SPLIT_BITS, "planner and GLV split disagree");
+using msmplan::make_plan;
 // does a call on n points (context configuration + per-call extra flags) use the GLV split, i.e. 2n base records?
 inline bool plan_glv(const msm_ctx* c, size_t n, uint32_t extra_flags = 0) {
     msm_plan_t pl;
@@ -290,31 +201,6 @@ float stage_ms(const msm_ctx* c, int a, int b) {
 
 inline dim3 grid1(size_t n, unsigned block) { return dim3((unsigned)((n + block - 1) / block)); }
 
-int32_t ensure_pow2_table(msm_ctx* c) {
-    if (c->pow2_ready) return MSM_OK;
-    using namespace hostg1;
-    std::vector<uint32_t> tab((size_t)msmk::SCALAR_BITS * 16);
-    Jac g{ONE, dbl(ONE), ONE};  // (1, 2) -- SH/constants.metal:121-174
-    for (int j = 0; j < msmk::SCALAR_BITS; j++) {
-        Fq zi = inv(g.z), zi2 = sqr(zi);
-        Fq x = mul(g.x, zi2), y = mul(g.y, mul(zi2, zi));  // Montgomery affine
-        store_words(&tab[(size_t)j * 16], x);
-        store_words(&tab[(size_t)j * 16 + 8], y);
-        g = jdbl(g);
-    }
-    int32_t rc = ensure(c, c->pow2, tab.size() * 4);
-    if (rc) return rc;
-    void* raw = nullptr;
-    HIPCHK(c, hipMalloc(&raw, tab.size() * 4));
-    HIPCHK(c, hipMemcpyAsync(raw, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, c->stream));
-    msmk::k_convert_bases<<<grid1(2 * (size_t)msmk::SCALAR_BITS, 64), 64, 0, c->stream>>>((const uint32_t*)raw, (uint32_t*)c->pow2.p,
-                                                                                     (uint32_t)msmk::SCALAR_BITS, 1u, 0u);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipFree(raw));
-    c->pow2_ready = true;
-    return MSM_OK;
-}
-
 void finish_outputs(const hostg1::Jac& r, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf) {
     if (out_jac) hostg1::store_jac(out_jac, r);
     if (out_inf) *out_inf = hostg1::is_identity(r) ? 1 : 0;
@@ -327,26 +213,33 @@ void finish_outputs(const hostg1::Jac& r, uint32_t* out_jac, uint32_t* out_aff, 
     }
 }
 
-struct PipeGeom {
-    uint32_t W, nb, cbits, kb;
+// Everything the three enqueue steps of one (chunk of an) MSM share.  The PLAN (window width, digit form, GLV split: what the
+// bucket array looks like) is made for plan_n points -- the whole instance, also when only a chunk of it is sorted and
+// accumulated -- the sort geometry follows the points at hand.
+struct PipeState {
+    msm_plan_t pl{};
+    size_t n_real = 0, n = 0;  // real / virtual (x2 with the GLV split) points of this chunk
+    uint32_t W = 0, nb = 0, cbits = 0, kb = 0, kb_lo = 0, kb_hi = 0, n_lo = 0, n_hi = 0;
+    size_t pairs = 0, tb = 0;
+    uint32_t chunk_len = 0;
+    size_t nchunks_max = 0;
 };
 
-// Queue the whole device pipeline for one (chunk of an) MSM on stream st; the W*(kb+1) bit sums and the flag words
-// are written by the last kernel straight into h_qsums_dst / h_flags_dst (pinned host memory).  No host synchronisation here.
-// d_bases: INTERNAL-domain records; with the GLV split (make_plan) 2*n_real of them, phi(P_i) at index n_real + i.
-int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, const uint32_t* d_scalars, size_t n_real,
-                         hipStream_t st, uint32_t* h_qsums_dst, uint32_t* h_flags_dst, PipeGeom* geom, uint32_t scalars_mont = 0,
-                         hipEvent_t bases_ready = nullptr, uint32_t extra_flags = 0) {
+// plan + workspace.  May reallocate buffers (hipFree synchronises the device), so with chunks in flight it must not grow
+// anything: the first chunk of a streamed MSM is the largest.
+int32_t pipe_prepare(msm_ctx* c, size_t n_real, size_t plan_n, uint32_t extra_flags, hipStream_t st, PipeState* ps) {
     if (n_real > 0x3FFFFFFFull) return fail(c, MSM_ERR_BAD_ARG, "n = %zu exceeds 2^30-1 points per context call", n_real);
-    msm_plan_t pl;
-    int32_t rc = make_plan(n_real, c->cfg.window_bits, c->cfg.flags | extra_flags, &pl);
+    int32_t rc = make_plan(plan_n ? plan_n : n_real, c->cfg.window_bits, c->cfg.flags | extra_flags, &ps->pl);
     if (rc) return fail(c, rc, "bad window_bits/flags (%u, 0x%x)", c->cfg.window_bits, c->cfg.flags);
-    const size_t n = (size_t)pl.virtual_points;  // what the sort, the accumulation and the reduction see
-    const uint32_t W = pl.num_windows, nb = pl.num_buckets, cbits = pl.window_bits;
-    const size_t pairs = (size_t)W * n, tb = (size_t)W * nb;
+    const msm_plan_t& pl = ps->pl;
+    ps->n_real = n_real;
+    const size_t n = ps->n = pl.glv ? 2 * n_real : n_real;  // what the sort, the accumulation and the reduction see
+    const uint32_t W = ps->W = pl.num_windows, nb = ps->nb = pl.num_buckets;
+    ps->cbits = pl.window_bits;
+    const size_t pairs = ps->pairs = (size_t)W * n, tb = ps->tb = (size_t)W * nb;
     if (pairs > 0xFFFFFFFFull) return fail(c, MSM_ERR_BAD_ARG, "n*W = %zu does not fit 32-bit offsets", pairs);
-    const uint32_t kb = ilog2(nb), kb_lo = kb / 2, kb_hi = kb - kb_lo;  // bucket index = hi * n_lo + lo
-    const uint32_t n_lo = 1u << kb_lo, n_hi = 1u << kb_hi;
+    ps->kb = ilog2(nb), ps->kb_lo = ps->kb / 2, ps->kb_hi = ps->kb - ps->kb_lo;  // bucket index = hi * n_lo + lo
+    ps->n_lo = 1u << ps->kb_lo, ps->n_hi = 1u << ps->kb_hi;
     const uint32_t ntiles = (uint32_t)((tb + msmk::SCAN_TILE - 1) / msmk::SCAN_TILE);
     // sorted entries folded by one k_accumulate thread: ~2^19 chunks per call (2.7 rounds of the 196608 threads that
     // 3 wavefronts/SIMD hold) keep the tail short, and the chunk grows with N so that buckets (mean n / nb entries)
@@ -361,7 +254,8 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
         int v = std::atoi(e);
         if (v >= 1 && v <= 4096) chunk_len = (uint32_t)v;
     }
-    const size_t nchunks_max = (pairs + chunk_len - 1) / chunk_len;
+    ps->chunk_len = chunk_len;
+    const size_t nchunks_max = ps->nchunks_max = (pairs + chunk_len - 1) / chunk_len;
     if ((rc = ensure(c, c->digits, pairs * 4))) return rc;
     if ((rc = ensure(c, c->sorted, pairs * 4))) return rc;
     if ((rc = ensure(c, c->hist, tb * 4))) return rc;
@@ -381,7 +275,20 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
     if ((rc = ensure(c, c->midlist, (nchunks_max / 2 + 16) * 4))) return rc;                  // a listed bucket owns >= 2 chunk borders
     if ((rc = ensure(c, c->rc, (tb + tb / 2 + 4) * XB))) return rc;  // two families x (1/2 + 1/4) ping-pong levels
     if ((rc = ensure(c, c->flags, 64))) return rc;
+    return MSM_OK;
+}
 
+// K1b + K2 + chunk map of one (chunk of an) MSM on stream st: digits -> offsets / sorted / chunk owners.  Needs the scalars
+// (and the infinity mask), NOT the bases.  first = false: a later chunk of a streamed MSM (error bits and the running count
+// of additions survive).
+int32_t enqueue_sort(msm_ctx* c, const PipeState& ps, const uint8_t* d_inf, const uint32_t* d_scalars, uint32_t scalars_mont,
+                     hipStream_t st, bool first) {
+    Range r_("msm:decompose+sort");
+    int32_t rc;
+    const msm_plan_t& pl = ps.pl;
+    const size_t n = ps.n, n_real = ps.n_real, pairs = ps.pairs, tb = ps.tb;
+    const uint32_t W = ps.W, nb = ps.nb, cbits = ps.cbits, kb = ps.kb;
+    const uint32_t ntiles = (uint32_t)((tb + msmk::SCAN_TILE - 1) / msmk::SCAN_TILE);
     uint32_t* hist = (uint32_t*)c->hist.p;
     uint32_t* offsets = (uint32_t*)c->offsets.p;
     uint32_t* flags = (uint32_t*)c->flags.p;
@@ -401,6 +308,7 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
     const bool lds_counts = two_level || tiled;  // no device-scope histogram / rank atomics in k_decompose
     const uint32_t NS = (uint32_t)((n + msmk::SUBTILE - 1) / msmk::SUBTILE);
     uint32_t T = 1, tile_len = (uint32_t)n;
+    c->last_sort_path = two_level ? 2u : tiled ? 1u : 0u;
     if (!lds_counts && (rc = ensure(c, c->ranks, pairs * 4))) return rc;
     if (two_level) {
         if ((rc = ensure(c, c->bigslot, (size_t)W * ncoarse * 4))) return rc;
@@ -415,7 +323,8 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
     } else {
         HIPCHK(c, hipMemsetAsync(hist, 0, tb * 4, st));
     }
-    HIPCHK(c, hipMemsetAsync(flags, 0, 64, st));
+    if (first) HIPCHK(c, hipMemsetAsync(flags, 0, 64, st));
+    else HIPCHK(c, hipMemsetAsync(flags + msmk::FLAG_LONG, 0, 8, st));  // the long / mid list counters of this chunk
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_CONVERT], st));
     // K1b: digits + signed recode (with the GLV split: two 127-bit halves per scalar, 2*n_real digit columns)
     {
@@ -445,7 +354,7 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
         const uint32_t fine_cap = fine_block * 16u;
         uint32_t* bigslot = (uint32_t*)c->bigslot.p;
         uint32_t* big = (uint32_t*)c->big.p;
-        msmk::k_coarse_starts<<<1, msmk::SCAN_BLOCK, 0, st>>>(rtotal, rstart, nregions, flags + 4, offsets + tb, bigslot, big, fine_cap);
+        msmk::k_coarse_starts<<<1, msmk::SCAN_BLOCK, 0, st>>>(rtotal, rstart, nregions, flags + msmk::FLAG_PAIRS, offsets + tb, bigslot, big, fine_cap);
         msmk::k_coarse_scatter<<<dim3(NS, W), msmk::TILE_BLOCK, 0, st>>>((uint32_t*)c->digits.p, counts, rstart, tmp, (uint32_t)n, fine_bits,
                                                                        idx_bits, ncoarse, NS);
         // workgroup size by mean region size (a workgroup stages up to 16 elements per thread); grid.x = the window's regions +
@@ -471,8 +380,8 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
         }
         // K2/2: bucket offsets
         msmk::k_scan_tiles<<<ntiles, msmk::SCAN_BLOCK, 0, st>>>(hist, offsets, (uint32_t*)c->blocksums.p, (uint32_t)tb);
-        msmk::k_scan_block_sums<<<1, msmk::SCAN_BLOCK, 0, st>>>((uint32_t*)c->blocksums.p, ntiles, flags + 4);
-        msmk::k_scan_add<<<grid1(tb, 256), 256, 0, st>>>(offsets, (uint32_t*)c->blocksums.p, (uint32_t)tb, flags + 4);
+        msmk::k_scan_block_sums<<<1, msmk::SCAN_BLOCK, 0, st>>>((uint32_t*)c->blocksums.p, ntiles, flags + msmk::FLAG_PAIRS);
+        msmk::k_scan_add<<<grid1(tb, 256), 256, 0, st>>>(offsets, (uint32_t*)c->blocksums.p, (uint32_t)tb, flags + msmk::FLAG_PAIRS);
         // K2/3: scatter
         if (tiled) {
             msmk::k_tile_scatter<<<dim3(T, W), msmk::TILE_BLOCK, (size_t)nb * 4, st>>>((uint32_t*)c->digits.p, offsets, (uint32_t*)c->tilecounts.p,
@@ -483,59 +392,80 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
         }
     }
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_SORT], st));
-    // K3: bucket accumulation (the graded kernel) -- bracketed by its own events on its own stream
-    msmk::k_chunk_map<<<grid1(tb, 1024), 1024, 0, st>>>(offsets, (uint32_t*)c->chunkmap.p, (uint32_t)tb, chunk_len, flags + 8,
-                                                      (uint32_t*)c->longlist.p, flags + 9, (uint32_t*)c->midlist.p);
+    msmk::k_chunk_map<<<grid1(tb, 1024), 1024, 0, st>>>(offsets, (uint32_t*)c->chunkmap.p, (uint32_t)tb, ps.chunk_len, flags,
+                                                      (uint32_t*)c->longlist.p, (uint32_t*)c->midlist.p);
+    return MSM_OK;
+}
+
+// K3: bucket accumulation (the graded kernel) -- bracketed by its own events on its own stream -- and the buckets cut by chunk
+// borders.  d_bases: INTERNAL-domain records; with the GLV split 2*n_real of them, phi(P_i) at index n_real + i.
+// into = true: the buckets keep what earlier chunks of the same MSM left in them (k_accumulate<true>).
+int32_t enqueue_accumulate(msm_ctx* c, const PipeState& ps, const uint32_t* d_bases, hipStream_t st, hipEvent_t bases_ready, bool into) {
+    Range r_("msm:accumulate");
+    uint32_t* flags = (uint32_t*)c->flags.p;
+    uint32_t* offsets = (uint32_t*)c->offsets.p;
+    const size_t tb = ps.tb;
     if (bases_ready) HIPCHK(c, hipStreamWaitEvent(st, bases_ready, 0));  // d_bases is being converted on another stream
     HIPCHK(c, hipEventRecord(c->ev[EV_ACC0], st));
-    msmk::k_accumulate<<<grid1(nchunks_max, 256), 256, 0, st>>>(d_bases, (uint32_t*)c->sorted.p, offsets, (uint32_t*)c->chunkmap.p,
-                                                              (uint32_t*)c->buckets.p, (uint32_t*)c->heads.p, (uint32_t*)c->tails.p,
-                                                              flags + 4, chunk_len, (uint32_t)tb);
+    if (into)
+        msmk::k_accumulate<true><<<grid1(ps.nchunks_max, 256), 256, 0, st>>>(d_bases, (uint32_t*)c->sorted.p, offsets, (uint32_t*)c->chunkmap.p,
+                                                                          (uint32_t*)c->buckets.p, (uint32_t*)c->heads.p, (uint32_t*)c->tails.p,
+                                                                          flags + msmk::FLAG_PAIRS, ps.chunk_len, (uint32_t)tb);
+    else
+        msmk::k_accumulate<false><<<grid1(ps.nchunks_max, 256), 256, 0, st>>>(d_bases, (uint32_t*)c->sorted.p, offsets, (uint32_t*)c->chunkmap.p,
+                                                                           (uint32_t*)c->buckets.p, (uint32_t*)c->heads.p, (uint32_t*)c->tails.p,
+                                                                           flags + msmk::FLAG_PAIRS, ps.chunk_len, (uint32_t)tb);
     HIPCHK(c, hipEventRecord(c->ev[EV_ACC1], st));
     msmk::k_combine<<<dim3(msmk::MID_BLOCKS + (unsigned)((tb + 255) / 256)), 256, 0, st>>>(offsets, (uint32_t*)c->heads.p, (uint32_t*)c->tails.p,
-                                                                                         (uint32_t*)c->buckets.p, (uint32_t)tb, chunk_len, flags + 9,
-                                                                                         (uint32_t*)c->midlist.p);
-    msmk::k_combine_long<<<1024, 512, 0, st>>>(offsets, (uint32_t*)c->heads.p, (uint32_t*)c->tails.p, (uint32_t*)c->buckets.p, flags + 8,
-                                               (uint32_t*)c->longlist.p, (uint32_t*)c->longdone.p, chunk_len);
-    // K4/K5: bucket reduction -- plain row/column sums by dense pairwise levels, then per-bit sums; the weights
-    // are applied on the host
-    {
-        const uint32_t* bk = (const uint32_t*)c->buckets.p;
-        // ping-pong buffers per family: [0, tb/2) and [tb/2, tb/2 + tb/4) elements
-        uint32_t* rbuf[2] = {(uint32_t*)c->rc.p, (uint32_t*)c->rc.p + (tb / 2) * msmk::XW};
-        uint32_t* cbuf[2] = {(uint32_t*)c->rc.p + (tb / 2 + tb / 4 + 1) * msmk::XW, (uint32_t*)c->rc.p + (tb + tb / 4 + 1) * msmk::XW};
-        const uint32_t *rin = bk, *cin = bk;
-        size_t rn = tb, cn = tb;  // current element counts
-        uint32_t levels = kb_hi > kb_lo ? kb_hi : kb_lo;
-        for (uint32_t l = 0; l < levels; l++) {
-            msmk::pair_job ja{nullptr, nullptr, 0, 1}, jb{nullptr, nullptr, 0, 1};
-            if (l < kb_lo) {
-                rn /= 2;
-                ja = msmk::pair_job{rin, rbuf[l & 1], (uint32_t)rn, 1};
-                rin = rbuf[l & 1];
-            }
-            if (l < kb_hi) {
-                cn /= 2;
-                jb = msmk::pair_job{cin, cbuf[l & 1], (uint32_t)cn, n_lo};
-                cin = cbuf[l & 1];
-            }
-            // levels with fewer additions than an eighth of the lanes the chip keeps resident: eight lanes per addition
-            const size_t nadds = (size_t)ja.n_out + jb.n_out;
-            if (nadds <= c->wide_max) msmk::k_pair_level_wide<<<grid1(nadds * msmk::WIDE_LANES, 256), 256, 0, st>>>(ja, jb);
-            else msmk::k_pair_level<<<grid1(nadds, 256), 256, 0, st>>>(ja, jb);
+                                                                                         (uint32_t*)c->buckets.p, (uint32_t)tb, ps.chunk_len,
+                                                                                         flags + msmk::FLAG_MID, (uint32_t*)c->midlist.p, into ? 1u : 0u);
+    msmk::k_combine_long<<<1024, 512, 0, st>>>(offsets, (uint32_t*)c->heads.p, (uint32_t*)c->tails.p, (uint32_t*)c->buckets.p,
+                                               flags + msmk::FLAG_LONG, (uint32_t*)c->longlist.p, (uint32_t*)c->longdone.p, ps.chunk_len);
+    return MSM_OK;
+}
+
+// K4/K5: bucket reduction -- plain row/column sums by dense pairwise levels, then per-bit sums; the weights are applied on
+// the host.  The W*(kb+1) bit sums and the flag words are written by the last kernel straight into h_qsums_dst / h_flags_dst
+// (pinned host memory).  No host synchronisation here.
+int32_t enqueue_reduce(msm_ctx* c, const PipeState& ps, hipStream_t st, uint32_t* h_qsums_dst, uint32_t* h_flags_dst) {
+    Range r_("msm:reduce");
+    const size_t tb = ps.tb;
+    const uint32_t W = ps.W, kb = ps.kb, kb_lo = ps.kb_lo, kb_hi = ps.kb_hi, n_lo = ps.n_lo, n_hi = ps.n_hi;
+    uint32_t* flags = (uint32_t*)c->flags.p;
+    const uint32_t* bk = (const uint32_t*)c->buckets.p;
+    // ping-pong buffers per family: [0, tb/2) and [tb/2, tb/2 + tb/4) elements
+    uint32_t* rbuf[2] = {(uint32_t*)c->rc.p, (uint32_t*)c->rc.p + (tb / 2) * msmk::XW};
+    uint32_t* cbuf[2] = {(uint32_t*)c->rc.p + (tb / 2 + tb / 4 + 1) * msmk::XW, (uint32_t*)c->rc.p + (tb + tb / 4 + 1) * msmk::XW};
+    const uint32_t *rin = bk, *cin = bk;
+    size_t rn = tb, cn = tb;  // current element counts
+    uint32_t levels = kb_hi > kb_lo ? kb_hi : kb_lo;
+    for (uint32_t l = 0; l < levels; l++) {
+        msmk::pair_job ja{nullptr, nullptr, 0, 1}, jb{nullptr, nullptr, 0, 1};
+        if (l < kb_lo) {
+            rn /= 2;
+            ja = msmk::pair_job{rin, rbuf[l & 1], (uint32_t)rn, 1};
+            rin = rbuf[l & 1];
         }
-        // the bit sums (and the flag words) are written by the kernel straight into the caller's PINNED host buffers:
-        // a D2H copy engine transfer started ~11 us after the kernel and took two launches (24 KB + 32 B)
-        uint32_t *q_dev = nullptr, *f_dev = nullptr;
-        HIPCHK(c, hipHostGetDevicePointer((void**)&q_dev, h_qsums_dst, 0));
-        HIPCHK(c, hipHostGetDevicePointer((void**)&f_dev, h_flags_dst, 0));
-        if (c->wide_max && n_hi / 2 <= msmk::WIDE_TREE_MAX && n_lo <= msmk::WIDE_TREE_MAX)
-            msmk::k_reduce_bits_wide<<<W * (kb + 1), 512, 0, st>>>(rin, cin, q_dev, n_hi, n_lo, kb_lo, kb, flags, f_dev);
-        else
-            msmk::k_reduce_bits<<<W * (kb + 1), 64, 0, st>>>(rin, cin, q_dev, n_hi, n_lo, kb_lo, kb, flags, f_dev);
+        if (l < kb_hi) {
+            cn /= 2;
+            jb = msmk::pair_job{cin, cbuf[l & 1], (uint32_t)cn, n_lo};
+            cin = cbuf[l & 1];
+        }
+        // levels with fewer additions than an eighth of the lanes the chip keeps resident: eight lanes per addition
+        const size_t nadds = (size_t)ja.n_out + jb.n_out;
+        if (nadds <= c->wide_max) msmk::k_pair_level_wide<<<grid1(nadds * msmk::WIDE_LANES, 256), 256, 0, st>>>(ja, jb);
+        else msmk::k_pair_level<<<grid1(nadds, 256), 256, 0, st>>>(ja, jb);
     }
+    // the bit sums (and the flag words) are written by the kernel straight into the caller's PINNED host buffers:
+    // a D2H copy engine transfer started ~11 us after the kernel and took two launches (24 KB + 32 B)
+    uint32_t *q_dev = nullptr, *f_dev = nullptr;
+    HIPCHK(c, hipHostGetDevicePointer((void**)&q_dev, h_qsums_dst, 0));
+    HIPCHK(c, hipHostGetDevicePointer((void**)&f_dev, h_flags_dst, 0));
+    if (c->wide_max && n_hi / 2 <= msmk::WIDE_TREE_MAX && n_lo <= msmk::WIDE_TREE_MAX)
+        msmk::k_reduce_bits_wide<<<W * (kb + 1), 512, 0, st>>>(rin, cin, q_dev, n_hi, n_lo, kb_lo, kb, flags, f_dev);
+    else
+        msmk::k_reduce_bits<<<W * (kb + 1), 64, 0, st>>>(rin, cin, q_dev, n_hi, n_lo, kb_lo, kb, flags, f_dev);
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_REDUCE], st));
-    *geom = PipeGeom{W, nb, cbits, kb};
     return MSM_OK;
 }
 
@@ -547,7 +477,8 @@ int32_t enqueue_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_i
 // host thread: 2 threads reach ~60 % of the serial time, 4 threads ~45 %, more add nothing because the shift of the top
 // segment is serial.  TWO threads by default: every further worker lowers the median by a few microseconds and raises the
 // MEAN through 2-8 ms outliers in ~1.3 % of the calls (busy hosts; a pool of 15: 2.5 %) -- tools/step_jitter.py.
-hostg1::Jac host_finish(msm_ctx* c, const uint32_t* h_qsums, const PipeGeom& g) {
+hostg1::Jac host_finish(msm_ctx* c, const uint32_t* h_qsums, const PipeState& g) {
+    Range r_("msm:host_finish");
     const uint32_t W = g.W, kb = g.kb, cbits = g.cbits;
     const uint32_t npos = cbits * (W - 1) + (kb > 0 ? kb : 1);  // positions 0 .. npos-1 carry terms
     auto segment = [&](uint32_t lo, uint32_t hi) {             // sum over p in [lo, hi) of 2^p * term(p)
@@ -589,35 +520,56 @@ int32_t check_flags(msm_ctx* c, const uint32_t* h_flags) {
     return MSM_OK;
 }
 
-// The pipeline proper: everything in HBM, one stream.  d_bases: INTERNAL-domain packed coordinates.
-int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, const uint32_t* d_scalars, size_t n,
-                     hipStream_t st, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf, uint32_t scalars_mont = 0,
-                     hipEvent_t bases_ready = nullptr, uint32_t extra_flags = 0) {
-    PipeGeom g;
-    int32_t rc = enqueue_pipeline(c, d_bases, d_inf, d_scalars, n, st, c->h_qsums, c->h_flags, &g, scalars_mont, bases_ready, extra_flags);
-    if (rc) return rc;
-    if (c->pool && n >= 256) c->pool->arm();  // workers wake up while the GPU works
+void trace_line(const msm_ctx* c, const char* entry, const PipeState& ps) {
+    if (!trace_enabled()) return;
+    const msm_timings_t& t = c->tm;
+    std::fprintf(stderr,
+                 "[msm_hip] %s dev %d n %zu c %u W %u nb %u glv %u sort_path %u chunk_len %u stream_chunks %u staged %u | h2d %.3f convert %.3f "
+                 "decompose %.3f sort %.3f accumulate %.3f reduce %.3f finish %.3f total %.3f ms, %llu adds\n",
+                 entry, c->device, (size_t)t.num_points, ps.cbits, ps.W, ps.nb, ps.pl.glv, c->last_sort_path, ps.chunk_len, t.stream_chunks,
+                 t.staged, t.h2d_ms, t.convert_ms, t.decompose_ms, t.sort_ms, t.accumulate_ms, t.reduce_ms, t.finish_ms, t.total_ms,
+                 (unsigned long long)t.num_adds);
+}
+
+// wait for the queued pipeline, finish on the CPU, fill outputs and timings
+int32_t finish_sync(msm_ctx* c, const PipeState& ps, size_t n_total, hipStream_t st, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf) {
+    if (c->pool && n_total >= 256) c->pool->arm();  // workers wake up while the GPU works
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());
     auto t_fin0 = std::chrono::steady_clock::now();
+    int32_t rc;
     if ((rc = check_flags(c, c->h_flags))) return rc;
-    hostg1::Jac total = host_finish(c, c->h_qsums, g);
+    hostg1::Jac total = host_finish(c, c->h_qsums, ps);
     finish_outputs(total, out_jac, out_aff, out_inf);
     auto t_fin1 = std::chrono::steady_clock::now();
-    // timings
     float ms = 0;
     msm_timings_t& tm = c->tm;
+    tm = msm_timings_t{};
     tm.decompose_ms = stage_ms(c, EV_CONVERT, EV_DECOMP);
     tm.sort_ms = stage_ms(c, EV_DECOMP, EV_SORT);
-    (void)hipEventElapsedTime(&ms, c->ev[EV_ACC0], c->ev[EV_ACC1]);
+    (void)hipEventElapsedTime(&ms, c->ev[EV_ACC0], c->ev[EV_ACC1]);  // of the last chunk, when the MSM was streamed
     tm.accumulate_ms = ms;
     c->acc_ms_sum += ms;
     c->acc_launches += 1;
     tm.reduce_ms = stage_ms(c, EV_ACC1, EV_REDUCE);
     tm.finish_ms = std::chrono::duration<float, std::milli>(t_fin1 - t_fin0).count();
-    tm.num_points = n;
-    tm.num_adds = c->h_flags[4];
+    tm.num_points = n_total;
+    tm.num_adds = (uint64_t)c->h_flags[msmk::FLAG_ADDS64] | ((uint64_t)c->h_flags[msmk::FLAG_ADDS64 + 1] << 32);
     return MSM_OK;
+}
+
+// The pipeline proper: everything in HBM, one stream.  d_bases: INTERNAL-domain packed coordinates.
+int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, const uint32_t* d_scalars, size_t n,
+                     hipStream_t st, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf, uint32_t scalars_mont = 0,
+                     hipEvent_t bases_ready = nullptr, uint32_t extra_flags = 0, PipeState* ps_out = nullptr) {
+    PipeState ps;
+    int32_t rc = pipe_prepare(c, n, 0, extra_flags, st, &ps);
+    if (rc) return rc;
+    if ((rc = enqueue_sort(c, ps, d_inf, d_scalars, scalars_mont, st, true))) return rc;
+    if ((rc = enqueue_accumulate(c, ps, d_bases, st, bases_ready, false))) return rc;
+    if ((rc = enqueue_reduce(c, ps, st, c->h_qsums, c->h_flags))) return rc;
+    if (ps_out) *ps_out = ps;
+    return finish_sync(c, ps, n, st, out_jac, out_aff, out_inf);
 }
 
 struct DeviceGuard {
@@ -639,80 +591,251 @@ int32_t check_common(msm_ctx* c, const void* a, const void* b, size_t n) {
     return MSM_OK;
 }
 
-// raw caller coordinates (host) -> c->bases (staging) -> c->ibases (internal domain)
-int32_t upload_bases_locked(msm_ctx* c, const uint32_t* bases_xy, uint32_t form, const uint8_t* inf_mask, size_t n) {
+// ---- host inputs ------------------------------------------------------------------------------------------------------------
+// What the two host-pointer entries hand over: packed x||y words (standard or Montgomery form) with an optional byte mask of
+// points at infinity, or an array of arkworks G1Affine structs read through (stride, offsets); scalars in standard form or as
+// arkworks Fr Montgomery words.
+enum : uint32_t { KIND_STD = 0, KIND_MONT = 1, KIND_ARK = 2 };
+struct HostInput {
+    const uint8_t* bases = nullptr;
+    size_t stride = 64;  // bytes per base record
+    uint32_t kind = KIND_STD;
+    uint32_t x_off = 0, y_off = 0, inf_off = 0;
+    bool has_inf_field = false;         // KIND_ARK: the struct has an `infinity` byte
+    const uint8_t* inf_mask = nullptr;  // packed kinds: nullable
+    const uint32_t* scalars = nullptr;
+    uint32_t scalars_mont = 0;
+    bool carries_inf() const { return kind == KIND_ARK || inf_mask != nullptr; }
+};
+
+bool is_pinned_host(const void* p) {
+    hipPointerAttribute_t a{};
+    const bool pinned = hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeHost;
+    (void)hipGetLastError();  // an unregistered pointer is not an error here
+    return pinned;
+}
+
+// Pageable caller memory -> device, through a pinned ring filled by host threads.  Why: measured on this runtime
+// (tools/pinned_vs_pageable.py) hipMemcpyAsync from pageable memory runs at full PCIe rate but does NOT overlap kernels of other
+// streams, and hipHostRegister costs as much as the copy itself.  Here job t of T owns ring slots 2t and 2t+1 and the pieces
+// t, t+T, ...: memcpy into a slot, hipMemcpyAsync from the slot on stream cs, one event per slot guards its reuse.  The host
+// returns when everything is staged; the DMAs are then still in flight on cs.
+constexpr size_t STAGE_PIECE = (size_t)2 << 20;
+int32_t stager_init(msm_ctx* c) {
+    if (c->h_stage) return MSM_OK;
+    int want = (int)std::thread::hardware_concurrency() - 1;
+    want = std::max(1, std::min(want, 7));
+    if (const char* e = std::getenv("MSM_HIP_STAGE_THREADS")) want = std::max(0, std::min(15, std::atoi(e) - 1));
+    const int T = want + 1;  // workers + the calling thread
+    HIPCHK(c, hipHostMalloc((void**)&c->h_stage, (size_t)T * 2 * STAGE_PIECE, hipHostMallocDefault));
+    for (int i = 0; i < 2 * T; i++) HIPCHK(c, hipEventCreateWithFlags(&c->ev_stage[i], hipEventDisableTiming));
+    if (want > 0) {
+        c->stage_pool = new (std::nothrow) HostPool(want);
+        if (!c->stage_pool) return fail(c, MSM_ERR_OOM, "host allocation failed");
+    }
+    c->stage_threads = T;
+    return MSM_OK;
+}
+int32_t staged_copy(msm_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t cs) {
+    int32_t rc = stager_init(c);
+    if (rc) return rc;
+    const int T = c->stage_threads;
+    const size_t npieces = (bytes + STAGE_PIECE - 1) / STAGE_PIECE;
+    std::atomic<int> herr{(int)hipSuccess};
+    const int dev = c->device;
+    auto job = [&](int t) {
+        (void)hipSetDevice(dev);  // per host thread
+        size_t k = 0;
+        for (size_t p = (size_t)t; p < npieces; p += (size_t)T, k++) {
+            const int slot = 2 * t + (int)(k & 1);
+            hipError_t e = hipSuccess;
+            if (c->stage_used[slot]) e = hipEventSynchronize(c->ev_stage[slot]);  // the DMA that last read this slot is done
+            uint8_t* ring = c->h_stage + (size_t)slot * STAGE_PIECE;
+            const size_t off = p * STAGE_PIECE, len = std::min(STAGE_PIECE, bytes - off);
+            if (e == hipSuccess) {
+                std::memcpy(ring, (const uint8_t*)src + off, len);
+                e = hipMemcpyAsync((uint8_t*)dst + off, ring, len, hipMemcpyHostToDevice, cs);
+            }
+            if (e == hipSuccess) e = hipEventRecord(c->ev_stage[slot], cs);
+            c->stage_used[slot] = true;
+            if (e != hipSuccess) {
+                herr.store((int)e);
+                return;
+            }
+        }
+    };
+    const int njobs = (int)std::min<size_t>((size_t)T, npieces);
+    if (c->stage_pool && njobs > 1) c->stage_pool->run(njobs, job);
+    else
+        for (int t = 0; t < njobs; t++) job(t);
+    if (herr.load() != (int)hipSuccess)
+        return fail(c, MSM_ERR_HIP, "staged host->device copy failed: %s", hipGetErrorString((hipError_t)herr.load()));
+    return MSM_OK;
+}
+// host -> device on stream cs; pageable sources of a megabyte or more go through the staging ring
+int32_t h2d(msm_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t cs, bool staged) {
+    if (staged && bytes >= ((size_t)1 << 20)) return staged_copy(c, dst, src, bytes, cs);
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, cs));
+    return MSM_OK;
+}
+
+// raw base records in HBM -> internal-domain records (+ infinity bytes for the struct form), on stream st
+void launch_convert(const HostInput& in, const void* d_raw, size_t cnt, uint32_t* d_ibases, uint8_t* d_inf, bool glv, hipStream_t st) {
+    if (in.kind == KIND_ARK)
+        msmk::k_import_ark<<<grid1(2 * cnt, 256), 256, 0, st>>>((const uint8_t*)d_raw, (uint64_t)in.stride, in.x_off, in.y_off,
+                                                             in.has_inf_field ? in.inf_off : 0u, in.has_inf_field ? 1u : 0u, (uint32_t)cnt,
+                                                             d_ibases, d_inf, glv ? 1u : 0u);
+    else
+        msmk::k_convert_bases<<<grid1(2 * cnt, 256), 256, 0, st>>>((const uint32_t*)d_raw, d_ibases, (uint32_t)cnt,
+                                                                in.kind == KIND_MONT ? 1u : 0u, glv ? 1u : 0u);
+}
+
+// Single shot: scalars (and the infinity mask) go first on the compute stream and are sorted while the bases -- two thirds of
+// the bytes, only needed by k_accumulate -- still travel and are converted on the copy stream.  (The struct form carries the
+// infinity flags inside the base records, which k_decompose needs: there the two copies merely share the link.)
+int32_t run_single(msm_ctx* c, const HostInput& in, size_t n, bool staged, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf) {
+    int32_t rc;
+    hipStream_t st = c->stream, cs = c->copy_stream;
+    const bool glv = plan_glv(c, n);
+    PipeState ps;
+    if ((rc = ensure(c, c->scalars, n * 32))) return rc;
+    if ((rc = ensure(c, c->bases, n * in.stride))) return rc;
+    if ((rc = ensure(c, c->ibases, (glv ? 2 : 1) * n * 64))) return rc;
+    if (in.carries_inf() && (rc = ensure(c, c->inf, n))) return rc;
+    if ((rc = pipe_prepare(c, n, 0, 0, st, &ps))) return rc;
+    const bool overlap = n >= 4096 && !c->stage_timing;  // below that two cross-stream waits cost more than the copy
+    hipStream_t bs = overlap ? cs : st;                  // stream the bases travel and are converted on
+    if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_START], st));
+    const uint8_t* d_inf = in.carries_inf() ? (const uint8_t*)c->inf.p : nullptr;
+    {
+        Range r_("msm:h2d");
+        if (in.kind == KIND_ARK) {
+            if ((rc = h2d(c, c->bases.p, in.bases, n * in.stride, bs, staged))) return rc;
+            if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_H2D], st));
+            launch_convert(in, c->bases.p, n, (uint32_t*)c->ibases.p, (uint8_t*)c->inf.p, glv, bs);
+            if (overlap) HIPCHK(c, hipEventRecord(c->ev_bases, bs));
+            if ((rc = h2d(c, c->scalars.p, in.scalars, n * 32, st, staged))) return rc;
+            if (overlap) HIPCHK(c, hipStreamWaitEvent(st, c->ev_bases, 0));  // k_decompose reads the infinity bytes
+            if ((rc = enqueue_sort(c, ps, d_inf, (const uint32_t*)c->scalars.p, in.scalars_mont, st, true))) return rc;
+            if ((rc = enqueue_accumulate(c, ps, (const uint32_t*)c->ibases.p, st, nullptr, false))) return rc;
+        } else {
+            if ((rc = h2d(c, c->scalars.p, in.scalars, n * 32, st, staged))) return rc;
+            if (in.inf_mask && (rc = h2d(c, c->inf.p, in.inf_mask, n, st, staged))) return rc;
+            if (overlap) {
+                // queue the sort BEFORE the bases are touched: a copy from pageable memory blocks the host, the GPU sorts meanwhile
+                if ((rc = enqueue_sort(c, ps, d_inf, (const uint32_t*)c->scalars.p, in.scalars_mont, st, true))) return rc;
+                if ((rc = h2d(c, c->bases.p, in.bases, n * in.stride, bs, staged))) return rc;
+                launch_convert(in, c->bases.p, n, (uint32_t*)c->ibases.p, nullptr, glv, bs);
+                HIPCHK(c, hipEventRecord(c->ev_bases, bs));
+                if ((rc = enqueue_accumulate(c, ps, (const uint32_t*)c->ibases.p, st, c->ev_bases, false))) return rc;
+            } else {
+                if ((rc = h2d(c, c->bases.p, in.bases, n * in.stride, st, staged))) return rc;
+                if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_H2D], st));
+                launch_convert(in, c->bases.p, n, (uint32_t*)c->ibases.p, nullptr, glv, st);
+                if ((rc = enqueue_sort(c, ps, d_inf, (const uint32_t*)c->scalars.p, in.scalars_mont, st, true))) return rc;
+                if ((rc = enqueue_accumulate(c, ps, (const uint32_t*)c->ibases.p, st, nullptr, false))) return rc;
+            }
+        }
+    }
+    if ((rc = enqueue_reduce(c, ps, st, c->h_qsums, c->h_flags))) return rc;
+    if ((rc = finish_sync(c, ps, n, st, out_jac, out_aff, out_inf))) return rc;
+    c->tm.h2d_ms = stage_ms(c, EV_START, EV_H2D);
+    c->tm.convert_ms = stage_ms(c, EV_H2D, EV_CONVERT);
+    c->tm.staged = staged ? 1u : 0u;
+    trace_line(c, "host single-shot", ps);
+    return MSM_OK;
+}
+
+// BASELINE config 5, and every host-pointer call from 2^19 points on: the instance does not have to be resident.  The point
+// range is cut into chunks of `chunk` points; chunk j+1 travels host->HBM on the copy stream (pageable memory: staged by host
+// threads) while chunk j is sorted and accumulated on the compute stream.  MSM is linear in the points, so every chunk adds
+// into the SAME bucket array (k_accumulate<INTO>, one plan for the whole instance): ONE bucket reduction, ONE host finish and
+// W*(kb+1) bit sums back, however many chunks.  Raw inputs are double-buffered.
+int32_t run_streamed(msm_ctx* c, const HostInput& in, size_t n, size_t chunk, bool staged, uint32_t* out_jac, uint32_t* out_aff,
+                     uint8_t* out_inf) {
+    const size_t nchunks = (n + chunk - 1) / chunk;
+    int32_t rc;
+    const bool glv = plan_glv(c, n);  // of the WHOLE instance: all chunks share one bucket array
+    for (int s = 0; s < 2; s++) {
+        if ((rc = ensure(c, c->sbases[s], chunk * in.stride))) return rc;
+        if ((rc = ensure(c, c->sscalars[s], chunk * 32))) return rc;
+        if (in.inf_mask && (rc = ensure(c, c->sinf[s], chunk))) return rc;
+    }
+    if ((rc = ensure(c, c->ibases, (glv ? 2 : 1) * chunk * 64))) return rc;
+    if (in.kind == KIND_ARK && (rc = ensure(c, c->inf, chunk))) return rc;
+    hipStream_t st = c->stream, cs = c->copy_stream;
+    PipeState ps;
+    for (size_t j = 0; j < nchunks; j++) {
+        const int s = (int)(j & 1);
+        const size_t lo = j * chunk, cnt = (lo + chunk <= n) ? chunk : n - lo;
+        {
+            Range r_("msm:h2d chunk");
+            if (j >= 2) HIPCHK(c, hipStreamWaitEvent(cs, c->ev_free[s], 0));  // the pipeline that read this slot is done
+            if ((rc = h2d(c, c->sscalars[s].p, in.scalars + lo * 8, cnt * 32, cs, staged))) return rc;
+            if (in.inf_mask && (rc = h2d(c, c->sinf[s].p, in.inf_mask + lo, cnt, cs, staged))) return rc;
+            if ((rc = h2d(c, c->sbases[s].p, in.bases + lo * in.stride, cnt * in.stride, cs, staged))) return rc;
+            HIPCHK(c, hipEventRecord(c->ev_copied[s], cs));
+        }
+        HIPCHK(c, hipStreamWaitEvent(st, c->ev_copied[s], 0));
+        launch_convert(in, c->sbases[s].p, cnt, (uint32_t*)c->ibases.p, (uint8_t*)c->inf.p, glv, st);
+        const uint8_t* d_inf = in.kind == KIND_ARK ? (const uint8_t*)c->inf.p : in.inf_mask ? (const uint8_t*)c->sinf[s].p : nullptr;
+        if ((rc = pipe_prepare(c, cnt, n, 0, st, &ps))) return rc;
+        if ((rc = enqueue_sort(c, ps, d_inf, (const uint32_t*)c->sscalars[s].p, in.scalars_mont, st, j == 0))) return rc;
+        if ((rc = enqueue_accumulate(c, ps, (const uint32_t*)c->ibases.p, st, nullptr, j > 0))) return rc;
+        HIPCHK(c, hipEventRecord(c->ev_free[s], st));
+    }
+    if ((rc = enqueue_reduce(c, ps, st, c->h_qsums, c->h_flags))) return rc;
+    if ((rc = finish_sync(c, ps, n, st, out_jac, out_aff, out_inf))) return rc;
+    c->tm.stream_chunks = (uint32_t)nchunks;
+    c->tm.staged = staged ? 1u : 0u;
+    trace_line(c, "host streamed", ps);
+    return MSM_OK;
+}
+
+// chunk length of the streamed path for n points, 0 = single shot
+size_t pick_stream_chunk(const msm_ctx* c, size_t n) {
+    if (c->cfg.stream_chunk_log2) {
+        const size_t chunk = (size_t)1 << c->cfg.stream_chunk_log2;
+        return n >= 2 * chunk ? chunk : 0;
+    }
+    // automatic.  A chunk costs its copy (96 B per point at ~54 GB/s: 0.47 ms per 2^18 points) or its sort + accumulation
+    // (~0.4 ms per 2^18 points), whichever is longer; the first copy and the last accumulation are exposed, so chunks stay small
+    // while the ~15 launches they add (~60 us) stay cheap against them.
+    uint32_t min_log2 = 19, lg = n < ((size_t)1 << 21) ? 18u : n < ((size_t)1 << 23) ? 19u : 20u;
+    if (const char* e = std::getenv("MSM_HIP_STREAM_MIN_LOG2")) min_log2 = (uint32_t)std::max(9, std::min(31, std::atoi(e)));
+    if (const char* e = std::getenv("MSM_HIP_STREAM_CHUNK_LOG2")) lg = (uint32_t)std::max(8, std::min(28, std::atoi(e)));
+    if (n < ((size_t)1 << min_log2)) return 0;
+    const size_t chunk = (size_t)1 << lg;
+    return n >= 2 * chunk ? chunk : 0;
+}
+
+int32_t run_host_input(msm_ctx* c, const HostInput& in, size_t n, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf) {
+    auto t0 = std::chrono::steady_clock::now();
+    // pageable caller memory is staged through the pinned ring; MSM_HIP_STAGE=0 leaves it to the runtime's own pageable path
+    bool staged = !(is_pinned_host(in.bases) && is_pinned_host(in.scalars));
+    if (const char* e = std::getenv("MSM_HIP_STAGE"))
+        if (*e == '0') staged = false;
+    const size_t chunk = pick_stream_chunk(c, n);
+    int32_t rc = chunk ? run_streamed(c, in, n, chunk, staged, out_jac, out_aff, out_inf) : run_single(c, in, n, staged, out_jac, out_aff, out_inf);
+    if (rc) return rc;
+    c->tm.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return MSM_OK;
+}
+
+// raw caller coordinates (host) -> c->bases (staging) -> the RESIDENT set c->rbases (internal domain)
+int32_t upload_resident_locked(msm_ctx* c, const uint32_t* bases_xy, uint32_t form, const uint8_t* inf_mask, size_t n) {
     if (form != MSM_FORM_STD && form != MSM_FORM_MONT) return fail(c, MSM_ERR_BAD_ARG, "unknown base_form %u", form);
     int32_t rc;
     const bool glv = plan_glv(c, n);
     if ((rc = ensure(c, c->bases, n * 64))) return rc;
-    if ((rc = ensure(c, c->ibases, (glv ? 2 : 1) * n * 64))) return rc;
+    if ((rc = ensure(c, c->rbases, (glv ? 2 : 1) * n * 64))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->bases.p, bases_xy, n * 64, hipMemcpyHostToDevice, c->stream));
     if (inf_mask) {
-        if ((rc = ensure(c, c->inf, n))) return rc;
-        HIPCHK(c, hipMemcpyAsync(c->inf.p, inf_mask, n, hipMemcpyHostToDevice, c->stream));
+        if ((rc = ensure(c, c->rinf, n))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->rinf.p, inf_mask, n, hipMemcpyHostToDevice, c->stream));
     }
-    if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_H2D], c->stream));
-    msmk::k_convert_bases<<<grid1(2 * n, 256), 256, 0, c->stream>>>((const uint32_t*)c->bases.p, (uint32_t*)c->ibases.p, (uint32_t)n,
+    msmk::k_convert_bases<<<grid1(2 * n, 256), 256, 0, c->stream>>>((const uint32_t*)c->bases.p, (uint32_t*)c->rbases.p, (uint32_t)n,
                                                                   form == MSM_FORM_MONT ? 1u : 0u, glv ? 1u : 0u);
-    return MSM_OK;
-}
-
-// BASELINE config 5: the instance does not have to be resident.  The point range is cut into chunks of 2^k points;
-// chunk j+1 travels host->HBM on the copy stream while the full pipeline of chunk j runs on the compute stream
-// (MSM is linear, so every chunk is an independent MSM and the partial results are added on the host).  Inputs are
-// double-buffered; nothing but W*(kb+1) bit sums per chunk comes back.
-int32_t run_streamed(msm_ctx* c, const uint32_t* bases_xy, uint32_t form, const uint8_t* inf_mask, const uint32_t* scalars,
-                     size_t n, size_t chunk, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf) {
-    if (form != MSM_FORM_STD && form != MSM_FORM_MONT) return fail(c, MSM_ERR_BAD_ARG, "unknown base_form %u", form);
-    const size_t nchunks = (n + chunk - 1) / chunk;
-    const size_t slot_words = MAX_QSUM_POINTS * 24 + 8;
-    int32_t rc;
-    if (c->h_sq_cap < nchunks * slot_words) {
-        if (c->h_sq) HIPCHK(c, hipHostFree(c->h_sq));
-        c->h_sq = nullptr;
-        c->h_sq_cap = 0;
-        HIPCHK(c, hipHostMalloc((void**)&c->h_sq, nchunks * slot_words * 4, hipHostMallocDefault));
-        c->h_sq_cap = nchunks * slot_words;
-    }
-    for (int s = 0; s < 2; s++) {
-        if ((rc = ensure(c, c->sbases[s], chunk * 64))) return rc;
-        if ((rc = ensure(c, c->sscalars[s], chunk * 32))) return rc;
-        if (inf_mask && (rc = ensure(c, c->sinf[s], chunk))) return rc;
-    }
-    if ((rc = ensure(c, c->ibases, 2 * chunk * 64))) return rc;  // room for the phi records of a GLV chunk
-    std::vector<PipeGeom> geom(nchunks);
-    hipStream_t st = c->stream, cs = c->copy_stream;
-    for (size_t j = 0; j < nchunks; j++) {
-        const int s = (int)(j & 1);
-        const size_t lo = j * chunk, cnt = (lo + chunk <= n) ? chunk : n - lo;
-        if (j >= 2) HIPCHK(c, hipStreamWaitEvent(cs, c->ev_free[s], 0));  // the pipeline that read this slot is done
-        HIPCHK(c, hipMemcpyAsync(c->sbases[s].p, bases_xy + lo * 16, cnt * 64, hipMemcpyHostToDevice, cs));
-        HIPCHK(c, hipMemcpyAsync(c->sscalars[s].p, scalars + lo * 8, cnt * 32, hipMemcpyHostToDevice, cs));
-        if (inf_mask) HIPCHK(c, hipMemcpyAsync(c->sinf[s].p, inf_mask + lo, cnt, hipMemcpyHostToDevice, cs));
-        HIPCHK(c, hipEventRecord(c->ev_copied[s], cs));
-        HIPCHK(c, hipStreamWaitEvent(st, c->ev_copied[s], 0));
-        msmk::k_convert_bases<<<grid1(2 * cnt, 256), 256, 0, st>>>((const uint32_t*)c->sbases[s].p, (uint32_t*)c->ibases.p, (uint32_t)cnt,
-                                                                 form == MSM_FORM_MONT ? 1u : 0u, plan_glv(c, cnt) ? 1u : 0u);
-        uint32_t* slot = c->h_sq + j * slot_words;
-        rc = enqueue_pipeline(c, (const uint32_t*)c->ibases.p, inf_mask ? (const uint8_t*)c->sinf[s].p : nullptr,
-                              (const uint32_t*)c->sscalars[s].p, cnt, st, slot + 8, slot, &geom[j]);
-        if (rc) return rc;
-        HIPCHK(c, hipEventRecord(c->ev_free[s], st));
-    }
-    HIPCHK(c, hipStreamSynchronize(st));
-    HIPCHK(c, hipGetLastError());
-    hostg1::Jac total = hostg1::identity();
-    uint64_t adds = 0;
-    for (size_t j = 0; j < nchunks; j++) {
-        const uint32_t* slot = c->h_sq + j * slot_words;
-        if ((rc = check_flags(c, slot))) return rc;
-        adds += slot[4];
-        total = hostg1::jadd(total, host_finish(c, slot + 8, geom[j]));
-    }
-    finish_outputs(total, out_jac, out_aff, out_inf);
-    c->tm = msm_timings_t{};
-    c->tm.num_points = n;
-    c->tm.num_adds = adds;
     return MSM_OK;
 }
 
@@ -745,6 +868,7 @@ int32_t msm_ctx_create(const msm_config_t* cfg, msm_ctx** out) {
     if (!c) return fail(nullptr, MSM_ERR_OOM, "host allocation failed");
     c->device = dev;
     c->cfg = c0;
+    c->stage_timing = trace_enabled();
     DeviceGuard g(dev);
     hipError_t e = g.ok ? hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) : hipErrorInvalidDevice;
     for (int i = 0; i < EV_COUNT && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
@@ -802,16 +926,22 @@ void msm_ctx_destroy(msm_ctx* c) {
     if (!c) return;
     delete c->pool;
     c->pool = nullptr;
+    delete c->stage_pool;
+    c->stage_pool = nullptr;
     {
         DeviceGuard g(c->device);
         if (c->stream) (void)hipStreamSynchronize(c->stream);
+        if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
         DevBuf* bufs[] = {&c->bases,   &c->inf,       &c->scalars, &c->digits,  &c->ranks,  &c->sorted, &c->hist,
                           &c->offsets, &c->blocksums, &c->buckets, &c->rc,      &c->flags,  &c->pow2,
-                          &c->heads,   &c->tails,     &c->chunkmap, &c->tilecounts, &c->ibases, &c->longlist, &c->longdone, &c->midlist, &c->ccounts, &c->cregion, &c->bigslot, &c->big};
+                          &c->heads,   &c->tails,     &c->chunkmap, &c->tilecounts, &c->ibases, &c->longlist, &c->longdone, &c->midlist, &c->ccounts, &c->cregion, &c->bigslot, &c->big,
+                          &c->rbases,  &c->rinf};
         for (DevBuf* b : bufs) release(*b);
         if (c->h_qsums) (void)hipHostFree(c->h_qsums);
         if (c->h_flags) (void)hipHostFree(c->h_flags);
-        if (c->h_sq) (void)hipHostFree(c->h_sq);
+        if (c->h_stage) (void)hipHostFree(c->h_stage);
+        for (hipEvent_t& e : c->ev_stage)
+            if (e) (void)hipEventDestroy(e);
         for (int i = 0; i < 2; i++) {
             release(c->sbases[i]);
             release(c->sscalars[i]);
@@ -833,43 +963,17 @@ int32_t msm_bn254_g1(msm_ctx* c, const uint32_t* bases_xy, uint32_t base_form, c
                      const uint32_t* scalars, size_t n, uint32_t out_jac[24], uint32_t out_aff[16], uint8_t* out_inf) {
     int32_t rc = check_common(c, bases_xy, scalars, n);
     if (rc) return rc;
+    if (base_form != MSM_FORM_STD && base_form != MSM_FORM_MONT) return fail(c, MSM_ERR_BAD_ARG, "unknown base_form %u", base_form);
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
-    auto t0 = std::chrono::steady_clock::now();
-    c->resident_n = 0;  // the scratch copies below are not a resident set
-    {
-        // Streaming needs copies that really run beside the kernels.  Measured (tools/pin_test.py, N = 2^22): from
-        // PINNED caller memory 10.5 ms streamed vs 15.0 ms single-shot; from pageable memory the runtime's staged
-        // copy does not overlap and chunking only adds its fixed costs (16.0 vs 15.1 ms); hipHostRegister costs as
-        // much as the copy itself (10.9 ms per 256 MB).  So: explicit stream_chunk_log2 => always stream;
-        // default => stream only when both caller buffers are pinned.
-        uint32_t lg = c->cfg.stream_chunk_log2 ? c->cfg.stream_chunk_log2 : 21u;
-        size_t chunk = (size_t)1 << lg;
-        bool want = n >= 2 * chunk;
-        if (want && !c->cfg.stream_chunk_log2) {
-            hipPointerAttribute_t a0{}, a1{};
-            want = hipPointerGetAttributes(&a0, bases_xy) == hipSuccess && a0.type == hipMemoryTypeHost &&
-                   hipPointerGetAttributes(&a1, scalars) == hipSuccess && a1.type == hipMemoryTypeHost;
-            (void)hipGetLastError();  // an unregistered pointer is not an error here
-        }
-        if (want) {
-            rc = run_streamed(c, bases_xy, base_form, inf_mask, scalars, n, chunk, out_jac, out_aff, out_inf);
-            if (rc) return rc;
-            c->tm.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            return MSM_OK;
-        }
-    }
-    if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_START], c->stream));
-    if ((rc = ensure(c, c->scalars, n * 32))) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->scalars.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
-    if ((rc = upload_bases_locked(c, bases_xy, base_form, inf_mask, n))) return rc;
-    rc = run_pipeline(c, (const uint32_t*)c->ibases.p, inf_mask ? (const uint8_t*)c->inf.p : nullptr,
-                      (const uint32_t*)c->scalars.p, n, c->stream, out_jac, out_aff, out_inf);
-    if (rc) return rc;
-    c->tm.h2d_ms = stage_ms(c, EV_START, EV_H2D);
-    c->tm.convert_ms = stage_ms(c, EV_H2D, EV_CONVERT);
-    c->tm.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    return MSM_OK;
+    Range r_("msm_bn254_g1");
+    HostInput in;
+    in.bases = (const uint8_t*)bases_xy;
+    in.stride = 64;
+    in.kind = base_form == MSM_FORM_MONT ? KIND_MONT : KIND_STD;
+    in.inf_mask = inf_mask;
+    in.scalars = scalars;
+    return run_host_input(c, in, n, out_jac, out_aff, out_inf);
 }
 
 int32_t msm_bn254_g1_arkworks(msm_ctx* c, const void* bases, size_t stride, size_t x_off, size_t y_off, size_t inf_off,
@@ -882,27 +986,16 @@ int32_t msm_bn254_g1_arkworks(msm_ctx* c, const void* bases, size_t stride, size
         return fail(c, MSM_ERR_BAD_ARG, "bad G1Affine layout: stride %zu x %zu y %zu inf %zu", stride, x_off, y_off, inf_off);
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
-    auto t0 = std::chrono::steady_clock::now();
-    c->resident_n = 0;
-    if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_START], c->stream));
-    if ((rc = ensure(c, c->scalars, n * 32))) return rc;
-    const bool glv = plan_glv(c, n);
-    if ((rc = ensure(c, c->bases, n * stride))) return rc;
-    if ((rc = ensure(c, c->ibases, (glv ? 2 : 1) * n * 64))) return rc;
-    if ((rc = ensure(c, c->inf, n))) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->scalars.p, scalars_mont, n * 32, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->bases.p, bases, n * stride, hipMemcpyHostToDevice, c->stream));
-    if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_H2D], c->stream));
-    msmk::k_import_ark<<<grid1(2 * n, 256), 256, 0, c->stream>>>((const uint8_t*)c->bases.p, (uint64_t)stride, (uint32_t)x_off, (uint32_t)y_off,
-                                                               has_inf ? (uint32_t)inf_off : 0u, has_inf ? 1u : 0u, (uint32_t)n,
-                                                               (uint32_t*)c->ibases.p, (uint8_t*)c->inf.p, glv ? 1u : 0u);
-    rc = run_pipeline(c, (const uint32_t*)c->ibases.p, (const uint8_t*)c->inf.p, (const uint32_t*)c->scalars.p, n, c->stream, out_jac,
-                      out_aff, out_inf, 1u);
-    if (rc) return rc;
-    c->tm.h2d_ms = stage_ms(c, EV_START, EV_H2D);
-    c->tm.convert_ms = stage_ms(c, EV_H2D, EV_CONVERT);
-    c->tm.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    return MSM_OK;
+    Range r_("msm_bn254_g1_arkworks");
+    HostInput in;
+    in.bases = (const uint8_t*)bases;
+    in.stride = stride;
+    in.kind = KIND_ARK;
+    in.x_off = (uint32_t)x_off, in.y_off = (uint32_t)y_off, in.inf_off = has_inf ? (uint32_t)inf_off : 0u;
+    in.has_inf_field = has_inf;
+    in.scalars = scalars_mont;
+    in.scalars_mont = 1u;
+    return run_host_input(c, in, n, out_jac, out_aff, out_inf);
 }
 
 int32_t msm_bn254_g1_upload_bases(msm_ctx* c, const uint32_t* bases_xy, uint32_t base_form, const uint8_t* inf_mask,
@@ -912,7 +1005,7 @@ int32_t msm_bn254_g1_upload_bases(msm_ctx* c, const uint32_t* bases_xy, uint32_t
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
     c->resident_n = 0;
-    if ((rc = upload_bases_locked(c, bases_xy, base_form, inf_mask, n))) return rc;
+    if ((rc = upload_resident_locked(c, bases_xy, base_form, inf_mask, n))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
     c->resident_n = n;
@@ -921,21 +1014,18 @@ int32_t msm_bn254_g1_upload_bases(msm_ctx* c, const uint32_t* bases_xy, uint32_t
     return MSM_OK;
 }
 
-// row f3: n x 32-byte arkworks compressed images (host) -> c->ibases (+ c->inf); out_ark picks the word domain written
-static int32_t decompress_locked(msm_ctx* c, const uint8_t* compressed, size_t n, uint32_t out_ark, int64_t* first_invalid) {
+// row f3: n x 32-byte arkworks compressed images (host) -> d_out (+ d_inf); out_ark picks the word domain written
+static int32_t decompress_locked(msm_ctx* c, const uint8_t* compressed, size_t n, uint32_t out_ark, bool glv, uint32_t* d_out,
+                                 uint8_t* d_inf, int64_t* first_invalid) {
     int32_t rc;
     if (first_invalid) *first_invalid = -1;
-    if (n > 0xFFFFFFF0ull) return fail(c, MSM_ERR_BAD_ARG, "too many points: %zu", n);
-    const bool glv = !out_ark && plan_glv(c, n);
     if ((rc = ensure(c, c->bases, n * 32 + 16))) return rc;
-    if ((rc = ensure(c, c->ibases, (glv ? 2 : 1) * n * 64))) return rc;
-    if ((rc = ensure(c, c->inf, n))) return rc;
     uint32_t* d_bad = (uint32_t*)((uint8_t*)c->bases.p + n * 32);  // lowest failing index, kept behind the images
     const uint32_t none = 0xFFFFFFFFu;
     HIPCHK(c, hipMemcpyAsync(c->bases.p, compressed, n * 32, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d_bad, &none, 4, hipMemcpyHostToDevice, c->stream));
-    msmk::k_decompress<<<grid1(n, 256), 256, 0, c->stream>>>((const uint32_t*)c->bases.p, (uint32_t)n, (uint32_t*)c->ibases.p,
-                                                          (uint8_t*)c->inf.p, d_bad, out_ark, glv ? 1u : 0u);
+    msmk::k_decompress<<<grid1(n, 256), 256, 0, c->stream>>>((const uint32_t*)c->bases.p, (uint32_t)n, d_out, d_inf, d_bad, out_ark,
+                                                          glv ? 1u : 0u);
     uint32_t bad = none;
     HIPCHK(c, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -952,10 +1042,12 @@ int32_t msm_bn254_g1_decompress(msm_ctx* c, const uint8_t* compressed, size_t n,
     int32_t rc = check_common(c, compressed, out_xy_mont, n);
     if (rc) return rc;
     if (!out_inf) return fail(c, MSM_ERR_BAD_ARG, "NULL out_inf");
+    if (n > 0xFFFFFFF0ull) return fail(c, MSM_ERR_BAD_ARG, "too many points: %zu", n);
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
-    c->resident_n = 0;  // ibases is used as the output staging area
-    if ((rc = decompress_locked(c, compressed, n, 1u, first_invalid))) return rc;
+    if ((rc = ensure(c, c->ibases, n * 64))) return rc;  // scratch: the resident set lives in its own buffers
+    if ((rc = ensure(c, c->inf, n))) return rc;
+    if ((rc = decompress_locked(c, compressed, n, 1u, false, (uint32_t*)c->ibases.p, (uint8_t*)c->inf.p, first_invalid))) return rc;
     HIPCHK(c, hipMemcpyAsync(out_xy_mont, c->ibases.p, n * 64, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(out_inf, c->inf.p, n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -965,12 +1057,16 @@ int32_t msm_bn254_g1_decompress(msm_ctx* c, const uint8_t* compressed, size_t n,
 int32_t msm_bn254_g1_upload_compressed(msm_ctx* c, const uint8_t* compressed, size_t n, int64_t* first_invalid) {
     int32_t rc = check_common(c, compressed, compressed, n);
     if (rc) return rc;
+    if (n > 0xFFFFFFF0ull) return fail(c, MSM_ERR_BAD_ARG, "too many points: %zu", n);
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
     c->resident_n = 0;
-    if ((rc = decompress_locked(c, compressed, n, 0u, first_invalid))) return rc;
+    const bool glv = plan_glv(c, n);
+    if ((rc = ensure(c, c->rbases, (glv ? 2 : 1) * n * 64))) return rc;
+    if ((rc = ensure(c, c->rinf, n))) return rc;
+    if ((rc = decompress_locked(c, compressed, n, 0u, glv, (uint32_t*)c->rbases.p, (uint8_t*)c->rinf.p, first_invalid))) return rc;
     c->resident_n = n;
-    c->resident_glv = plan_glv(c, n);
+    c->resident_glv = glv;
     c->resident_has_inf = true;
     return MSM_OK;
 }
@@ -1019,6 +1115,7 @@ int32_t msm_bn254_g1_resident(msm_ctx* c, const uint32_t* scalars, size_t n, uin
     if (c->resident_n == 0) return fail(c, MSM_ERR_STATE, "no resident bases: call msm_bn254_g1_upload_bases first");
     if (n > c->resident_n) n = c->resident_n;  // unequal lengths truncate to the shorter (metal_msm.rs:652-656)
     DeviceGuard g(c->device);
+    Range r_("msm_bn254_g1_resident");
     auto t0 = std::chrono::steady_clock::now();
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_START], c->stream));
     if ((rc = ensure(c, c->scalars, n * 32))) return rc;
@@ -1026,12 +1123,14 @@ int32_t msm_bn254_g1_resident(msm_ctx* c, const uint32_t* scalars, size_t n, uin
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_H2D], c->stream));
     // the phi records sit at index resident_n + i: a call on fewer scalars (truncation) or a set uploaded without them runs unsplit
     const uint32_t extra = (c->resident_glv && n == c->resident_n) ? 0u : MSM_FLAG_NO_GLV;
-    rc = run_pipeline(c, (const uint32_t*)c->ibases.p, c->resident_has_inf ? (const uint8_t*)c->inf.p : nullptr,
-                      (const uint32_t*)c->scalars.p, n, c->stream, out_jac, out_aff, out_inf, 0, nullptr, extra);
+    PipeState ps;
+    rc = run_pipeline(c, (const uint32_t*)c->rbases.p, c->resident_has_inf ? (const uint8_t*)c->rinf.p : nullptr,
+                      (const uint32_t*)c->scalars.p, n, c->stream, out_jac, out_aff, out_inf, 0, nullptr, extra, &ps);
     if (rc) return rc;
     c->tm.h2d_ms = stage_ms(c, EV_START, EV_H2D);
     c->tm.convert_ms = 0;
     c->tm.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    trace_line(c, "resident", ps);
     return MSM_OK;
 }
 
@@ -1041,17 +1140,19 @@ int32_t msm_bn254_g1_device(msm_ctx* c, const void* d_bases_mont, const void* d_
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
+    Range r_("msm_bn254_g1_device");
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
     auto t0 = std::chrono::steady_clock::now();
     const uint32_t glv = plan_glv(c, n) ? 1u : 0u;
-    if ((rc = ensure(c, c->ibases, (glv ? 2 : 1) * n * 64))) return rc;
+    if ((rc = ensure(c, c->ibases, (glv ? 2 : 1) * n * 64))) return rc;  // scratch (the resident set has its own buffers)
+    PipeState ps;
     // Each event record / cross-stream wait costs ~6 us of stream time (measured gaps in the kernel trace), so the
     // conversion only moves to the second stream when it is longer than that (n > 2^18: 32 us at 2^20, 5 us at 2^16).
     if (c->stage_timing || n <= ((size_t)1 << 18)) {  // serialised (also: so that convert_ms means something)
         if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_H2D], st));
         msmk::k_convert_bases<<<grid1(2 * n, 256), 256, 0, st>>>((const uint32_t*)d_bases_mont, (uint32_t*)c->ibases.p, (uint32_t)n, 1u, glv);
         rc = run_pipeline(c, (const uint32_t*)c->ibases.p, (const uint8_t*)d_inf_mask, (const uint32_t*)d_scalars, n, st, out_jac,
-                          out_aff, out_inf);
+                          out_aff, out_inf, 0, nullptr, 0, &ps);
     } else {  // the bases are not needed before k_accumulate: convert them on the second stream beside the sort
         if (hip_stream) {  // the caller's stream may still be producing the inputs; the context's own stream is idle between calls
             HIPCHK(c, hipEventRecord(c->ev_fork, st));
@@ -1061,12 +1162,13 @@ int32_t msm_bn254_g1_device(msm_ctx* c, const void* d_bases_mont, const void* d_
                                                                            (uint32_t)n, 1u, glv);
         HIPCHK(c, hipEventRecord(c->ev_bases, c->copy_stream));
         rc = run_pipeline(c, (const uint32_t*)c->ibases.p, (const uint8_t*)d_inf_mask, (const uint32_t*)d_scalars, n, st, out_jac,
-                          out_aff, out_inf, 0, c->ev_bases);
+                          out_aff, out_inf, 0, c->ev_bases, 0, &ps);
     }
     if (rc) return rc;
     c->tm.h2d_ms = 0;
     c->tm.convert_ms = stage_ms(c, EV_H2D, EV_CONVERT);
     c->tm.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    trace_line(c, "device", ps);
     return MSM_OK;
 }
 
@@ -1100,7 +1202,7 @@ int32_t msm_get_accumulate_kernel_stats(const msm_ctx* c, double* avg_ms, uint64
 int32_t msm_set_stage_timing(msm_ctx* c, int32_t enabled) {
     if (!c) return MSM_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
-    c->stage_timing = enabled != 0;
+    c->stage_timing = enabled != 0 || trace_enabled();
     return MSM_OK;
 }
 void msm_reset_kernel_stats(msm_ctx* c) {
@@ -1109,124 +1211,10 @@ void msm_reset_kernel_stats(msm_ctx* c) {
     c->acc_launches = 0;
 }
 
-int32_t msm_bn254_g1_generate_device(msm_ctx* c, uint64_t base_seed, uint64_t scalar_seed, size_t n, void* d_bases_out,
-                                     void* d_scalars_out) {
-    if (!c) return MSM_ERR_BAD_ARG;
-    if (n == 0) return fail(c, MSM_ERR_EMPTY, "Empty input");
-    if (n > 0x7FFFFFFFull) return fail(c, MSM_ERR_BAD_ARG, "n too large");
-    std::lock_guard<std::mutex> lk(c->mu);
-    DeviceGuard g(c->device);
-    int32_t rc;
-    if (d_bases_out) {
-        if ((rc = ensure_pow2_table(c))) return rc;
-        msmk::k_gen_bases<<<grid1(n, 128), 128, 0, c->stream>>>(base_seed, (uint32_t)n, (const uint32_t*)c->pow2.p,
-                                                             (uint32_t*)d_bases_out);
-    }
-    if (d_scalars_out) msmk::k_gen_scalars<<<grid1(n, 256), 256, 0, c->stream>>>(scalar_seed, (uint32_t)n, (uint32_t*)d_scalars_out);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipGetLastError());
-    return MSM_OK;
-}
-
-int32_t msm_bn254_generate_scalars_host(uint64_t seed, size_t n, int nonzero, uint32_t* out) {
-    if (!out) return MSM_ERR_BAD_ARG;
-    for (size_t i = 0; i < n; i++) msmk::gen_scalar(seed, i, nonzero != 0, out + i * 8);
-    return MSM_OK;
-}
-
-// ---- device-math unit-test hooks --------------------------------------------------------------------
-static int32_t run_test_kernel(msm_ctx* c, bool g1, uint32_t op, const uint32_t* a, size_t a_words, const uint32_t* b,
-                               size_t b_words, uint32_t* out, size_t out_words, size_t n) {
-    if (!c || !a || !out) return MSM_ERR_BAD_ARG;
-    if (n == 0) return MSM_ERR_EMPTY;
-    std::lock_guard<std::mutex> lk(c->mu);
-    DeviceGuard g(c->device);
-    void *da = nullptr, *db = nullptr, *dout = nullptr;
-    HIPCHK(c, hipMalloc(&da, n * a_words * 4));
-    HIPCHK(c, hipMalloc(&dout, n * out_words * 4));
-    HIPCHK(c, hipMemcpy(da, a, n * a_words * 4, hipMemcpyHostToDevice));
-    if (b) {
-        HIPCHK(c, hipMalloc(&db, n * b_words * 4));
-        HIPCHK(c, hipMemcpy(db, b, n * b_words * 4, hipMemcpyHostToDevice));
-    }
-    if (g1 && op == MSM_OP_G1_ADD_WIDE) msmk::k_test_g1_wide<<<grid1(n, 8), 64, 0, c->stream>>>((uint32_t*)da, (uint32_t*)db, (uint32_t*)dout, (uint32_t)n);
-    else if (g1) msmk::k_test_g1<<<grid1(n, 64), 64, 0, c->stream>>>(op, (uint32_t*)da, (uint32_t*)db, (uint32_t*)dout, (uint32_t)n);
-    else msmk::k_test_fp<<<grid1(n, 64), 64, 0, c->stream>>>(op, (uint32_t*)da, (uint32_t*)db, (uint32_t*)dout, (uint32_t)n);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpy(out, dout, n * out_words * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(da);
-    (void)hipFree(dout);
-    if (db) (void)hipFree(db);
-    return MSM_OK;
-}
-int32_t msm_test_fp_op(msm_ctx* c, uint32_t op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n) {
-    if (op > MSM_OP_FP_INV) return MSM_ERR_BAD_ARG;
-    if (op <= MSM_OP_FP_MONT_MUL && !b) return MSM_ERR_BAD_ARG;
-    return run_test_kernel(c, false, op, a, 8, op <= MSM_OP_FP_MONT_MUL ? b : nullptr, 8, out, 8, n);
-}
-int32_t msm_test_g1_op(msm_ctx* c, uint32_t op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n) {
-    if (op > MSM_OP_G1_ADD_WIDE) return MSM_ERR_BAD_ARG;
-    if (op != MSM_OP_G1_DBL && !b) return MSM_ERR_BAD_ARG;
-    return run_test_kernel(c, true, op, a, 24, op == MSM_OP_G1_DBL ? nullptr : b, op == MSM_OP_G1_MADD ? 16 : 24, out, 24, n);
-}
-int32_t msm_calibrate(msm_ctx* c, double* mad_per_s, double* fp_mul_per_s) {
-    if (!c) return MSM_ERR_BAD_ARG;
-    std::lock_guard<std::mutex> lk(c->mu);
-    DeviceGuard g(c->device);
-    int32_t rc;
-    if ((rc = ensure(c, c->flags, 64))) return rc;
-    hipDeviceProp_t prop;
-    HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
-    const unsigned blocks = (unsigned)prop.multiProcessorCount * 4u * 4u;  // 256-thread blocks: 4 wavefronts on each of a CU's 4 SIMDs
-    hipEvent_t e0, e1;
-    HIPCHK(c, hipEventCreate(&e0));
-    HIPCHK(c, hipEventCreate(&e1));
-    double out[2] = {0, 0};
-    for (uint32_t what = 0; what < 2; what++) {
-        const uint32_t iters = what == 0 ? 500u : 100u;  // ~1 ms each
-        const double ops_per_thread = what == 0 ? 64.0 * iters : 4.0 * iters;
-        msmk::k_calibrate<<<blocks, 256, 0, c->stream>>>(what, iters / 10, (uint32_t*)c->flags.p + 15);  // warm-up
-        HIPCHK(c, hipEventRecord(e0, c->stream));
-        msmk::k_calibrate<<<blocks, 256, 0, c->stream>>>(what, iters, (uint32_t*)c->flags.p + 15);
-        HIPCHK(c, hipEventRecord(e1, c->stream));
-        HIPCHK(c, hipEventSynchronize(e1));
-        float ms = 0;
-        HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
-        out[what] = ops_per_thread * (double)blocks * 256.0 / ((double)ms * 1e-3);
-    }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    HIPCHK(c, hipGetLastError());
-    if (mad_per_s) *mad_per_s = out[0];
-    if (fp_mul_per_s) *fp_mul_per_s = out[1];
-    return MSM_OK;
-}
-
-int32_t msm_test_decompose(msm_ctx* c, const uint32_t* scalars, size_t n, uint32_t window_bits, int32_t* digits) {
-    if (!c || !scalars || !digits) return MSM_ERR_BAD_ARG;
-    if (n == 0) return MSM_ERR_EMPTY;
-    msm_plan_t pl;
-    if (make_plan(n, window_bits ? window_bits : c->cfg.window_bits, c->cfg.flags | MSM_FLAG_NO_GLV, &pl)) return MSM_ERR_BAD_ARG;  // plain 254-bit digits
-    std::lock_guard<std::mutex> lk(c->mu);
-    DeviceGuard g(c->device);
-    void *ds = nullptr, *dd = nullptr;
-    size_t out_bytes = (size_t)pl.num_windows * n * 4;
-    HIPCHK(c, hipMalloc(&ds, n * 32));
-    HIPCHK(c, hipMalloc(&dd, out_bytes));
-    HIPCHK(c, hipMemcpy(ds, scalars, n * 32, hipMemcpyHostToDevice));
-    if (pl.signed_digits)
-        msmk::k_decompose_plain<true><<<grid1(n, 256), 256, 0, c->stream>>>((uint32_t*)ds, (uint32_t)n, pl.window_bits,
-                                                                         pl.num_windows, (int32_t*)dd);
-    else
-        msmk::k_decompose_plain<false><<<grid1(n, 256), 256, 0, c->stream>>>((uint32_t*)ds, (uint32_t)n, pl.window_bits,
-                                                                          pl.num_windows, (int32_t*)dd);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpy(digits, dd, out_bytes, hipMemcpyDeviceToHost));
-    (void)hipFree(ds);
-    (void)hipFree(dd);
-    return MSM_OK;
-}
-
 }  // extern "C"
+
+#include "msm_multi.inc"
+
+#ifdef MSM_HIP_TEST_HOOKS
+#include "msm_testhooks.inc"
+#endif

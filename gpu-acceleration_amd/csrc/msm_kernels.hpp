@@ -420,31 +420,6 @@ __global__ void k_decompose_glv(const uint32_t* __restrict__ scalars, const uint
     }
 }
 
-// test hook: plain signed digits as int32
-template <bool SIGNED>
-__global__ void k_decompose_plain(const uint32_t* __restrict__ scalars, uint32_t n, uint32_t c, uint32_t W,
-                                  int32_t* __restrict__ out) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t s[8];
-    for (int k = 0; k < 8; k++) s[k] = scalars[(size_t)i * 8 + k];
-    const uint32_t H = 1u << (c - 1);
-    uint32_t carry = 0;
-    for (uint32_t w = 0; w < W; w++) {
-        uint32_t v = scalar_window(s, w * c, c) + carry;
-        int32_t d = (int32_t)v;
-        if (SIGNED) {
-            if (v > H) {
-                d = (int32_t)v - (int32_t)(2u * H);
-                carry = 1;
-            } else {
-                carry = 0;
-            }
-        }
-        out[(size_t)w * n + i] = d;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // K2 phase 2: exclusive prefix sum of the W*nb bucket counts (three small launches).
 constexpr int SCAN_BLOCK = 256;
@@ -975,12 +950,18 @@ __global__ void k_scatter(const uint32_t* __restrict__ digits, const uint32_t* _
 // every one of its wavefronts runs exactly one XYZZ add (a few 3-chunk buckets per wavefront used to double its time).
 constexpr uint32_t LONG_SPAN = 8;
 constexpr uint32_t LONG_SEG = 2048;  // pieces of a long bucket folded by one k_combine_long workgroup
+// flags (u32 words, one per context): [0] error bits  [4] sorted entries of this (chunk of an) MSM  [6,7] running 64-bit total
+// of sorted entries over the chunks of a streamed MSM  [8] long-list entries  [9] mid-list entries
+constexpr uint32_t FLAG_ERR = 0, FLAG_PAIRS = 4, FLAG_ADDS64 = 6, FLAG_LONG = 8, FLAG_MID = 9;
 __global__ void __launch_bounds__(1024) k_chunk_map(const uint32_t* __restrict__ offsets, uint32_t* __restrict__ chunk_bucket,
-                                                   uint32_t total_buckets, uint32_t L, uint32_t* __restrict__ long_count,
-                                                   uint32_t* __restrict__ long_list, uint32_t* __restrict__ mid_count,
-                                                   uint32_t* __restrict__ mid_list) {
+                                                   uint32_t total_buckets, uint32_t L, uint32_t* __restrict__ flags,
+                                                   uint32_t* __restrict__ long_list, uint32_t* __restrict__ mid_list) {
+    uint32_t* const long_count = flags + FLAG_LONG;
+    uint32_t* const mid_count = flags + FLAG_MID;
     __shared__ uint32_t s_n[2], s_base[2];  // [0] mid, [1] long: list slots are reserved once per workgroup
     if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0)  // mixed additions executed so far (msm_timings_t.num_adds), all chunks of a streamed MSM
+        *reinterpret_cast<unsigned long long*>(flags + FLAG_ADDS64) += (unsigned long long)flags[FLAG_PAIRS];
     __syncthreads();
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t kindl = 2, slot = 0, nseg = 1;  // 0 = mid list, 1 = long list, 2 = neither
@@ -1013,6 +994,10 @@ __global__ void __launch_bounds__(1024) k_chunk_map(const uint32_t* __restrict__
     }
 }
 
+// INTO = true (chunks 2.. of a streamed MSM, run_streamed): the bucket array already holds the sums of the earlier chunks; the
+// thread in whose chunk a bucket STARTS folds the old value in (it becomes the first term of that bucket's first piece), and
+// k_combine leaves buckets that this chunk does not touch alone.  One reduction and one host finish per MSM, however many chunks.
+template <bool INTO>
 __global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
                                                     const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ chunk_bucket,
                                                     uint32_t* __restrict__ buckets, uint32_t* __restrict__ heads,
@@ -1027,6 +1012,7 @@ __global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__
     uint32_t seg_end = offsets[k + 1];
     bool is_head = offsets[k] < j0;  // the first bucket of this chunk began in an earlier chunk
     xyzz acc = xyzz_identity();
+    if (INTO && !is_head) acc = load_xyzz(buckets + (size_t)k * XW);
     // software pipeline: the 64-byte record of entry j+1 (and the index of entry j+2) are in flight while entry j
     // is folded.  Only ONE raw record is kept: it is unpacked to 29-bit limbs before the next gather is issued.
     uint32_t e_cur = sorted[j0];
@@ -1069,7 +1055,8 @@ __global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__
                 seg_end = offsets[k + 1];
             }
             is_head = false;
-            acc = xyzz_identity();
+            if (INTO) acc = load_xyzz(buckets + (size_t)k * XW);
+            else acc = xyzz_identity();
         }
         xyzz_madd(acc, q);
         e_cur = e_nxt;
@@ -1087,7 +1074,7 @@ constexpr uint32_t MID_BLOCKS = 256;
 __global__ void __launch_bounds__(256) k_combine(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ heads,
                                                  const uint32_t* __restrict__ tails, uint32_t* __restrict__ buckets,
                                                  uint32_t total_buckets, uint32_t L, const uint32_t* __restrict__ mid_count,
-                                                 const uint32_t* __restrict__ mid_list) {
+                                                 const uint32_t* __restrict__ mid_list, uint32_t into) {
     if (blockIdx.x < MID_BLOCKS) {
         const uint32_t nmid = *mid_count;
         for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nmid; i += MID_BLOCKS * blockDim.x) {
@@ -1103,7 +1090,7 @@ __global__ void __launch_bounds__(256) k_combine(const uint32_t* __restrict__ of
     if (k >= total_buckets) return;
     uint32_t beg = offsets[k], end = offsets[k + 1];
     if (beg == end) {
-        store_xyzz(buckets + (size_t)k * XW, xyzz_identity());
+        if (!into) store_xyzz(buckets + (size_t)k * XW, xyzz_identity());  // into: the bucket keeps the earlier chunks' sum
         return;
     }
     uint32_t t0 = beg / L, t1 = (end - 1) / L;
@@ -1320,166 +1307,6 @@ __global__ void __launch_bounds__(64) k_reduce_bits(const uint32_t* __restrict__
     if (threadIdx.x == 0) {
         store_jacobian_mont256(q + (size_t)blockIdx.x * 24, xyzz_to_jacobian(acc));
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// synthetic inputs (counterpart of test_utils::generate_random_bases_and_scalars, metal_msm.rs:698-731)
-__host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t& st) {
-    uint64_t z = (st += 0x9E3779B97F4A7C15ULL);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-    return z ^ (z >> 31);
-}
-// element i of stream `seed`: 254-bit rejection sampling below r (and != 0 when nonzero)
-__host__ __device__ inline void gen_scalar(uint64_t seed, uint64_t i, bool nonzero, uint32_t out[8]) {
-    const uint64_t R[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
-    uint64_t st = seed + i * 0xD1342543DE82EF95ULL;
-    uint64_t v[4];
-    for (;;) {
-        for (int k = 0; k < 4; k++) v[k] = splitmix64(st);
-        v[3] &= 0x3FFFFFFFFFFFFFFFULL;
-        bool lt = false;
-        for (int k = 3; k >= 0; k--) {
-            if (v[k] != R[k]) {
-                lt = v[k] < R[k];
-                break;
-            }
-        }
-        if (!lt) continue;
-        if (nonzero && (v[0] | v[1] | v[2] | v[3]) == 0) continue;
-        break;
-    }
-    for (int k = 0; k < 4; k++) {
-        out[2 * k] = (uint32_t)v[k];
-        out[2 * k + 1] = (uint32_t)(v[k] >> 32);
-    }
-}
-__global__ void k_gen_scalars(uint64_t seed, uint32_t n, uint32_t* __restrict__ out) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t s[8];
-    gen_scalar(seed, i, false, s);
-    uint4* q = reinterpret_cast<uint4*>(out + (size_t)i * 8);
-    q[0] = make_uint4(s[0], s[1], s[2], s[3]);
-    q[1] = make_uint4(s[4], s[5], s[6], s[7]);
-}
-// base i = k_i * G with k_i = nonzero stream element; pow2_table[j] = 2^j * G (affine, internal domain, packed,
-// 254 entries); the result is written as canonical R = 2^256 Montgomery words (what arkworks holds)
-__global__ void __launch_bounds__(128) k_gen_bases(uint64_t seed, uint32_t n, const uint32_t* __restrict__ pow2_table,
-                                                   uint32_t* __restrict__ out) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t k[8];
-    gen_scalar(seed, i, true, k);
-    xyzz acc = xyzz_identity();
-    for (int j = 0; j < SCALAR_BITS; j++) {
-        if ((k[j >> 5] >> (j & 31)) & 1u) xyzz_madd(acc, load_affine(pow2_table + (size_t)j * 16));
-    }
-    affine a;
-    xyzz_to_affine(acc, a);
-    uint32_t w[8];
-    fp_to_mont256(w, a.x);
-    store_words8(out + (size_t)i * 16, w);
-    fp_to_mont256(w, a.y);
-    store_words8(out + (size_t)i * 16 + 8, w);
-}
-
-// ---------------------------------------------------------------------------------------------
-// device-math unit-test kernels (counterpart of the reference's test_* kernels)
-__global__ void k_test_fp(uint32_t op, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
-                          uint32_t* __restrict__ out, uint32_t n) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    // operands and results cross the ABI as canonical R = 2^256 Montgomery words (ops 0,1,2,5) or as the
-    // standard/Montgomery pair of the conversion ops (3: std -> mont, 4: mont -> std)
-    uint32_t wa[8], wb[8], wr[8];
-    for (int k = 0; k < 8; k++) {
-        wa[k] = a[(size_t)i * 8 + k];
-        wb[k] = b ? b[(size_t)i * 8 + k] : 0u;
-    }
-    switch (op) {
-        case 0: fp_to_mont256(wr, fp_add(fp_from_mont256(wa), fp_from_mont256(wb))); break;
-        case 1: fp_to_mont256(wr, fp_sub<3>(fp_from_mont256(wa), fp_from_mont256(wb))); break;
-        case 2: fp_to_mont256(wr, fp_mul(fp_from_mont256(wa), fp_from_mont256(wb))); break;
-        case 3: fp_to_mont256(wr, fp_from_std(wa)); break;
-        case 4: fp_to_std(wr, fp_from_mont256(wa)); break;
-        default: {
-            fp x = fp_from_mont256(wa);
-            if (fp_is_zero_lt2p(x)) fp_to_mont256(wr, fp_zero());
-            else fp_to_mont256(wr, fp_inv(x));
-            break;
-        }
-    }
-    for (int k = 0; k < 8; k++) out[(size_t)i * 8 + k] = wr[k];
-}
-__global__ void __launch_bounds__(64) k_test_g1(uint32_t op, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
-                                                uint32_t* __restrict__ out, uint32_t n) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    xyzz p = xyzz_from_jacobian(load_jacobian_mont256(a + (size_t)i * 24));
-    xyzz r;
-    if (op == 0) {
-        const uint32_t* bp = b + (size_t)i * 16;
-        uint32_t wx[8], wy[8];
-        for (int k = 0; k < 8; k++) {
-            wx[k] = bp[k];
-            wy[k] = bp[8 + k];
-        }
-        affine q{fp_from_mont256(wx), fp_from_mont256(wy)};
-        r = p;
-        xyzz_madd(r, q);
-    } else if (op == 1) {
-        r = xyzz_add(p, xyzz_from_jacobian(load_jacobian_mont256(b + (size_t)i * 24)));
-    } else if (op == 3) {
-        // never reached: op 3 (wide addition) has its own kernel, k_test_g1_wide
-        r = p;
-    } else {
-        r = xyzz_dbl(p);
-    }
-    store_jacobian_mont256(out + (size_t)i * 24, xyzz_to_jacobian(r));
-}
-
-// Calibration kernels for the integer-multiplier roofline ("against the measured v_mad_u64_u32 peak of
-// a calibration micro-kernel on the same device"): dependent chains at 4 wavefronts per SIMD, as k_accumulate runs them.
-//   what = 0: raw v_mad_u64_u32 (64 per iteration);  1: fp_mul, the 9 x 29-bit Montgomery multiplication (4 per iteration)
-__global__ void __launch_bounds__(256) k_calibrate(uint32_t what, uint32_t iters, uint32_t* __restrict__ sink) {
-    uint32_t acc_out = 0;
-    if (what == 0) {
-        uint64_t a = threadIdx.x * 0x9E3779B97F4A7C15ull + 12345u;
-        const uint32_t y = (uint32_t)(a >> 32) | 1u;
-        for (uint32_t i = 0; i < iters; i++) {
-#pragma unroll
-            for (int k = 0; k < 64; k++) a = (uint64_t)(uint32_t)a * y + a;  // one v_mad_u64_u32, operand and addend from the chain (wraps)
-        }
-        acc_out = (uint32_t)a ^ (uint32_t)(a >> 32);
-    } else {
-        fp v = fp_one(), m = fp_one();
-        v.v[0] += threadIdx.x;
-        m.v[1] += 7 + threadIdx.x;
-        for (uint32_t i = 0; i < iters; i++) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) v = fp_mul(v, m);
-        }
-#pragma unroll
-        for (int k = 0; k < 9; k++) acc_out ^= v.v[k];
-    }
-    if (acc_out == 0x12345u) sink[0] = acc_out;  // never true in practice: keeps the chains alive
-}
-
-// test hook for ec_wide.hpp: pair i is added by the 8 lanes of group i (records staged in LDS by the group's first lane)
-__global__ void __launch_bounds__(64) k_test_g1_wide(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
-                                                     uint32_t* __restrict__ out, uint32_t n) {
-    __shared__ uint32_t e[16 * XW];
-    const uint32_t g = threadIdx.x / WIDE_LANES, role = threadIdx.x % WIDE_LANES;
-    const uint32_t i = blockIdx.x * 8 + g;
-    if (i < n && role == 0) {
-        store_xyzz(e + (size_t)(2 * g) * XW, xyzz_from_jacobian(load_jacobian_mont256(a + (size_t)i * 24)));
-        store_xyzz(e + (size_t)(2 * g + 1) * XW, xyzz_from_jacobian(load_jacobian_mont256(b + (size_t)i * 24)));
-    }
-    __syncthreads();
-    if (i < n) wide_add_records(e + (size_t)(2 * g) * XW, e + (size_t)(2 * g + 1) * XW, e + (size_t)(2 * g) * XW);
-    __syncthreads();
-    if (i < n && role == 0) store_jacobian_mont256(out + (size_t)i * 24, xyzz_to_jacobian(load_xyzz(e + (size_t)(2 * g) * XW)));
 }
 
 }  // namespace msmk

@@ -29,9 +29,12 @@ ABI_SYMBOLS = [
     "msm_abi_version", "msm_ctx_create", "msm_ctx_destroy", "msm_last_error", "msm_bn254_g1",
     "msm_bn254_g1_arkworks", "msm_bn254_g1_upload_bases", "msm_bn254_g1_resident", "msm_bn254_g1_device", "msm_bn254_g1_combine",
     "msm_plan", "msm_get_timings", "msm_set_stage_timing", "msm_get_accumulate_kernel_stats", "msm_reset_kernel_stats",
-    "msm_bn254_g1_generate_device", "msm_bn254_generate_scalars_host", "msm_test_fp_op", "msm_test_g1_op",
-    "msm_test_decompose", "msm_bn254_g1_decompress", "msm_bn254_g1_upload_compressed", "msm_bn254_g1_compress", "msm_calibrate",
+    "msm_bn254_g1_decompress", "msm_bn254_g1_upload_compressed", "msm_bn254_g1_compress",
+    "msm_multi_create", "msm_multi_destroy", "msm_multi_last_error", "msm_multi_num_devices", "msm_multi_exchange",
+    "msm_bn254_g1_multi", "msm_bn254_g1_multi_arkworks", "msm_bn254_g1_multi_device", "msm_multi_get_timings",
 ]
+ERR_RCCL = -8
+EXCHANGE_AUTO, EXCHANGE_RCCL, EXCHANGE_HOST = 0, 1, 2
 
 
 class MsmError(RuntimeError):
@@ -57,7 +60,7 @@ class Timings(C.Structure):
     _fields_ = [("h2d_ms", C.c_float), ("convert_ms", C.c_float), ("decompose_ms", C.c_float),
                 ("sort_ms", C.c_float), ("accumulate_ms", C.c_float), ("reduce_ms", C.c_float),
                 ("finish_ms", C.c_float), ("total_ms", C.c_float), ("num_points", C.c_uint64),
-                ("num_adds", C.c_uint64)]
+                ("num_adds", C.c_uint64), ("stream_chunks", C.c_uint32), ("staged", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -68,14 +71,7 @@ _u8p = C.POINTER(C.c_uint8)
 _lib = None
 
 
-def load_library():
-    """dlopen the in-tree libmsm_hip.so; fails loudly if it was not built (no fallback)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise MsmError(ERR_NO_DEVICE, f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                                      "(make -C gpu-acceleration_amd/csrc); there is no CPU fallback")
+def _preload_torch():
     # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64 and the
     # library links the same soname from /opt/rocm.  Whichever is loaded first serves both, and loading
     # ours first leaves torch with a mixed runtime ("No HIP GPUs are available").  Python callers use torch
@@ -84,7 +80,10 @@ def load_library():
         import torch  # noqa: F401
     except ImportError:
         pass
-    L = C.CDLL(LIB_PATH)
+
+
+def bind_product_abi(L):
+    """ctypes signatures of every include/msm_hip.h entry point on a loaded library (product or hooks build)"""
     vp = C.c_void_p
     L.msm_abi_version.restype = C.c_uint32
     L.msm_ctx_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
@@ -104,21 +103,39 @@ def load_library():
     L.msm_get_accumulate_kernel_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.msm_reset_kernel_stats.argtypes = [vp]
     L.msm_reset_kernel_stats.restype = None
-    L.msm_bn254_g1_generate_device.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_size_t, vp, vp]
-    L.msm_bn254_generate_scalars_host.argtypes = [C.c_uint64, C.c_size_t, C.c_int, _u32p]
-    L.msm_test_fp_op.argtypes = [vp, C.c_uint32, _u32p, _u32p, _u32p, C.c_size_t]
-    L.msm_test_g1_op.argtypes = [vp, C.c_uint32, _u32p, _u32p, _u32p, C.c_size_t]
-    L.msm_test_decompose.argtypes = [vp, _u32p, C.c_size_t, C.c_uint32, C.POINTER(C.c_int32)]
     L.msm_bn254_g1_decompress.argtypes = [vp, _u8p, C.c_size_t, _u32p, _u8p, C.POINTER(C.c_int64)]
     L.msm_bn254_g1_upload_compressed.argtypes = [vp, _u8p, C.c_size_t, C.POINTER(C.c_int64)]
     L.msm_bn254_g1_compress.argtypes = [_u32p, C.c_uint32, _u8p, C.c_size_t, _u8p]
-    L.msm_calibrate.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.msm_multi_create.argtypes = [C.POINTER(C.c_int32), C.c_int32, C.POINTER(Config), C.c_uint32, C.POINTER(vp)]
+    L.msm_multi_destroy.argtypes = [vp]
+    L.msm_multi_destroy.restype = None
+    L.msm_multi_last_error.argtypes = [vp]
+    L.msm_multi_last_error.restype = C.c_char_p
+    L.msm_multi_num_devices.argtypes = [vp]
+    L.msm_multi_exchange.argtypes = [vp]
+    L.msm_multi_exchange.restype = C.c_uint32
+    L.msm_bn254_g1_multi.argtypes = [vp, _u32p, C.c_uint32, _u8p, _u32p, C.c_size_t, _u32p, _u32p, _u8p]
+    L.msm_bn254_g1_multi_arkworks.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _u32p, C.c_size_t, _u32p, _u32p, _u8p]
+    L.msm_bn254_g1_multi_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_size_t), _u32p, _u32p, _u8p]
+    L.msm_multi_get_timings.argtypes = [vp, C.c_int32, C.POINTER(Timings)]
     for name in ABI_SYMBOLS:
         f = getattr(L, name)
         if f.restype is C.c_int:  # default
             f.restype = C.c_int32
-    _lib = L
     return L
+
+
+def load_library():
+    """dlopen the in-tree libmsm_hip.so (the PRODUCT); fails loudly if it was not built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MsmError(ERR_NO_DEVICE, f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                      "(make -C gpu-acceleration_amd/csrc); there is no CPU fallback")
+    _preload_torch()
+    _lib = bind_product_abi(C.CDLL(LIB_PATH))
+    return _lib
 
 
 def _words(a, width):
@@ -189,17 +206,13 @@ def compress_points(bases, form=FORM_STD, inf=None):
     return out.tobytes()
 
 
-def generate_scalars_host(seed, n, nonzero=False):
-    out = np.zeros((n, 8), np.uint32)
-    load_library().msm_bn254_generate_scalars_host(seed, n, int(nonzero), _p32(out))
-    return out
-
-
 class MsmContext:
     """Persistent engine context (replaces MetalMSMPipeline, rebuilt per call in the reference)."""
 
+    _loader = staticmethod(lambda: load_library())  # testhooks.HooksContext runs the same class on the hooks build
+
     def __init__(self, device=-1, window_bits=0, flags=0, max_points=0, stream_chunk_log2=0):
-        self._lib = load_library()
+        self._lib = self._loader()
         cfg = Config(device, window_bits, flags, stream_chunk_log2, max_points)
         h = C.c_void_p()
         rc = self._lib.msm_ctx_create(C.byref(cfg), C.byref(h))
@@ -322,9 +335,6 @@ class MsmContext:
                                                   None, C.byref(oi)))
         return MsmResult(jac, None, oi.value)  # affine words on demand (MsmResult.affine_std)
 
-    def generate_device(self, base_seed, scalar_seed, n, d_bases_ptr, d_scalars_ptr):
-        self._check(self._lib.msm_bn254_g1_generate_device(self._h, base_seed, scalar_seed, n, d_bases_ptr, d_scalars_ptr))
-
     def set_stage_timing(self, enabled=True):
         self._check(self._lib.msm_set_stage_timing(self._h, int(bool(enabled))))
 
@@ -341,34 +351,85 @@ class MsmContext:
     def reset_kernel_stats(self):
         self._lib.msm_reset_kernel_stats(self._h)
 
-    # -- device-math unit-test hooks -----------------------------------------------------------
-    def test_fp_op(self, op, a, b=None):
-        a = _words(a, 8)
-        b = _words(b, 8) if b is not None else None
-        out = np.zeros_like(a)
-        self._check(self._lib.msm_test_fp_op(self._h, op, _p32(a), _p32(b), _p32(out), a.shape[0]))
-        return out
 
-    def test_g1_op(self, op, a, b=None):
-        a = _words(a, 24)
-        b = _words(b, 16 if op == 0 else 24) if b is not None else None
-        out = np.zeros_like(a)
-        self._check(self._lib.msm_test_g1_op(self._h, op, _p32(a), _p32(b), _p32(out), a.shape[0]))
-        return out
+class MsmMulti:
+    """One MSM over several GPUs of ONE process (include/msm_hip.h "multi-GPU"): contiguous point-range shards, one context
+    and one host thread per device, partials exchanged with RCCL (all-gather of 24 words + fold in rank order) or folded on
+    the host.  Same call signatures as MsmContext."""
 
-    def calibrate(self):
-        """(v_mad_u64_u32 per second, field multiplications per second) this device sustains -- two ~1 ms micro-kernels."""
-        a, b = C.c_double(0), C.c_double(0)
-        self._check(self._lib.msm_calibrate(self._h, C.byref(a), C.byref(b)))
-        return a.value, b.value
+    def __init__(self, devices=None, window_bits=0, flags=0, stream_chunk_log2=0, exchange=EXCHANGE_AUTO, _lib=None):
+        self._lib = _lib or load_library()
+        cfg = Config(-1, window_bits, flags, stream_chunk_log2, 0)
+        h = C.c_void_p()
+        if devices is None:
+            rc = self._lib.msm_multi_create(None, 0, C.byref(cfg), exchange, C.byref(h))
+        else:
+            arr = (C.c_int32 * len(devices))(*devices)
+            rc = self._lib.msm_multi_create(arr, len(devices), C.byref(cfg), exchange, C.byref(h))
+        if rc != OK:
+            raise MsmError(rc, (self._lib.msm_multi_last_error(None) or b"").decode())
+        self._h = h
+        self.num_devices = int(self._lib.msm_multi_num_devices(h))
+        self.exchange = int(self._lib.msm_multi_exchange(h))
 
-    def test_decompose(self, scalars, window_bits=0):
-        scalars = _words(scalars, 8)
-        n = scalars.shape[0]
-        p = plan(n, window_bits or self.window_bits, self.flags | FLAG_NO_GLV)  # the hook returns the plain 254-bit digits
-        out = np.zeros((p.num_windows, n), np.int32)
-        self._check(self._lib.msm_test_decompose(self._h, _p32(scalars), n, window_bits, out.ctypes.data_as(C.POINTER(C.c_int32))))
-        return out
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.msm_multi_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc != OK:
+            raise MsmError(rc, (self._lib.msm_multi_last_error(self._h) or b"").decode() or f"status {rc}")
+
+    def msm(self, bases, scalars, form=FORM_STD, inf=None):
+        bases, scalars = _words(bases, 16), _words(scalars, 8)
+        if bases.shape[0] == 0 or scalars.shape[0] == 0:
+            raise MsmError(ERR_EMPTY, "Empty input")
+        n = min(bases.shape[0], scalars.shape[0])
+        infp = None
+        if inf is not None:
+            inf = np.ascontiguousarray(inf, dtype=np.uint8)
+            infp = inf.ctypes.data_as(_u8p)
+        jac, aff, oi = np.zeros(24, np.uint32), np.zeros(16, np.uint32), C.c_uint8(0)
+        self._check(self._lib.msm_bn254_g1_multi(self._h, _p32(bases), form, infp, _p32(scalars), n, _p32(jac), _p32(aff), C.byref(oi)))
+        return MsmResult(jac, aff, oi.value)
+
+    def msm_arkworks(self, raw_structs, stride, x_off, y_off, inf_off, scalars_mont):
+        raw = np.ascontiguousarray(raw_structs, dtype=np.uint8).reshape(-1)
+        sc = _words(scalars_mont, 8)
+        n = min(raw.size // stride, sc.shape[0])
+        if n == 0:
+            raise MsmError(ERR_EMPTY, "Empty input")
+        jac, aff, oi = np.zeros(24, np.uint32), np.zeros(16, np.uint32), C.c_uint8(0)
+        self._check(self._lib.msm_bn254_g1_multi_arkworks(self._h, raw.ctypes.data_as(C.c_void_p), stride, x_off, y_off,
+                                                          inf_off if inf_off is not None else C.c_size_t(-1).value, _p32(sc), n,
+                                                          _p32(jac), _p32(aff), C.byref(oi)))
+        return MsmResult(jac, aff, oi.value)
+
+    def msm_device(self, d_bases_ptrs, d_scalars_ptrs, counts, d_inf_ptrs=None):
+        """shard g already sits in device g's HBM: raw device pointers and point counts per device"""
+        G = self.num_devices
+        assert len(d_bases_ptrs) == G and len(d_scalars_ptrs) == G and len(counts) == G
+        vpa = C.c_void_p * G
+        pb, ps = vpa(*d_bases_ptrs), vpa(*d_scalars_ptrs)
+        pi = vpa(*d_inf_ptrs) if d_inf_ptrs is not None else None
+        cn = (C.c_size_t * G)(*counts)
+        jac, oi = np.zeros(24, np.uint32), C.c_uint8(0)
+        self._check(self._lib.msm_bn254_g1_multi_device(self._h, pb, pi, ps, cn, _p32(jac), None, C.byref(oi)))
+        return MsmResult(jac, None, oi.value)
+
+    def timings(self, g=0):
+        t = Timings()
+        self._check(self._lib.msm_multi_get_timings(self._h, g, C.byref(t)))
+        return t.as_dict()
 
 
 _default_ctx = None

@@ -115,19 +115,26 @@ def deserialize_input(dir):
 
 def gen_vectors(instance_size, num_instance, dir, ctx=None, seed=0xB2540003):
     """preprocess.rs:180-191: `num_instance` instances of 2^instance_size random points and scalars.
-    Points are k_i*G from the engine's on-device generator (the reference draws GAffine::rand from thread_rng)."""
+    Points are k_i*G from the on-device generator of the hooks build (testhooks.HooksContext; the reference draws
+    GAffine::rand from thread_rng).  `ctx` may be a HooksContext to reuse; a product MsmContext has no generator."""
     import torch
 
-    ctx = ctx or default_context()
+    from .testhooks import HooksContext
+
+    gen = ctx if isinstance(ctx, HooksContext) else HooksContext()
     n = 1 << instance_size
     d_b = torch.empty(n * 16, dtype=torch.int32, device="cuda")
     d_s = torch.empty(n * 8, dtype=torch.int32, device="cuda")
-    for i in range(num_instance):
-        ctx.generate_device((seed + 2 * i) & (2 ** 64 - 1), (seed + 2 * i + 1) & (2 ** 64 - 1), n, d_b.data_ptr(), d_s.data_ptr())
-        torch.cuda.synchronize()
-        bases = d_b.cpu().numpy().view(np.uint32).reshape(n, 16)
-        scalars = d_s.cpu().numpy().view(np.uint32).reshape(n, 8)
-        serialize_input(dir, compress_points(bases, FORM_MONT), scalars, append=i != 0)
+    try:
+        for i in range(num_instance):
+            gen.generate_device((seed + 2 * i) & (2 ** 64 - 1), (seed + 2 * i + 1) & (2 ** 64 - 1), n, d_b.data_ptr(), d_s.data_ptr())
+            torch.cuda.synchronize()
+            bases = d_b.cpu().numpy().view(np.uint32).reshape(n, 16)
+            scalars = d_s.cpu().numpy().view(np.uint32).reshape(n, 8)
+            serialize_input(dir, compress_points(bases, FORM_MONT), scalars, append=i != 0)
+    finally:
+        if gen is not ctx:
+            gen.close()
 
 
 @dataclass

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MSM_HIP_ABI_VERSION 1u
+#define MSM_HIP_ABI_VERSION 2u
 
 /* status codes */
 #define MSM_OK 0
@@ -45,6 +45,7 @@ extern "C" {
 #define MSM_ERR_OOM (-5)
 #define MSM_ERR_STATE (-6)      /* e.g. resident call without uploaded bases                            */
 #define MSM_ERR_INVALID_DATA (-7) /* a compressed point does not decode (arkworks SerializationError::InvalidData) */
+#define MSM_ERR_RCCL (-8)       /* an RCCL call of the multi-GPU exchange failed; see msm_multi_last_error()            */
 
 /* coordinate form of the bases handed in */
 #define MSM_FORM_STD 0u  /* plain integers < p   (what pack_affine_and_scalars emits)          */
@@ -61,10 +62,12 @@ typedef struct {
     int32_t device;       /* HIP device ordinal; -1 = current device                                   */
     uint32_t window_bits; /* c; 0 = planner (replaces the N->window table at metal_msm.rs:661-673)     */
     uint32_t flags;       /* MSM_FLAG_*                                                                */
-    uint32_t stream_chunk_log2; /* msm_bn254_g1 with n >= 2 * 2^this points streams host->HBM chunks of 2^this points
-                                   overlapped with the pipeline of the previous chunk (BASELINE config 5).
-                                   0 = automatic: 2^21-point chunks, and only when the caller's buffers are pinned
-                                   (pageable copies do not overlap kernels on this runtime) */
+    uint32_t stream_chunk_log2; /* the host-pointer entries cut n >= 2 * 2^this points into chunks of 2^this points: chunk j+1
+                                   travels host->HBM (copy stream) while chunk j is sorted and accumulated INTO the shared bucket
+                                   array; one bucket reduction and one host finish per MSM (BASELINE config 5).
+                                   0 = automatic: from 2^19 points on, chunks of 2^18..2^20 points.  Pageable caller memory is
+                                   staged through a pinned ring by host threads (copies from pageable memory do not overlap
+                                   kernels on this runtime); pinned caller memory is read by the copy engine directly */
     uint64_t max_points;  /* pre-size the HBM workspace for this many points; 0 = grow on demand        */
 } msm_config_t;
 
@@ -91,6 +94,8 @@ typedef struct {
     float total_ms;      /* wall clock of the whole call                        */
     uint64_t num_points;
     uint64_t num_adds;   /* mixed additions executed by accumulate (non-zero digits) */
+    uint32_t stream_chunks; /* host->HBM chunks the call was cut into (0 = single shot / device-resident)      */
+    uint32_t staged;        /* 1 = caller memory was pageable and went through the pinned staging ring          */
 } msm_timings_t;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
@@ -158,6 +163,41 @@ int32_t msm_bn254_g1_device(msm_ctx *ctx, const void *d_bases_mont, const void *
 int32_t msm_bn254_g1_combine(const uint32_t *partials_jacobian_mont, size_t k, uint32_t out_jacobian_mont[24],
                              uint32_t out_affine_std[16], uint8_t *out_is_inf);
 
+/* ---- multi-GPU inside ONE process (the reference has no multi-device code: host/gpu.rs:3-5 opens the
+ *      system default device).  The caller-facing signature is the same as the single-GPU calls; the point range is cut
+ *      into `ndev` contiguous shards, device g pulls ITS OWN shard over its own PCIe link (one host thread + one context
+ *      per device), runs the whole single-GPU pipeline on it, and the 96-byte partial group elements are exchanged:
+ *        MSM_MULTI_EXCHANGE_RCCL  ncclAllGather of 24 words per rank over RCCL/xGMI (librccl is dlopen'ed: no link-time
+ *                                 dependency), every rank folds in rank order, rank 0's bits are returned;
+ *        MSM_MULTI_EXCHANGE_HOST  the partials already sit in pinned host memory: the calling thread folds them.
+ *      AUTO picks RCCL when librccl loads, ndev > 1 and the device list has no duplicates, HOST otherwise.  Identical bits
+ *      either way (fixed rank order).  A device may be listed more than once (tests on a 1-GPU box: {0, 0}). ---------- */
+#define MSM_MULTI_EXCHANGE_AUTO 0u
+#define MSM_MULTI_EXCHANGE_RCCL 1u
+#define MSM_MULTI_EXCHANGE_HOST 2u
+typedef struct msm_multi msm_multi;
+/* devices == NULL: all visible devices (ndev ignored), or the comma-separated list in MSM_HIP_DEVICES.
+ * cfg->device is ignored; the other fields apply to every per-device context.  NULL cfg = defaults. */
+int32_t msm_multi_create(const int32_t *devices, int32_t ndev, const msm_config_t *cfg, uint32_t exchange, msm_multi **out);
+void msm_multi_destroy(msm_multi *m);
+const char *msm_multi_last_error(const msm_multi *m); /* m == NULL: last failed msm_multi_create on this thread */
+int32_t msm_multi_num_devices(const msm_multi *m);
+uint32_t msm_multi_exchange(const msm_multi *m);      /* MSM_MULTI_EXCHANGE_RCCL or _HOST: what the calls really use */
+/* same arguments and semantics as msm_bn254_g1 / msm_bn254_g1_arkworks, host pointers */
+int32_t msm_bn254_g1_multi(msm_multi *m, const uint32_t *bases_xy, uint32_t base_form, const uint8_t *inf_mask,
+                           const uint32_t *scalars, size_t n, uint32_t out_jacobian_mont[24],
+                           uint32_t out_affine_std[16], uint8_t *out_is_inf);
+int32_t msm_bn254_g1_multi_arkworks(msm_multi *m, const void *bases, size_t stride, size_t x_off, size_t y_off,
+                                    size_t inf_off, const uint32_t *scalars_mont, size_t n,
+                                    uint32_t out_jacobian_mont[24], uint32_t out_affine_std[16], uint8_t *out_is_inf);
+/* shards already resident: d_bases_mont[g] / d_scalars[g] / d_inf_masks[g] (nullable array, nullable entries) are device
+ * pointers on device g holding n_per_dev[g] points (as for msm_bn254_g1_device); entries with n_per_dev[g] == 0 are skipped */
+int32_t msm_bn254_g1_multi_device(msm_multi *m, const void *const *d_bases_mont, const void *const *d_inf_masks,
+                                  const void *const *d_scalars, const size_t *n_per_dev,
+                                  uint32_t out_jacobian_mont[24], uint32_t out_affine_std[16], uint8_t *out_is_inf);
+/* timings of device g's part of the last call */
+int32_t msm_multi_get_timings(const msm_multi *m, int32_t g, msm_timings_t *out);
+
 /* ---- introspection --------------------------------------------------------------------------- */
 int32_t msm_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_plan_t *out);
 int32_t msm_get_timings(const msm_ctx *ctx, msm_timings_t *out);
@@ -168,39 +208,6 @@ int32_t msm_set_stage_timing(msm_ctx *ctx, int32_t enabled);
  * hipEvents on the stream the kernel runs on; *launches receives the count */
 int32_t msm_get_accumulate_kernel_stats(const msm_ctx *ctx, double *avg_ms, uint64_t *launches);
 void msm_reset_kernel_stats(msm_ctx *ctx);
-
-/* ---- synthetic inputs: counterpart of test_utils::generate_random_bases_and_scalars
- *      (metal_msm.rs:698-731).  Base i is k_i*G with k_i = SplitMix64 stream (seed, i) reduced below r,
- *      scalar i likewise from scalar_seed; both written to DEVICE memory (Montgomery bases). ------- */
-int32_t msm_bn254_g1_generate_device(msm_ctx *ctx, uint64_t base_seed, uint64_t scalar_seed, size_t n,
-                                     void *d_bases_mont_out, void *d_scalars_out);
-/* the same k_i / s_i streams on the host (8 words each), for closed-form checks */
-int32_t msm_bn254_generate_scalars_host(uint64_t seed, size_t n, int nonzero, uint32_t *out);
-
-/* ---- device-math unit-test hooks: counterpart of the reference's test_* kernels (SURVEY C10,
- *      e.g. mont_mul_cios.metal:8-15, jacobian_add_2007_bl.metal:8-40).  Host arrays in/out. ------ */
-#define MSM_OP_FP_ADD 0u
-#define MSM_OP_FP_SUB 1u
-#define MSM_OP_FP_MONT_MUL 2u
-#define MSM_OP_FP_TO_MONT 3u
-#define MSM_OP_FP_FROM_MONT 4u
-#define MSM_OP_FP_INV 5u
-int32_t msm_test_fp_op(msm_ctx *ctx, uint32_t op, const uint32_t *a, const uint32_t *b, uint32_t *out, size_t n);
-#define MSM_OP_G1_MADD 0u /* a: Jacobian(24) + b: affine Montgomery(16) -> Jacobian(24) */
-#define MSM_OP_G1_ADD 1u  /* a: Jacobian(24) + b: Jacobian(24)          -> Jacobian(24) */
-#define MSM_OP_G1_DBL 2u  /* a: Jacobian(24)                            -> Jacobian(24) */
-#define MSM_OP_G1_ADD_WIDE 3u /* as ADD, computed by 8 cooperating lanes (csrc/ec_wide.hpp, the reduction-tree path) */
-int32_t msm_test_g1_op(msm_ctx *ctx, uint32_t op, const uint32_t *a, const uint32_t *b, uint32_t *out, size_t n);
-/* signed/unsigned digit decomposition of the planner's choice, digits[w*n + i] as int32 */
-int32_t msm_test_decompose(msm_ctx *ctx, const uint32_t *scalars, size_t n, uint32_t window_bits, int32_t *digits);
-
-/* ---- integer-multiplier calibration --------------------------------------------
- * Runs two saturating micro-kernels on the context's device (4 wavefronts per SIMD, dependent chains, ~1 ms each) and
- * reports what THIS device sustains, per second over the whole chip, lane level:
- *   *mad_per_s     v_mad_u64_u32 operations (the instruction the field multiplication is made of)
- *   *fp_mul_per_s  9 x 29-bit Montgomery multiplications (fp_mul of csrc/fp_bn254.hpp, 171 multiplier instructions each)
- * bench.py prices k_accumulate against these instead of a datasheet figure. */
-int32_t msm_calibrate(msm_ctx *ctx, double *mad_per_s, double *fp_mul_per_s);
 
 #ifdef __cplusplus
 }

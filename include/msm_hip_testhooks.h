@@ -1,0 +1,69 @@
+/*
+ * msm_hip_testhooks.h -- test, benchmark and calibration hooks of the MI355X BN254 G1 MSM engine.
+ *
+ * NOT part of the product ABI: these symbols exist only in libmsm_hip_hooks.so, a second build of the same sources with
+ * -DMSM_HIP_TEST_HOOKS (make -C gpu-acceleration_amd/csrc hooks).  That library also contains the complete engine
+ * (include/msm_hip.h), so a hooks context runs exactly the kernels the product runs.  Users: tests/, bench.py (input
+ * generation, multiplier calibration), tools/.
+ */
+#ifndef MSM_HIP_TESTHOOKS_H
+#define MSM_HIP_TESTHOOKS_H
+#include "msm_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- synthetic inputs: counterpart of test_utils::generate_random_bases_and_scalars
+ *      (metal_msm.rs:698-731).  Base i is k_i*G with k_i = SplitMix64 stream (seed, i) reduced below r,
+ *      scalar i likewise from scalar_seed; both written to DEVICE memory (Montgomery bases). ------- */
+int32_t msm_bn254_g1_generate_device(msm_ctx *ctx, uint64_t base_seed, uint64_t scalar_seed, size_t n,
+                                     void *d_bases_mont_out, void *d_scalars_out);
+/* the same k_i / s_i streams on the host (8 words each), for closed-form checks */
+int32_t msm_bn254_generate_scalars_host(uint64_t seed, size_t n, int nonzero, uint32_t *out);
+
+/* ---- device-math unit-test hooks: counterpart of the reference's test_* kernels (SURVEY C10,
+ *      e.g. mont_mul_cios.metal:8-15, jacobian_add_2007_bl.metal:8-40).  Host arrays in/out. ------ */
+#define MSM_OP_FP_ADD 0u
+#define MSM_OP_FP_SUB 1u
+#define MSM_OP_FP_MONT_MUL 2u
+#define MSM_OP_FP_TO_MONT 3u
+#define MSM_OP_FP_FROM_MONT 4u
+#define MSM_OP_FP_INV 5u
+int32_t msm_test_fp_op(msm_ctx *ctx, uint32_t op, const uint32_t *a, const uint32_t *b, uint32_t *out, size_t n);
+#define MSM_OP_G1_MADD 0u /* a: Jacobian(24) + b: affine Montgomery(16) -> Jacobian(24) */
+#define MSM_OP_G1_ADD 1u  /* a: Jacobian(24) + b: Jacobian(24)          -> Jacobian(24) */
+#define MSM_OP_G1_DBL 2u  /* a: Jacobian(24)                            -> Jacobian(24) */
+#define MSM_OP_G1_ADD_WIDE 3u /* as ADD, computed by 8 cooperating lanes (csrc/ec_wide.hpp, the reduction-tree path) */
+int32_t msm_test_g1_op(msm_ctx *ctx, uint32_t op, const uint32_t *a, const uint32_t *b, uint32_t *out, size_t n);
+/* signed/unsigned digit decomposition of the planner's choice, digits[w*n + i] as int32 */
+int32_t msm_test_decompose(msm_ctx *ctx, const uint32_t *scalars, size_t n, uint32_t window_bits, int32_t *digits);
+
+/* ---- integer-multiplier calibration --------------------------------------------
+ * Runs two saturating micro-kernels on the context's device (4 wavefronts per SIMD, dependent chains, ~1 ms each) and
+ * reports what THIS device sustains, per second over the whole chip, lane level:
+ *   *mad_per_s     v_mad_u64_u32 operations (the instruction the field multiplication is made of)
+ *   *fp_mul_per_s  9 x 29-bit Montgomery multiplications (fp_mul of csrc/fp_bn254.hpp, 171 multiplier instructions each)
+ * bench.py prices k_accumulate against these instead of a datasheet figure. */
+int32_t msm_calibrate(msm_ctx *ctx, double *mad_per_s, double *fp_mul_per_s);
+
+/* ---- stage-level parity (counterpart of the reference's per-kernel tests: tests/cuzk/transpose.rs:6-118,
+ *      smvp.rs:119-303, pbpr.rs:26-247).  Runs the whole pipeline once on host inputs (as msm_bn254_g1, single shot) and
+ *      copies the intermediates of every stage back.  All output pointers are nullable; sizes follow msm_plan(n, ...)
+ *      with W = num_windows, nb = num_buckets, nv = virtual_points, kb = log2(nb):
+ *        digits      W x nv     bucket index | negate << 31, 0xFFFFFFFF = skipped (zero digit / base at infinity)
+ *        offsets     W*nb + 1   exclusive prefix of the bucket sizes (CSC column pointer)
+ *        sorted      W x nv     first offsets[W*nb] entries valid: virtual point index | negate << 31, grouped by bucket
+ *        buckets     W*nb x 24  bucket sums, Jacobian Montgomery words (bucket b of window w holds the digit magnitude b + 1)
+ *        bit_sums    W x (kb+1) x 24   Q_{w,u} (u < kb: buckets whose index has bit u set) and Q_{w,kb} = all buckets
+ *      sort_path (nullable) receives 2 = two-level LDS sort, 1 = tiled LDS histogram, 0 = global-atomic fallback;
+ *      big_items (nullable) the number of (region, batch) items of oversized sort regions handed to k_big_place. */
+int32_t msm_test_stage_dump(msm_ctx *ctx, const uint32_t *bases_xy, uint32_t base_form, const uint8_t *inf_mask,
+                            const uint32_t *scalars, size_t n, uint32_t *digits, uint32_t *offsets, uint32_t *sorted,
+                            uint32_t *buckets_jacobian_mont, uint32_t *bit_sums_jacobian_mont, uint32_t *sort_path,
+                            uint32_t *big_items, uint32_t out_jacobian_mont[24]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSM_HIP_TESTHOOKS_H */

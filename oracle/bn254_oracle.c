@@ -552,6 +552,54 @@ int oracle_msm_cuzk(const uint32_t *bases, uint32_t form, const uint8_t *inf, co
     return 0;
 }
 
+/* ---- stage mirrors for the stage-level GPU tests (counterparts of tests/cuzk/smvp.rs:119-303 and pbpr.rs:26-247) ---------
+ * digits: W x n signed digits (int32, window-major).  Bucket b of window w collects the points whose digit has MAGNITUDE b + 1,
+ * negated when the digit is negative: the SMVP sign folding of smvp.metal:46-105 with the engine's index convention (the
+ * reference keeps magnitude t in slot t and magnitude H in slot 0).  out: W*nb Jacobian Montgomery points. */
+int oracle_bucket_sums(const uint32_t *bases, uint32_t form, const uint8_t *inf, const int32_t *digits, size_t n, uint32_t W,
+                       uint32_t nb, uint32_t *out_jac) {
+    if (!bases || !digits || !out_jac || n == 0) return -1;
+    aff *b = load_bases(bases, form, inf, n);
+    if (!b) return -2;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int w = 0; w < (int)W; w++) {
+        jac *bk = (jac *)malloc(sizeof(jac) * nb);
+        for (uint32_t t = 0; t < nb; t++) jac_set_inf(&bk[t]);
+        for (size_t i = 0; i < n; i++) {
+            int32_t d = digits[(size_t)w * n + i];
+            if (d == 0 || b[i].inf) continue;
+            uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+            if (mag > nb) continue; /* caller error: left out so that the comparison fails */
+            aff q = b[i];
+            if (d < 0) aff_neg(&q, &q);
+            jac_madd(&bk[mag - 1], &bk[mag - 1], &q);
+        }
+        for (uint32_t t = 0; t < nb; t++) jac_store(out_jac + ((size_t)w * nb + t) * 24, &bk[t]);
+        free(bk);
+    }
+    free(b);
+    return 0;
+}
+/* The weights of the bucket reduction pushed to bit sums (what the engine's reduction produces instead of the running sums
+ * of pbpr.metal:33-148): Q[w][u] = sum of the buckets whose index has bit u set (u < kb), Q[w][kb] = sum of all buckets, so
+ * that sum_b (b+1)*B[w][b] = Q[w][kb] + sum_u 2^u Q[w][u].  buckets: W*nb Jacobian points; out: W*(kb+1). */
+int oracle_bit_sums(const uint32_t *buckets_jac, uint32_t W, uint32_t nb, uint32_t kb, uint32_t *out_jac) {
+    if (!buckets_jac || !out_jac) return -1;
+    for (uint32_t w = 0; w < W; w++)
+        for (uint32_t u = 0; u <= kb; u++) {
+            jac acc;
+            jac_set_inf(&acc);
+            for (uint32_t t = 0; t < nb; t++) {
+                if (u < kb && !((t >> u) & 1u)) continue;
+                jac q;
+                jac_load(&q, buckets_jac + ((size_t)w * nb + t) * 24);
+                jac_add(&acc, &acc, &q);
+            }
+            jac_store(out_jac + ((size_t)w * (kb + 1) + u) * 24, &acc);
+        }
+    return 0;
+}
+
 /* ------------------------------------------------------ synthetic inputs --- */
 static inline uint64_t splitmix64(uint64_t *st) {
     uint64_t z = (*st += 0x9E3779B97F4A7C15ULL);

@@ -92,6 +92,12 @@ void oracle_decompose_signed(const uint32_t *scalars, size_t n, uint32_t window_
 void oracle_transpose(const uint32_t *chunks, size_t n, uint32_t num_windows, uint32_t num_cols,
                       uint32_t *col_ptr, uint32_t *val_idxs);
 
+/* bucket sums from signed digits (SMVP sign folding, smvp.metal:46-105; bucket b = digit magnitude b + 1) and the bit sums of
+ * the buckets (the plain sums the engine's reduction forms instead of pbpr.metal:33-148's running sums); Jacobian Montgomery */
+int oracle_bucket_sums(const uint32_t *bases, uint32_t form, const uint8_t *inf, const int32_t *digits, size_t n, uint32_t W,
+                       uint32_t nb, uint32_t *out_jac);
+int oracle_bit_sums(const uint32_t *buckets_jac, uint32_t W, uint32_t nb, uint32_t kb, uint32_t *out_jac);
+
 /* ---- deterministic synthetic inputs (SplitMix64), used by tests ----------- */
 /* k[i] uniform in [1, r), 8 words each */
 void oracle_gen_scalars(uint64_t seed, size_t n, int nonzero, uint32_t *out);

@@ -43,6 +43,10 @@ def lib():
         L.oracle_num_windows.restype = C.c_uint32
         L.oracle_decompose_signed.argtypes = [_u32p, C.c_size_t, C.c_uint32, _u32p]
         L.oracle_transpose.argtypes = [_u32p, C.c_size_t, C.c_uint32, C.c_uint32, _u32p, _u32p]
+        L.oracle_bucket_sums.argtypes = [_u32p, C.c_uint32, _u8p, C.POINTER(C.c_int32), C.c_size_t, C.c_uint32, C.c_uint32, _u32p]
+        L.oracle_bucket_sums.restype = C.c_int
+        L.oracle_bit_sums.argtypes = [_u32p, C.c_uint32, C.c_uint32, C.c_uint32, _u32p]
+        L.oracle_bit_sums.restype = C.c_int
         L.oracle_gen_scalars.argtypes = [C.c_uint64, C.c_size_t, C.c_int, _u32p]
         L.oracle_gen_bases_from_logs.argtypes = [_u32p, C.c_size_t, C.c_uint32, _u32p]
         L.oracle_g1_to_affine_std.restype = C.c_int
@@ -185,6 +189,32 @@ def transpose(chunks, num_cols):
     val = np.zeros((W, n), np.uint32)
     lib().oracle_transpose(_p32(chunks), n, W, num_cols, _p32(col_ptr), _p32(val))
     return col_ptr, val
+
+
+def bucket_sums(bases, digits, nb, form=FORM_STD, inf=None):
+    """digits: (W, n) signed ints -> (W*nb, 24) Jacobian bucket sums (bucket b = magnitude b + 1)"""
+    bases = _w(bases).reshape(-1, 16)
+    d = np.ascontiguousarray(digits, dtype=np.int32)
+    W, n = d.shape
+    out = np.zeros((W * nb, 24), np.uint32)
+    ip = None
+    if inf is not None:
+        inf = np.ascontiguousarray(inf, dtype=np.uint8)
+        ip = inf.ctypes.data_as(_u8p)
+    rc = lib().oracle_bucket_sums(_p32(bases), form, ip, d.ctypes.data_as(C.POINTER(C.c_int32)), n, W, nb, _p32(out))
+    if rc != 0:
+        raise RuntimeError(f"oracle_bucket_sums failed rc={rc}")
+    return out
+
+
+def bit_sums(buckets_jac, W, nb):
+    kb = nb.bit_length() - 1
+    b = _w(buckets_jac).reshape(W * nb, 24)
+    out = np.zeros((W, kb + 1, 24), np.uint32)
+    rc = lib().oracle_bit_sums(_p32(b), W, nb, kb, _p32(out))
+    if rc != 0:
+        raise RuntimeError(f"oracle_bit_sums failed rc={rc}")
+    return out
 
 
 # ---- synthetic inputs ----------------------------------------------------------

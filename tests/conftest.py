@@ -19,8 +19,9 @@ def pytest_sessionstart(session):
     """The built libraries are git-ignored; build them in-tree when a fresh checkout lacks them (hipcc cross-compiles
     gfx950 without a GPU).  The product library is never replaced by anything else: no build => tests fail loudly."""
     import subprocess
-    if not os.path.exists(os.path.join(ROOT, "gpu-acceleration_amd", "libmsm_hip.so")):
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "gpu-acceleration_amd", "csrc")])
+    pkg = os.path.join(ROOT, "gpu-acceleration_amd")
+    if not (os.path.exists(os.path.join(pkg, "libmsm_hip.so")) and os.path.exists(os.path.join(pkg, "libmsm_hip_hooks.so"))):
+        subprocess.check_call(["make", "-s", "-j2", "-C", os.path.join(pkg, "csrc")])  # product + hooks build
     if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle_bn254.so")):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
 

@@ -1,0 +1,58 @@
+"""Worker of tests/test_gpu_configs.py::test_two_ranks_on_one_gpu (launched by torch.distributed.run, 2 processes, both on
+cuda:0, exchange over gloo): rank r generates and runs its point range of one 2^18-point instance through
+distributed_msm_device, then EVERY rank checks its own bits against the closed form and prints one JSON line."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "gpu-acceleration_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    import mopro_msm_hip as mh
+    from mopro_msm_hip import distributed as md
+    from mopro_msm_hip import testhooks as th
+    from oracle import bn254_oracle as orc
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo")
+    torch.cuda.set_device(0)
+    n_total = 1 << 18
+    lo, hi = md.shard_range(n_total, rank, world)
+    n = hi - lo
+    mul, mask = 0xD1342543DE82EF95, (1 << 64) - 1
+    bs, ss = (0xB2540091 + lo * mul) & mask, (0xB2540092 + lo * mul) & mask
+    d_b = torch.empty(n * 16, dtype=torch.int32, device="cuda:0")
+    d_s = torch.empty(n * 8, dtype=torch.int32, device="cuda:0")
+    with th.HooksContext(device=0) as gen:
+        gen.generate_device(bs, ss, n, d_b.data_ptr(), d_s.data_ptr())
+    torch.cuda.synchronize()
+    with mh.MsmContext(device=0) as ctx:
+        res = None
+        for _ in range(3):
+            res = md.distributed_msm_device(ctx, d_b.data_ptr(), d_s.data_ptr(), n, device=None)
+    k = th.generate_scalars_host(bs, n, nonzero=True)
+    s = th.generate_scalars_host(ss, n)
+    to_int = lambda a: [sum(int(w) << (32 * j) for j, w in enumerate(row)) for row in a.tolist()]
+    dot = sum(a * b for a, b in zip(to_int(k), to_int(s)))
+    dots = [None] * world
+    dist.all_gather_object(dots, dot)
+    g = np.zeros(16, np.uint32)
+    g[0], g[8] = 1, 2
+    exp, einf = orc.g1_to_affine_std(orc.g1_scalar_mul(g, orc.int_to_words(sum(dots) % orc.R_ORDER)))
+    ok = bool((res.affine_std == exp).all()) and not res.is_infinity
+    print(json.dumps({"rank": rank, "ok": ok, "affine": res.affine_std.tolist()}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()

@@ -8,12 +8,13 @@ import numpy as np
 import pytest
 
 import mopro_msm_hip as mh
+from mopro_msm_hip import testhooks as th
 from conftest import ROOT, load_golden
 from oracle import bn254_oracle as orc
 
 
-def header_symbols():
-    txt = open(os.path.join(ROOT, "include", "msm_hip.h")).read()
+def header_symbols(name="msm_hip.h"):
+    txt = open(os.path.join(ROOT, "include", name)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(msm_[a-z0-9_]+)\s*\(", txt)))
 
@@ -25,7 +26,20 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/msm_hip.h but not exported"
     assert sorted(mh.ABI_SYMBOLS) == syms
-    assert lib.msm_abi_version() == 1
+    assert lib.msm_abi_version() == 2
+
+
+def test_hooks_live_in_their_own_library():
+    """include/msm_hip_testhooks.h: exported by libmsm_hip_hooks.so (which also carries the whole product ABI), by the product
+    library not at all"""
+    prod, hooks = mh.load_library(), th.load_hooks_library()
+    hs = header_symbols("msm_hip_testhooks.h")
+    assert sorted(th.HOOK_SYMBOLS) == hs and len(hs) >= 7
+    for s in hs:
+        assert hasattr(hooks, s), f"{s} declared in include/msm_hip_testhooks.h but not exported by the hooks build"
+        assert not hasattr(prod, s), f"{s} is a test hook and must not be exported by the product library"
+    for s in header_symbols():
+        assert hasattr(hooks, s)
 
 
 def test_planner_matches_design():
@@ -82,10 +96,10 @@ def test_combine_partials_host_arithmetic():
 
 
 def test_host_scalar_stream_matches_oracle_stream():
-    a = mh.generate_scalars_host(0xB2540002, 257)
+    a = th.generate_scalars_host(0xB2540002, 257)
     b = orc.gen_scalars(0xB2540002, 257)
     assert (a == b).all()
-    a = mh.generate_scalars_host(0xB2540001, 33, nonzero=True)
+    a = th.generate_scalars_host(0xB2540001, 33, nonzero=True)
     assert (a == orc.gen_scalars(0xB2540001, 33, nonzero=True)).all()
     assert all(orc.words_to_int(x) < orc.R_ORDER for x in a)
 

@@ -1,0 +1,297 @@
+"""GPU tests (-m gpu) of the BASELINE.json configurations at their FULL per-GPU sizes and of the host-side paths around the
+pipeline, by size-independent properties (closed form (sum s_i k_i mod r) * G on synthetic bases k_i * G):
+
+  config 2  N = 2^16, fixed 16-bit window, plain digits, unsplit           test_config2_literal_shape
+  config 4  2^24 over 8 GPUs = 2^21 points per GPU                          test_shard_sizes_of_configs_4_and_5[21]
+  config 5  2^26 over 8 GPUs = 2^23 points per GPU, streamed                test_shard_sizes_of_configs_4_and_5[23],
+                                                                            test_automatic_streaming_* (host->HBM chunks)
+  N > 1     two ranks on ONE GPU through torch.distributed (gloo)           test_two_ranks_on_one_gpu
+            two/three shards in ONE process through msm_multi              test_multi_*
+  f1        msm_bn254_g1_arkworks at 2^20 with the (72, 0, 32, 64) layout  test_arkworks_entry_at_2_pow_20
+Mirrors the reference's e2e test shape (tests/cuzk/e2e.rs:14-63: random instance, compare with the CPU result)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import mopro_msm_hip as mh
+from mopro_msm_hip import testhooks as th
+from conftest import ROOT, golden_cases, load_golden
+from oracle import bn254_oracle as orc
+
+pytestmark = pytest.mark.gpu
+R = orc.R_ORDER
+
+
+def _ints(words):
+    a = np.ascontiguousarray(words, dtype=np.uint32).reshape(-1, 8)
+    cols = [a[:, j].tolist() for j in range(8)]
+    out = []
+    for i in range(a.shape[0]):
+        v = 0
+        for j in range(7, -1, -1):
+            v = (v << 32) | cols[j][i]
+        out.append(v)
+    return out
+
+
+def _expected(dot):
+    g = np.zeros(16, np.uint32)
+    g[0], g[8] = 1, 2
+    return orc.g1_to_affine_std(orc.g1_scalar_mul(g, orc.int_to_words(dot % R)))
+
+
+class Instance:
+    """synthetic instance in HBM (bases k_i*G as Montgomery words, scalars s_i) + the host-side logs for the closed form"""
+
+    def __init__(self, hk, logn, seed=0xB2540031):
+        import torch
+        self.n = n = 1 << logn
+        self.d_b = torch.empty(n * 16, dtype=torch.int32, device="cuda:0")
+        self.d_s = torch.empty(n * 8, dtype=torch.int32, device="cuda:0")
+        hk.generate_device(seed, seed + 1, n, self.d_b.data_ptr(), self.d_s.data_ptr())
+        torch.cuda.synchronize()
+        self.k = _ints(th.generate_scalars_host(seed, n, nonzero=True))
+        self.s = _ints(th.generate_scalars_host(seed + 1, n))
+
+    def dot(self, lo=0, hi=None, skip=None):
+        hi = self.n if hi is None else hi
+        if skip is None:
+            return sum(a * b for a, b in zip(self.k[lo:hi], self.s[lo:hi]))
+        return sum(a * b for i, (a, b) in enumerate(zip(self.k[lo:hi], self.s[lo:hi])) if not skip[lo + i])
+
+
+@pytest.fixture(scope="module")
+def hk():
+    c = th.HooksContext()
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = mh.MsmContext()
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def inst20(hk):
+    return Instance(hk, 20)
+
+
+@pytest.mark.parametrize("logn", [21, 23])
+def test_shard_sizes_of_configs_4_and_5(ctx, hk, logn):
+    """the per-GPU shards of BASELINE config 4 (2^24 / 8) and config 5 (2^26 / 8), resident, closed form + a point-range split"""
+    it = Instance(hk, logn, seed=0xB2540041 + logn)
+    r = ctx.msm_device(it.d_b.data_ptr(), it.d_s.data_ptr(), it.n)
+    exp, einf = _expected(it.dot())
+    assert not r.is_infinity and einf == 0 and (r.affine_std == exp).all()
+    assert mh.plan(it.n).glv == 0 and mh.plan(it.n).window_bits == 16
+    h = it.n // 2 + 12345  # uneven split: the two halves of a 2-GPU run of twice the size
+    p0 = ctx.msm_device(it.d_b.data_ptr(), it.d_s.data_ptr(), h)
+    p1 = ctx.msm_device(it.d_b.data_ptr() + h * 64, it.d_s.data_ptr() + h * 32, it.n - h)
+    assert (mh.combine_partials(np.stack([p0.jacobian_mont, p1.jacobian_mont])).affine_std == exp).all()
+
+
+def test_config2_literal_shape(hk):
+    """BASELINE config 2 as literally stated: N = 2^16, fixed 16-bit window, plain (unsigned) digits, no GLV split --
+    W = 16 windows of 65536 buckets"""
+    it = Instance(hk, 16, seed=0xB2540051)
+    flags = mh.FLAG_UNSIGNED_DIGITS | mh.FLAG_NO_GLV
+    p = mh.plan(it.n, 16, flags)
+    assert (p.window_bits, p.num_windows, p.num_buckets, p.signed_digits, p.glv) == (16, 16, 65536, 0, 0)
+    exp, _ = _expected(it.dot())
+    with mh.MsmContext(window_bits=16, flags=flags) as c:
+        for _ in range(2):
+            r = c.msm_device(it.d_b.data_ptr(), it.d_s.data_ptr(), it.n)
+            assert (r.affine_std == exp).all() and not r.is_infinity
+    # and with the planner's own choice
+    with mh.MsmContext() as c:
+        assert (c.msm_device(it.d_b.data_ptr(), it.d_s.data_ptr(), it.n).affine_std == exp).all()
+
+
+def test_automatic_streaming_pinned_and_pageable_at_2_pow_22(hk):
+    """config 5's mechanism with the DEFAULT configuration (stream_chunk_log2 = 0): from 2^19 points on a host-pointer call is cut
+    into chunks that travel while the previous chunk is accumulated INTO the shared buckets.  Pinned caller memory is read by the
+    copy engine directly, pageable memory goes through the pinned staging ring; MSM_HIP_STAGE=0 leaves pageable copies to the
+    runtime.  Same bits every way."""
+    import torch
+    it = Instance(hk, 22, seed=0xB2540061)
+    exp, _ = _expected(it.dot())
+    hb_t, hs_t = it.d_b.cpu(), it.d_s.cpu()
+    hb = hb_t.numpy().view(np.uint32).reshape(it.n, 16)
+    hs = hs_t.numpy().view(np.uint32).reshape(it.n, 8)
+    hbp, hsp = hb_t.pin_memory(), hs_t.pin_memory()
+    with mh.MsmContext() as c:
+        r = c.msm(hbp.numpy().view(np.uint32).reshape(it.n, 16), hsp.numpy().view(np.uint32).reshape(it.n, 8), mh.FORM_MONT)
+        tm = c.timings()
+        assert (r.affine_std == exp).all() and tm["stream_chunks"] >= 4 and tm["staged"] == 0 and tm["num_points"] == it.n
+        assert tm["num_adds"] > 15 * it.n  # the running count covers every chunk (16 windows, ~1 - 2^-16 non-zero digits)
+        r = c.msm(hb, hs, mh.FORM_MONT)  # pageable numpy memory
+        tm = c.timings()
+        assert (r.affine_std == exp).all() and tm["stream_chunks"] >= 4 and tm["staged"] == 1
+        # a ragged size: the last chunk is shorter
+        m = it.n - 77777
+        e2, _ = _expected(it.dot(0, m))
+        r = c.msm(hb[:m], hs[:m], mh.FORM_MONT)
+        assert (r.affine_std == e2).all() and c.timings()["stream_chunks"] >= 4
+        # below the streaming threshold: single shot (bases travel on the copy stream beside the sort)
+        m = 1 << 18
+        e3, _ = _expected(it.dot(0, m))
+        r = c.msm(hb[:m], hs[:m], mh.FORM_MONT)
+        assert (r.affine_std == e3).all() and c.timings()["stream_chunks"] == 0
+    os.environ["MSM_HIP_STAGE"] = "0"
+    try:
+        with mh.MsmContext() as c:
+            r = c.msm(hb, hs, mh.FORM_MONT)
+            assert (r.affine_std == exp).all() and c.timings()["staged"] == 0
+    finally:
+        del os.environ["MSM_HIP_STAGE"]
+
+
+def test_streamed_shared_buckets_small_chunks(hk):
+    """forced tiny chunks: GLV plan of the whole instance shared by all chunks, infinity masks, the staged (pageable) ring with
+    pieces smaller and larger than a chunk, a scalar error in a late chunk"""
+    n = 1 << 17
+    k = orc.gen_scalars(0xB2540071, n, nonzero=True)
+    s = orc.gen_scalars(0xB2540072, n)
+    bases = orc.gen_bases_from_logs(k, orc.FORM_MONT)
+    inf = np.zeros(n, np.uint8)
+    inf[[0, 5, 40000, n - 1]] = 1
+    kk, ss = _ints(k), _ints(s)
+    exp, _ = _expected(sum(a * b for i, (a, b) in enumerate(zip(kk, ss)) if not inf[i]))
+    for lg in (12, 15):
+        with mh.MsmContext(stream_chunk_log2=lg) as c:
+            r = c.msm(bases, s, mh.FORM_MONT, inf)
+            tm = c.timings()
+            assert (r.affine_std == exp).all(), lg
+            assert tm["stream_chunks"] == n >> lg and tm["staged"] == 1
+            assert mh.plan(n).glv == 1  # 2n virtual points per chunk, one bucket array
+            bad = s.copy()
+            bad[n - 3, 7] |= 0x40000000
+            with pytest.raises(mh.MsmError) as e:
+                c.msm(bases, bad, mh.FORM_MONT, inf)
+            assert e.value.code == mh.ERR_BAD_ARG
+            r = c.msm(bases, s, mh.FORM_MONT, inf)  # the context recovers
+            assert (r.affine_std == exp).all()
+    with mh.MsmContext(stream_chunk_log2=13, flags=mh.FLAG_NO_GLV, window_bits=13) as c:
+        assert (c.msm(bases, s, mh.FORM_MONT, inf).affine_std == exp).all()
+
+
+def _ark_image(hb, stride=72, x_off=0, y_off=32, inf_off=64, inf=None):
+    n = hb.shape[0]
+    img = np.zeros((n, stride), np.uint8)
+    raw = hb.view(np.uint8).reshape(n, 64)
+    img[:, x_off:x_off + 32] = raw[:, :32]
+    img[:, y_off:y_off + 32] = raw[:, 32:]
+    if inf is not None and inf_off is not None:
+        img[:, inf_off] = inf
+    return img
+
+
+def test_arkworks_entry_at_2_pow_20(ctx, inst20):
+    """msm_bn254_g1_arkworks at the BASELINE size with arkworks' real layout shape (72-byte G1Affine: x, y, infinity), a few
+    infinity flags, Fr words in Montgomery form.  The scalar words are taken AS Montgomery words, i.e. the scalars are
+    s_i * 2^-256 mod r: by linearity the expected point is (2^-256 * sum s_i k_i) * G.  Streamed (>= 2^19 points) and,
+    on a 2^18 prefix, single shot."""
+    it = inst20
+    hb = it.d_b.cpu().numpy().view(np.uint32).reshape(it.n, 16)
+    hs = it.d_s.cpu().numpy().view(np.uint32).reshape(it.n, 8)
+    inf = np.zeros(it.n, np.uint8)
+    inf[[1, 77, 300000, it.n - 1]] = 1
+    img = _ark_image(hb, inf=inf)
+    rinv = pow(1 << 256, -1, R)
+    exp, _ = _expected(it.dot(skip=inf) * rinv)
+    r = ctx.msm_arkworks(img, 72, 0, 32, 64, hs)
+    assert (r.affine_std == exp).all() and ctx.timings()["stream_chunks"] >= 2
+    m = 1 << 18
+    e2, _ = _expected(it.dot(0, m, skip=inf) * rinv)
+    r = ctx.msm_arkworks(img[:m], 72, 0, 32, 64, hs[:m])
+    assert (r.affine_std == e2).all() and ctx.timings()["stream_chunks"] == 0
+
+
+def test_resident_set_survives_other_calls(ctx, inst20):
+    """upload_bases -> msm_device on OTHER bases -> msm_resident must still use the uploaded set (the resident bases
+    live in their own buffers; device / host calls use scratch)"""
+    it = inst20
+    n = 1 << 16
+    k = orc.gen_scalars(0xB2540081, n, nonzero=True)
+    s = orc.gen_scalars(0xB2540082, n)
+    bases = orc.gen_bases_from_logs(k, orc.FORM_MONT)
+    exp, _ = orc.closed_form_expected(k, s)
+    ctx.upload_bases(bases, mh.FORM_MONT)
+    assert (ctx.msm_resident(s).affine_std == exp).all()
+    ctx.msm_device(it.d_b.data_ptr(), it.d_s.data_ptr(), it.n)                      # other bases, larger
+    ctx.msm_device(it.d_b.data_ptr() + 64 * 999, it.d_s.data_ptr(), n)              # other bases, same size (GLV scratch)
+    g = load_golden("rand_n1024")
+    ctx.msm(g["bases"], g["scalars"], mh.FORM_STD, g["inf"])                          # host call with an infinity mask
+    assert (ctx.msm_resident(s).affine_std == exp).all()
+    e2, _ = orc.closed_form_expected(k[:5000], s[:5000])
+    assert (ctx.msm_resident(s[:5000]).affine_std == e2).all()
+
+
+# ---- N > 1 -------------------------------------------------------------------------------------------------------------------
+def test_multi_in_process_on_one_gpu(hk, inst20):
+    """msm_multi (include/msm_hip.h "multi-GPU"): one context + host thread per listed device.  On a 1-GPU box the list names
+    device 0 several times, which selects the host fold of the partials; a single device with the exchange forced to RCCL runs
+    the dlopen'ed ncclCommInitAll / ncclAllGather path with one rank."""
+    it = inst20
+    exp, _ = _expected(it.dot())
+    hb = it.d_b.cpu().numpy().view(np.uint32).reshape(it.n, 16)
+    hs = it.d_s.cpu().numpy().view(np.uint32).reshape(it.n, 8)
+    for devices in ([0, 0], [0, 0, 0]):
+        with mh.MsmMulti(devices=devices) as m:
+            assert m.num_devices == len(devices) and m.exchange == mh.EXCHANGE_HOST
+            for name in golden_cases():
+                g = load_golden(name)
+                r = m.msm(g["bases"], g["scalars"], mh.FORM_STD, g["inf"])  # includes n = 1, 2, 3 < ndev: idle ranks add the identity
+                assert r.is_infinity == bool(g["expected_inf"]) and (r.affine_std == g["expected"]).all(), (name, devices)
+            r = m.msm(hb, hs, mh.FORM_MONT)  # 2^20 host pointers: every shard streams its own range
+            assert (r.affine_std == exp).all()
+            assert sum(m.timings(g)["num_points"] for g in range(len(devices))) == it.n
+            # shards already resident
+            G = len(devices)
+            cuts = [g * it.n // G for g in range(G + 1)]
+            r = m.msm_device([it.d_b.data_ptr() + 64 * cuts[g] for g in range(G)], [it.d_s.data_ptr() + 32 * cuts[g] for g in range(G)],
+                             [cuts[g + 1] - cuts[g] for g in range(G)])
+            assert (r.affine_std == exp).all()
+            # zero-copy arkworks structs, sharded
+            img = _ark_image(hb[: 1 << 17])
+            e2, _ = _expected(it.dot(0, 1 << 17) * pow(1 << 256, -1, R))
+            assert (m.msm_arkworks(img, 72, 0, 32, 64, hs[: 1 << 17]).affine_std == e2).all()
+            with pytest.raises(mh.MsmError) as e:
+                m.msm(np.zeros((0, 16), np.uint32), np.zeros((0, 8), np.uint32))
+            assert e.value.code == mh.ERR_EMPTY
+    with pytest.raises(mh.MsmError) as e:
+        mh.MsmMulti(devices=[0, 0], exchange=mh.EXCHANGE_RCCL)  # RCCL needs distinct devices
+    assert e.value.code == mh.ERR_RCCL
+    with pytest.raises(mh.MsmError):
+        mh.MsmMulti(devices=[99])
+    try:
+        m = mh.MsmMulti(devices=[0], exchange=mh.EXCHANGE_RCCL)
+    except mh.MsmError as err:  # no librccl on this box: the AUTO mode would have used the host fold
+        assert err.code == mh.ERR_RCCL
+    else:
+        with m:
+            assert m.exchange == mh.EXCHANGE_RCCL
+            g = load_golden("rand_n1024")
+            assert (m.msm(g["bases"], g["scalars"], mh.FORM_STD, g["inf"]).affine_std == g["expected"]).all()
+            r = m.msm_device([it.d_b.data_ptr()], [it.d_s.data_ptr()], [it.n])
+            assert (r.affine_std == exp).all()
+
+
+def test_two_ranks_on_one_gpu():
+    """the torch.distributed path of bench.py / distributed.py with two REAL processes sharing cuda:0 (exchange over gloo):
+    every rank must end with the same, correct bits (tests/dist_gpu_worker.py asserts on every rank)"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    port = 29500 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_gpu_worker.py")]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 2 and all(l["ok"] for l in lines) and lines[0]["affine"] == lines[1]["affine"]

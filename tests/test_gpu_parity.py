@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 import mopro_msm_hip as mh
+from mopro_msm_hip import testhooks as th
 from conftest import golden_cases, load_golden
 from oracle import bn254_oracle as orc
 
@@ -14,7 +15,16 @@ P, R = orc.P, orc.R_ORDER
 
 @pytest.fixture(scope="module")
 def ctx():
+    """the PRODUCT library (libmsm_hip.so): every end-to-end parity test runs through it"""
     c = mh.MsmContext()
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def hk():
+    """the hooks build (libmsm_hip_hooks.so): device-math unit tests, the synthetic-instance generator, calibration"""
+    c = th.HooksContext()
     yield c
     c.close()
 
@@ -27,25 +37,25 @@ def rand_fp(rng, n):
 
 
 # ---- device math library (counterpart of T/field, T/bigint, T/mont_backend tests) -------------
-def test_fp_ops_match_oracle(ctx):
+def test_fp_ops_match_oracle(hk):
     rng = np.random.default_rng(1)
     n = 600
     a, b = rand_fp(rng, n), rand_fp(rng, n)[::-1].copy()
     table = [(0, orc.fq_add), (1, orc.fq_sub), (2, orc.fq_mont_mul)]
     for op, ref in table:
-        out = ctx.test_fp_op(op, a, b)
+        out = hk.test_fp_op(op, a, b)
         exp = np.stack([ref(a[i], b[i]) for i in range(n)])
         assert (out == exp).all(), f"fp op {op}"
     for op, ref in [(3, orc.fq_to_mont), (4, orc.fq_from_mont)]:
-        out = ctx.test_fp_op(op, a)
+        out = hk.test_fp_op(op, a)
         exp = np.stack([ref(a[i]) for i in range(n)])
         assert (out == exp).all(), f"fp op {op}"
     m = 40
-    out = ctx.test_fp_op(5, a[:m])
+    out = hk.test_fp_op(5, a[:m])
     exp = np.stack([orc.fq_inv_mont(a[i]) for i in range(m)])
     assert (out == exp).all()
     # a * a^-1 == R (Montgomery one), skipping a == 0
-    prod = ctx.test_fp_op(2, a[1:m], out[1:m])
+    prod = hk.test_fp_op(2, a[1:m], out[1:m])
     assert all(orc.words_to_int(p) == (1 << 256) % P for p in prod)
 
 
@@ -71,7 +81,7 @@ def _same_affine(x, y):
     return ai == bi and (ax == bx).all()
 
 
-def test_g1_ops_match_oracle(ctx):
+def test_g1_ops_match_oracle(hk):
     """madd / add / dbl incl. 0+Q, P+0, 0+0, P+P, P+P with different Z, P+(-P)
     (T/curve/jacobian_add_2007_b1.rs:121-180 cases, plus the ones the reference gets wrong)."""
     n = 40
@@ -89,11 +99,11 @@ def test_g1_ops_match_oracle(ctx):
     b[5] = _neg(a[5])
     b[6] = _neg(orc.g1_add(orc.g1_dbl(a[6]), _neg(a[6])))  # -a6 with a different Z
     assert _same_affine(a[4], b[4]) and not (a[4] == b[4]).all()
-    out = ctx.test_g1_op(1, a, b)
+    out = hk.test_g1_op(1, a, b)
     for i in range(n):
         assert _same_affine(out[i], orc.g1_add(a[i], b[i])), ("add", i)
     assert orc.g1_to_affine_std(out[5])[1] == 1 and orc.g1_to_affine_std(out[6])[1] == 1
-    out = ctx.test_g1_op(2, a)
+    out = hk.test_g1_op(2, a)
     for i in range(n):
         assert _same_affine(out[i], orc.g1_dbl(a[i])), ("dbl", i)
     # mixed add: q affine Montgomery (identity cannot be an affine operand: use a fresh point there)
@@ -105,14 +115,14 @@ def test_g1_ops_match_oracle(ctx):
         assert inf == 0
         baff.append(np.concatenate([orc.fq_to_mont(xy[:8]), orc.fq_to_mont(xy[8:])]))
     baff = np.stack(baff)
-    out = ctx.test_g1_op(0, a, baff)
+    out = hk.test_g1_op(0, a, baff)
     for i in range(n):
         assert _same_affine(out[i], orc.g1_madd(a[i], baff[i])), ("madd", i)
     assert orc.g1_to_affine_std(out[5])[1] == 1  # P + (-P)
     assert _same_affine(out[3], orc.g1_dbl(a[3])) and _same_affine(out[4], orc.g1_dbl(a[4]))
 
 
-def test_wide_add_matches_scalar_add_and_oracle(ctx):
+def test_wide_add_matches_scalar_add_and_oracle(hk):
     """ec_wide.hpp: the 8-lane addition used by the reduction trees == the scalar complete addition == the oracle,
     on random pairs and on every special case (identity operands, P + P, P + P with another Z, P + (-P)),
     at group counts that leave partial wavefronts."""
@@ -131,8 +141,8 @@ def test_wide_add_matches_scalar_add_and_oracle(ctx):
             b[4] = orc.g1_add(orc.g1_dbl(a[4]), _neg(a[4]))
             b[5] = _neg(a[5])
             b[6] = _neg(orc.g1_add(orc.g1_dbl(a[6]), _neg(a[6])))
-        wide = ctx.test_g1_op(3, a, b)
-        scalar = ctx.test_g1_op(1, a, b)
+        wide = hk.test_g1_op(3, a, b)
+        scalar = hk.test_g1_op(1, a, b)
         for i in range(n):
             assert _same_affine(wide[i], orc.g1_add(a[i], b[i])), ("wide add", n, i)
             assert _same_affine(wide[i], scalar[i]), ("wide vs scalar", n, i)
@@ -140,19 +150,19 @@ def test_wide_add_matches_scalar_add_and_oracle(ctx):
             assert orc.g1_to_affine_std(wide[5])[1] == 1 and orc.g1_to_affine_std(wide[6])[1] == 1 and orc.g1_to_affine_std(wide[2])[1] == 1
 
 
-def test_calibration_reports_plausible_multiplier_rates(ctx):
+def test_calibration_reports_plausible_multiplier_rates(hk):
     """msm_calibrate (the live peaks bench.py prices k_accumulate against): MI355X sustains ~3.9e13 v_mad_u64_u32/s and
     ~1.6e11 field multiplications/s; a field multiplication is 171 multiplier instructions plus bookkeeping."""
-    mad, fpm = ctx.calibrate()
+    mad, fpm = hk.calibrate()
     assert 5e12 < mad < 2e14 and 2e10 < fpm < 1e12
     assert 171 < mad / fpm < 400
 
 
-def test_signed_digits_reconstruct_scalar(ctx):
+def test_signed_digits_reconstruct_scalar(hk):
     g = load_golden("edge_carry_patterns")
     sc = np.concatenate([g["scalars"], orc.gen_scalars(5, 200), np.stack([orc.int_to_words(v) for v in (0, 1, R - 1, R - 2, (1 << 253) + 12345)])])
     for wb in (4, 8, 13, 15, 16, 17):
-        d = ctx.test_decompose(sc, wb).astype(object)
+        d = hk.test_decompose(sc, wb).astype(object)
         H = 1 << (wb - 1)
         assert d.shape[0] == 254 // wb + 1
         assert d.max() <= H and d.min() >= -(H - 1)
@@ -185,9 +195,9 @@ def test_msm_golden_window_overrides(wb, flags):
             assert (r.affine_std == g["expected"]).all(), (name, wb)
 
 
-def test_mont_form_and_resident_bases(ctx):
+def test_mont_form_and_resident_bases(ctx, hk):
     g = load_golden("rand_n1024")
-    bm = np.concatenate([ctx.test_fp_op(3, g["bases"][:, :8]), ctx.test_fp_op(3, g["bases"][:, 8:])], axis=1)
+    bm = np.concatenate([hk.test_fp_op(3, g["bases"][:, :8]), hk.test_fp_op(3, g["bases"][:, 8:])], axis=1)
     r = ctx.msm(bm, g["scalars"], mh.FORM_MONT)
     assert (r.affine_std == g["expected"]).all()
     ctx.upload_bases(g["bases"], mh.FORM_STD)
@@ -305,17 +315,17 @@ def test_randomised_parity_fuzz():
 
 # ---- BASELINE.json full sizes: size-independent properties ---------------------------------------
 @pytest.mark.parametrize("logn", [16, 20])
-def test_full_size_closed_form_and_linearity(ctx, logn):
+def test_full_size_closed_form_and_linearity(ctx, hk, logn):
     import torch
     n = 1 << logn
     dev = torch.device("cuda:0")
     d_bases = torch.empty(n * 16, dtype=torch.int32, device=dev)
     d_s = torch.empty(n * 8, dtype=torch.int32, device=dev)
-    ctx.generate_device(0xB2540001, 0xB2540002, n, d_bases.data_ptr(), d_s.data_ptr())
+    hk.generate_device(0xB2540001, 0xB2540002, n, d_bases.data_ptr(), d_s.data_ptr())
     torch.cuda.synchronize()
     # generated bases are k_i*G: spot-check against the oracle
-    k = mh.generate_scalars_host(0xB2540001, n, nonzero=True)
-    s = mh.generate_scalars_host(0xB2540002, n)
+    k = th.generate_scalars_host(0xB2540001, n, nonzero=True)
+    s = th.generate_scalars_host(0xB2540002, n)
     hb = d_bases.cpu().numpy().view(np.uint32).reshape(n, 16)
     idx = [0, 1, 2, n // 2, n - 1, 12345 % n]
     assert (hb[idx] == orc.gen_bases_from_logs(k[idx], orc.FORM_MONT)).all()
@@ -324,7 +334,7 @@ def test_full_size_closed_form_and_linearity(ctx, logn):
     exp, einf = orc.closed_form_expected(k, s)
     assert not r.is_infinity and (r.affine_std == exp).all()
     # linearity: MSM(B, s) + MSM(B, t) == MSM(B, s + t mod r), through the same HIP path
-    t = mh.generate_scalars_host(0xB2540003, n)
+    t = th.generate_scalars_host(0xB2540003, n)
     d_t = torch.from_numpy(t.view(np.int32).reshape(-1)).to(dev)
     rt = ctx.msm_device(d_bases.data_ptr(), d_t.data_ptr(), n)
     to_int = lambda a: [sum(int(w) << (32 * j) for j, w in enumerate(row)) for row in a.tolist()]
@@ -349,7 +359,7 @@ def test_full_size_closed_form_and_linearity(ctx, logn):
 
 
 @pytest.mark.parametrize("logn", [17, 20])
-def test_skewed_scalars_full_size_closed_form(ctx, logn):
+def test_skewed_scalars_full_size_closed_form(ctx, hk, logn):
     """Skewed digit distributions at full size: buckets of up to N entries (thousands of chunks -> the segmented
     k_combine_long with its last-arriver finish, the direct-placement branch of the fine sort, wave-aggregated LDS
     counters).  Expected value by the closed form (sum s_i k_i) * G; every case twice (per-bucket counters self-clean)."""
@@ -358,10 +368,10 @@ def test_skewed_scalars_full_size_closed_form(ctx, logn):
     dev = torch.device("cuda:0")
     d_bases = torch.empty(n * 16, dtype=torch.int32, device=dev)
     d_s = torch.empty(n * 8, dtype=torch.int32, device=dev)
-    ctx.generate_device(0xB2540011, 0xB2540012, n, d_bases.data_ptr(), d_s.data_ptr())
+    hk.generate_device(0xB2540011, 0xB2540012, n, d_bases.data_ptr(), d_s.data_ptr())
     torch.cuda.synchronize()
-    k = mh.generate_scalars_host(0xB2540011, n, nonzero=True)
-    s = mh.generate_scalars_host(0xB2540012, n)
+    k = th.generate_scalars_host(0xB2540011, n, nonzero=True)
+    s = th.generate_scalars_host(0xB2540012, n)
     idx = np.arange(n)
     cases = {"all-equal": np.tile(s[:1], (n, 1)), "2-distinct": s[idx % 2], "3-blocked": s[(idx * 3) // n], "256-distinct": s[idx % 256],
              "below-2^32": np.pad(s[:, :1], ((0, 0), (0, 7))), "ones-and-zeros": np.pad((idx % 3 != 0).astype(np.uint32)[:, None], ((0, 0), (0, 7)))}
@@ -375,20 +385,20 @@ def test_skewed_scalars_full_size_closed_form(ctx, logn):
 
 
 @pytest.mark.parametrize("logn", [18, 20])
-def test_glv_split_full_size_matches_unsplit_and_closed_form(monkeypatch, logn):
-    """The GLV split (default up to 2^18 points, forced here at 2^20 too) against the unsplit pipeline and the closed form."""
+def test_glv_split_full_size_matches_unsplit_and_closed_form(monkeypatch, hk, logn):
+    """The GLV split (default up to 2^19 points, forced here at 2^20 too) against the unsplit pipeline and the closed form."""
     import torch
     n = 1 << logn
     dev = torch.device("cuda:0")
     d_bases = torch.empty(n * 16, dtype=torch.int32, device=dev)
     d_s = torch.empty(n * 8, dtype=torch.int32, device=dev)
-    k = mh.generate_scalars_host(0xB2540021, n, nonzero=True)
-    s = mh.generate_scalars_host(0xB2540022, n)
+    k = th.generate_scalars_host(0xB2540021, n, nonzero=True)
+    s = th.generate_scalars_host(0xB2540022, n)
     exp, einf = orc.closed_form_expected(k, s)
     monkeypatch.setenv("MSM_HIP_GLV_MAX_LOG2", "23")
     assert mh.plan(n).glv == 1 and mh.plan(n, 0, mh.FLAG_NO_GLV).glv == 0
     with mh.MsmContext() as cg, mh.MsmContext(flags=mh.FLAG_NO_GLV) as cp:
-        cg.generate_device(0xB2540021, 0xB2540022, n, d_bases.data_ptr(), d_s.data_ptr())
+        hk.generate_device(0xB2540021, 0xB2540022, n, d_bases.data_ptr(), d_s.data_ptr())
         torch.cuda.synchronize()
         rg = cg.msm_device(d_bases.data_ptr(), d_s.data_ptr(), n)
         rp = cp.msm_device(d_bases.data_ptr(), d_s.data_ptr(), n)
@@ -403,7 +413,7 @@ def test_glv_split_full_size_matches_unsplit_and_closed_form(monkeypatch, logn):
 
 
 # ---- BASELINE config 5: streamed host->HBM chunks overlapped with the pipeline ---------------------
-def test_streamed_chunks_match_oracle():
+def test_streamed_chunks_match_oracle(hk):
     """msm_bn254_g1 cuts n >= 2*chunk points into chunks (double-buffered H2D on a copy stream, partials added on
     the host).  Forced to tiny chunks here so that the golden cases exercise it; ragged last chunk and infinity
     masks included."""
@@ -421,7 +431,7 @@ def test_streamed_chunks_match_oracle():
         exp, einf, _ = orc.msm_pippenger(g["bases"][:n], g["scalars"][:n], orc.FORM_STD, inf)
         assert (r.affine_std == exp).all() and r.is_infinity == bool(einf)
         # Montgomery-form input through the streamed path
-        bm = np.concatenate([c.test_fp_op(3, g["bases"][:, :8]), c.test_fp_op(3, g["bases"][:, 8:])], axis=1)
+        bm = np.concatenate([hk.test_fp_op(3, g["bases"][:, :8]), hk.test_fp_op(3, g["bases"][:, 8:])], axis=1)
         r = c.msm(bm, g["scalars"], mh.FORM_MONT)
         assert (r.affine_std == g["expected"]).all()
         # a non-canonical scalar in a LATER chunk is still rejected
@@ -436,14 +446,14 @@ def test_streamed_chunks_match_oracle():
         assert (r.affine_std == g["expected"]).all()
 
 
-def test_streamed_equals_single_shot_at_2_pow_18(ctx):
+def test_streamed_equals_single_shot_at_2_pow_18(ctx, hk):
     n = 1 << 18
-    k = mh.generate_scalars_host(0xB2540001, n, nonzero=True)
-    s = mh.generate_scalars_host(0xB2540009, n)
+    k = th.generate_scalars_host(0xB2540001, n, nonzero=True)
+    s = th.generate_scalars_host(0xB2540009, n)
     import torch
     d_b = torch.empty(n * 16, dtype=torch.int32, device="cuda:0")
     d_s = torch.empty(n * 8, dtype=torch.int32, device="cuda:0")
-    ctx.generate_device(0xB2540001, 0xB2540009, n, d_b.data_ptr(), d_s.data_ptr())
+    hk.generate_device(0xB2540001, 0xB2540009, n, d_b.data_ptr(), d_s.data_ptr())
     hb = d_b.cpu().numpy().view(np.uint32).reshape(n, 16)
     single = ctx.msm(hb, s, mh.FORM_MONT)
     with mh.MsmContext(stream_chunk_log2=15) as c:  # 8 chunks of 32768

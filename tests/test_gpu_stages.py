@@ -1,0 +1,179 @@
+"""Stage-level GPU parity (-m gpu): every stage of the pipeline against its own specification, through the stage-dump hook of
+the hooks build (include/msm_hip_testhooks.h: msm_test_stage_dump runs the whole pipeline once and copies the intermediates of
+each stage back).
+
+Counterparts of the reference's per-kernel tests:
+  decompose  tests/cuzk/convert_point_coords_and_decompose_scalars.rs:177-235   digits rebuild the scalar, |d| <= H
+  sort       tests/cuzk/transpose.rs:6-118     offsets = exclusive prefix of the digit histogram; `sorted` is a permutation
+                                               of the non-zero digits grouped by bucket, signs preserved
+  accumulate tests/cuzk/smvp.rs:119-303        bucket sums == oracle_bucket_sums (SMVP sign folding, smvp.metal:46-105)
+  reduce     tests/cuzk/pbpr.rs:26-247         bit sums == oracle_bit_sums; Horner over them == the MSM
+on the two-level LDS sort, the tiled-histogram fallback, the global-atomic fallback and an oversized region (k_big_place)."""
+import numpy as np
+import pytest
+
+import mopro_msm_hip as mh
+from mopro_msm_hip import testhooks as th
+from conftest import load_golden
+from oracle import bn254_oracle as orc
+
+pytestmark = pytest.mark.gpu
+SKIP, SIGN = 0xFFFFFFFF, 0x80000000
+
+
+def signed_digits(scalars, c, W, signed=True):
+    """the engine's recoding (csrc/msm_kernels.hpp k_decompose): v = window + carry; v > H => digit v - 2H, carry 1.
+    (The reference recodes v >= H, convert_point...metal:97-116: same value, other tie rule -- Appendix B of SURVEY.md.)"""
+    n = scalars.shape[0]
+    vals = [orc.words_to_int(s) for s in scalars]
+    H = 1 << (c - 1)
+    out = np.zeros((W, n), np.int64)
+    for i, v in enumerate(vals):
+        carry = 0
+        for w in range(W):
+            d = ((v >> (c * w)) & ((1 << c) - 1)) + carry
+            carry = 0
+            if signed and d > H:
+                d -= 2 * H
+                carry = 1
+            out[w, i] = d
+        assert carry == 0
+    return out
+
+
+def check_sort(d, digits_signed, inf=None):
+    """offsets / sorted against the digits (transpose.rs:95-118: stable counting sort; here grouped, order inside a bucket free)"""
+    W, nb, nv = d.W, d.nb, d.nv
+    assert d.offsets[0] == 0
+    total = 0
+    for w in range(W):
+        row = digits_signed[w].copy()
+        if inf is not None:
+            row[inf != 0] = 0
+        mag = np.abs(row)
+        hist = np.bincount(mag[mag > 0] - 1, minlength=nb)
+        off = d.offsets[w * nb: (w + 1) * nb + 1].astype(np.int64)
+        assert (np.diff(off) == hist).all(), ("offsets != exclusive prefix of the digit histogram", w)
+        # the device's digit codes: bucket | negate << 31, SKIP for zero digits / infinity
+        code = np.where(mag > 0, (mag - 1).astype(np.uint32) | np.where(row < 0, SIGN, 0).astype(np.uint32), SKIP).astype(np.uint32)
+        assert (d.digits[w] == code).all(), ("digit codes", w)
+        seg = d.sorted[off[0]: off[-1]]
+        idx = (seg & ~np.uint32(SIGN)).astype(np.int64)
+        # a permutation of the non-skipped points of this window ...
+        assert np.array_equal(np.sort(idx), np.flatnonzero(mag > 0)), ("sorted is not a permutation of the non-zero digits", w)
+        # ... grouped by bucket, signs preserved
+        bucket_of_slot = np.repeat(np.arange(nb), hist)
+        assert (mag[idx] - 1 == bucket_of_slot).all(), ("entry in the wrong bucket", w)
+        assert (((seg & SIGN) != 0) == (row[idx] < 0)).all(), ("sign lost", w)
+        total += int((mag > 0).sum())
+    assert int(d.offsets[W * nb]) == total  # the CSC end pointer == number of mixed additions k_accumulate will run
+
+
+def same_point(a, b):
+    xa, ia = orc.g1_to_affine_std(a)
+    xb, ib = orc.g1_to_affine_std(b)
+    return ia == ib and (xa == xb).all()
+
+
+def check_buckets_and_bits(d, bases, form, digits_signed, inf, expected_affine):
+    exp_b = orc.bucket_sums(bases, digits_signed, d.nb, form, inf)
+    for k in range(d.W * d.nb):
+        assert same_point(d.buckets[k], exp_b[k]), ("bucket sum", k // d.nb, k % d.nb)
+    exp_q = orc.bit_sums(exp_b, d.W, d.nb)
+    for w in range(d.W):
+        for u in range(d.kb + 1):
+            assert same_point(d.bit_sums[w, u], exp_q[w, u]), ("bit sum", w, u)
+    aff, inf_r = orc.g1_to_affine_std(d.jacobian)
+    assert (aff == expected_affine).all()
+
+
+CASES = [  # (window_bits, flags, golden case, what it exercises)
+    (6, mh.FLAG_NO_GLV, "rand_n1024"),                            # two-level sort, tiny windows: long buckets, k_combine_long
+    (10, mh.FLAG_NO_GLV, "rand_n4096"),                           # two-level sort
+    (13, mh.FLAG_NO_GLV, "rand_n4096"),                           # mostly empty buckets
+    (9, mh.FLAG_NO_GLV | mh.FLAG_UNSIGNED_DIGITS, "rand_n1024"),  # plain digits
+    (8, mh.FLAG_NO_GLV, "edge_inf_bases"),
+    (8, mh.FLAG_NO_GLV, "edge_same_base_same_scalar"),
+    (7, mh.FLAG_NO_GLV, "edge_p_minus_p"),
+]
+
+
+@pytest.mark.parametrize("wb,flags,name", CASES)
+def test_stages_two_level_sort(wb, flags, name):
+    g = load_golden(name)
+    with th.HooksContext(window_bits=wb, flags=flags) as c:
+        d = c.stage_dump(g["bases"], g["scalars"], mh.FORM_STD, g["inf"])
+    assert d.sort_path == 2
+    ds = signed_digits(g["scalars"], wb, d.W, signed=not (flags & mh.FLAG_UNSIGNED_DIGITS))
+    check_sort(d, ds, g["inf"])
+    check_buckets_and_bits(d, g["bases"], orc.FORM_STD, ds, g["inf"], g["expected"])
+
+
+def test_stages_tiled_fallback(monkeypatch):
+    """MSM_HIP_DIRECT_SCATTER: per-tile LDS histograms + k_scan_* + k_tile_scatter (the path of n > 2^24 points)"""
+    monkeypatch.setenv("MSM_HIP_DIRECT_SCATTER", "1")
+    g = load_golden("rand_n4096")
+    with th.HooksContext(window_bits=11, flags=mh.FLAG_NO_GLV) as c:
+        d = c.stage_dump(g["bases"], g["scalars"], mh.FORM_STD, g["inf"])
+    assert d.sort_path == 1
+    ds = signed_digits(g["scalars"], 11, d.W)
+    check_sort(d, ds, g["inf"])
+    check_buckets_and_bits(d, g["bases"], orc.FORM_STD, ds, g["inf"], g["expected"])
+
+
+def test_stages_global_atomic_fallback():
+    """c = 19: 2^18 buckets per window do not fit an LDS histogram -> device-scope atomics in k_decompose + k_scatter.
+    (offsets and sorted only: 14 x 2^18 bucket records would be 340 MB of Jacobian words)"""
+    g = load_golden("rand_n1024")
+    with th.HooksContext(window_bits=19, flags=mh.FLAG_NO_GLV) as c:
+        d = c.stage_dump(g["bases"], g["scalars"], mh.FORM_STD, g["inf"], want_buckets=False)
+    assert d.sort_path == 0
+    check_sort(d, signed_digits(g["scalars"], 19, d.W), g["inf"])
+    aff, _ = orc.g1_to_affine_std(d.jacobian)
+    assert (aff == g["expected"]).all()
+
+
+def test_stages_oversized_region_big_place():
+    """skewed scalars: one bucket holds most of every window, its sort region exceeds a workgroup's staging area and is cut
+    into batches that worker blocks count and k_big_place places (msm_kernels.hpp k_coarse_starts / k_big_place)"""
+    n = 1 << 15
+    k = orc.gen_scalars(31, n, nonzero=True)
+    bases = orc.gen_bases_from_logs(k, orc.FORM_MONT)
+    s = orc.gen_scalars(32, n)
+    s[: n - n // 8] = s[0]           # 7/8 of the points share one scalar: every window has one region of ~28000 entries
+    s[n // 2: n // 2 + 100, 1:] = 0  # and some tiny ones
+    with th.HooksContext(window_bits=12, flags=mh.FLAG_NO_GLV) as c:
+        d = c.stage_dump(bases, s, mh.FORM_MONT, None)
+    assert d.sort_path == 2 and d.big_items > 0, "the oversized-region path was not taken"
+    ds = signed_digits(s, 12, d.W)
+    check_sort(d, ds)
+    exp, einf = orc.closed_form_expected(k, s)
+    check_buckets_and_bits(d, bases, orc.FORM_MONT, ds, None, exp)
+
+
+def test_stages_glv_plan_sort_invariants_and_result():
+    """default plan at n = 4096 (GLV split: 2n virtual points, digits of the two 127-bit halves): the sort invariants hold on the
+    dumped digit codes, the bit sums are the bit sums of the dumped buckets, Horner over them is the golden MSM"""
+    g = load_golden("rand_n4096")
+    with th.HooksContext() as c:
+        d = c.stage_dump(g["bases"], g["scalars"], mh.FORM_STD, g["inf"])
+    assert d.plan.glv == 1 and d.nv == 2 * 4096
+    W, nb = d.W, d.nb
+    for w in range(W):
+        code = d.digits[w]
+        live = code != SKIP
+        mag = np.where(live, (code & ~np.uint32(SIGN)).astype(np.int64) + 1, 0)
+        hist = np.bincount(mag[mag > 0] - 1, minlength=nb)
+        off = d.offsets[w * nb: (w + 1) * nb + 1].astype(np.int64)
+        assert (np.diff(off) == hist).all()
+        seg = d.sorted[off[0]: off[-1]]
+        idx = (seg & ~np.uint32(SIGN)).astype(np.int64)
+        assert np.array_equal(np.sort(idx), np.flatnonzero(live))
+        assert (mag[idx] - 1 == np.repeat(np.arange(nb), hist)).all()
+        assert ((seg & SIGN) == (code[idx] & SIGN)).all()
+    exp_q = orc.bit_sums(d.buckets, W, nb)
+    for w in range(W):
+        for u in range(d.kb + 1):
+            assert same_point(d.bit_sums[w, u], exp_q[w, u])
+    aff, _ = orc.g1_to_affine_std(d.jacobian)
+    assert (aff == g["expected"]).all()

@@ -4,11 +4,13 @@ import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "gpu-acceleration_amd")]
 import numpy as np, torch, mopro_msm_hip as mh
+from mopro_msm_hip import testhooks as th
+GEN = th.HooksContext()  # the synthetic-instance generator lives in the hooks build
 n = 1 << 20
 with mh.MsmContext() as c:
     c.set_stage_timing(True)
     d_b = torch.empty(n * 16, dtype=torch.int32, device="cuda:0"); d_s = torch.empty(n * 8, dtype=torch.int32, device="cuda:0")
-    c.generate_device(1, 2, n, d_b.data_ptr(), d_s.data_ptr())
+    GEN.generate_device(1, 2, n, d_b.data_ptr(), d_s.data_ptr())
     s = d_s.cpu().numpy().view(np.uint32).reshape(n, 8)
     idx = np.arange(n)
     cases = [("uniform", s), ("all-equal", np.tile(s[:1], (n, 1))), ("2-distinct-interleaved", s[idx % 2]), ("3-distinct-interleaved", s[idx % 3]),

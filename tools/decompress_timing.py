@@ -5,6 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "gpu-acceleration_amd")]
 import numpy as np, torch
 import mopro_msm_hip as mh
+from mopro_msm_hip import testhooks as th
+GEN = th.HooksContext()  # the synthetic-instance generator lives in the hooks build
 from mopro_msm_hip import instances as inst
 from oracle import bn254_oracle as orc
 
@@ -12,7 +14,7 @@ ctx = mh.MsmContext()
 for logn in (16, 20, 22):
     n = 1 << logn
     d_b = torch.empty(n * 16, dtype=torch.int32, device="cuda"); d_s = torch.empty(n * 8, dtype=torch.int32, device="cuda")
-    ctx.generate_device(1, 2, n, d_b.data_ptr(), d_s.data_ptr()); torch.cuda.synchronize()
+    GEN.generate_device(1, 2, n, d_b.data_ptr(), d_s.data_ptr()); torch.cuda.synchronize()
     bases = d_b.cpu().numpy().view(np.uint32).reshape(n, 16); scalars = d_s.cpu().numpy().view(np.uint32).reshape(n, 8)
     t0 = time.perf_counter(); img = mh.compress_points(bases, mh.FORM_MONT); t_c = time.perf_counter() - t0
     ctx.upload_compressed(img)

@@ -7,6 +7,8 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "gpu-acceleration_amd")]
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
 import numpy as np, torch, torch.distributed as dist
 import mopro_msm_hip as mh
+from mopro_msm_hip import testhooks as th
+GEN = th.HooksContext()  # the synthetic-instance generator lives in the hooks build
 from mopro_msm_hip import distributed as md
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
@@ -14,7 +16,7 @@ dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 n = 1 << 14
 ctx = mh.MsmContext(max_points=n)
 d_b = torch.empty(n * 16, dtype=torch.int32, device=dev); d_s = torch.empty(n * 8, dtype=torch.int32, device=dev)
-ctx.generate_device(1, 2, n, d_b.data_ptr(), d_s.data_ptr()); torch.cuda.synchronize()
+GEN.generate_device(1, 2, n, d_b.data_ptr(), d_s.data_ptr()); torch.cuda.synchronize()
 r = ctx.msm_device(d_b.data_ptr(), d_s.data_ptr(), n)
 
 def old(partial):

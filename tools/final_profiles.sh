@@ -1,6 +1,7 @@
 #!/bin/bash
 # Regenerates the judged evidence of a round on the GPU box (run through gpurun): bench line, rocprofv3 kernel stats of
 # the same command, size sweep, PMC traffic of k_accumulate.  Outputs under gpurun_out/final/ (copy into profiles/).
+: "${GRAFT_REPO_ROOT:=$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}"  # default: the checkout this script lives in
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/final

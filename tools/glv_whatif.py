@@ -7,6 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "gpu-acceleration_amd")]
 import numpy as np, torch
 import mopro_msm_hip as mh
+from mopro_msm_hip import testhooks as th
+GEN = th.HooksContext()  # the synthetic-instance generator lives in the hooks build
 def med(ctx, b, s, n, reps=60):
     for _ in range(5): ctx.msm_device(b.data_ptr(), s.data_ptr(), n)
     ts = []
@@ -19,7 +21,7 @@ for logn in [int(x) for x in (sys.argv[1:] or ["17", "20"])]:
     d_b = torch.empty(2 * n * 16, dtype=torch.int32, device="cuda"); d_s = torch.empty(2 * n * 8, dtype=torch.int32, device="cuda")
     os.environ.pop("MSM_HIP_EXPERIMENT_WINDOWS", None)
     ctx = mh.MsmContext(window_bits=16 if logn >= 18 else 0)
-    ctx.generate_device(1, 2, 2 * n, d_b.data_ptr(), d_s.data_ptr()); torch.cuda.synchronize()
+    GEN.generate_device(1, 2, 2 * n, d_b.data_ptr(), d_s.data_ptr()); torch.cuda.synchronize()
     base = med(ctx, d_b, d_s, n); ctx.close()
     v = d_s.view(2 * n, 8); v[:, 4:] = 0; v[:, 3] &= 0x3FFFFFFF; torch.cuda.synchronize()   # scalars < 2^126
     for c in ([16] if logn >= 18 else [13, 15, 16]):

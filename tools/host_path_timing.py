@@ -5,11 +5,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "gpu-acceleration_amd")]
 import numpy as np, torch
 import mopro_msm_hip as mh
+from mopro_msm_hip import testhooks as th
+GEN = th.HooksContext()  # the synthetic-instance generator lives in the hooks build
 for logn in (20, 22):
     n = 1 << logn
     with mh.MsmContext(stream_chunk_log2=28) as c0:  # never streams
         d_b = torch.empty(n * 16, dtype=torch.int32, device="cuda:0"); d_s = torch.empty(n * 8, dtype=torch.int32, device="cuda:0")
-        c0.generate_device(1, 2, n, d_b.data_ptr(), d_s.data_ptr())
+        GEN.generate_device(1, 2, n, d_b.data_ptr(), d_s.data_ptr())
         hb = d_b.cpu().numpy().view(np.uint32).reshape(n, 16); hs = d_s.cpu().numpy().view(np.uint32).reshape(n, 8)
         dev = c0.msm_device(d_b.data_ptr(), d_s.data_ptr(), n)
         for _ in range(2): r0 = c0.msm(hb, hs, mh.FORM_MONT)

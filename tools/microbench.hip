@@ -6,7 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
-#include "../gpu-acceleration_amd/csrc/fp_bn254_8x32.hpp"  // the r1a field these numbers were taken with
+#include "fp_bn254_8x32.hpp"  // the r1a field these numbers were taken with
 #include "../gpu-acceleration_amd/csrc/ec_bn254.hpp"
 using namespace bn254;
 

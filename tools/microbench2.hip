@@ -5,7 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
-#include "../gpu-acceleration_amd/csrc/fp_bn254_8x32.hpp"  // A/B baseline: 8 x 32-bit CIOS with carry chains
+#include "fp_bn254_8x32.hpp"  // A/B baseline: 8 x 32-bit CIOS with carry chains
 #include "../gpu-acceleration_amd/csrc/fp_bn254.hpp"       // the product field (this prototype, productised)
 using bn254_8x32::fp;
 using bn254_8x32::fp_mul;

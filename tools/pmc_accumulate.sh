@@ -1,6 +1,7 @@
 #!/bin/bash
 # Collect HBM traffic counters for k_accumulate (separate --pmc passes, kernel-trace only: see the guide's
 # rocprofv3 rules) and the counter calibration of tools/calib_gather.  Output under gpurun_out/pmc_acc/.
+: "${GRAFT_REPO_ROOT:=$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}"  # default: the checkout this script lives in
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/pmc_acc

@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage: tools/prof_c.sh <log_n> <c> [<c> ...]  -> k_accumulate / total per window size (rocprofv3 kernel stats)
+: "${GRAFT_REPO_ROOT:=$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}"  # default: the checkout this script lives in
 cd /tmp && export TMPDIR=/tmp
 n=$1; shift
 for c in "$@"; do

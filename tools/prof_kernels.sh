@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage (on the GPU box, via gpurun): tools/prof_kernels.sh <log_n> [more log_n...]   -> per-kernel averages (rocprofv3 --kernel-trace --stats)
+: "${GRAFT_REPO_ROOT:=$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}"  # default: the checkout this script lives in
 cd /tmp && export TMPDIR=/tmp
 for n in "$@"; do
   out=$GRAFT_REPO_ROOT/gpurun_out/prof$n

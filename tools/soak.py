@@ -6,11 +6,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "gpu-acceleration_amd")]
 import numpy as np, torch
 import mopro_msm_hip as mh
+from mopro_msm_hip import testhooks as th
+GEN = th.HooksContext()  # the synthetic-instance generator lives in the hooks build
 calls = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 nmax = 1 << 18
 ctx = mh.MsmContext()
 d_b = torch.empty(nmax * 16, dtype=torch.int32, device="cuda"); d_s = torch.empty(nmax * 8, dtype=torch.int32, device="cuda")
-ctx.generate_device(11, 12, nmax, d_b.data_ptr(), d_s.data_ptr()); torch.cuda.synchronize()
+GEN.generate_device(11, 12, nmax, d_b.data_ptr(), d_s.data_ptr()); torch.cuda.synchronize()
 sizes = [1, 17, 1000, 4096, 30000, 1 << 16, 100003, nmax]
 ref = {n: ctx.msm_device(d_b.data_ptr(), d_s.data_ptr(), n).jacobian_mont.copy() for n in sizes}
 ref_aff = {n: mh.combine_partials(ref[n].reshape(1, 24)).affine_std.copy() for n in sizes}

@@ -5,11 +5,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "gpu-acceleration_amd")]
 import numpy as np, torch
 import mopro_msm_hip as mh
+from mopro_msm_hip import testhooks as th
+GEN = th.HooksContext()  # the synthetic-instance generator lives in the hooks build
 for logn in [int(x) for x in (sys.argv[1:] or ["16", "20"])]:
     n = 1 << logn
     ctx = mh.MsmContext(max_points=n)
     d_b = torch.empty(n * 16, dtype=torch.int32, device="cuda"); d_s = torch.empty(n * 8, dtype=torch.int32, device="cuda")
-    ctx.generate_device(1, 2, n, d_b.data_ptr(), d_s.data_ptr()); torch.cuda.synchronize()
+    GEN.generate_device(1, 2, n, d_b.data_ptr(), d_s.data_ptr()); torch.cuda.synchronize()
     for _ in range(5): ctx.msm_device(d_b.data_ptr(), d_s.data_ptr(), n)
     ts = []
     for _ in range(int(os.environ.get("JITTER_CALLS", "400"))):
