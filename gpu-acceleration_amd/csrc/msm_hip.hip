@@ -13,8 +13,8 @@
 //   * launches are queued back to back; the only host synchronisation is the final wait for W*(kb+1) bit sums that
 //     the last kernel writes into pinned host memory.  The reference blocks after each of its 9 submits;
 //   * host inputs are pipelined: the bases travel on the copy stream while the scalars are already being sorted, and
-//     from 2^19 points on the point range is cut into chunks that are copied (pageable memory: staged through a
-//     pinned ring by host threads) while the previous chunk is accumulated INTO the shared bucket array.
+//     from 2^19 points on the point range is cut into chunks that travel (pinned caller memory: read in place by the conversion
+//     kernel) while the previous chunk is accumulated INTO the shared bucket array.
 // There is NO CPU fallback: without a HIP device every compute entry point returns MSM_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
@@ -97,18 +97,13 @@ bool trace_enabled() {
 struct msm_ctx {
     std::mutex mu;
     HostPool* pool = nullptr;        // CPU finish: the caller + one worker
-    HostPool* stage_pool = nullptr;  // staging copies of pageable inputs (created on first use)
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;     // host->HBM uploads and base conversion beside the sort
     hipEvent_t ev_copied[2]{}, ev_free[2]{};
     hipEvent_t ev_fork = nullptr, ev_bases = nullptr;  // base conversion runs on copy_stream beside the sort kernels
     DevBuf sbases[2], sscalars[2], sinf[2];  // double-buffered raw inputs of the streamed path
-    // pinned staging ring for pageable caller memory: stage threads x 2 slots x STAGE_PIECE bytes, one event per slot
-    uint8_t* h_stage = nullptr;
-    int stage_threads = 0;
-    hipEvent_t ev_stage[32]{};
-    bool stage_used[32]{};
+    DevBuf sibases[2];                        // ... and of the converted bases when the conversion runs on the copy stream (pull mode)
     msm_config_t cfg{};
     std::string err;
     hipEvent_t ev[EV_COUNT]{};
@@ -524,10 +519,10 @@ void trace_line(const msm_ctx* c, const char* entry, const PipeState& ps) {
     if (!trace_enabled()) return;
     const msm_timings_t& t = c->tm;
     std::fprintf(stderr,
-                 "[msm_hip] %s dev %d n %zu c %u W %u nb %u glv %u sort_path %u chunk_len %u stream_chunks %u staged %u | h2d %.3f convert %.3f "
+                 "[msm_hip] %s dev %d n %zu c %u W %u nb %u glv %u sort_path %u chunk_len %u stream_chunks %u pulled %u | h2d %.3f convert %.3f "
                  "decompose %.3f sort %.3f accumulate %.3f reduce %.3f finish %.3f total %.3f ms, %llu adds\n",
                  entry, c->device, (size_t)t.num_points, ps.cbits, ps.W, ps.nb, ps.pl.glv, c->last_sort_path, ps.chunk_len, t.stream_chunks,
-                 t.staged, t.h2d_ms, t.convert_ms, t.decompose_ms, t.sort_ms, t.accumulate_ms, t.reduce_ms, t.finish_ms, t.total_ms,
+                 t.pulled, t.h2d_ms, t.convert_ms, t.decompose_ms, t.sort_ms, t.accumulate_ms, t.reduce_ms, t.finish_ms, t.total_ms,
                  (unsigned long long)t.num_adds);
 }
 
@@ -615,67 +610,24 @@ bool is_pinned_host(const void* p) {
     return pinned;
 }
 
-// Pageable caller memory -> device, through a pinned ring filled by host threads.  Why: measured on this runtime
-// (tools/pinned_vs_pageable.py) hipMemcpyAsync from pageable memory runs at full PCIe rate but does NOT overlap kernels of other
-// streams, and hipHostRegister costs as much as the copy itself.  Here job t of T owns ring slots 2t and 2t+1 and the pieces
-// t, t+T, ...: memcpy into a slot, hipMemcpyAsync from the slot on stream cs, one event per slot guards its reuse.  The host
-// returns when everything is staged; the DMAs are then still in flight on cs.
-constexpr size_t STAGE_PIECE = (size_t)2 << 20;
-int32_t stager_init(msm_ctx* c) {
-    if (c->h_stage) return MSM_OK;
-    int want = (int)std::thread::hardware_concurrency() - 1;
-    want = std::max(1, std::min(want, 7));
-    if (const char* e = std::getenv("MSM_HIP_STAGE_THREADS")) want = std::max(0, std::min(15, std::atoi(e) - 1));
-    const int T = want + 1;  // workers + the calling thread
-    HIPCHK(c, hipHostMalloc((void**)&c->h_stage, (size_t)T * 2 * STAGE_PIECE, hipHostMallocDefault));
-    for (int i = 0; i < 2 * T; i++) HIPCHK(c, hipEventCreateWithFlags(&c->ev_stage[i], hipEventDisableTiming));
-    if (want > 0) {
-        c->stage_pool = new (std::nothrow) HostPool(want);
-        if (!c->stage_pool) return fail(c, MSM_ERR_OOM, "host allocation failed");
-    }
-    c->stage_threads = T;
-    return MSM_OK;
-}
-int32_t staged_copy(msm_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t cs) {
-    int32_t rc = stager_init(c);
-    if (rc) return rc;
-    const int T = c->stage_threads;
-    const size_t npieces = (bytes + STAGE_PIECE - 1) / STAGE_PIECE;
-    std::atomic<int> herr{(int)hipSuccess};
-    const int dev = c->device;
-    auto job = [&](int t) {
-        (void)hipSetDevice(dev);  // per host thread
-        size_t k = 0;
-        for (size_t p = (size_t)t; p < npieces; p += (size_t)T, k++) {
-            const int slot = 2 * t + (int)(k & 1);
-            hipError_t e = hipSuccess;
-            if (c->stage_used[slot]) e = hipEventSynchronize(c->ev_stage[slot]);  // the DMA that last read this slot is done
-            uint8_t* ring = c->h_stage + (size_t)slot * STAGE_PIECE;
-            const size_t off = p * STAGE_PIECE, len = std::min(STAGE_PIECE, bytes - off);
-            if (e == hipSuccess) {
-                std::memcpy(ring, (const uint8_t*)src + off, len);
-                e = hipMemcpyAsync((uint8_t*)dst + off, ring, len, hipMemcpyHostToDevice, cs);
-            }
-            if (e == hipSuccess) e = hipEventRecord(c->ev_stage[slot], cs);
-            c->stage_used[slot] = true;
-            if (e != hipSuccess) {
-                herr.store((int)e);
-                return;
-            }
-        }
-    };
-    const int njobs = (int)std::min<size_t>((size_t)T, npieces);
-    if (c->stage_pool && njobs > 1) c->stage_pool->run(njobs, job);
-    else
-        for (int t = 0; t < njobs; t++) job(t);
-    if (herr.load() != (int)hipSuccess)
-        return fail(c, MSM_ERR_HIP, "staged host->device copy failed: %s", hipGetErrorString((hipError_t)herr.load()));
-    return MSM_OK;
-}
-// host -> device on stream cs; pageable sources of a megabyte or more go through the staging ring
-int32_t h2d(msm_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t cs, bool staged) {
-    if (staged && bytes >= ((size_t)1 << 20)) return staged_copy(c, dst, src, bytes, cs);
+// host -> device copy on stream cs (hipMemcpyAsync: from pageable memory the runtime stages the data itself and the call returns
+// when the source has been consumed; from pinned memory it is fully asynchronous)
+int32_t h2d(msm_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t cs) {
     HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, cs));
+    return MSM_OK;
+}
+// PINNED caller memory is mapped into the device's address space: kernels read it in place ("pull"), so the base conversion
+// consumes the host records directly and nothing is copied twice.  Measured on this runtime (profiles/NOTES_r2.md): hipMemcpyAsync
+// from pinned memory is executed by a blit KERNEL that queues behind k_accumulate's wavefronts and does not overlap them
+// (2^20 points in 4 chunks: 3.7 ms against 2.9 ms from pageable memory, whose staged copies use the DMA engines), while a
+// pull kernel with a bounded grid holds its few wavefronts from the start of the chunk and runs at the PCIe rate (54 GB/s).
+constexpr unsigned PULL_BLOCKS = 512;
+int32_t pull(msm_ctx* c, void* dst, const void* src_host, size_t bytes, hipStream_t cs) {
+    void* dsrc = nullptr;
+    HIPCHK(c, hipHostGetDevicePointer(&dsrc, const_cast<void*>(src_host), 0));
+    const size_t n16 = bytes / 16, tail = bytes - n16 * 16;
+    if (n16) msmk::k_pull16<<<(unsigned)std::min<size_t>(PULL_BLOCKS, (n16 + 255) / 256), 256, 0, cs>>>((const uint4*)dsrc, (uint4*)dst, n16);
+    if (tail) msmk::k_pull1<<<1, 64, 0, cs>>>((const uint8_t*)dsrc + n16 * 16, (uint8_t*)dst + n16 * 16, (uint32_t)tail);
     return MSM_OK;
 }
 
@@ -690,16 +642,50 @@ void launch_convert(const HostInput& in, const void* d_raw, size_t cnt, uint32_t
                                                                 in.kind == KIND_MONT ? 1u : 0u, glv ? 1u : 0u);
 }
 
+// How the raw inputs of a (chunk of a) host call reach HBM.  PULL (pinned caller memory): kernels read the host records in place.
+// COPY (pageable memory): hipMemcpyAsync into raw staging buffers, then the conversion kernel.
+struct Feed {
+    bool pull = false;
+};
+// scalars (+ the infinity mask of the packed forms) of points [lo, lo+cnt) -> d_scalars / d_inf on stream s
+int32_t feed_scalars(msm_ctx* c, const HostInput& in, const Feed& f, size_t lo, size_t cnt, void* d_scalars, void* d_inf, hipStream_t s) {
+    int32_t rc;
+    if (f.pull) {
+        if ((rc = pull(c, d_scalars, in.scalars + lo * 8, cnt * 32, s))) return rc;
+        if (in.inf_mask && (rc = pull(c, d_inf, in.inf_mask + lo, cnt, s))) return rc;
+    } else {
+        if ((rc = h2d(c, d_scalars, in.scalars + lo * 8, cnt * 32, s))) return rc;
+        if (in.inf_mask && (rc = h2d(c, d_inf, in.inf_mask + lo, cnt, s))) return rc;
+    }
+    return MSM_OK;
+}
+// base records of points [lo, lo+cnt) -> internal-domain records d_ibases (+ infinity bytes d_inf for the struct form) on stream s;
+// d_raw: staging for the COPY feed
+int32_t feed_bases(msm_ctx* c, const HostInput& in, const Feed& f, size_t lo, size_t cnt, void* d_raw, uint32_t* d_ibases, uint8_t* d_inf,
+                   bool glv, hipStream_t s) {
+    const uint8_t* src = in.bases + lo * in.stride;
+    if (f.pull) {
+        void* dsrc = nullptr;
+        HIPCHK(c, hipHostGetDevicePointer(&dsrc, const_cast<uint8_t*>(src), 0));
+        launch_convert(in, dsrc, cnt, d_ibases, d_inf, glv, s);
+        return MSM_OK;
+    }
+    int32_t rc = h2d(c, d_raw, src, cnt * in.stride, s);
+    if (rc) return rc;
+    launch_convert(in, d_raw, cnt, d_ibases, d_inf, glv, s);
+    return MSM_OK;
+}
+
 // Single shot: scalars (and the infinity mask) go first on the compute stream and are sorted while the bases -- two thirds of
 // the bytes, only needed by k_accumulate -- still travel and are converted on the copy stream.  (The struct form carries the
-// infinity flags inside the base records, which k_decompose needs: there the two copies merely share the link.)
-int32_t run_single(msm_ctx* c, const HostInput& in, size_t n, bool staged, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf) {
+// infinity flags inside the base records, which k_decompose needs: there the two transfers merely share the link.)
+int32_t run_single(msm_ctx* c, const HostInput& in, size_t n, const Feed& f, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf) {
     int32_t rc;
     hipStream_t st = c->stream, cs = c->copy_stream;
     const bool glv = plan_glv(c, n);
     PipeState ps;
     if ((rc = ensure(c, c->scalars, n * 32))) return rc;
-    if ((rc = ensure(c, c->bases, n * in.stride))) return rc;
+    if (!f.pull && (rc = ensure(c, c->bases, n * in.stride))) return rc;
     if ((rc = ensure(c, c->ibases, (glv ? 2 : 1) * n * 64))) return rc;
     if (in.carries_inf() && (rc = ensure(c, c->inf, n))) return rc;
     if ((rc = pipe_prepare(c, n, 0, 0, st, &ps))) return rc;
@@ -707,33 +693,30 @@ int32_t run_single(msm_ctx* c, const HostInput& in, size_t n, bool staged, uint3
     hipStream_t bs = overlap ? cs : st;                  // stream the bases travel and are converted on
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_START], st));
     const uint8_t* d_inf = in.carries_inf() ? (const uint8_t*)c->inf.p : nullptr;
+    uint32_t* ib = (uint32_t*)c->ibases.p;
     {
         Range r_("msm:h2d");
         if (in.kind == KIND_ARK) {
-            if ((rc = h2d(c, c->bases.p, in.bases, n * in.stride, bs, staged))) return rc;
-            if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_H2D], st));
-            launch_convert(in, c->bases.p, n, (uint32_t*)c->ibases.p, (uint8_t*)c->inf.p, glv, bs);
+            if ((rc = feed_bases(c, in, f, 0, n, c->bases.p, ib, (uint8_t*)c->inf.p, glv, bs))) return rc;
             if (overlap) HIPCHK(c, hipEventRecord(c->ev_bases, bs));
-            if ((rc = h2d(c, c->scalars.p, in.scalars, n * 32, st, staged))) return rc;
+            if ((rc = feed_scalars(c, in, f, 0, n, c->scalars.p, nullptr, st))) return rc;
+            if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_H2D], st));
             if (overlap) HIPCHK(c, hipStreamWaitEvent(st, c->ev_bases, 0));  // k_decompose reads the infinity bytes
             if ((rc = enqueue_sort(c, ps, d_inf, (const uint32_t*)c->scalars.p, in.scalars_mont, st, true))) return rc;
-            if ((rc = enqueue_accumulate(c, ps, (const uint32_t*)c->ibases.p, st, nullptr, false))) return rc;
+            if ((rc = enqueue_accumulate(c, ps, ib, st, nullptr, false))) return rc;
         } else {
-            if ((rc = h2d(c, c->scalars.p, in.scalars, n * 32, st, staged))) return rc;
-            if (in.inf_mask && (rc = h2d(c, c->inf.p, in.inf_mask, n, st, staged))) return rc;
+            if ((rc = feed_scalars(c, in, f, 0, n, c->scalars.p, c->inf.p, st))) return rc;
             if (overlap) {
                 // queue the sort BEFORE the bases are touched: a copy from pageable memory blocks the host, the GPU sorts meanwhile
                 if ((rc = enqueue_sort(c, ps, d_inf, (const uint32_t*)c->scalars.p, in.scalars_mont, st, true))) return rc;
-                if ((rc = h2d(c, c->bases.p, in.bases, n * in.stride, bs, staged))) return rc;
-                launch_convert(in, c->bases.p, n, (uint32_t*)c->ibases.p, nullptr, glv, bs);
+                if ((rc = feed_bases(c, in, f, 0, n, c->bases.p, ib, nullptr, glv, bs))) return rc;
                 HIPCHK(c, hipEventRecord(c->ev_bases, bs));
-                if ((rc = enqueue_accumulate(c, ps, (const uint32_t*)c->ibases.p, st, c->ev_bases, false))) return rc;
+                if ((rc = enqueue_accumulate(c, ps, ib, st, c->ev_bases, false))) return rc;
             } else {
-                if ((rc = h2d(c, c->bases.p, in.bases, n * in.stride, st, staged))) return rc;
+                if ((rc = feed_bases(c, in, f, 0, n, c->bases.p, ib, nullptr, glv, st))) return rc;
                 if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_H2D], st));
-                launch_convert(in, c->bases.p, n, (uint32_t*)c->ibases.p, nullptr, glv, st);
                 if ((rc = enqueue_sort(c, ps, d_inf, (const uint32_t*)c->scalars.p, in.scalars_mont, st, true))) return rc;
-                if ((rc = enqueue_accumulate(c, ps, (const uint32_t*)c->ibases.p, st, nullptr, false))) return rc;
+                if ((rc = enqueue_accumulate(c, ps, ib, st, nullptr, false))) return rc;
             }
         }
     }
@@ -741,82 +724,102 @@ int32_t run_single(msm_ctx* c, const HostInput& in, size_t n, bool staged, uint3
     if ((rc = finish_sync(c, ps, n, st, out_jac, out_aff, out_inf))) return rc;
     c->tm.h2d_ms = stage_ms(c, EV_START, EV_H2D);
     c->tm.convert_ms = stage_ms(c, EV_H2D, EV_CONVERT);
-    c->tm.staged = staged ? 1u : 0u;
+    c->tm.pulled = f.pull ? 1u : 0u;
     trace_line(c, "host single-shot", ps);
     return MSM_OK;
 }
 
 // BASELINE config 5, and every host-pointer call from 2^19 points on: the instance does not have to be resident.  The point
-// range is cut into chunks of `chunk` points; chunk j+1 travels host->HBM on the copy stream (pageable memory: staged by host
-// threads) while chunk j is sorted and accumulated on the compute stream.  MSM is linear in the points, so every chunk adds
-// into the SAME bucket array (k_accumulate<INTO>, one plan for the whole instance): ONE bucket reduction, ONE host finish and
-// W*(kb+1) bit sums back, however many chunks.  Raw inputs are double-buffered.
-int32_t run_streamed(msm_ctx* c, const HostInput& in, size_t n, size_t chunk, bool staged, uint32_t* out_jac, uint32_t* out_aff,
-                     uint8_t* out_inf) {
-    const size_t nchunks = (n + chunk - 1) / chunk;
+// range is cut into chunks; chunk j+1 travels host->HBM and is converted on the copy stream while chunk j is sorted and
+// accumulated on the compute stream.  MSM is linear in the points, so every chunk adds into the SAME bucket array
+// (k_accumulate<INTO>, one plan for the whole instance): ONE bucket reduction, ONE host finish and W*(kb+1) bit sums back,
+// however many chunks.  Raw and converted inputs are double-buffered.  The link is the bottleneck (96 B per point at ~55 GB/s
+// against ~1.2 ns of sort + accumulation), so what the call pays beyond the transfer is the work left when the last byte
+// has arrived: the automatic schedule ends with short chunks.
+int32_t run_streamed(msm_ctx* c, const HostInput& in, size_t n, const std::vector<size_t>& sizes, const Feed& f, uint32_t* out_jac,
+                     uint32_t* out_aff, uint8_t* out_inf) {
     int32_t rc;
     const bool glv = plan_glv(c, n);  // of the WHOLE instance: all chunks share one bucket array
+    const size_t chunk = *std::max_element(sizes.begin(), sizes.end());
     for (int s = 0; s < 2; s++) {
-        if ((rc = ensure(c, c->sbases[s], chunk * in.stride))) return rc;
+        if (!f.pull && (rc = ensure(c, c->sbases[s], chunk * in.stride))) return rc;
         if ((rc = ensure(c, c->sscalars[s], chunk * 32))) return rc;
-        if (in.inf_mask && (rc = ensure(c, c->sinf[s], chunk))) return rc;
+        if (in.carries_inf() && (rc = ensure(c, c->sinf[s], chunk))) return rc;
+        if ((rc = ensure(c, c->sibases[s], (glv ? 2 : 1) * chunk * 64))) return rc;
     }
-    if ((rc = ensure(c, c->ibases, (glv ? 2 : 1) * chunk * 64))) return rc;
-    if (in.kind == KIND_ARK && (rc = ensure(c, c->inf, chunk))) return rc;
     hipStream_t st = c->stream, cs = c->copy_stream;
     PipeState ps;
-    for (size_t j = 0; j < nchunks; j++) {
+    if ((rc = pipe_prepare(c, chunk, n, 0, st, &ps))) return rc;  // workspace for the largest chunk before anything is in flight
+    size_t lo = 0;
+    for (size_t j = 0; j < sizes.size(); j++) {
         const int s = (int)(j & 1);
-        const size_t lo = j * chunk, cnt = (lo + chunk <= n) ? chunk : n - lo;
+        const size_t cnt = sizes[j];
+        uint8_t* d_inf = in.carries_inf() ? (uint8_t*)c->sinf[s].p : nullptr;
         {
             Range r_("msm:h2d chunk");
             if (j >= 2) HIPCHK(c, hipStreamWaitEvent(cs, c->ev_free[s], 0));  // the pipeline that read this slot is done
-            if ((rc = h2d(c, c->sscalars[s].p, in.scalars + lo * 8, cnt * 32, cs, staged))) return rc;
-            if (in.inf_mask && (rc = h2d(c, c->sinf[s].p, in.inf_mask + lo, cnt, cs, staged))) return rc;
-            if ((rc = h2d(c, c->sbases[s].p, in.bases + lo * in.stride, cnt * in.stride, cs, staged))) return rc;
+            if ((rc = feed_scalars(c, in, f, lo, cnt, c->sscalars[s].p, d_inf, cs))) return rc;
+            if ((rc = feed_bases(c, in, f, lo, cnt, c->sbases[s].p, (uint32_t*)c->sibases[s].p, d_inf, glv, cs))) return rc;
             HIPCHK(c, hipEventRecord(c->ev_copied[s], cs));
         }
         HIPCHK(c, hipStreamWaitEvent(st, c->ev_copied[s], 0));
-        launch_convert(in, c->sbases[s].p, cnt, (uint32_t*)c->ibases.p, (uint8_t*)c->inf.p, glv, st);
-        const uint8_t* d_inf = in.kind == KIND_ARK ? (const uint8_t*)c->inf.p : in.inf_mask ? (const uint8_t*)c->sinf[s].p : nullptr;
         if ((rc = pipe_prepare(c, cnt, n, 0, st, &ps))) return rc;
         if ((rc = enqueue_sort(c, ps, d_inf, (const uint32_t*)c->sscalars[s].p, in.scalars_mont, st, j == 0))) return rc;
-        if ((rc = enqueue_accumulate(c, ps, (const uint32_t*)c->ibases.p, st, nullptr, j > 0))) return rc;
+        if ((rc = enqueue_accumulate(c, ps, (const uint32_t*)c->sibases[s].p, st, nullptr, j > 0))) return rc;
         HIPCHK(c, hipEventRecord(c->ev_free[s], st));
+        lo += cnt;
     }
     if ((rc = enqueue_reduce(c, ps, st, c->h_qsums, c->h_flags))) return rc;
     if ((rc = finish_sync(c, ps, n, st, out_jac, out_aff, out_inf))) return rc;
-    c->tm.stream_chunks = (uint32_t)nchunks;
-    c->tm.staged = staged ? 1u : 0u;
+    c->tm.stream_chunks = (uint32_t)sizes.size();
+    c->tm.pulled = f.pull ? 1u : 0u;
     trace_line(c, "host streamed", ps);
     return MSM_OK;
 }
 
-// chunk length of the streamed path for n points, 0 = single shot
-size_t pick_stream_chunk(const msm_ctx* c, size_t n) {
-    if (c->cfg.stream_chunk_log2) {
+// chunk schedule of the streamed path for n points; empty = single shot
+std::vector<size_t> stream_schedule(const msm_ctx* c, size_t n) {
+    std::vector<size_t> sizes;
+    if (c->cfg.stream_chunk_log2) {  // explicit: uniform chunks of 2^k points, ragged last one
         const size_t chunk = (size_t)1 << c->cfg.stream_chunk_log2;
-        return n >= 2 * chunk ? chunk : 0;
+        if (n < 2 * chunk) return sizes;
+        for (size_t lo = 0; lo < n; lo += chunk) sizes.push_back(std::min(chunk, n - lo));
+        return sizes;
     }
-    // automatic.  A chunk costs its copy (96 B per point at ~54 GB/s: 0.47 ms per 2^18 points) or its sort + accumulation
-    // (~0.4 ms per 2^18 points), whichever is longer; the first copy and the last accumulation are exposed, so chunks stay small
-    // while the ~15 launches they add (~60 us) stay cheap against them.
-    uint32_t min_log2 = 19, lg = n < ((size_t)1 << 21) ? 18u : n < ((size_t)1 << 23) ? 19u : 20u;
+    // automatic.  A chunk costs its transfer (96 B per point at ~55 GB/s: 0.46 ms per 2^18 points) or its sort + accumulation
+    // (~0.4 ms per 2^18 points), whichever is longer, and ~15 launches.  Chunks of 2^18 points (2^19 / 2^20 for large instances)
+    // keep the link busy; the last `chunk` points go as 1/2 + 1/4 + 1/4 (not below 2^16) so that little is left to compute when
+    // the transfer ends.
+    uint32_t min_log2 = 19, lg = n < ((size_t)1 << 21) ? 18u : n < ((size_t)1 << 23) ? 19u : 20u, tail_min_log2 = 16;
     if (const char* e = std::getenv("MSM_HIP_STREAM_MIN_LOG2")) min_log2 = (uint32_t)std::max(9, std::min(31, std::atoi(e)));
     if (const char* e = std::getenv("MSM_HIP_STREAM_CHUNK_LOG2")) lg = (uint32_t)std::max(8, std::min(28, std::atoi(e)));
-    if (n < ((size_t)1 << min_log2)) return 0;
-    const size_t chunk = (size_t)1 << lg;
-    return n >= 2 * chunk ? chunk : 0;
+    if (const char* e = std::getenv("MSM_HIP_STREAM_TAIL_LOG2")) tail_min_log2 = (uint32_t)std::max(8, std::min(28, std::atoi(e)));
+    const size_t chunk = (size_t)1 << lg, tail_min = (size_t)1 << tail_min_log2;
+    if (n < ((size_t)1 << min_log2) || n < 2 * chunk) return sizes;
+    size_t left = n;
+    while (left > chunk + chunk / 2) {
+        sizes.push_back(chunk);
+        left -= chunk;
+    }
+    // the rest (between 1/2 and 3/2 of a chunk): halves until the pieces reach tail_min
+    while (left >= 2 * tail_min && sizes.size() < 64) {
+        const size_t h = (left / 2 + 63) & ~(size_t)63;
+        sizes.push_back(h);
+        left -= h;
+        if (left <= chunk / 4) break;
+    }
+    if (left) sizes.push_back(left);
+    return sizes;
 }
 
 int32_t run_host_input(msm_ctx* c, const HostInput& in, size_t n, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf) {
     auto t0 = std::chrono::steady_clock::now();
-    // pageable caller memory is staged through the pinned ring; MSM_HIP_STAGE=0 leaves it to the runtime's own pageable path
-    bool staged = !(is_pinned_host(in.bases) && is_pinned_host(in.scalars));
-    if (const char* e = std::getenv("MSM_HIP_STAGE"))
-        if (*e == '0') staged = false;
-    const size_t chunk = pick_stream_chunk(c, n);
-    int32_t rc = chunk ? run_streamed(c, in, n, chunk, staged, out_jac, out_aff, out_inf) : run_single(c, in, n, staged, out_jac, out_aff, out_inf);
+    Feed f;
+    f.pull = is_pinned_host(in.bases) && is_pinned_host(in.scalars) && (!in.inf_mask || is_pinned_host(in.inf_mask));
+    if (const char* e = std::getenv("MSM_HIP_PINNED_PULL"))  // A/B knob: 0 = hipMemcpyAsync also from pinned memory
+        if (*e == '0') f.pull = false;
+    const std::vector<size_t> sizes = stream_schedule(c, n);
+    int32_t rc = sizes.empty() ? run_single(c, in, n, f, out_jac, out_aff, out_inf) : run_streamed(c, in, n, sizes, f, out_jac, out_aff, out_inf);
     if (rc) return rc;
     c->tm.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return MSM_OK;
@@ -926,8 +929,6 @@ void msm_ctx_destroy(msm_ctx* c) {
     if (!c) return;
     delete c->pool;
     c->pool = nullptr;
-    delete c->stage_pool;
-    c->stage_pool = nullptr;
     {
         DeviceGuard g(c->device);
         if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -939,13 +940,11 @@ void msm_ctx_destroy(msm_ctx* c) {
         for (DevBuf* b : bufs) release(*b);
         if (c->h_qsums) (void)hipHostFree(c->h_qsums);
         if (c->h_flags) (void)hipHostFree(c->h_flags);
-        if (c->h_stage) (void)hipHostFree(c->h_stage);
-        for (hipEvent_t& e : c->ev_stage)
-            if (e) (void)hipEventDestroy(e);
         for (int i = 0; i < 2; i++) {
             release(c->sbases[i]);
             release(c->sscalars[i]);
             release(c->sinf[i]);
+            release(c->sibases[i]);
             if (c->ev_copied[i]) (void)hipEventDestroy(c->ev_copied[i]);
             if (c->ev_free[i]) (void)hipEventDestroy(c->ev_free[i]);
         }

@@ -65,9 +65,9 @@ typedef struct {
     uint32_t stream_chunk_log2; /* the host-pointer entries cut n >= 2 * 2^this points into chunks of 2^this points: chunk j+1
                                    travels host->HBM (copy stream) while chunk j is sorted and accumulated INTO the shared bucket
                                    array; one bucket reduction and one host finish per MSM (BASELINE config 5).
-                                   0 = automatic: from 2^19 points on, chunks of 2^18..2^20 points.  Pageable caller memory is
-                                   staged through a pinned ring by host threads (copies from pageable memory do not overlap
-                                   kernels on this runtime); pinned caller memory is read by the copy engine directly */
+                                   0 = automatic: from 2^19 points on, chunks of 2^18..2^20 points ending in a few short ones.
+                                   Pinned caller memory is read in place by the conversion kernels; pageable memory goes through
+                                   hipMemcpyAsync (the runtime stages it; those copies overlap the kernels) */
     uint64_t max_points;  /* pre-size the HBM workspace for this many points; 0 = grow on demand        */
 } msm_config_t;
 
@@ -95,7 +95,7 @@ typedef struct {
     uint64_t num_points;
     uint64_t num_adds;   /* mixed additions executed by accumulate (non-zero digits) */
     uint32_t stream_chunks; /* host->HBM chunks the call was cut into (0 = single shot / device-resident)      */
-    uint32_t staged;        /* 1 = caller memory was pageable and went through the pinned staging ring          */
+    uint32_t pulled;        /* 1 = caller memory was pinned and was read in place by the kernels (no copy engine) */
 } msm_timings_t;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */

@@ -116,9 +116,9 @@ def test_config2_literal_shape(hk):
 
 def test_automatic_streaming_pinned_and_pageable_at_2_pow_22(hk):
     """config 5's mechanism with the DEFAULT configuration (stream_chunk_log2 = 0): from 2^19 points on a host-pointer call is cut
-    into chunks that travel while the previous chunk is accumulated INTO the shared buckets.  Pinned caller memory is read by the
-    copy engine directly, pageable memory goes through the pinned staging ring; MSM_HIP_STAGE=0 leaves pageable copies to the
-    runtime.  Same bits every way."""
+    into chunks that travel while the previous chunk is accumulated INTO the shared buckets.  Pinned caller memory is read in
+    place by the conversion kernels ("pull"), pageable memory goes through hipMemcpyAsync; MSM_HIP_PINNED_PULL=0 copies pinned
+    memory too.  Same bits every way."""
     import torch
     it = Instance(hk, 22, seed=0xB2540061)
     exp, _ = _expected(it.dot())
@@ -126,36 +126,49 @@ def test_automatic_streaming_pinned_and_pageable_at_2_pow_22(hk):
     hb = hb_t.numpy().view(np.uint32).reshape(it.n, 16)
     hs = hs_t.numpy().view(np.uint32).reshape(it.n, 8)
     hbp, hsp = hb_t.pin_memory(), hs_t.pin_memory()
+    hbpn, hspn = hbp.numpy().view(np.uint32).reshape(it.n, 16), hsp.numpy().view(np.uint32).reshape(it.n, 8)
     with mh.MsmContext() as c:
-        r = c.msm(hbp.numpy().view(np.uint32).reshape(it.n, 16), hsp.numpy().view(np.uint32).reshape(it.n, 8), mh.FORM_MONT)
+        r = c.msm(hbpn, hspn, mh.FORM_MONT)
         tm = c.timings()
-        assert (r.affine_std == exp).all() and tm["stream_chunks"] >= 4 and tm["staged"] == 0 and tm["num_points"] == it.n
+        assert (r.affine_std == exp).all() and tm["stream_chunks"] >= 4 and tm["pulled"] == 1 and tm["num_points"] == it.n
         assert tm["num_adds"] > 15 * it.n  # the running count covers every chunk (16 windows, ~1 - 2^-16 non-zero digits)
         r = c.msm(hb, hs, mh.FORM_MONT)  # pageable numpy memory
         tm = c.timings()
-        assert (r.affine_std == exp).all() and tm["stream_chunks"] >= 4 and tm["staged"] == 1
-        # a ragged size: the last chunk is shorter
+        assert (r.affine_std == exp).all() and tm["stream_chunks"] >= 4 and tm["pulled"] == 0
+        # a ragged size: the short chunks at the end are cut differently
         m = it.n - 77777
         e2, _ = _expected(it.dot(0, m))
-        r = c.msm(hb[:m], hs[:m], mh.FORM_MONT)
-        assert (r.affine_std == e2).all() and c.timings()["stream_chunks"] >= 4
+        for b, s in ((hb, hs), (hbpn, hspn)):
+            r = c.msm(b[:m], s[:m], mh.FORM_MONT)
+            assert (r.affine_std == e2).all() and c.timings()["stream_chunks"] >= 4
+        # pinned bases with a pageable infinity mask: everything is copied (the mask decides)
+        inf = np.zeros(it.n, np.uint8)
+        inf[[3, 1 << 20, it.n - 1]] = 1
+        e4, _ = _expected(it.dot(skip=inf))
+        r = c.msm(hbpn, hspn, mh.FORM_MONT, inf)
+        assert (r.affine_std == e4).all() and c.timings()["pulled"] == 0
+        infp = torch.from_numpy(inf).pin_memory()
+        r = c.msm(hbpn, hspn, mh.FORM_MONT, infp.numpy())
+        assert (r.affine_std == e4).all() and c.timings()["pulled"] == 1
         # below the streaming threshold: single shot (bases travel on the copy stream beside the sort)
         m = 1 << 18
         e3, _ = _expected(it.dot(0, m))
-        r = c.msm(hb[:m], hs[:m], mh.FORM_MONT)
-        assert (r.affine_std == e3).all() and c.timings()["stream_chunks"] == 0
-    os.environ["MSM_HIP_STAGE"] = "0"
+        for b, s, pulled in ((hb, hs, 0), (hbpn, hspn, 1)):
+            r = c.msm(b[:m], s[:m], mh.FORM_MONT)
+            tm = c.timings()
+            assert (r.affine_std == e3).all() and tm["stream_chunks"] == 0 and tm["pulled"] == pulled
+    os.environ["MSM_HIP_PINNED_PULL"] = "0"
     try:
         with mh.MsmContext() as c:
-            r = c.msm(hb, hs, mh.FORM_MONT)
-            assert (r.affine_std == exp).all() and c.timings()["staged"] == 0
+            r = c.msm(hbpn, hspn, mh.FORM_MONT)
+            assert (r.affine_std == exp).all() and c.timings()["pulled"] == 0
     finally:
-        del os.environ["MSM_HIP_STAGE"]
+        del os.environ["MSM_HIP_PINNED_PULL"]
 
 
 def test_streamed_shared_buckets_small_chunks(hk):
-    """forced tiny chunks: GLV plan of the whole instance shared by all chunks, infinity masks, the staged (pageable) ring with
-    pieces smaller and larger than a chunk, a scalar error in a late chunk"""
+    """forced tiny chunks: GLV plan of the whole instance shared by all chunks, infinity masks, a scalar error in a
+    late chunk"""
     n = 1 << 17
     k = orc.gen_scalars(0xB2540071, n, nonzero=True)
     s = orc.gen_scalars(0xB2540072, n)
@@ -169,7 +182,7 @@ def test_streamed_shared_buckets_small_chunks(hk):
             r = c.msm(bases, s, mh.FORM_MONT, inf)
             tm = c.timings()
             assert (r.affine_std == exp).all(), lg
-            assert tm["stream_chunks"] == n >> lg and tm["staged"] == 1
+            assert tm["stream_chunks"] == n >> lg and tm["pulled"] == 0
             assert mh.plan(n).glv == 1  # 2n virtual points per chunk, one bucket array
             bad = s.copy()
             bad[n - 3, 7] |= 0x40000000
