@@ -13,8 +13,8 @@
 //   * launches are queued back to back; the only host synchronisation is the final wait for W*(kb+1) bit sums that
 //     the last kernel writes into pinned host memory.  The reference blocks after each of its 9 submits;
 //   * host inputs are pipelined: the bases travel on the copy stream while the scalars are already being sorted, and
-//     from 2^19 points on the point range is cut into chunks that travel (pinned caller memory: read in place by the conversion
-//     kernel) while the previous chunk is accumulated INTO the shared bucket array.
+//     from 2^19 points on the point range is cut into chunks that travel while the previous chunk is accumulated INTO the
+//     shared bucket array.
 // There is NO CPU fallback: without a HIP device every compute entry point returns MSM_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
@@ -103,7 +103,7 @@ struct msm_ctx {
     hipEvent_t ev_copied[2]{}, ev_free[2]{};
     hipEvent_t ev_fork = nullptr, ev_bases = nullptr;  // base conversion runs on copy_stream beside the sort kernels
     DevBuf sbases[2], sscalars[2], sinf[2];  // double-buffered raw inputs of the streamed path
-    DevBuf sibases[2];                        // ... and of the converted bases when the conversion runs on the copy stream (pull mode)
+    DevBuf sibases[2];                        // ... and of the converted bases (the conversion of chunk j+1 runs beside the accumulation of chunk j)
     msm_config_t cfg{};
     std::string err;
     hipEvent_t ev[EV_COUNT]{};
@@ -241,7 +241,11 @@ int32_t pipe_prepare(msm_ctx* c, size_t n_real, size_t plan_n, uint32_t extra_fl
     // are cut into few pieces for k_combine.  Measured sweep at N = 2^20: L = 32 (profiles/NOTES_r1.md).
     // 16 from 2^13 points up (8 loses there: more buckets are cut 3+ times than the finer granularity wins back); tiny instances
     // (<= 2^17 sorted entries: a quarter of the SIMDs would hold a wavefront at 16) take 8: 0.262 vs 0.296 ms at 2^10
-    uint32_t chunk_len = pairs <= ((size_t)1 << 17) ? 8 : 16;
+    // (round 2, tools/chunk_len_sweep.py: up to 2^21 sorted entries -- 2^17 points with the GLV split -- L = 8 beats 16 by ~20 us:
+    // 2^16 0.403 vs 0.425 ms, 2^17 0.490 vs 0.509; from 2^22 entries on 16 wins because the buckets cut three and more times
+    // cost k_combine more than the finer granularity saves in k_accumulate)
+    // -- only where buckets are short, though: 2^14 points on c = 10 windows (64 entries per bucket) turn every bucket into a long one)
+    uint32_t chunk_len = (pairs <= ((size_t)1 << 17) || (pairs <= ((size_t)1 << 21) && n / nb <= 8)) ? 8 : 16;
     // ... and from there the chunk follows the mean bucket occupancy n/nb (32 at 2^20 unsplit, 64 with the GLV split: measured
     // 1.728 ms at L = 32 against 1.698 at 64), as long as ~2^17 chunks remain to fill the chip
     while (chunk_len < 1024 && chunk_len < n / nb && pairs / (chunk_len * 2) >= 131072) chunk_len *= 2;
@@ -519,10 +523,10 @@ void trace_line(const msm_ctx* c, const char* entry, const PipeState& ps) {
     if (!trace_enabled()) return;
     const msm_timings_t& t = c->tm;
     std::fprintf(stderr,
-                 "[msm_hip] %s dev %d n %zu c %u W %u nb %u glv %u sort_path %u chunk_len %u stream_chunks %u pulled %u | h2d %.3f convert %.3f "
+                 "[msm_hip] %s dev %d n %zu c %u W %u nb %u glv %u sort_path %u chunk_len %u stream_chunks %u | h2d %.3f convert %.3f "
                  "decompose %.3f sort %.3f accumulate %.3f reduce %.3f finish %.3f total %.3f ms, %llu adds\n",
                  entry, c->device, (size_t)t.num_points, ps.cbits, ps.W, ps.nb, ps.pl.glv, c->last_sort_path, ps.chunk_len, t.stream_chunks,
-                 t.pulled, t.h2d_ms, t.convert_ms, t.decompose_ms, t.sort_ms, t.accumulate_ms, t.reduce_ms, t.finish_ms, t.total_ms,
+                 t.h2d_ms, t.convert_ms, t.decompose_ms, t.sort_ms, t.accumulate_ms, t.reduce_ms, t.finish_ms, t.total_ms,
                  (unsigned long long)t.num_adds);
 }
 
@@ -610,27 +614,15 @@ bool is_pinned_host(const void* p) {
     return pinned;
 }
 
-// host -> device copy on stream cs (hipMemcpyAsync: from pageable memory the runtime stages the data itself and the call returns
-// when the source has been consumed; from pinned memory it is fully asynchronous)
+// host -> device copy on stream cs (hipMemcpyAsync: from pageable memory the runtime stages the data itself -- ~40 GB/s -- and the
+// call returns when the source has been consumed; from pinned memory it is fully asynchronous at the link rate, 56 GB/s).
+// Tried and dropped in round 2 (profiles/NOTES_r2.md): a pinned staging ring filled by 8 host threads (slower than the runtime's
+// own staging) and kernels reading pinned caller memory in place (their wavefronts wait on PCIe while holding the slots
+// k_accumulate needs: 4.2 ms against 2.7 ms at 2^20).
 int32_t h2d(msm_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t cs) {
     HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, cs));
     return MSM_OK;
 }
-// PINNED caller memory is mapped into the device's address space: kernels read it in place ("pull"), so the base conversion
-// consumes the host records directly and nothing is copied twice.  Measured on this runtime (profiles/NOTES_r2.md): hipMemcpyAsync
-// from pinned memory is executed by a blit KERNEL that queues behind k_accumulate's wavefronts and does not overlap them
-// (2^20 points in 4 chunks: 3.7 ms against 2.9 ms from pageable memory, whose staged copies use the DMA engines), while a
-// pull kernel with a bounded grid holds its few wavefronts from the start of the chunk and runs at the PCIe rate (54 GB/s).
-constexpr unsigned PULL_BLOCKS = 512;
-int32_t pull(msm_ctx* c, void* dst, const void* src_host, size_t bytes, hipStream_t cs) {
-    void* dsrc = nullptr;
-    HIPCHK(c, hipHostGetDevicePointer(&dsrc, const_cast<void*>(src_host), 0));
-    const size_t n16 = bytes / 16, tail = bytes - n16 * 16;
-    if (n16) msmk::k_pull16<<<(unsigned)std::min<size_t>(PULL_BLOCKS, (n16 + 255) / 256), 256, 0, cs>>>((const uint4*)dsrc, (uint4*)dst, n16);
-    if (tail) msmk::k_pull1<<<1, 64, 0, cs>>>((const uint8_t*)dsrc + n16 * 16, (uint8_t*)dst + n16 * 16, (uint32_t)tail);
-    return MSM_OK;
-}
-
 // raw base records in HBM -> internal-domain records (+ infinity bytes for the struct form), on stream st
 void launch_convert(const HostInput& in, const void* d_raw, size_t cnt, uint32_t* d_ibases, uint8_t* d_inf, bool glv, hipStream_t st) {
     if (in.kind == KIND_ARK)
@@ -642,35 +634,18 @@ void launch_convert(const HostInput& in, const void* d_raw, size_t cnt, uint32_t
                                                                 in.kind == KIND_MONT ? 1u : 0u, glv ? 1u : 0u);
 }
 
-// How the raw inputs of a (chunk of a) host call reach HBM.  PULL (pinned caller memory): kernels read the host records in place.
-// COPY (pageable memory): hipMemcpyAsync into raw staging buffers, then the conversion kernel.
-struct Feed {
-    bool pull = false;
-};
 // scalars (+ the infinity mask of the packed forms) of points [lo, lo+cnt) -> d_scalars / d_inf on stream s
-int32_t feed_scalars(msm_ctx* c, const HostInput& in, const Feed& f, size_t lo, size_t cnt, void* d_scalars, void* d_inf, hipStream_t s) {
+int32_t feed_scalars(msm_ctx* c, const HostInput& in, size_t lo, size_t cnt, void* d_scalars, void* d_inf, hipStream_t s) {
     int32_t rc;
-    if (f.pull) {
-        if ((rc = pull(c, d_scalars, in.scalars + lo * 8, cnt * 32, s))) return rc;
-        if (in.inf_mask && (rc = pull(c, d_inf, in.inf_mask + lo, cnt, s))) return rc;
-    } else {
-        if ((rc = h2d(c, d_scalars, in.scalars + lo * 8, cnt * 32, s))) return rc;
-        if (in.inf_mask && (rc = h2d(c, d_inf, in.inf_mask + lo, cnt, s))) return rc;
-    }
+    if ((rc = h2d(c, d_scalars, in.scalars + lo * 8, cnt * 32, s))) return rc;
+    if (in.inf_mask && (rc = h2d(c, d_inf, in.inf_mask + lo, cnt, s))) return rc;
     return MSM_OK;
 }
-// base records of points [lo, lo+cnt) -> internal-domain records d_ibases (+ infinity bytes d_inf for the struct form) on stream s;
-// d_raw: staging for the COPY feed
-int32_t feed_bases(msm_ctx* c, const HostInput& in, const Feed& f, size_t lo, size_t cnt, void* d_raw, uint32_t* d_ibases, uint8_t* d_inf,
-                   bool glv, hipStream_t s) {
-    const uint8_t* src = in.bases + lo * in.stride;
-    if (f.pull) {
-        void* dsrc = nullptr;
-        HIPCHK(c, hipHostGetDevicePointer(&dsrc, const_cast<uint8_t*>(src), 0));
-        launch_convert(in, dsrc, cnt, d_ibases, d_inf, glv, s);
-        return MSM_OK;
-    }
-    int32_t rc = h2d(c, d_raw, src, cnt * in.stride, s);
+// base records of points [lo, lo+cnt) -> raw staging d_raw -> internal-domain records d_ibases (+ infinity bytes d_inf for the
+// struct form), all on stream s
+int32_t feed_bases(msm_ctx* c, const HostInput& in, size_t lo, size_t cnt, void* d_raw, uint32_t* d_ibases, uint8_t* d_inf, bool glv,
+                   hipStream_t s) {
+    int32_t rc = h2d(c, d_raw, in.bases + lo * in.stride, cnt * in.stride, s);
     if (rc) return rc;
     launch_convert(in, d_raw, cnt, d_ibases, d_inf, glv, s);
     return MSM_OK;
@@ -679,13 +654,13 @@ int32_t feed_bases(msm_ctx* c, const HostInput& in, const Feed& f, size_t lo, si
 // Single shot: scalars (and the infinity mask) go first on the compute stream and are sorted while the bases -- two thirds of
 // the bytes, only needed by k_accumulate -- still travel and are converted on the copy stream.  (The struct form carries the
 // infinity flags inside the base records, which k_decompose needs: there the two transfers merely share the link.)
-int32_t run_single(msm_ctx* c, const HostInput& in, size_t n, const Feed& f, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf) {
+int32_t run_single(msm_ctx* c, const HostInput& in, size_t n, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf) {
     int32_t rc;
     hipStream_t st = c->stream, cs = c->copy_stream;
     const bool glv = plan_glv(c, n);
     PipeState ps;
     if ((rc = ensure(c, c->scalars, n * 32))) return rc;
-    if (!f.pull && (rc = ensure(c, c->bases, n * in.stride))) return rc;
+    if ((rc = ensure(c, c->bases, n * in.stride))) return rc;
     if ((rc = ensure(c, c->ibases, (glv ? 2 : 1) * n * 64))) return rc;
     if (in.carries_inf() && (rc = ensure(c, c->inf, n))) return rc;
     if ((rc = pipe_prepare(c, n, 0, 0, st, &ps))) return rc;
@@ -697,23 +672,23 @@ int32_t run_single(msm_ctx* c, const HostInput& in, size_t n, const Feed& f, uin
     {
         Range r_("msm:h2d");
         if (in.kind == KIND_ARK) {
-            if ((rc = feed_bases(c, in, f, 0, n, c->bases.p, ib, (uint8_t*)c->inf.p, glv, bs))) return rc;
+            if ((rc = feed_bases(c, in, 0, n, c->bases.p, ib, (uint8_t*)c->inf.p, glv, bs))) return rc;
             if (overlap) HIPCHK(c, hipEventRecord(c->ev_bases, bs));
-            if ((rc = feed_scalars(c, in, f, 0, n, c->scalars.p, nullptr, st))) return rc;
+            if ((rc = feed_scalars(c, in, 0, n, c->scalars.p, nullptr, st))) return rc;
             if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_H2D], st));
             if (overlap) HIPCHK(c, hipStreamWaitEvent(st, c->ev_bases, 0));  // k_decompose reads the infinity bytes
             if ((rc = enqueue_sort(c, ps, d_inf, (const uint32_t*)c->scalars.p, in.scalars_mont, st, true))) return rc;
             if ((rc = enqueue_accumulate(c, ps, ib, st, nullptr, false))) return rc;
         } else {
-            if ((rc = feed_scalars(c, in, f, 0, n, c->scalars.p, c->inf.p, st))) return rc;
+            if ((rc = feed_scalars(c, in, 0, n, c->scalars.p, c->inf.p, st))) return rc;
             if (overlap) {
                 // queue the sort BEFORE the bases are touched: a copy from pageable memory blocks the host, the GPU sorts meanwhile
                 if ((rc = enqueue_sort(c, ps, d_inf, (const uint32_t*)c->scalars.p, in.scalars_mont, st, true))) return rc;
-                if ((rc = feed_bases(c, in, f, 0, n, c->bases.p, ib, nullptr, glv, bs))) return rc;
+                if ((rc = feed_bases(c, in, 0, n, c->bases.p, ib, nullptr, glv, bs))) return rc;
                 HIPCHK(c, hipEventRecord(c->ev_bases, bs));
                 if ((rc = enqueue_accumulate(c, ps, ib, st, c->ev_bases, false))) return rc;
             } else {
-                if ((rc = feed_bases(c, in, f, 0, n, c->bases.p, ib, nullptr, glv, st))) return rc;
+                if ((rc = feed_bases(c, in, 0, n, c->bases.p, ib, nullptr, glv, st))) return rc;
                 if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_H2D], st));
                 if ((rc = enqueue_sort(c, ps, d_inf, (const uint32_t*)c->scalars.p, in.scalars_mont, st, true))) return rc;
                 if ((rc = enqueue_accumulate(c, ps, ib, st, nullptr, false))) return rc;
@@ -724,7 +699,6 @@ int32_t run_single(msm_ctx* c, const HostInput& in, size_t n, const Feed& f, uin
     if ((rc = finish_sync(c, ps, n, st, out_jac, out_aff, out_inf))) return rc;
     c->tm.h2d_ms = stage_ms(c, EV_START, EV_H2D);
     c->tm.convert_ms = stage_ms(c, EV_H2D, EV_CONVERT);
-    c->tm.pulled = f.pull ? 1u : 0u;
     trace_line(c, "host single-shot", ps);
     return MSM_OK;
 }
@@ -736,13 +710,13 @@ int32_t run_single(msm_ctx* c, const HostInput& in, size_t n, const Feed& f, uin
 // however many chunks.  Raw and converted inputs are double-buffered.  The link is the bottleneck (96 B per point at ~55 GB/s
 // against ~1.2 ns of sort + accumulation), so what the call pays beyond the transfer is the work left when the last byte
 // has arrived: the automatic schedule ends with short chunks.
-int32_t run_streamed(msm_ctx* c, const HostInput& in, size_t n, const std::vector<size_t>& sizes, const Feed& f, uint32_t* out_jac,
+int32_t run_streamed(msm_ctx* c, const HostInput& in, size_t n, const std::vector<size_t>& sizes, uint32_t* out_jac,
                      uint32_t* out_aff, uint8_t* out_inf) {
     int32_t rc;
     const bool glv = plan_glv(c, n);  // of the WHOLE instance: all chunks share one bucket array
     const size_t chunk = *std::max_element(sizes.begin(), sizes.end());
     for (int s = 0; s < 2; s++) {
-        if (!f.pull && (rc = ensure(c, c->sbases[s], chunk * in.stride))) return rc;
+        if ((rc = ensure(c, c->sbases[s], chunk * in.stride))) return rc;
         if ((rc = ensure(c, c->sscalars[s], chunk * 32))) return rc;
         if (in.carries_inf() && (rc = ensure(c, c->sinf[s], chunk))) return rc;
         if ((rc = ensure(c, c->sibases[s], (glv ? 2 : 1) * chunk * 64))) return rc;
@@ -758,8 +732,8 @@ int32_t run_streamed(msm_ctx* c, const HostInput& in, size_t n, const std::vecto
         {
             Range r_("msm:h2d chunk");
             if (j >= 2) HIPCHK(c, hipStreamWaitEvent(cs, c->ev_free[s], 0));  // the pipeline that read this slot is done
-            if ((rc = feed_scalars(c, in, f, lo, cnt, c->sscalars[s].p, d_inf, cs))) return rc;
-            if ((rc = feed_bases(c, in, f, lo, cnt, c->sbases[s].p, (uint32_t*)c->sibases[s].p, d_inf, glv, cs))) return rc;
+            if ((rc = feed_scalars(c, in, lo, cnt, c->sscalars[s].p, d_inf, cs))) return rc;
+            if ((rc = feed_bases(c, in, lo, cnt, c->sbases[s].p, (uint32_t*)c->sibases[s].p, d_inf, glv, cs))) return rc;
             HIPCHK(c, hipEventRecord(c->ev_copied[s], cs));
         }
         HIPCHK(c, hipStreamWaitEvent(st, c->ev_copied[s], 0));
@@ -772,7 +746,6 @@ int32_t run_streamed(msm_ctx* c, const HostInput& in, size_t n, const std::vecto
     if ((rc = enqueue_reduce(c, ps, st, c->h_qsums, c->h_flags))) return rc;
     if ((rc = finish_sync(c, ps, n, st, out_jac, out_aff, out_inf))) return rc;
     c->tm.stream_chunks = (uint32_t)sizes.size();
-    c->tm.pulled = f.pull ? 1u : 0u;
     trace_line(c, "host streamed", ps);
     return MSM_OK;
 }
@@ -786,27 +759,25 @@ std::vector<size_t> stream_schedule(const msm_ctx* c, size_t n) {
         for (size_t lo = 0; lo < n; lo += chunk) sizes.push_back(std::min(chunk, n - lo));
         return sizes;
     }
-    // automatic.  A chunk costs its transfer (96 B per point at ~55 GB/s: 0.46 ms per 2^18 points) or its sort + accumulation
-    // (~0.4 ms per 2^18 points), whichever is longer, and ~15 launches.  Chunks of 2^18 points (2^19 / 2^20 for large instances)
-    // keep the link busy; the last `chunk` points go as 1/2 + 1/4 + 1/4 (not below 2^16) so that little is left to compute when
-    // the transfer ends.
-    uint32_t min_log2 = 19, lg = n < ((size_t)1 << 21) ? 18u : n < ((size_t)1 << 23) ? 19u : 20u, tail_min_log2 = 16;
+    // automatic.  A chunk costs its transfer (96 B per point: 0.43 ms per 2^18 points at the link's 56 GB/s, ~0.6 ms from pageable
+    // memory, which the runtime stages at ~40 GB/s) or its sort + accumulation + combine (~0.47 ms per 2^18 points, of which
+    // ~0.2 ms do not shrink with the chunk: sort launches, k_combine over all buckets, bucket read-modify-write), whichever is
+    // longer.  Uniform chunks of 2^18 points (2^19 / 2^20 for large instances): shorter chunks at the end, meant to leave less work
+    // after the last byte, cost more in fixed per-chunk work than they hide (measured: 2^20 in 4 chunks 2.89 ms, 3 x 2^18 +
+    // 2^17 + 2 x 2^16: 3.48 ms -- profiles/NOTES_r2.md).  A remainder below half a chunk joins the last chunk.
+    uint32_t min_log2 = 19, lg = n < ((size_t)1 << 21) ? 18u : n < ((size_t)1 << 23) ? 19u : 20u;
     if (const char* e = std::getenv("MSM_HIP_STREAM_MIN_LOG2")) min_log2 = (uint32_t)std::max(9, std::min(31, std::atoi(e)));
     if (const char* e = std::getenv("MSM_HIP_STREAM_CHUNK_LOG2")) lg = (uint32_t)std::max(8, std::min(28, std::atoi(e)));
-    if (const char* e = std::getenv("MSM_HIP_STREAM_TAIL_LOG2")) tail_min_log2 = (uint32_t)std::max(8, std::min(28, std::atoi(e)));
-    const size_t chunk = (size_t)1 << lg, tail_min = (size_t)1 << tail_min_log2;
+    const size_t chunk = (size_t)1 << lg;
     if (n < ((size_t)1 << min_log2) || n < 2 * chunk) return sizes;
     size_t left = n;
-    while (left > chunk + chunk / 2) {
+    while (left >= chunk + chunk / 2) {
         sizes.push_back(chunk);
         left -= chunk;
     }
-    // the rest (between 1/2 and 3/2 of a chunk): halves until the pieces reach tail_min
-    while (left >= 2 * tail_min && sizes.size() < 64) {
-        const size_t h = (left / 2 + 63) & ~(size_t)63;
-        sizes.push_back(h);
-        left -= h;
-        if (left <= chunk / 4) break;
+    if (left > chunk) {  // (chunk, 1.5 chunk): two halves
+        sizes.push_back((left / 2 + 63) & ~(size_t)63);
+        left -= sizes.back();
     }
     if (left) sizes.push_back(left);
     return sizes;
@@ -814,12 +785,8 @@ std::vector<size_t> stream_schedule(const msm_ctx* c, size_t n) {
 
 int32_t run_host_input(msm_ctx* c, const HostInput& in, size_t n, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf) {
     auto t0 = std::chrono::steady_clock::now();
-    Feed f;
-    f.pull = is_pinned_host(in.bases) && is_pinned_host(in.scalars) && (!in.inf_mask || is_pinned_host(in.inf_mask));
-    if (const char* e = std::getenv("MSM_HIP_PINNED_PULL"))  // A/B knob: 0 = hipMemcpyAsync also from pinned memory
-        if (*e == '0') f.pull = false;
     const std::vector<size_t> sizes = stream_schedule(c, n);
-    int32_t rc = sizes.empty() ? run_single(c, in, n, f, out_jac, out_aff, out_inf) : run_streamed(c, in, n, sizes, f, out_jac, out_aff, out_inf);
+    int32_t rc = sizes.empty() ? run_single(c, in, n, out_jac, out_aff, out_inf) : run_streamed(c, in, n, sizes, out_jac, out_aff, out_inf);
     if (rc) return rc;
     c->tm.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return MSM_OK;
@@ -875,7 +842,17 @@ int32_t msm_ctx_create(const msm_config_t* cfg, msm_ctx** out) {
     DeviceGuard g(dev);
     hipError_t e = g.ok ? hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) : hipErrorInvalidDevice;
     for (int i = 0; i < EV_COUNT && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) {
+        // The copy stream must own a HARDWARE queue of its own.  Streams of equal priority are spread over a small pool of HSA
+        // queues shared with every other stream of the process (PyTorch's included); when both of this context's streams landed on
+        // one queue, the barrier packets of their cross-stream event waits executed in queue order and every chunk upload waited
+        // for the PREVIOUS chunk's kernels (rocprofv3 kernel trace: one Queue_Id, profiles/NOTES_r2.md).  A stream of another
+        // priority comes from another pool.
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
+        e = least != greatest ? hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, greatest)
+                              : hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_bases, hipEventDisableTiming);
     for (int i = 0; i < 2 && e == hipSuccess; i++) {

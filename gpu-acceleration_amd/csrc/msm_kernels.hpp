@@ -160,17 +160,6 @@ __device__ __forceinline__ jacobian load_jacobian_mont256(const uint32_t* p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// "pull": copy of PINNED host memory (mapped into the device's address space) into HBM by a bounded grid -- the streamed host
-// path runs it on the copy stream beside k_accumulate (msm_hip.hip: pull()); 16 bytes per lane and step, grid-stride.
-__global__ void __launch_bounds__(256) k_pull16(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
-}
-__global__ void k_pull1(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint32_t n) {
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
-}
-
-// ---------------------------------------------------------------------------------------------
 // K1's coordinate half: caller coordinates (standard form, or arkworks' R = 2^256 Montgomery words) -> the
 // internal domain x*2^261 mod p, canonical, packed.  One Montgomery product per coordinate (the reference
 // spends two 17x17-limb Barrett multiplications here, barrett_reduction.metal:84-118).

@@ -66,8 +66,8 @@ typedef struct {
                                    travels host->HBM (copy stream) while chunk j is sorted and accumulated INTO the shared bucket
                                    array; one bucket reduction and one host finish per MSM (BASELINE config 5).
                                    0 = automatic: from 2^19 points on, chunks of 2^18..2^20 points ending in a few short ones.
-                                   Pinned caller memory is read in place by the conversion kernels; pageable memory goes through
-                                   hipMemcpyAsync (the runtime stages it; those copies overlap the kernels) */
+                                   Copies run on a stream with a hardware queue of its own: from pinned caller memory at the link
+                                   rate, from pageable memory as fast as the runtime stages it (both overlap the kernels) */
     uint64_t max_points;  /* pre-size the HBM workspace for this many points; 0 = grow on demand        */
 } msm_config_t;
 
@@ -95,7 +95,7 @@ typedef struct {
     uint64_t num_points;
     uint64_t num_adds;   /* mixed additions executed by accumulate (non-zero digits) */
     uint32_t stream_chunks; /* host->HBM chunks the call was cut into (0 = single shot / device-resident)      */
-    uint32_t pulled;        /* 1 = caller memory was pinned and was read in place by the kernels (no copy engine) */
+    uint32_t reserved;
 } msm_timings_t;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */

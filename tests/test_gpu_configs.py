@@ -116,9 +116,8 @@ def test_config2_literal_shape(hk):
 
 def test_automatic_streaming_pinned_and_pageable_at_2_pow_22(hk):
     """config 5's mechanism with the DEFAULT configuration (stream_chunk_log2 = 0): from 2^19 points on a host-pointer call is cut
-    into chunks that travel while the previous chunk is accumulated INTO the shared buckets.  Pinned caller memory is read in
-    place by the conversion kernels ("pull"), pageable memory goes through hipMemcpyAsync; MSM_HIP_PINNED_PULL=0 copies pinned
-    memory too.  Same bits every way."""
+    into chunks that travel on the copy stream while the previous chunk is accumulated INTO the shared buckets -- from pinned
+    caller memory (asynchronous copies) and from pageable memory (the runtime stages them).  Same bits either way."""
     import torch
     it = Instance(hk, 22, seed=0xB2540061)
     exp, _ = _expected(it.dot())
@@ -128,42 +127,29 @@ def test_automatic_streaming_pinned_and_pageable_at_2_pow_22(hk):
     hbp, hsp = hb_t.pin_memory(), hs_t.pin_memory()
     hbpn, hspn = hbp.numpy().view(np.uint32).reshape(it.n, 16), hsp.numpy().view(np.uint32).reshape(it.n, 8)
     with mh.MsmContext() as c:
-        r = c.msm(hbpn, hspn, mh.FORM_MONT)
-        tm = c.timings()
-        assert (r.affine_std == exp).all() and tm["stream_chunks"] >= 4 and tm["pulled"] == 1 and tm["num_points"] == it.n
-        assert tm["num_adds"] > 15 * it.n  # the running count covers every chunk (16 windows, ~1 - 2^-16 non-zero digits)
-        r = c.msm(hb, hs, mh.FORM_MONT)  # pageable numpy memory
-        tm = c.timings()
-        assert (r.affine_std == exp).all() and tm["stream_chunks"] >= 4 and tm["pulled"] == 0
-        # a ragged size: the short chunks at the end are cut differently
-        m = it.n - 77777
-        e2, _ = _expected(it.dot(0, m))
-        for b, s in ((hb, hs), (hbpn, hspn)):
-            r = c.msm(b[:m], s[:m], mh.FORM_MONT)
-            assert (r.affine_std == e2).all() and c.timings()["stream_chunks"] >= 4
-        # pinned bases with a pageable infinity mask: everything is copied (the mask decides)
+        for b, s in ((hbpn, hspn), (hb, hs)):
+            r = c.msm(b, s, mh.FORM_MONT)
+            tm = c.timings()
+            assert (r.affine_std == exp).all() and tm["stream_chunks"] >= 4 and tm["num_points"] == it.n
+            assert tm["num_adds"] > 15 * it.n  # the running count covers every chunk (16 windows, ~1 - 2^-16 non-zero digits)
+        # ragged sizes: a remainder below half a chunk joins the last chunk, a larger one is split
+        for m in (it.n - 77777, it.n - (1 << 19) + 5, (1 << 21) + 3):
+            e2, _ = _expected(it.dot(0, m))
+            for b, s in ((hb, hs), (hbpn, hspn)):
+                r = c.msm(b[:m], s[:m], mh.FORM_MONT)
+                assert (r.affine_std == e2).all() and c.timings()["stream_chunks"] >= 4, m
+        # an infinity mask travels with the chunks
         inf = np.zeros(it.n, np.uint8)
         inf[[3, 1 << 20, it.n - 1]] = 1
         e4, _ = _expected(it.dot(skip=inf))
         r = c.msm(hbpn, hspn, mh.FORM_MONT, inf)
-        assert (r.affine_std == e4).all() and c.timings()["pulled"] == 0
-        infp = torch.from_numpy(inf).pin_memory()
-        r = c.msm(hbpn, hspn, mh.FORM_MONT, infp.numpy())
-        assert (r.affine_std == e4).all() and c.timings()["pulled"] == 1
+        assert (r.affine_std == e4).all()
         # below the streaming threshold: single shot (bases travel on the copy stream beside the sort)
         m = 1 << 18
         e3, _ = _expected(it.dot(0, m))
-        for b, s, pulled in ((hb, hs, 0), (hbpn, hspn, 1)):
+        for b, s in ((hb, hs), (hbpn, hspn)):
             r = c.msm(b[:m], s[:m], mh.FORM_MONT)
-            tm = c.timings()
-            assert (r.affine_std == e3).all() and tm["stream_chunks"] == 0 and tm["pulled"] == pulled
-    os.environ["MSM_HIP_PINNED_PULL"] = "0"
-    try:
-        with mh.MsmContext() as c:
-            r = c.msm(hbpn, hspn, mh.FORM_MONT)
-            assert (r.affine_std == exp).all() and c.timings()["pulled"] == 0
-    finally:
-        del os.environ["MSM_HIP_PINNED_PULL"]
+            assert (r.affine_std == e3).all() and c.timings()["stream_chunks"] == 0
 
 
 def test_streamed_shared_buckets_small_chunks(hk):
@@ -182,7 +168,7 @@ def test_streamed_shared_buckets_small_chunks(hk):
             r = c.msm(bases, s, mh.FORM_MONT, inf)
             tm = c.timings()
             assert (r.affine_std == exp).all(), lg
-            assert tm["stream_chunks"] == n >> lg and tm["pulled"] == 0
+            assert tm["stream_chunks"] == n >> lg
             assert mh.plan(n).glv == 1  # 2n virtual points per chunk, one bucket array
             bad = s.copy()
             bad[n - 3, 7] |= 0x40000000

@@ -14,8 +14,6 @@ gen.generate_device(1, 2, n, d_b.data_ptr(), d_s.data_ptr()); torch.cuda.synchro
 tb, ts = d_b.cpu(), d_s.cpu()
 if mode != "pageable":
     tb, ts = tb.pin_memory(), ts.pin_memory()
-if mode == "pinned-copy":
-    os.environ["MSM_HIP_PINNED_PULL"] = "0"
 hb, hs = tb.numpy().view(np.uint32).reshape(n, 16), ts.numpy().view(np.uint32).reshape(n, 8)
 with mh.MsmContext() as c:
     for _ in range(6):

@@ -38,17 +38,13 @@ def main():
                         ("chunk 2^17", {"MSM_HIP_STREAM_MIN_LOG2": "18", "MSM_HIP_STREAM_CHUNK_LOG2": "17"}),
                         ("chunk 2^18", {"MSM_HIP_STREAM_MIN_LOG2": "18", "MSM_HIP_STREAM_CHUNK_LOG2": "18"})]
         if lg >= 20:
-            configs += [("chunk 2^19", {"MSM_HIP_STREAM_MIN_LOG2": "18", "MSM_HIP_STREAM_CHUNK_LOG2": "19"}),
-                        ("c18 tail15", {"MSM_HIP_STREAM_CHUNK_LOG2": "18", "MSM_HIP_STREAM_TAIL_LOG2": "15"}),
-                        ("c18 tail17", {"MSM_HIP_STREAM_CHUNK_LOG2": "18", "MSM_HIP_STREAM_TAIL_LOG2": "17"}),
-                        ("c18 notail", {"MSM_HIP_STREAM_CHUNK_LOG2": "18", "MSM_HIP_STREAM_TAIL_LOG2": "28"})]
+            configs += [("chunk 2^19", {"MSM_HIP_STREAM_MIN_LOG2": "18", "MSM_HIP_STREAM_CHUNK_LOG2": "19"})]
         if lg >= 22:
             configs += [("chunk 2^20", {"MSM_HIP_STREAM_MIN_LOG2": "18", "MSM_HIP_STREAM_CHUNK_LOG2": "20"})]
         for label, env in configs:
             for kind, b, s in (("pinned  ", hbp, hsp), ("pageable", hb, hs)):
-                for stage in (("1", "0") if kind == "pinned  " else ("",)):   # pinned: pull kernels (1) or hipMemcpyAsync (0)
+                for stage in ("",):
                     e = dict(env)
-                    if stage: e["MSM_HIP_PINNED_PULL"] = stage
                     os.environ.update(e)
                     try:
                         with mh.MsmContext() as c:
@@ -56,7 +52,7 @@ def main():
                             tm = c.timings()
                     finally:
                         for k in e: os.environ.pop(k, None)
-                    print(f"2^{lg} {kind} {label:12s} pull={stage or '-'} median {med:7.3f} min {mn:7.3f} ms  chunks {tm['stream_chunks']} pulled {tm['pulled']}", flush=True)
+                    print(f"2^{lg} {kind} {label:12s} median {med:7.3f} min {mn:7.3f} ms  chunks {tm['stream_chunks']}", flush=True)
         with mh.MsmContext() as c:
             med, mn = timed(lambda: c.msm_arkworks(img, 72, 0, 32, 64, hs))
             print(f"2^{lg} arkworks pageable auto         median {med:7.3f} min {mn:7.3f} ms  chunks {c.timings()['stream_chunks']}", flush=True)
