@@ -199,13 +199,8 @@ def main():
     elapsed = time.perf_counter() - t0
     if ctx is not None:
         acc_avg_ms, acc_launches = ctx.accumulate_kernel_stats()
-        tm_last = ctx.timings()
     else:
-        tm_last = multi.timings(0)
-        acc_avg_ms, acc_launches = tm_last["accumulate_ms"], 1
-    # windows covered by the TIMED k_accumulate launch (all, or the first group of a window-split MSM) and the additions it ran
-    acc_windows = int(tm_last.get("accumulate_windows", 0))
-    adds_timed_step = int(tm_last.get("num_adds", 0))
+        acc_avg_ms, acc_launches = multi.timings(0)["accumulate_ms"], 1
     mad_peak, fpmul_peak = (0.0, 0.0)
     if rank == 0:  # two ~1 ms micro-kernels, outside the timed region
         with th.HooksContext(device=devs[my_shards[0]].index) as cal:
@@ -258,10 +253,7 @@ def main():
         W, H = pl.num_windows, pl.num_buckets
         # ALGORITHMIC bytes of one accumulate launch: W*(N*(4 B index + 64 B affine point) + H*96 B)
         # (with the GLV split a window sorts and accumulates 2n virtual points in half as many windows: same point term)
-        # The timed launch is k_accumulate<false, 0>: every window, or -- when the MSM is window-split so that the first group's bucket
-        # reduction runs beside the last group's accumulation -- the first `acc_windows` windows; its bytes are counted accordingly.
-        Wt = acc_windows if 0 < acc_windows <= W else W
-        alg_bytes = Wt * (int(pl.virtual_points) * 68 + H * 96)
+        alg_bytes = W * (int(pl.virtual_points) * 68 + H * 96)
         achieved = alg_bytes / (acc_avg_ms * 1e-3) / 1e9 if acc_avg_ms > 0 and not args.streamed else 0.0
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "accumulate_pmc.json")
@@ -296,7 +288,7 @@ def main():
             "bit_exact": bit_exact,
             "roofline": {"bound": "hbm", "kernel": "k_accumulate", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": alg_bytes, "windows_in_timed_launch": Wt, "avg_kernel_ms": round(acc_avg_ms, 4),
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_ms": round(acc_avg_ms, 4),
                          "launches_timed": int(acc_launches),
                          "note": "integer-multiply (VALU) bound kernel; HBM fraction reported because BASELINE.json asks for it; "
                                  "the multiplier roofline is in roofline_valu"},
@@ -308,7 +300,7 @@ def main():
                                "note": "latency/LDS-atomic bound at this size (6 dependent launches over 64 MB of digits)"} if sort_ms > 0 else None),
             # the bound that actually holds: multiplier work of the launch against what two calibration
             # micro-kernels sustain on THIS device (dependent chains, 4 wavefronts per SIMD, like k_accumulate)
-            "roofline_valu": valu_roofline(adds_timed_step * Wt // W, acc_avg_ms, mad_peak, fpmul_peak) if not args.streamed else None,
+            "roofline_valu": valu_roofline(int(tm.get("num_adds", 0)), acc_avg_ms, mad_peak, fpmul_peak) if not args.streamed else None,
             "stage_ms_untimed_diagnostic_step": {k: round(v, 4) for k, v in tm.items() if k.endswith("_ms")},
         }
 

@@ -102,7 +102,6 @@ struct msm_ctx {
     hipStream_t copy_stream = nullptr;     // host->HBM uploads and base conversion beside the sort
     hipEvent_t ev_copied[2]{}, ev_free[2]{};
     hipEvent_t ev_fork = nullptr, ev_bases = nullptr;  // base conversion runs on copy_stream beside the sort kernels
-    hipEvent_t ev_grp = nullptr, ev_red = nullptr;     // window-split MSM: first group accumulated / its reduction done
     DevBuf sbases[2], sscalars[2], sinf[2];  // double-buffered raw inputs of the streamed path
     DevBuf sibases[2];                        // ... and of the converted bases (the conversion of chunk j+1 runs beside the accumulation of chunk j)
     msm_config_t cfg{};
@@ -124,7 +123,6 @@ struct msm_ctx {
     bool stage_timing = false;  // record the per-stage hipEvents (each costs ~6 us of stream time); k_accumulate's pair is always on
     double acc_ms_sum = 0;
     uint64_t acc_launches = 0;
-    uint32_t last_acc_windows = 0;  // windows covered by the TIMED k_accumulate launch of the last call (all, or the first group of a split)
     uint32_t last_sort_path = 0;  // 2 = two-level LDS sort, 1 = tiled LDS histogram, 0 = global atomics (stage tests, trace)
 };
 
@@ -398,70 +396,59 @@ int32_t enqueue_sort(msm_ctx* c, const PipeState& ps, const uint8_t* d_inf, cons
     return MSM_OK;
 }
 
-// K3: bucket accumulation (the graded kernel) over the chunks [t0, t1) of the sorted array.  d_bases: INTERNAL-domain records; with
-// the GLV split 2*n_real of them, phi(P_i) at index n_real + i.  into = true: the buckets keep what earlier chunks of the same
-// streamed MSM left in them.  part: 0 = the whole MSM or its first window group, 1 = the last window group (own kernel name).
-// timed: bracketed by the EV_ACC0/EV_ACC1 hipEvents on the stream the kernel runs on (bench.py's roofline reads them).
-int32_t launch_accumulate(msm_ctx* c, const PipeState& ps, const uint32_t* d_bases, hipStream_t st, bool into, int part, size_t t0,
-                          size_t t1, bool timed) {
-    if (t1 <= t0) return MSM_OK;
-    uint32_t* flags = (uint32_t*)c->flags.p;
-    const uint32_t *srt = (const uint32_t*)c->sorted.p, *off = (const uint32_t*)c->offsets.p, *cm = (const uint32_t*)c->chunkmap.p;
-    uint32_t *bk = (uint32_t*)c->buckets.p, *hd = (uint32_t*)c->heads.p, *tl = (uint32_t*)c->tails.p;
-    const uint32_t* tp = flags + msmk::FLAG_PAIRS;
-    const dim3 g = grid1(t1 - t0, 256);
-    const uint32_t L = ps.chunk_len, tb = (uint32_t)ps.tb, a = (uint32_t)t0, b = (uint32_t)t1;
-    if (timed) HIPCHK(c, hipEventRecord(c->ev[EV_ACC0], st));
-    if (into) msmk::k_accumulate<true, 0><<<g, 256, 0, st>>>(d_bases, srt, off, cm, bk, hd, tl, tp, L, tb, a, b);
-    else if (part == 0) msmk::k_accumulate<false, 0><<<g, 256, 0, st>>>(d_bases, srt, off, cm, bk, hd, tl, tp, L, tb, a, b);
-    else msmk::k_accumulate<false, 1><<<g, 256, 0, st>>>(d_bases, srt, off, cm, bk, hd, tl, tp, L, tb, a, b);
-    if (timed) HIPCHK(c, hipEventRecord(c->ev[EV_ACC1], st));
-    return MSM_OK;
-}
-// the buckets [k_lo, k_hi) that chunk borders cut: once (dense), 3..7 times (listed), 8+ times (long, LDS trees)
-void launch_combine(msm_ctx* c, const PipeState& ps, hipStream_t st, bool into, size_t k_lo, size_t k_hi) {
+// K3: bucket accumulation (the graded kernel) -- bracketed by its own events on its own stream -- and the buckets cut by chunk
+// borders.  d_bases: INTERNAL-domain records; with the GLV split 2*n_real of them, phi(P_i) at index n_real + i.
+// into = true: the buckets keep what earlier chunks of the same MSM left in them (k_accumulate<true>).
+int32_t enqueue_accumulate(msm_ctx* c, const PipeState& ps, const uint32_t* d_bases, hipStream_t st, hipEvent_t bases_ready, bool into) {
+    Range r_("msm:accumulate");
     uint32_t* flags = (uint32_t*)c->flags.p;
     uint32_t* offsets = (uint32_t*)c->offsets.p;
-    msmk::k_combine<<<dim3(msmk::MID_BLOCKS + (unsigned)((k_hi - k_lo + 255) / 256)), 256, 0, st>>>(
-        offsets, (uint32_t*)c->heads.p, (uint32_t*)c->tails.p, (uint32_t*)c->buckets.p, (uint32_t)k_lo, (uint32_t)k_hi, ps.chunk_len,
-        flags + msmk::FLAG_MID, (uint32_t*)c->midlist.p, into ? 1u : 0u);
+    const size_t tb = ps.tb;
+    if (bases_ready) HIPCHK(c, hipStreamWaitEvent(st, bases_ready, 0));  // d_bases is being converted on another stream
+    HIPCHK(c, hipEventRecord(c->ev[EV_ACC0], st));
+    if (into)
+        msmk::k_accumulate<true><<<grid1(ps.nchunks_max, 256), 256, 0, st>>>(d_bases, (uint32_t*)c->sorted.p, offsets, (uint32_t*)c->chunkmap.p,
+                                                                          (uint32_t*)c->buckets.p, (uint32_t*)c->heads.p, (uint32_t*)c->tails.p,
+                                                                          flags + msmk::FLAG_PAIRS, ps.chunk_len, (uint32_t)tb);
+    else
+        msmk::k_accumulate<false><<<grid1(ps.nchunks_max, 256), 256, 0, st>>>(d_bases, (uint32_t*)c->sorted.p, offsets, (uint32_t*)c->chunkmap.p,
+                                                                           (uint32_t*)c->buckets.p, (uint32_t*)c->heads.p, (uint32_t*)c->tails.p,
+                                                                           flags + msmk::FLAG_PAIRS, ps.chunk_len, (uint32_t)tb);
+    HIPCHK(c, hipEventRecord(c->ev[EV_ACC1], st));
+    msmk::k_combine<<<dim3(msmk::MID_BLOCKS + (unsigned)((tb + 255) / 256)), 256, 0, st>>>(offsets, (uint32_t*)c->heads.p, (uint32_t*)c->tails.p,
+                                                                                         (uint32_t*)c->buckets.p, (uint32_t)tb, ps.chunk_len,
+                                                                                         flags + msmk::FLAG_MID, (uint32_t*)c->midlist.p, into ? 1u : 0u);
     msmk::k_combine_long<<<1024, 512, 0, st>>>(offsets, (uint32_t*)c->heads.p, (uint32_t*)c->tails.p, (uint32_t*)c->buckets.p,
-                                               flags + msmk::FLAG_LONG, (uint32_t*)c->longlist.p, (uint32_t*)c->longdone.p, ps.chunk_len,
-                                               (uint32_t)k_lo, (uint32_t)k_hi);
+                                               flags + msmk::FLAG_LONG, (uint32_t*)c->longlist.p, (uint32_t*)c->longdone.p, ps.chunk_len);
+    return MSM_OK;
 }
 
-// K4/K5: bucket reduction of the windows [w_lo, w_hi) -- plain row/column sums by dense pairwise levels, then per-bit sums; the
-// weights are applied on the host.  The (kb+1) bit sums per window are written by the last kernel straight into h_qsums_dst
-// (pinned host memory, indexed by window), the flag words into h_flags_dst when it is not NULL (the launch that finishes the
-// MSM).  wait_before_last: an event of another stream the last kernel must wait for.  No host synchronisation here.
-int32_t enqueue_reduce(msm_ctx* c, const PipeState& ps, hipStream_t st, uint32_t w_lo, uint32_t w_hi, uint32_t* h_qsums_dst,
-                       uint32_t* h_flags_dst, hipEvent_t wait_before_last = nullptr) {
+// K4/K5: bucket reduction -- plain row/column sums by dense pairwise levels, then per-bit sums; the weights are applied on
+// the host.  The W*(kb+1) bit sums and the flag words are written by the last kernel straight into h_qsums_dst / h_flags_dst
+// (pinned host memory).  No host synchronisation here.
+int32_t enqueue_reduce(msm_ctx* c, const PipeState& ps, hipStream_t st, uint32_t* h_qsums_dst, uint32_t* h_flags_dst) {
     Range r_("msm:reduce");
     const size_t tb = ps.tb;
-    const uint32_t nb = ps.nb, kb = ps.kb, kb_lo = ps.kb_lo, kb_hi = ps.kb_hi, n_lo = ps.n_lo, n_hi = ps.n_hi;
-    const uint32_t Wr = w_hi - w_lo;
-    const size_t b0 = (size_t)w_lo * nb;  // first bucket of the range; at level l a window holds nb >> (l+1) partial sums
+    const uint32_t W = ps.W, kb = ps.kb, kb_lo = ps.kb_lo, kb_hi = ps.kb_hi, n_lo = ps.n_lo, n_hi = ps.n_hi;
     uint32_t* flags = (uint32_t*)c->flags.p;
-    const uint32_t* bk = (const uint32_t*)c->buckets.p + b0 * msmk::XW;
-    // ping-pong buffers per family, for ALL windows: [0, tb/2) and [tb/2, tb/2 + tb/4) elements
+    const uint32_t* bk = (const uint32_t*)c->buckets.p;
+    // ping-pong buffers per family: [0, tb/2) and [tb/2, tb/2 + tb/4) elements
     uint32_t* rbuf[2] = {(uint32_t*)c->rc.p, (uint32_t*)c->rc.p + (tb / 2) * msmk::XW};
     uint32_t* cbuf[2] = {(uint32_t*)c->rc.p + (tb / 2 + tb / 4 + 1) * msmk::XW, (uint32_t*)c->rc.p + (tb + tb / 4 + 1) * msmk::XW};
     const uint32_t *rin = bk, *cin = bk;
-    size_t rn = (size_t)Wr * nb, cn = (size_t)Wr * nb;  // current element counts of the range
+    size_t rn = tb, cn = tb;  // current element counts
     uint32_t levels = kb_hi > kb_lo ? kb_hi : kb_lo;
     for (uint32_t l = 0; l < levels; l++) {
         msmk::pair_job ja{nullptr, nullptr, 0, 1}, jb{nullptr, nullptr, 0, 1};
         if (l < kb_lo) {
             rn /= 2;
-            uint32_t* out = rbuf[l & 1] + (b0 >> (l + 1)) * msmk::XW;
-            ja = msmk::pair_job{rin, out, (uint32_t)rn, 1};
-            rin = out;
+            ja = msmk::pair_job{rin, rbuf[l & 1], (uint32_t)rn, 1};
+            rin = rbuf[l & 1];
         }
         if (l < kb_hi) {
             cn /= 2;
-            uint32_t* out = cbuf[l & 1] + (b0 >> (l + 1)) * msmk::XW;
-            jb = msmk::pair_job{cin, out, (uint32_t)cn, n_lo};
-            cin = out;
+            jb = msmk::pair_job{cin, cbuf[l & 1], (uint32_t)cn, n_lo};
+            cin = cbuf[l & 1];
         }
         // levels with fewer additions than an eighth of the lanes the chip keeps resident: eight lanes per addition
         const size_t nadds = (size_t)ja.n_out + jb.n_out;
@@ -472,61 +459,13 @@ int32_t enqueue_reduce(msm_ctx* c, const PipeState& ps, hipStream_t st, uint32_t
     // a D2H copy engine transfer started ~11 us after the kernel and took two launches (24 KB + 32 B)
     uint32_t *q_dev = nullptr, *f_dev = nullptr;
     HIPCHK(c, hipHostGetDevicePointer((void**)&q_dev, h_qsums_dst, 0));
-    if (h_flags_dst) HIPCHK(c, hipHostGetDevicePointer((void**)&f_dev, h_flags_dst, 0));
-    q_dev += (size_t)w_lo * (kb + 1) * 24;
-    if (wait_before_last) HIPCHK(c, hipStreamWaitEvent(st, wait_before_last, 0));
+    HIPCHK(c, hipHostGetDevicePointer((void**)&f_dev, h_flags_dst, 0));
     if (c->wide_max && n_hi / 2 <= msmk::WIDE_TREE_MAX && n_lo <= msmk::WIDE_TREE_MAX)
-        msmk::k_reduce_bits_wide<<<Wr * (kb + 1), 512, 0, st>>>(rin, cin, q_dev, n_hi, n_lo, kb_lo, kb, flags, f_dev);
+        msmk::k_reduce_bits_wide<<<W * (kb + 1), 512, 0, st>>>(rin, cin, q_dev, n_hi, n_lo, kb_lo, kb, flags, f_dev);
     else
-        msmk::k_reduce_bits<<<Wr * (kb + 1), 64, 0, st>>>(rin, cin, q_dev, n_hi, n_lo, kb_lo, kb, flags, f_dev);
-    if (c->stage_timing && h_flags_dst) HIPCHK(c, hipEventRecord(c->ev[EV_REDUCE], st));
+        msmk::k_reduce_bits<<<W * (kb + 1), 64, 0, st>>>(rin, cin, q_dev, n_hi, n_lo, kb_lo, kb, flags, f_dev);
+    if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_REDUCE], st));
     return MSM_OK;
-}
-
-// Windows in the LAST group of a window-split MSM (0 = no split).  The bucket reduction is a chain of ~10 dependent, mostly
-// latency-bound launches (~0.2-0.3 ms at every size); k_accumulate is ALU-bound and leaves them room.  So the windows are cut in
-// two groups: as soon as the first group is accumulated its reduction starts on the second stream (a hardware queue of its own)
-// and runs BESIDE the accumulation of the last group; only the last group's reduction is left on the critical path.  The last
-// group is sized so that its accumulation lasts about as long as a reduction chain.
-uint32_t split_windows(const msm_ctx* c, const PipeState& ps) {
-    if (c->stage_timing || ps.W < 4) return 0;
-    uint32_t min_log2 = 21;  // sorted entries below which the split does not pay (its events and waits cost ~20 us)
-    if (const char* e = std::getenv("MSM_HIP_SPLIT_MIN_LOG2")) min_log2 = (uint32_t)std::max(0, std::min(40, std::atoi(e)));
-    if (ps.pairs < ((size_t)1 << min_log2)) return 0;
-    const double t_acc_ms = (double)ps.pairs * 72e-9, t_reduce_ms = 0.22;  // ~72 ps per mixed addition chip-wide
-    uint32_t wb = (uint32_t)((double)ps.W * t_reduce_ms / t_acc_ms + 0.5);
-    if (const char* e = std::getenv("MSM_HIP_SPLIT_B")) wb = (uint32_t)std::max(0, std::atoi(e));  // A/B knob; 0 = never split
-    else wb = std::max(1u, wb);
-    return std::min(wb, ps.W / 2);
-}
-
-// accumulate + combine + reduce of one whole (non-streamed) MSM on stream st, window-split when it pays
-int32_t enqueue_accumulate_reduce(msm_ctx* c, const PipeState& ps, const uint32_t* d_bases, hipStream_t st, hipEvent_t bases_ready,
-                                  uint32_t* h_qsums_dst, uint32_t* h_flags_dst) {
-    Range r_("msm:accumulate+reduce");
-    int32_t rc;
-    if (bases_ready) HIPCHK(c, hipStreamWaitEvent(st, bases_ready, 0));  // d_bases is being converted on another stream
-    const uint32_t wb = split_windows(c, ps);
-    c->last_acc_windows = ps.W - wb;
-    if (!wb) {
-        if ((rc = launch_accumulate(c, ps, d_bases, st, false, 0, 0, ps.nchunks_max, true))) return rc;
-        launch_combine(c, ps, st, false, 0, ps.tb);
-        return enqueue_reduce(c, ps, st, 0, ps.W, h_qsums_dst, h_flags_dst);
-    }
-    const uint32_t wa = ps.W - wb;
-    // chunks that can hold entries of the first wa windows (an upper bound: zero digits are not sorted; the few chunks beyond
-    // the real border carry entries of the next window and are simply accumulated early)
-    const size_t ta = std::min(ps.nchunks_max, ((size_t)wa * ps.n + ps.chunk_len - 1) / ps.chunk_len);
-    hipStream_t s2 = c->copy_stream;
-    if ((rc = launch_accumulate(c, ps, d_bases, st, false, 0, 0, ta, true))) return rc;
-    launch_combine(c, ps, st, false, 0, (size_t)wa * ps.nb);
-    HIPCHK(c, hipEventRecord(c->ev_grp, st));
-    HIPCHK(c, hipStreamWaitEvent(s2, c->ev_grp, 0));
-    if ((rc = enqueue_reduce(c, ps, s2, 0, wa, h_qsums_dst, nullptr))) return rc;
-    HIPCHK(c, hipEventRecord(c->ev_red, s2));
-    if ((rc = launch_accumulate(c, ps, d_bases, st, false, 1, ta, ps.nchunks_max, false))) return rc;
-    launch_combine(c, ps, st, false, (size_t)wa * ps.nb, ps.tb);
-    return enqueue_reduce(c, ps, st, wa, ps.W, h_qsums_dst, h_flags_dst, c->ev_red);
 }
 
 // final_reduction (metal_msm.rs:204-261) on the CPU.  With S_w = Q_all,w + sum_u 2^u Q_w,u the result is
@@ -585,9 +524,9 @@ void trace_line(const msm_ctx* c, const char* entry, const PipeState& ps) {
     const msm_timings_t& t = c->tm;
     std::fprintf(stderr,
                  "[msm_hip] %s dev %d n %zu c %u W %u nb %u glv %u sort_path %u chunk_len %u stream_chunks %u | h2d %.3f convert %.3f "
-                 "decompose %.3f sort %.3f accumulate %.3f (%u of the windows) reduce %.3f finish %.3f total %.3f ms, %llu adds\n",
+                 "decompose %.3f sort %.3f accumulate %.3f reduce %.3f finish %.3f total %.3f ms, %llu adds\n",
                  entry, c->device, (size_t)t.num_points, ps.cbits, ps.W, ps.nb, ps.pl.glv, c->last_sort_path, ps.chunk_len, t.stream_chunks,
-                 t.h2d_ms, t.convert_ms, t.decompose_ms, t.sort_ms, t.accumulate_ms, t.accumulate_windows, t.reduce_ms, t.finish_ms, t.total_ms,
+                 t.h2d_ms, t.convert_ms, t.decompose_ms, t.sort_ms, t.accumulate_ms, t.reduce_ms, t.finish_ms, t.total_ms,
                  (unsigned long long)t.num_adds);
 }
 
@@ -614,7 +553,6 @@ int32_t finish_sync(msm_ctx* c, const PipeState& ps, size_t n_total, hipStream_t
     tm.reduce_ms = stage_ms(c, EV_ACC1, EV_REDUCE);
     tm.finish_ms = std::chrono::duration<float, std::milli>(t_fin1 - t_fin0).count();
     tm.num_points = n_total;
-    tm.accumulate_windows = c->last_acc_windows;
     tm.num_adds = (uint64_t)c->h_flags[msmk::FLAG_ADDS64] | ((uint64_t)c->h_flags[msmk::FLAG_ADDS64 + 1] << 32);
     return MSM_OK;
 }
@@ -627,7 +565,8 @@ int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, 
     int32_t rc = pipe_prepare(c, n, 0, extra_flags, st, &ps);
     if (rc) return rc;
     if ((rc = enqueue_sort(c, ps, d_inf, d_scalars, scalars_mont, st, true))) return rc;
-    if ((rc = enqueue_accumulate_reduce(c, ps, d_bases, st, bases_ready, c->h_qsums, c->h_flags))) return rc;
+    if ((rc = enqueue_accumulate(c, ps, d_bases, st, bases_ready, false))) return rc;
+    if ((rc = enqueue_reduce(c, ps, st, c->h_qsums, c->h_flags))) return rc;
     if (ps_out) *ps_out = ps;
     return finish_sync(c, ps, n, st, out_jac, out_aff, out_inf);
 }
@@ -739,7 +678,7 @@ int32_t run_single(msm_ctx* c, const HostInput& in, size_t n, uint32_t* out_jac,
             if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_H2D], st));
             if (overlap) HIPCHK(c, hipStreamWaitEvent(st, c->ev_bases, 0));  // k_decompose reads the infinity bytes
             if ((rc = enqueue_sort(c, ps, d_inf, (const uint32_t*)c->scalars.p, in.scalars_mont, st, true))) return rc;
-            if ((rc = enqueue_accumulate_reduce(c, ps, ib, st, nullptr, c->h_qsums, c->h_flags))) return rc;
+            if ((rc = enqueue_accumulate(c, ps, ib, st, nullptr, false))) return rc;
         } else {
             if ((rc = feed_scalars(c, in, 0, n, c->scalars.p, c->inf.p, st))) return rc;
             if (overlap) {
@@ -747,15 +686,16 @@ int32_t run_single(msm_ctx* c, const HostInput& in, size_t n, uint32_t* out_jac,
                 if ((rc = enqueue_sort(c, ps, d_inf, (const uint32_t*)c->scalars.p, in.scalars_mont, st, true))) return rc;
                 if ((rc = feed_bases(c, in, 0, n, c->bases.p, ib, nullptr, glv, bs))) return rc;
                 HIPCHK(c, hipEventRecord(c->ev_bases, bs));
-                if ((rc = enqueue_accumulate_reduce(c, ps, ib, st, c->ev_bases, c->h_qsums, c->h_flags))) return rc;
+                if ((rc = enqueue_accumulate(c, ps, ib, st, c->ev_bases, false))) return rc;
             } else {
                 if ((rc = feed_bases(c, in, 0, n, c->bases.p, ib, nullptr, glv, st))) return rc;
                 if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_H2D], st));
                 if ((rc = enqueue_sort(c, ps, d_inf, (const uint32_t*)c->scalars.p, in.scalars_mont, st, true))) return rc;
-                if ((rc = enqueue_accumulate_reduce(c, ps, ib, st, nullptr, c->h_qsums, c->h_flags))) return rc;
+                if ((rc = enqueue_accumulate(c, ps, ib, st, nullptr, false))) return rc;
             }
         }
     }
+    if ((rc = enqueue_reduce(c, ps, st, c->h_qsums, c->h_flags))) return rc;
     if ((rc = finish_sync(c, ps, n, st, out_jac, out_aff, out_inf))) return rc;
     c->tm.h2d_ms = stage_ms(c, EV_START, EV_H2D);
     c->tm.convert_ms = stage_ms(c, EV_H2D, EV_CONVERT);
@@ -799,13 +739,11 @@ int32_t run_streamed(msm_ctx* c, const HostInput& in, size_t n, const std::vecto
         HIPCHK(c, hipStreamWaitEvent(st, c->ev_copied[s], 0));
         if ((rc = pipe_prepare(c, cnt, n, 0, st, &ps))) return rc;
         if ((rc = enqueue_sort(c, ps, d_inf, (const uint32_t*)c->sscalars[s].p, in.scalars_mont, st, j == 0))) return rc;
-        c->last_acc_windows = ps.W;
-        if ((rc = launch_accumulate(c, ps, (const uint32_t*)c->sibases[s].p, st, j > 0, 0, 0, ps.nchunks_max, true))) return rc;
-        launch_combine(c, ps, st, j > 0, 0, ps.tb);
+        if ((rc = enqueue_accumulate(c, ps, (const uint32_t*)c->sibases[s].p, st, nullptr, j > 0))) return rc;
         HIPCHK(c, hipEventRecord(c->ev_free[s], st));
         lo += cnt;
     }
-    if ((rc = enqueue_reduce(c, ps, st, 0, ps.W, c->h_qsums, c->h_flags))) return rc;
+    if ((rc = enqueue_reduce(c, ps, st, c->h_qsums, c->h_flags))) return rc;
     if ((rc = finish_sync(c, ps, n, st, out_jac, out_aff, out_inf))) return rc;
     c->tm.stream_chunks = (uint32_t)sizes.size();
     trace_line(c, "host streamed", ps);
@@ -917,8 +855,6 @@ int32_t msm_ctx_create(const msm_config_t* cfg, msm_ctx** out) {
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_bases, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_grp, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_red, hipEventDisableTiming);
     for (int i = 0; i < 2 && e == hipSuccess; i++) {
         e = hipEventCreateWithFlags(&c->ev_copied[i], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_free[i], hipEventDisableTiming);
@@ -991,8 +927,6 @@ void msm_ctx_destroy(msm_ctx* c) {
         }
         if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
         if (c->ev_bases) (void)hipEventDestroy(c->ev_bases);
-        if (c->ev_grp) (void)hipEventDestroy(c->ev_grp);
-        if (c->ev_red) (void)hipEventDestroy(c->ev_red);
         if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
         for (int i = 0; i < EV_COUNT; i++)
             if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);

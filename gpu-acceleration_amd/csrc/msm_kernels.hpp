@@ -997,17 +997,14 @@ __global__ void __launch_bounds__(1024) k_chunk_map(const uint32_t* __restrict__
 // INTO = true (chunks 2.. of a streamed MSM, run_streamed): the bucket array already holds the sums of the earlier chunks; the
 // thread in whose chunk a bucket STARTS folds the old value in (it becomes the first term of that bucket's first piece), and
 // k_combine leaves buckets that this chunk does not touch alone.  One reduction and one host finish per MSM, however many chunks.
-// A launch covers the chunks [t_begin, t_end).  PART only names the launch (rocprofv3 lists the two launches of a window-split
-// MSM -- msm_hip.hip: enqueue_accumulate -- as two kernels): 0 = the whole MSM or its first window group, 1 = the last group.
-template <bool INTO, int PART>
+template <bool INTO>
 __global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
                                                     const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ chunk_bucket,
                                                     uint32_t* __restrict__ buckets, uint32_t* __restrict__ heads,
                                                     uint32_t* __restrict__ tails, const uint32_t* __restrict__ total_pairs_ptr,
-                                                    uint32_t L, uint32_t total_buckets, uint32_t t_begin, uint32_t t_end) {
+                                                    uint32_t L, uint32_t total_buckets) {
     const uint32_t total_pairs = *total_pairs_ptr;  // non-zero digits, known only on the device (k_scan_block_sums)
-    uint32_t t = t_begin + blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= t_end) return;
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t j0 = t * L;
     if (j0 >= total_pairs) return;
     uint32_t j1 = min(total_pairs, j0 + L);
@@ -1076,15 +1073,12 @@ __global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__
 constexpr uint32_t MID_BLOCKS = 256;
 __global__ void __launch_bounds__(256) k_combine(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ heads,
                                                  const uint32_t* __restrict__ tails, uint32_t* __restrict__ buckets,
-                                                 uint32_t k_lo, uint32_t k_hi, uint32_t L, const uint32_t* __restrict__ mid_count,
+                                                 uint32_t total_buckets, uint32_t L, const uint32_t* __restrict__ mid_count,
                                                  const uint32_t* __restrict__ mid_list, uint32_t into) {
-    // buckets [k_lo, k_hi): the whole MSM, or the windows of one group when the reduction of the first windows runs beside the
-    // accumulation of the last ones
     if (blockIdx.x < MID_BLOCKS) {
         const uint32_t nmid = *mid_count;
         for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nmid; i += MID_BLOCKS * blockDim.x) {
             const uint32_t k = mid_list[i];
-            if (k < k_lo || k >= k_hi) continue;
             const uint32_t t0 = offsets[k] / L, t1 = (offsets[k + 1] - 1) / L;
             xyzz acc = load_xyzz(tails + (size_t)t0 * XW);
             for (uint32_t t = t0 + 1; t <= t1; t++) acc = xyzz_add(acc, load_xyzz(heads + (size_t)t * XW));
@@ -1092,8 +1086,8 @@ __global__ void __launch_bounds__(256) k_combine(const uint32_t* __restrict__ of
         }
         return;
     }
-    uint32_t k = k_lo + (blockIdx.x - MID_BLOCKS) * blockDim.x + threadIdx.x;
-    if (k >= k_hi) return;
+    uint32_t k = (blockIdx.x - MID_BLOCKS) * blockDim.x + threadIdx.x;
+    if (k >= total_buckets) return;
     uint32_t beg = offsets[k], end = offsets[k + 1];
     if (beg == end) {
         if (!into) store_xyzz(buckets + (size_t)k * XW, xyzz_identity());  // into: the bucket keeps the earlier chunks' sum
@@ -1134,13 +1128,12 @@ __device__ __forceinline__ void long_fold(uint32_t* e, const uint32_t* heads, co
 __global__ void __launch_bounds__(512) k_combine_long(const uint32_t* __restrict__ offsets, uint32_t* __restrict__ heads,
                                                       uint32_t* __restrict__ tails, uint32_t* __restrict__ buckets,
                                                       const uint32_t* __restrict__ long_count, const uint32_t* __restrict__ long_list,
-                                                      uint32_t* __restrict__ long_done, uint32_t L, uint32_t k_lo, uint32_t k_hi) {
+                                                      uint32_t* __restrict__ long_done, uint32_t L) {
     __shared__ uint32_t e[WIDE_TREE_MAX * XW];
     __shared__ uint32_t s_last;
     const uint32_t nlong = *long_count;
     for (uint32_t item = blockIdx.x; item < nlong; item += gridDim.x) {
         const uint32_t k = long_list[2 * (size_t)item], seg = long_list[2 * (size_t)item + 1];
-        if (k < k_lo || k >= k_hi) continue;  // uniform per workgroup: another window group's bucket
         const uint32_t beg = offsets[k], end = offsets[k + 1];
         const uint32_t t0 = beg / L, t1 = (end - 1) / L;
         const uint32_t cnt = t1 - t0 + 1, nseg = (cnt + LONG_SEG - 1) / LONG_SEG;
@@ -1231,8 +1224,7 @@ __global__ void __launch_bounds__(256) k_pair_level_wide(pair_job ja, pair_job j
 __global__ void __launch_bounds__(512) k_reduce_bits_wide(const uint32_t* __restrict__ R, const uint32_t* __restrict__ C,
                                                           uint32_t* __restrict__ q, uint32_t n_hi, uint32_t n_lo, uint32_t kb_lo,
                                                           uint32_t kb, const uint32_t* __restrict__ flags, uint32_t* __restrict__ flags_out) {
-    // q, flags_out: pinned HOST memory; flags_out == nullptr: another launch (the last window group's) reports the flag words
-    if (flags_out != nullptr && blockIdx.x == 0 && threadIdx.x < 8) flags_out[threadIdx.x] = flags[threadIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x < 8) flags_out[threadIdx.x] = flags[threadIdx.x];  // q, flags_out: pinned HOST memory
     __shared__ uint32_t e[WIDE_TREE_MAX * XW];
     uint32_t w = blockIdx.x / (kb + 1), u = blockIdx.x % (kb + 1);
     const uint32_t* src;
@@ -1266,8 +1258,7 @@ __global__ void __launch_bounds__(512) k_reduce_bits_wide(const uint32_t* __rest
 __global__ void __launch_bounds__(64) k_reduce_bits(const uint32_t* __restrict__ R, const uint32_t* __restrict__ C,
                                                     uint32_t* __restrict__ q, uint32_t n_hi, uint32_t n_lo, uint32_t kb_lo,
                                                     uint32_t kb, const uint32_t* __restrict__ flags, uint32_t* __restrict__ flags_out) {
-    // q, flags_out: pinned HOST memory; flags_out == nullptr: another launch (the last window group's) reports the flag words
-    if (flags_out != nullptr && blockIdx.x == 0 && threadIdx.x < 8) flags_out[threadIdx.x] = flags[threadIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x < 8) flags_out[threadIdx.x] = flags[threadIdx.x];  // q, flags_out: pinned HOST memory
     uint32_t w = blockIdx.x / (kb + 1), u = blockIdx.x % (kb + 1);
     const uint32_t* src;
     uint32_t cnt, bit;

@@ -60,7 +60,7 @@ class Timings(C.Structure):
     _fields_ = [("h2d_ms", C.c_float), ("convert_ms", C.c_float), ("decompose_ms", C.c_float),
                 ("sort_ms", C.c_float), ("accumulate_ms", C.c_float), ("reduce_ms", C.c_float),
                 ("finish_ms", C.c_float), ("total_ms", C.c_float), ("num_points", C.c_uint64),
-                ("num_adds", C.c_uint64), ("stream_chunks", C.c_uint32), ("accumulate_windows", C.c_uint32)]
+                ("num_adds", C.c_uint64), ("stream_chunks", C.c_uint32), ("reserved", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -88,16 +88,14 @@ typedef struct {
     float convert_ms;    /* bases to Montgomery / internal layout               */
     float decompose_ms;  /* scalar windowing + signed digits + bucket histogram */
     float sort_ms;       /* bucket offsets (scan) + scatter of point indices    */
-    float accumulate_ms; /* per-bucket point accumulation -- the graded kernel (the launch covering accumulate_windows windows) */
+    float accumulate_ms; /* per-bucket point accumulation -- the graded kernel  */
     float reduce_ms;     /* running-sum bucket reduction + per-window sums      */
     float finish_ms;     /* host Horner over the bit sums (+ normalisation if asked) */
     float total_ms;      /* wall clock of the whole call                        */
     uint64_t num_points;
     uint64_t num_adds;   /* mixed additions executed by accumulate (non-zero digits) */
     uint32_t stream_chunks; /* host->HBM chunks the call was cut into (0 = single shot / device-resident)      */
-    uint32_t accumulate_windows; /* windows the TIMED k_accumulate launch covered: all of them, or the first group when the MSM
-                                    was window-split (the last group's launch, k_accumulate<false, 1>, runs beside the first group's
-                                    bucket reduction and is not timed) */
+    uint32_t reserved;
 } msm_timings_t;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
