@@ -109,7 +109,7 @@ struct msm_ctx {
     hipEvent_t ev[EV_COUNT]{};
     // HBM workspace
     DevBuf bases, ibases, inf, scalars, digits, ranks, sorted, hist, offsets, blocksums, buckets, heads, tails, chunkmap, rc, flags,
-        pow2, tilecounts, longlist, longdone, midlist, ccounts, cregion, bigslot, big;
+        pow2, tilecounts, longlist, longdone, midlist, oncelist, ccounts, cregion, bigslot, big;
     DevBuf rbases, rinf;  // the RESIDENT base set (msm_bn254_g1_upload_bases / _upload_compressed): never used as scratch
     bool pow2_ready = false;
     uint32_t* h_qsums = nullptr;  // pinned: W x (kb+1) Jacobian bit sums
@@ -123,6 +123,7 @@ struct msm_ctx {
     bool stage_timing = false;  // record the per-stage hipEvents (each costs ~6 us of stream time); k_accumulate's pair is always on
     double acc_ms_sum = 0;
     uint64_t acc_launches = 0;
+    bool flags_clean = false;     // the device flag words are known to be zero (set when an MSM completes)
     uint32_t last_sort_path = 0;  // 2 = two-level LDS sort, 1 = tiled LDS histogram, 0 = global atomics (stage tests, trace)
 };
 
@@ -272,6 +273,7 @@ int32_t pipe_prepare(msm_ctx* c, size_t n_real, size_t plan_n, uint32_t extra_fl
         if (c->longdone.cap != had) HIPCHK(c, hipMemsetAsync(c->longdone.p, 0, c->longdone.cap, st));  // self-cleaning afterwards
     }
     if ((rc = ensure(c, c->midlist, (nchunks_max / 2 + 16) * 4))) return rc;                  // a listed bucket owns >= 2 chunk borders
+    if ((rc = ensure(c, c->oncelist, (std::min(nchunks_max, tb) + 16) * 4))) return rc;       // a once-cut bucket owns one chunk border
     if ((rc = ensure(c, c->rc, (tb + tb / 2 + 4) * XB))) return rc;  // two families x (1/2 + 1/4) ping-pong levels
     if ((rc = ensure(c, c->flags, 64))) return rc;
     return MSM_OK;
@@ -322,8 +324,11 @@ int32_t enqueue_sort(msm_ctx* c, const PipeState& ps, const uint8_t* d_inf, cons
     } else {
         HIPCHK(c, hipMemsetAsync(hist, 0, tb * 4, st));
     }
-    if (first) HIPCHK(c, hipMemsetAsync(flags, 0, 64, st));
-    else HIPCHK(c, hipMemsetAsync(flags + msmk::FLAG_LONG, 0, 8, st));  // the long / mid list counters of this chunk
+    // The flag words clean themselves (a hipMemsetAsync is its own dispatch: ~5 us + a ~12 us bubble in front of it, per call and per
+    // streamed chunk): k_decompose zeroes the list counters of the chunk, the kernel that ends an MSM zeroes the error and count
+    // words after copying them out.  Only a context whose last call did not complete (error paths) is cleaned from the host.
+    if (first && !c->flags_clean) HIPCHK(c, hipMemsetAsync(flags, 0, 64, st));
+    if (first) c->flags_clean = false;
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_CONVERT], st));
     // K1b: digits + signed recode (with the GLV split: two 127-bit halves per scalar, 2*n_real digit columns)
     {
@@ -392,7 +397,8 @@ int32_t enqueue_sort(msm_ctx* c, const PipeState& ps, const uint8_t* d_inf, cons
     }
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_SORT], st));
     msmk::k_chunk_map<<<grid1(tb, 1024), 1024, 0, st>>>(offsets, (uint32_t*)c->chunkmap.p, (uint32_t)tb, ps.chunk_len, flags,
-                                                      (uint32_t*)c->longlist.p, (uint32_t*)c->midlist.p);
+                                                      (uint32_t*)c->longlist.p, (uint32_t*)c->midlist.p, (uint32_t*)c->oncelist.p,
+                                                      (uint32_t*)c->buckets.p, first ? 0u : 1u);  // not the first chunk: accumulating INTO the buckets
     return MSM_OK;
 }
 
@@ -406,18 +412,20 @@ int32_t enqueue_accumulate(msm_ctx* c, const PipeState& ps, const uint32_t* d_ba
     const size_t tb = ps.tb;
     if (bases_ready) HIPCHK(c, hipStreamWaitEvent(st, bases_ready, 0));  // d_bases is being converted on another stream
     HIPCHK(c, hipEventRecord(c->ev[EV_ACC0], st));
+    const unsigned ab = 256;  // (64- and 128-thread workgroups: no difference at any size, tools/env_sweep.py)
     if (into)
-        msmk::k_accumulate<true><<<grid1(ps.nchunks_max, 256), 256, 0, st>>>(d_bases, (uint32_t*)c->sorted.p, offsets, (uint32_t*)c->chunkmap.p,
+        msmk::k_accumulate<true><<<grid1(ps.nchunks_max, ab), ab, 0, st>>>(d_bases, (uint32_t*)c->sorted.p, offsets, (uint32_t*)c->chunkmap.p,
                                                                           (uint32_t*)c->buckets.p, (uint32_t*)c->heads.p, (uint32_t*)c->tails.p,
                                                                           flags + msmk::FLAG_PAIRS, ps.chunk_len, (uint32_t)tb);
     else
-        msmk::k_accumulate<false><<<grid1(ps.nchunks_max, 256), 256, 0, st>>>(d_bases, (uint32_t*)c->sorted.p, offsets, (uint32_t*)c->chunkmap.p,
+        msmk::k_accumulate<false><<<grid1(ps.nchunks_max, ab), ab, 0, st>>>(d_bases, (uint32_t*)c->sorted.p, offsets, (uint32_t*)c->chunkmap.p,
                                                                            (uint32_t*)c->buckets.p, (uint32_t*)c->heads.p, (uint32_t*)c->tails.p,
                                                                            flags + msmk::FLAG_PAIRS, ps.chunk_len, (uint32_t)tb);
     HIPCHK(c, hipEventRecord(c->ev[EV_ACC1], st));
-    msmk::k_combine<<<dim3(msmk::MID_BLOCKS + (unsigned)((tb + 255) / 256)), 256, 0, st>>>(offsets, (uint32_t*)c->heads.p, (uint32_t*)c->tails.p,
-                                                                                         (uint32_t*)c->buckets.p, (uint32_t)tb, ps.chunk_len,
-                                                                                         flags + msmk::FLAG_MID, (uint32_t*)c->midlist.p, into ? 1u : 0u);
+    const size_t once_max = std::min(ps.nchunks_max, tb);  // a once-cut bucket owns one chunk border
+    msmk::k_combine<<<dim3(msmk::MID_BLOCKS + (unsigned)((once_max + 255) / 256)), 256, 0, st>>>(
+        offsets, (uint32_t*)c->heads.p, (uint32_t*)c->tails.p, (uint32_t*)c->buckets.p, ps.chunk_len, flags + msmk::FLAG_MID,
+        (uint32_t*)c->midlist.p, flags + msmk::FLAG_ONCE, (uint32_t*)c->oncelist.p);
     msmk::k_combine_long<<<1024, 512, 0, st>>>(offsets, (uint32_t*)c->heads.p, (uint32_t*)c->tails.p, (uint32_t*)c->buckets.p,
                                                flags + msmk::FLAG_LONG, (uint32_t*)c->longlist.p, (uint32_t*)c->longdone.p, ps.chunk_len);
     return MSM_OK;
@@ -535,6 +543,7 @@ int32_t finish_sync(msm_ctx* c, const PipeState& ps, size_t n_total, hipStream_t
     if (c->pool && n_total >= 256) c->pool->arm();  // workers wake up while the GPU works
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());
+    c->flags_clean = true;  // the last kernel zeroed the flag words after copying them out
     auto t_fin0 = std::chrono::steady_clock::now();
     int32_t rc;
     if ((rc = check_flags(c, c->h_flags))) return rc;
@@ -912,7 +921,7 @@ void msm_ctx_destroy(msm_ctx* c) {
         if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
         DevBuf* bufs[] = {&c->bases,   &c->inf,       &c->scalars, &c->digits,  &c->ranks,  &c->sorted, &c->hist,
                           &c->offsets, &c->blocksums, &c->buckets, &c->rc,      &c->flags,  &c->pow2,
-                          &c->heads,   &c->tails,     &c->chunkmap, &c->tilecounts, &c->ibases, &c->longlist, &c->longdone, &c->midlist, &c->ccounts, &c->cregion, &c->bigslot, &c->big,
+                          &c->heads,   &c->tails,     &c->chunkmap, &c->tilecounts, &c->ibases, &c->longlist, &c->longdone, &c->midlist, &c->oncelist, &c->ccounts, &c->cregion, &c->bigslot, &c->big,
                           &c->rbases,  &c->rinf};
         for (DevBuf* b : bufs) release(*b);
         if (c->h_qsums) (void)hipHostFree(c->h_qsums);

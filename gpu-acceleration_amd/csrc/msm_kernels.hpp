@@ -35,6 +35,9 @@ constexpr uint32_t SIGN_BIT = 0x80000000u;
 constexpr int SCALAR_BITS = 254;
 
 constexpr int XW = 36;  // words per XYZZ record in HBM: 4 coordinates x 9 limbs
+// flags (u32 words, one set per context): [0] error bits  [4] sorted entries of this (chunk of an) MSM  [6,7] running 64-bit total of
+// sorted entries over the chunks of a streamed MSM  [8] long-list entries  [9] mid-list entries  [10] once-cut-list entries
+constexpr uint32_t FLAG_ERR = 0, FLAG_PAIRS = 4, FLAG_ADDS64 = 6, FLAG_LONG = 8, FLAG_MID = 9, FLAG_ONCE = 10;
 
 // packed 8-word field element (canonical value) -> 9 x 29-bit limbs
 __device__ __forceinline__ fp load_fp_packed(const uint32_t* p) {
@@ -338,6 +341,7 @@ __global__ void k_decompose(const uint32_t* __restrict__ scalars, const uint8_t*
                             uint32_t* __restrict__ digits, uint32_t* __restrict__ ranks, uint32_t* __restrict__ err,
                             uint32_t scalars_mont) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) err[FLAG_LONG] = 0, err[FLAG_MID] = 0, err[FLAG_ONCE] = 0;  // list counters of this (chunk of an) MSM: k_chunk_map fills them later in the stream
     if (i >= n) return;
     const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
     uint4 a = sp[0], b = sp[1];
@@ -386,6 +390,7 @@ template <bool SIGNED>
 __global__ void k_decompose_glv(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_mask, uint32_t n, uint32_t c,
                                 uint32_t W, uint32_t* __restrict__ digits, uint32_t* __restrict__ err, uint32_t scalars_mont) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) err[FLAG_LONG] = 0, err[FLAG_MID] = 0, err[FLAG_ONCE] = 0;  // list counters of this (chunk of an) MSM: k_chunk_map fills them later in the stream
     if (i >= n) return;
     const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
     uint4 a = sp[0], b = sp[1];
@@ -950,21 +955,20 @@ __global__ void k_scatter(const uint32_t* __restrict__ digits, const uint32_t* _
 // every one of its wavefronts runs exactly one XYZZ add (a few 3-chunk buckets per wavefront used to double its time).
 constexpr uint32_t LONG_SPAN = 8;
 constexpr uint32_t LONG_SEG = 2048;  // pieces of a long bucket folded by one k_combine_long workgroup
-// flags (u32 words, one per context): [0] error bits  [4] sorted entries of this (chunk of an) MSM  [6,7] running 64-bit total
-// of sorted entries over the chunks of a streamed MSM  [8] long-list entries  [9] mid-list entries
-constexpr uint32_t FLAG_ERR = 0, FLAG_PAIRS = 4, FLAG_ADDS64 = 6, FLAG_LONG = 8, FLAG_MID = 9;
 __global__ void __launch_bounds__(1024) k_chunk_map(const uint32_t* __restrict__ offsets, uint32_t* __restrict__ chunk_bucket,
                                                    uint32_t total_buckets, uint32_t L, uint32_t* __restrict__ flags,
-                                                   uint32_t* __restrict__ long_list, uint32_t* __restrict__ mid_list) {
+                                                   uint32_t* __restrict__ long_list, uint32_t* __restrict__ mid_list,
+                                                   uint32_t* __restrict__ once_list, uint32_t* __restrict__ buckets, uint32_t into) {
     uint32_t* const long_count = flags + FLAG_LONG;
     uint32_t* const mid_count = flags + FLAG_MID;
-    __shared__ uint32_t s_n[2], s_base[2];  // [0] mid, [1] long: list slots are reserved once per workgroup
-    if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
+    uint32_t* const once_count = flags + FLAG_ONCE;
+    __shared__ uint32_t s_n[3], s_base[3];  // [0] mid, [1] long, [2] cut once: list slots are reserved once per workgroup
+    if (threadIdx.x < 3) s_n[threadIdx.x] = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0)  // mixed additions executed so far (msm_timings_t.num_adds), all chunks of a streamed MSM
         *reinterpret_cast<unsigned long long*>(flags + FLAG_ADDS64) += (unsigned long long)flags[FLAG_PAIRS];
     __syncthreads();
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t kindl = 2, slot = 0, nseg = 1;  // 0 = mid list, 1 = long list, 2 = neither
+    uint32_t kindl = 3, slot = 0, nseg = 1;  // 0 = mid list, 1 = long list, 2 = once-cut list, 3 = none
     if (k < total_buckets) {
         uint32_t beg = offsets[k], end = offsets[k + 1];
         if (beg != end) {
@@ -975,17 +979,24 @@ __global__ void __launch_bounds__(1024) k_chunk_map(const uint32_t* __restrict__
                 nseg = (span + 1 + LONG_SEG - 1) / LONG_SEG;
             } else if (span >= 2) {
                 kindl = 0;
+            } else if (span == 1) {
+                kindl = 2;
             }
             for (uint32_t t = tf; t <= tl; t++) chunk_bucket[t] = k;
+        } else if (!into) {
+            store_xyzz(buckets + (size_t)k * XW, xyzz_identity());  // empty bucket (into: it keeps the earlier chunks' sum)
         }
     }
-    if (kindl < 2) slot = atomicAdd(&s_n[kindl], nseg);  // LDS
+    if (kindl < 3) slot = atomicAdd(&s_n[kindl], nseg);  // LDS
     __syncthreads();
     if (threadIdx.x == 0 && s_n[0]) s_base[0] = atomicAdd(mid_count, s_n[0]);
     if (threadIdx.x == 1 && s_n[1]) s_base[1] = atomicAdd(long_count, s_n[1]);
+    if (threadIdx.x == 2 && s_n[2]) s_base[2] = atomicAdd(once_count, s_n[2]);
     __syncthreads();
     if (kindl == 0) {
         mid_list[s_base[0] + slot] = k;
+    } else if (kindl == 2) {
+        once_list[s_base[2] + slot] = k;
     } else if (kindl == 1) {  // one entry per LONG_SEG pieces: (bucket, segment | first entry of the bucket)
         for (uint32_t j = 0; j < nseg; j++) {
             long_list[2 * (size_t)(s_base[1] + slot + j)] = k;
@@ -1069,12 +1080,14 @@ __global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__
 // ONE launch, two kinds of workgroups (the listed buckets take 2..6 dependent adds, so their workgroups come FIRST in
 // the grid and run beside the single-add bulk instead of after it):
 //   blockIdx <  MID_BLOCKS : one thread per LISTED bucket (cut into 3..LONG_SPAN-1 chunks), grid-stride over the list
-//   blockIdx >= MID_BLOCKS : one thread per bucket: empty -> identity; cut once -> tails[t0] + heads[t1]
+//   blockIdx >= MID_BLOCKS : one thread per bucket of the ONCE-CUT list: tails[t0] + heads[t1].  The list (k_chunk_map) makes
+//                            these wavefronts dense -- with one thread per bucket ~40 % of the lanes idled through the addition
+//                            (buckets lying inside one chunk, empty ones): 74 -> 5x us at 2^20.
 constexpr uint32_t MID_BLOCKS = 256;
 __global__ void __launch_bounds__(256) k_combine(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ heads,
-                                                 const uint32_t* __restrict__ tails, uint32_t* __restrict__ buckets,
-                                                 uint32_t total_buckets, uint32_t L, const uint32_t* __restrict__ mid_count,
-                                                 const uint32_t* __restrict__ mid_list, uint32_t into) {
+                                                 const uint32_t* __restrict__ tails, uint32_t* __restrict__ buckets, uint32_t L,
+                                                 const uint32_t* __restrict__ mid_count, const uint32_t* __restrict__ mid_list,
+                                                 const uint32_t* __restrict__ once_count, const uint32_t* __restrict__ once_list) {
     if (blockIdx.x < MID_BLOCKS) {
         const uint32_t nmid = *mid_count;
         for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nmid; i += MID_BLOCKS * blockDim.x) {
@@ -1086,17 +1099,11 @@ __global__ void __launch_bounds__(256) k_combine(const uint32_t* __restrict__ of
         }
         return;
     }
-    uint32_t k = (blockIdx.x - MID_BLOCKS) * blockDim.x + threadIdx.x;
-    if (k >= total_buckets) return;
-    uint32_t beg = offsets[k], end = offsets[k + 1];
-    if (beg == end) {
-        if (!into) store_xyzz(buckets + (size_t)k * XW, xyzz_identity());  // into: the bucket keeps the earlier chunks' sum
-        return;
-    }
-    uint32_t t0 = beg / L, t1 = (end - 1) / L;
-    if (t0 == t1) return;      // written by k_accumulate
-    if (t1 - t0 >= 2) return;  // listed: the MID workgroups above, or k_combine_long
-    store_xyzz(buckets + (size_t)k * XW, xyzz_add(load_xyzz(tails + (size_t)t0 * XW), load_xyzz(heads + (size_t)t1 * XW)));
+    const uint32_t i = (blockIdx.x - MID_BLOCKS) * blockDim.x + threadIdx.x;
+    if (i >= *once_count) return;
+    const uint32_t k = once_list[i];
+    const uint32_t t0 = offsets[k] / L;
+    store_xyzz(buckets + (size_t)k * XW, xyzz_add(load_xyzz(tails + (size_t)t0 * XW), load_xyzz(heads + (size_t)(t0 + 1) * XW)));
 }
 
 // Long buckets (cut into LONG_SPAN or more pieces: tiny top windows, skewed scalars).  Pieces e(0) = tails[t0],
@@ -1223,8 +1230,11 @@ __global__ void __launch_bounds__(256) k_pair_level_wide(pair_job ja, pair_job j
 // and folded by a pairwise tree (log2(nsel) levels of 4 multiplications each).  Needs nsel <= WIDE_TREE_MAX.
 __global__ void __launch_bounds__(512) k_reduce_bits_wide(const uint32_t* __restrict__ R, const uint32_t* __restrict__ C,
                                                           uint32_t* __restrict__ q, uint32_t n_hi, uint32_t n_lo, uint32_t kb_lo,
-                                                          uint32_t kb, const uint32_t* __restrict__ flags, uint32_t* __restrict__ flags_out) {
-    if (blockIdx.x == 0 && threadIdx.x < 8) flags_out[threadIdx.x] = flags[threadIdx.x];  // q, flags_out: pinned HOST memory
+                                                          uint32_t kb, uint32_t* __restrict__ flags, uint32_t* __restrict__ flags_out) {
+    if (blockIdx.x == 0 && threadIdx.x < 8) {  // q, flags_out: pinned HOST memory
+        flags_out[threadIdx.x] = flags[threadIdx.x];
+        flags[threadIdx.x] = 0;  // this kernel ends the MSM: the next one starts from clean error / count words
+    }
     __shared__ uint32_t e[WIDE_TREE_MAX * XW];
     uint32_t w = blockIdx.x / (kb + 1), u = blockIdx.x % (kb + 1);
     const uint32_t* src;
@@ -1257,8 +1267,11 @@ __global__ void __launch_bounds__(512) k_reduce_bits_wide(const uint32_t* __rest
 // one wavefront per (window, bit): R[w][0..n_hi), C[w][0..n_lo);  q[w][u] Jacobian
 __global__ void __launch_bounds__(64) k_reduce_bits(const uint32_t* __restrict__ R, const uint32_t* __restrict__ C,
                                                     uint32_t* __restrict__ q, uint32_t n_hi, uint32_t n_lo, uint32_t kb_lo,
-                                                    uint32_t kb, const uint32_t* __restrict__ flags, uint32_t* __restrict__ flags_out) {
-    if (blockIdx.x == 0 && threadIdx.x < 8) flags_out[threadIdx.x] = flags[threadIdx.x];  // q, flags_out: pinned HOST memory
+                                                    uint32_t kb, uint32_t* __restrict__ flags, uint32_t* __restrict__ flags_out) {
+    if (blockIdx.x == 0 && threadIdx.x < 8) {  // q, flags_out: pinned HOST memory
+        flags_out[threadIdx.x] = flags[threadIdx.x];
+        flags[threadIdx.x] = 0;  // this kernel ends the MSM: the next one starts from clean error / count words
+    }
     uint32_t w = blockIdx.x / (kb + 1), u = blockIdx.x % (kb + 1);
     const uint32_t* src;
     uint32_t cnt, bit;
