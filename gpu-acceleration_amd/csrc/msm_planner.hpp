@@ -21,12 +21,16 @@ constexpr uint32_t GLV_SPLIT_BITS = 127;  // == glv::SPLIT_BITS (glv_bn254.hpp);
 //    top bits) are used.
 //  * below ~2^17 points the per-window fixed costs (dependent reduction levels, launches) outweigh the bucket count:
 //    fewer, wider windows win earlier than the arithmetic model says.
-// c is capped where one window's histogram still fits the LDS sort path (nb <= 32768: 16 signed, 15 unsigned).
+// c is capped where the two-level LDS sort still covers a window (<= 2^17 buckets; unsigned digits stay at 15).
 inline uint32_t plan_window_bits(size_t n, bool is_signed) {
     // re-measured after the reduction-tree and host-latency work (tools/sweep_c.py): 2^13: c = 8 0.335 ms (13: 0.455);
     // 2^14: c = 10 0.397 (13: 0.431); 2^15: 10 0.412 (13: 0.440); 2^16: 13 0.489; 2^17: 15 0.587; 2^18: 15 0.769 (16: 0.790);
     // 2^19: 16 1.125 (15: 1.197).  c = 10 leaves the top window 4 bits (9 buckets of n/16 points): fine for the long-bucket path.
-    uint32_t c = n <= ((size_t)1 << 13) ? 8u : n <= ((size_t)1 << 15) ? 10u : n <= ((size_t)1 << 16) ? 13u : n <= ((size_t)1 << 18) ? 15u : 16u;
+    // Round 2 (tools/c17_sweep.py, interleaved): c = 17 (15 windows of 65536 buckets; the two-level sort covers them) against 16:
+    // 2^20 +4.5 % (1.735 vs 1.661 ms: the doubled bucket reduction outweighs the 6 % fewer additions), 2^21 -2.3 %, 2^22 -4.1 %,
+    // 2^23 -6.0 %, 2^24 -5.9 % (22.39 vs 23.79 ms)  => 17 above 2^20 points.
+    uint32_t c = n <= ((size_t)1 << 13) ? 8u : n <= ((size_t)1 << 15) ? 10u : n <= ((size_t)1 << 16) ? 13u : n <= ((size_t)1 << 18) ? 15u
+               : n <= ((size_t)1 << 20) ? 16u : 17u;
     if (!is_signed && c > 15u) c = 15u;
     return c;
 }

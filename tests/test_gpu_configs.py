@@ -90,7 +90,7 @@ def test_shard_sizes_of_configs_4_and_5(ctx, hk, logn):
     r = ctx.msm_device(it.d_b.data_ptr(), it.d_s.data_ptr(), it.n)
     exp, einf = _expected(it.dot())
     assert not r.is_infinity and einf == 0 and (r.affine_std == exp).all()
-    assert mh.plan(it.n).glv == 0 and mh.plan(it.n).window_bits == 16
+    assert mh.plan(it.n).glv == 0 and mh.plan(it.n).window_bits == 17  # 15 windows of 65536 buckets above 2^20 points
     h = it.n // 2 + 12345  # uneven split: the two halves of a 2-GPU run of twice the size
     p0 = ctx.msm_device(it.d_b.data_ptr(), it.d_s.data_ptr(), h)
     p1 = ctx.msm_device(it.d_b.data_ptr() + h * 64, it.d_s.data_ptr() + h * 32, it.n - h)
@@ -131,7 +131,7 @@ def test_automatic_streaming_pinned_and_pageable_at_2_pow_22(hk):
             r = c.msm(b, s, mh.FORM_MONT)
             tm = c.timings()
             assert (r.affine_std == exp).all() and tm["stream_chunks"] >= 4 and tm["num_points"] == it.n
-            assert tm["num_adds"] > 15 * it.n  # the running count covers every chunk (16 windows, ~1 - 2^-16 non-zero digits)
+            assert tm["num_adds"] > 14 * it.n  # the running count covers every chunk (15 windows, ~1 - 2^-17 non-zero digits)
         # ragged sizes: a remainder below half a chunk joins the last chunk, a larger one is split
         for m in (it.n - 77777, it.n - (1 << 19) + 5, (1 << 21) + 3):
             e2, _ = _expected(it.dot(0, m))

@@ -29,19 +29,21 @@ __global__ void __launch_bounds__(256) k_mfma(int* out, int iters) {
     for (int k = 0; k < NACC; k++) for (int j = 0; j < 16; j++) s ^= c[k][j];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
-__global__ void __launch_bounds__(256) k_mad(uint32_t* out, int iters) {
-    uint64_t a0 = threadIdx.x * 0x9E3779B97F4A7C15ull + 12345u, a1 = a0 + 77, a2 = a0 + 99, a3 = a0 + 1234;
-    const uint32_t y = (uint32_t)(a0 >> 32) | 1u;
+__global__ void __launch_bounds__(256) k_mad(uint32_t* out, int iters) {  // 8 independent accumulators, inline asm (the compiler folds a C loop)
+    uint64_t x0 = threadIdx.x, x1 = 11, x2 = 22, x3 = 3, x4 = 4, x5 = 5, x6 = 6, x7 = 7;
+    uint32_t m = 12345u + threadIdx.x, n = 0x9E3779B9u;
     for (int i = 0; i < iters; i++) {
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            a0 = (uint64_t)(uint32_t)a0 * y + a0;
-            a1 = (uint64_t)(uint32_t)a1 * y + a1;
-            a2 = (uint64_t)(uint32_t)a2 * y + a2;
-            a3 = (uint64_t)(uint32_t)a3 * y + a3;
-        }
+        for (int k = 0; k < 8; k++)
+            asm volatile(
+                "v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_mad_u64_u32 %1, vcc, %8, %9, %1\n"
+                "v_mad_u64_u32 %2, vcc, %8, %9, %2\n v_mad_u64_u32 %3, vcc, %8, %9, %3\n"
+                "v_mad_u64_u32 %4, vcc, %8, %9, %4\n v_mad_u64_u32 %5, vcc, %8, %9, %5\n"
+                "v_mad_u64_u32 %6, vcc, %8, %9, %6\n v_mad_u64_u32 %7, vcc, %8, %9, %7\n"
+                : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)
+                : "v"(m), "v"(n) : "vcc");
     }
-    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a0 ^ a1 ^ a2 ^ a3);
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7);
 }
 __global__ void __launch_bounds__(256) k_fpmul(uint32_t* out, int iters) {
     fp v = fp_one(), m = fp_one();
@@ -58,8 +60,8 @@ __global__ void __launch_bounds__(256) k_fpmul(uint32_t* out, int iters) {
 // VALU and MFMA together: every wavefront alternates 81 mads (the a*b half) with 18 MFMAs (m*p and the half product) -- do the two
 // pipes really run side by side, i.e. is the pair as fast as the slower of the two?
 __global__ void __launch_bounds__(256) k_both(uint32_t* out, int iters) {
-    uint64_t a0 = threadIdx.x * 0x9E3779B97F4A7C15ull + 12345u, a1 = a0 + 77, a2 = a0 + 99;
-    const uint32_t y = (uint32_t)(a0 >> 32) | 1u;
+    uint64_t x0 = threadIdx.x, x1 = 11, x2 = 22, x3 = 3, x4 = 4, x5 = 5, x6 = 6, x7 = 7, x8 = 8;
+    uint32_t m = 12345u + threadIdx.x, n = 0x9E3779B9u;
     v4i a = {(int)threadIdx.x, 2, 3, 4}, b = {5, 6, 7, (int)blockIdx.x};
     v16i c[6];
     for (int k = 0; k < 6; k++) for (int j = 0; j < 16; j++) c[k][j] = k + j;
@@ -69,16 +71,18 @@ __global__ void __launch_bounds__(256) k_both(uint32_t* out, int iters) {
 #pragma unroll
             for (int k = 0; k < 6; k++) c[k] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c[k], 0, 0, 0);
 #pragma unroll
-            for (int k = 0; k < 9; k++) {
-                a0 = (uint64_t)(uint32_t)a0 * y + a0;
-                a1 = (uint64_t)(uint32_t)a1 * y + a1;
-                a2 = (uint64_t)(uint32_t)a2 * y + a2;
-            }
+            for (int k = 0; k < 3; k++)  // 27 mads per third: 81 per round
+                asm volatile(
+                    "v_mad_u64_u32 %0, vcc, %9, %10, %0\n v_mad_u64_u32 %1, vcc, %9, %10, %1\n v_mad_u64_u32 %2, vcc, %9, %10, %2\n"
+                    "v_mad_u64_u32 %3, vcc, %9, %10, %3\n v_mad_u64_u32 %4, vcc, %9, %10, %4\n v_mad_u64_u32 %5, vcc, %9, %10, %5\n"
+                    "v_mad_u64_u32 %6, vcc, %9, %10, %6\n v_mad_u64_u32 %7, vcc, %9, %10, %7\n v_mad_u64_u32 %8, vcc, %9, %10, %8\n"
+                    : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7), "+v"(x8)
+                    : "v"(m), "v"(n) : "vcc");
         }
     }
     int s = 0;
     for (int k = 0; k < 6; k++) for (int j = 0; j < 16; j++) s ^= c[k][j];
-    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)s ^ (uint32_t)(a0 ^ a1 ^ a2);
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)s ^ (uint32_t)(x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + x8);
 }
 template <typename F>
 static float time_ms(F f) {
@@ -97,7 +101,7 @@ int main() {
     auto cyc = [&](float ms, double per_wave_instr) { return ms * 1e-3 * ghz * 1e9 / per_wave_instr / 4.0; };  // 4 waves share a SIMD
     float m1 = time_ms([&] { k_mfma<1><<<blocks, 256>>>(d, IT); });
     float m4 = time_ms([&] { k_mfma<4><<<blocks, 256>>>(d, IT); });
-    float md = time_ms([&] { k_mad<<<blocks, 256>>>((uint32_t*)d, IT); });
+    float md = time_ms([&] { k_mad<<<blocks, 256>>>((uint32_t*)d, IT); });  // 64 mads per iteration and wavefront
     float fm = time_ms([&] { k_fpmul<<<blocks, 256>>>((uint32_t*)d, IT / 4); });
     float bo = time_ms([&] { k_both<<<blocks, 256>>>((uint32_t*)d, IT / 4); });
     const double c_mfma1 = cyc(m1, IT), c_mfma4 = cyc(m4, IT * 4.0), c_mad = cyc(md, IT * 64.0), c_fp = cyc(fm, IT);
@@ -108,7 +112,14 @@ int main() {
     const double best = c_mfma1 < c_mfma4 ? c_mfma1 : c_mfma4;
     printf("constant-operand work of one wavefront multiplication on the VALU: 90 instructions (81 m*p + 9 digit) = %.0f cycles\n", 90 * c_mad);
     printf("the same on the MFMA pipe: 12 (m*p) + 6 (m = T*p' mod R) instructions = %.0f cycles, BEFORE any operand marshalling\n", 18 * best);
-    printf("VALU + MFMA issued from the same wavefronts (81 mads + 18 MFMAs per round): %.0f cycles per round (slower pipe alone: %.0f)\n",
-           cyc(bo, IT / 4.0), (81 * c_mad > 18 * best ? 81 * c_mad : 18 * best));
+    printf("VALU + MFMA issued from the same wavefronts (81 mads + 18 MFMAs per round): %.0f cycles per round (slower pipe alone: %.0f, sum %.0f)\n",
+           cyc(bo, IT / 4.0), (81 * c_mad > 18 * best ? 81 * c_mad : 18 * best), 81 * c_mad + 18 * best);
+    // fp_mul today = 171 multiplier instructions + shifts/masks/digit products; offloaded = the a*b half (81 mads) co-issued with the 18
+    // MFMAs (measured above) + the same shifts/masks -- before a single instruction of operand marshalling (7-bit digit split of T,
+    // the 32x32 accumulator tiles transposed back to one row per lane, 74 column sums carried into 29-bit limbs: >= 130 more
+    // multiplier-instruction equivalents by count)
+    const double other = c_fp - 171 * c_mad, offl = cyc(bo, IT / 4.0) + other;
+    printf("=> fp_mul now %.0f cycles (171 mads = %.0f + %.0f of shifts/masks); with the constant half on the MFMA pipe and marshalling FREE: %.0f + %.0f = %.0f cycles = %.2fx (adoption bar: 1.25x)\n",
+           c_fp, 171 * c_mad, other, cyc(bo, IT / 4.0), other, offl, c_fp / offl);
     return 0;
 }
