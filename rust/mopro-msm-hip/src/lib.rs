@@ -31,6 +31,10 @@ struct MsmConfig {
 struct MsmCtx {
     _private: [u8; 0],
 }
+#[repr(C)]
+struct MsmMulti {
+    _private: [u8; 0],
+}
 const MSM_FORM_MONT: u32 = 1;
 
 extern "C" {
@@ -42,6 +46,13 @@ extern "C" {
     ) -> i32;
     fn msm_bn254_g1_arkworks(
         ctx: *mut MsmCtx, bases: *const core::ffi::c_void, stride: usize, x_off: usize, y_off: usize, inf_off: usize,
+        scalars_mont: *const u32, n: usize, out_jacobian_mont: *mut u32, out_affine_std: *mut u32, out_is_inf: *mut u8,
+    ) -> i32;
+    fn msm_multi_create(devices: *const i32, ndev: i32, cfg: *const MsmConfig, exchange: u32, out: *mut *mut MsmMulti) -> i32;
+    fn msm_multi_num_devices(m: *const MsmMulti) -> i32;
+    fn msm_multi_last_error(m: *const MsmMulti) -> *const c_char;
+    fn msm_bn254_g1_multi_arkworks(
+        m: *mut MsmMulti, bases: *const core::ffi::c_void, stride: usize, x_off: usize, y_off: usize, inf_off: usize,
         scalars_mont: *const u32, n: usize, out_jacobian_mont: *mut u32, out_affine_std: *mut u32, out_is_inf: *mut u8,
     ) -> i32;
     fn msm_bn254_g1_upload_compressed(ctx: *mut MsmCtx, compressed: *const u8, n: usize, first_invalid: *mut i64) -> i32;
@@ -62,6 +73,13 @@ static CTX: Lazy<Mutex<Result<Ctx, String>>> = Lazy::new(|| {
     Mutex::new(if rc == 0 { Ok(Ctx(p)) } else { Err(last_error(std::ptr::null())) })
 });
 
+fn multi_error(m: *const MsmMulti) -> String {
+    unsafe {
+        let s = msm_multi_last_error(m);
+        if s.is_null() { "msm_hip multi-GPU error".into() } else { std::ffi::CStr::from_ptr(s).to_string_lossy().into_owned() }
+    }
+}
+
 fn last_error(ctx: *const MsmCtx) -> String {
     unsafe {
         let s = msm_last_error(ctx);
@@ -69,18 +87,124 @@ fn last_error(ctx: *const MsmCtx) -> String {
     }
 }
 
-/// Same name and signature as the reference entry point.
-pub fn metal_variable_base_msm(mut bases: &[G1Affine], mut scalars: &[Fr]) -> Result<G1Projective, Box<dyn Error>> {
+/// How `[G1Affine]` sits in memory.  The struct is not `repr(C)`: the offsets are MEASURED once (addr_of!) and then CHECKED against
+/// the field accessors on a probe value before the raw slice is ever handed to the GPU.
+#[derive(Clone, Copy)]
+struct Layout {
+    stride: usize,
+    x_off: usize,
+    y_off: usize,
+    inf_off: usize,
+}
+static LAYOUT: Lazy<Option<Layout>> = Lazy::new(|| {
+    use ark_ec::AffineRepr;
+    let probe = [G1Affine::generator(), G1Affine::identity()];
+    let base = &probe[0] as *const G1Affine as usize;
+    let l = Layout {
+        stride: core::mem::size_of::<G1Affine>(),
+        x_off: core::ptr::addr_of!(probe[0].x) as usize - base,
+        y_off: core::ptr::addr_of!(probe[0].y) as usize - base,
+        inf_off: core::ptr::addr_of!(probe[0].infinity) as usize - base,
+    };
+    // what the C side requires (include/msm_hip.h msm_bn254_g1_arkworks) and what the raw bytes must say about the two probes
+    let ok = core::mem::size_of::<Fq>() == 32
+        && core::mem::size_of::<Fr>() == 32
+        && l.stride >= 64 && l.stride % 4 == 0 && l.x_off % 4 == 0 && l.y_off % 4 == 0
+        && l.x_off + 32 <= l.stride && l.y_off + 32 <= l.stride && l.inf_off < l.stride
+        && (l.x_off + 32 <= l.y_off || l.y_off + 32 <= l.x_off)
+        && unsafe {
+            let raw = core::slice::from_raw_parts(base as *const u8, 2 * l.stride);
+            let word = |off: usize| u64::from_le_bytes(raw[off..off + 8].try_into().unwrap());
+            (0..4).all(|k| word(l.x_off + 8 * k) == probe[0].x.0 .0[k] && word(l.y_off + 8 * k) == probe[0].y.0 .0[k])
+                && raw[l.inf_off] == 0 && raw[l.stride + l.inf_off] == 1
+        };
+    if ok { Some(l) } else { None }
+});
+
+/// Multi-GPU handle over every visible device (or `MSM_HIP_DEVICES=0,1,...`): one context + host thread per device, point-range
+/// shards, partials exchanged with RCCL (include/msm_hip.h "multi-GPU").  `None` on a single-GPU host.
+struct Multi(*mut MsmMulti);
+unsafe impl Send for Multi {}
+static MULTI: Lazy<Mutex<Option<Multi>>> = Lazy::new(|| {
+    let cfg = MsmConfig { device: -1, window_bits: 0, flags: 0, stream_chunk_log2: 0, max_points: 0 };
+    let mut p: *mut MsmMulti = std::ptr::null_mut();
+    let rc = unsafe { msm_multi_create(std::ptr::null(), 0, &cfg, 0 /* MSM_MULTI_EXCHANGE_AUTO */, &mut p) };
+    Mutex::new(if rc == 0 && unsafe { msm_multi_num_devices(p) } > 1 { Some(Multi(p)) } else { None })
+});
+/// below this many points one GPU is faster than several (per-GPU fixed costs ~0.35 ms)
+const MULTI_MIN_POINTS: usize = 1 << 19;
+
+fn to_projective(jac: &[u64; 12]) -> G1Projective {
+    // Jacobian Montgomery limbs -> G1Projective without any conversion (reference: metal_msm.rs:228-241)
+    let f = |w: &[u64]| Fq::new_unchecked(BigInt::<4>([w[0], w[1], w[2], w[3]]));
+    G1Projective::new_unchecked(f(&jac[0..4]), f(&jac[4..8]), f(&jac[8..12]))
+}
+
+/// Same name and signature as the reference entry point (metal_msm.rs:642-645).
+///
+/// The two slices go to the GPU(s) AS THEY ARE: `Fq`/`Fr` are arkworks' Montgomery words (R = 2^256), the engine reads the struct
+/// array through the measured layout and reduces the scalars on the device -- the reference's whole `pack_affine_and_scalars`
+/// stage (utils/limbs_conversion.rs:311-378: 3 CPU Montgomery reductions + 3 heap allocations per point) is gone.  From 2^19 points
+/// on, a multi-GPU host shards the point range over all devices behind this unchanged signature.  Only if the layout probe fails
+/// (a future arkworks changing `G1Affine`) are the points repacked -- in parallel, still without any field reduction.
+pub fn metal_variable_base_msm(bases: &[G1Affine], scalars: &[Fr]) -> Result<G1Projective, Box<dyn Error>> {
+    if bases.is_empty() || scalars.is_empty() {
+        return Err("Empty input".into()); // metal_msm.rs:647-649
+    }
+    let n = bases.len().min(scalars.len()); // metal_msm.rs:652-656
+    let repacked: Vec<[u64; 9]>;
+    let (ptr, l) = match *LAYOUT {
+        Some(l) => (bases.as_ptr() as *const core::ffi::c_void, l),
+        None => {
+            use ark_std::{cfg_iter, vec::Vec};
+            #[cfg(feature = "parallel")]
+            use rayon::prelude::*;
+            repacked = cfg_iter!(bases[..n])
+                .map(|b| {
+                    let mut r = [0u64; 9];
+                    r[0..4].copy_from_slice(&b.x.0 .0);
+                    r[4..8].copy_from_slice(&b.y.0 .0);
+                    r[8] = b.infinity as u64;
+                    r
+                })
+                .collect::<Vec<_>>();
+            (repacked.as_ptr() as *const core::ffi::c_void, Layout { stride: 72, x_off: 0, y_off: 32, inf_off: 64 })
+        }
+    };
+    let mut jac = [0u64; 12];
+    let mut is_inf = 0u8;
+    if n >= MULTI_MIN_POINTS {
+        if let Some(m) = MULTI.lock().unwrap().as_ref() {
+            let rc = unsafe {
+                msm_bn254_g1_multi_arkworks(
+                    m.0, ptr, l.stride, l.x_off, l.y_off, l.inf_off, scalars.as_ptr() as *const u32, n,
+                    jac.as_mut_ptr() as *mut u32, std::ptr::null_mut(), &mut is_inf,
+                )
+            };
+            return if rc == 0 { Ok(to_projective(&jac)) } else { Err(multi_error(m.0).into()) };
+        }
+    }
+    let guard = CTX.lock().unwrap();
+    let ctx = guard.as_ref().map_err(|e| e.clone())?;
+    let rc = unsafe {
+        msm_bn254_g1_arkworks(
+            ctx.0, ptr, l.stride, l.x_off, l.y_off, l.inf_off, scalars.as_ptr() as *const u32, n,
+            jac.as_mut_ptr() as *mut u32, std::ptr::null_mut(), &mut is_inf,
+        )
+    };
+    if rc != 0 {
+        return Err(last_error(ctx.0).into());
+    }
+    Ok(to_projective(&jac))
+}
+
+/// The packed-word call (`msm_bn254_g1`): coordinates copied out of the structs (Montgomery words, no reduction), scalars through
+/// `into_bigint()` on the CPU.  Kept for callers that already hold packed words; `metal_variable_base_msm` does not use it.
+pub fn hip_variable_base_msm_packed(bases: &[G1Affine], scalars: &[Fr]) -> Result<G1Projective, Box<dyn Error>> {
     if bases.is_empty() || scalars.is_empty() {
         return Err("Empty input".into());
     }
     let n = bases.len().min(scalars.len());
-    bases = &bases[..n];
-    scalars = &scalars[..n];
-
-    // Pack: x.0.0 / y.0.0 are already Montgomery (R = 2^256) limbs -> plain copy, no field reduction
-    // (the reference does 3 Montgomery reductions + 3 heap allocations per point here,
-    //  utils/limbs_conversion.rs:311-378).  G1Affine is not repr(C): read fields, never offsets.
     let mut xy = vec![0u64; n * 8];
     let mut inf = vec![0u8; n];
     let mut sc = vec![0u64; n * 4];
@@ -94,7 +218,6 @@ pub fn metal_variable_base_msm(mut bases: &[G1Affine], mut scalars: &[Fr]) -> Re
         }
         sc[i * 4..i * 4 + 4].copy_from_slice(&scalars[i].into_bigint().0); // standard form, < r
     }
-
     let guard = CTX.lock().unwrap();
     let ctx = guard.as_ref().map_err(|e| e.clone())?;
     let mut jac = [0u64; 12];
@@ -108,39 +231,12 @@ pub fn metal_variable_base_msm(mut bases: &[G1Affine], mut scalars: &[Fr]) -> Re
     if rc != 0 {
         return Err(last_error(ctx.0).into());
     }
-    // Jacobian Montgomery limbs -> G1Projective without any conversion (reference: metal_msm.rs:228-241)
-    let f = |w: &[u64]| Fq::new_unchecked(BigInt::<4>([w[0], w[1], w[2], w[3]]));
-    Ok(G1Projective::new_unchecked(f(&jac[0..4]), f(&jac[4..8]), f(&jac[8..12])))
+    Ok(to_projective(&jac))
 }
 
-/// Zero-copy variant (include/msm_hip.h `msm_bn254_g1_arkworks`): the `[G1Affine]` and `[Fr]` slices go to the GPU as
-/// they are.  The struct layout is MEASURED here (G1Affine is not repr(C)); Fr is `Fp<MontBackend<_,4>,4>` = [u64;4].
+/// Earlier name of the zero-copy call; `metal_variable_base_msm` is that call now.
 pub fn hip_variable_base_msm_zero_copy(bases: &[G1Affine], scalars: &[Fr]) -> Result<G1Projective, Box<dyn Error>> {
-    if bases.is_empty() || scalars.is_empty() {
-        return Err("Empty input".into());
-    }
-    let n = bases.len().min(scalars.len());
-    let probe = &bases[0];
-    let base_addr = probe as *const G1Affine as usize;
-    let x_off = core::ptr::addr_of!(probe.x) as usize - base_addr;
-    let y_off = core::ptr::addr_of!(probe.y) as usize - base_addr;
-    let inf_off = core::ptr::addr_of!(probe.infinity) as usize - base_addr;
-    assert_eq!(core::mem::size_of::<Fr>(), 32);
-    let guard = CTX.lock().unwrap();
-    let ctx = guard.as_ref().map_err(|e| e.clone())?;
-    let mut jac = [0u64; 12];
-    let mut is_inf = 0u8;
-    let rc = unsafe {
-        msm_bn254_g1_arkworks(
-            ctx.0, bases.as_ptr() as *const core::ffi::c_void, core::mem::size_of::<G1Affine>(), x_off, y_off, inf_off,
-            scalars.as_ptr() as *const u32, n, jac.as_mut_ptr() as *mut u32, std::ptr::null_mut(), &mut is_inf,
-        )
-    };
-    if rc != 0 {
-        return Err(last_error(ctx.0).into());
-    }
-    let f = |w: &[u64]| Fq::new_unchecked(BigInt::<4>([w[0], w[1], w[2], w[3]]));
-    Ok(G1Projective::new_unchecked(f(&jac[0..4]), f(&jac[4..8]), f(&jac[8..12])))
+    metal_variable_base_msm(bases, scalars)
 }
 
 /// The benchmark harness's read path (utils/preprocess.rs:101-131 + arkworks_pippenger.rs:7-43) without the CPU square
@@ -177,8 +273,7 @@ pub fn hip_msm_from_compressed_instance(
     if rc != 0 {
         return Err(last_error(ctx.0).into());
     }
-    let f = |w: &[u64]| Fq::new_unchecked(BigInt::<4>([w[0], w[1], w[2], w[3]]));
-    Ok(G1Projective::new_unchecked(f(&jac[0..4]), f(&jac[4..8]), f(&jac[8..12])))
+    Ok(to_projective(&jac))
 }
 
 /// Alias under the engine's own name.
@@ -203,6 +298,15 @@ mod tests {
             assert_eq!(metal_variable_base_msm(&bases, &scalars).unwrap(), G1Projective::msm(&bases, &scalars).unwrap());
         }
         assert!(metal_variable_base_msm(&[], &[]).is_err());
+        // points at infinity inside the slice, truncation to the shorter slice, and the packed-word variant
+        let n = 1 << 10;
+        let mut bases: Vec<G1Affine> = (0..n).map(|_| G1Projective::rand(&mut rng).into_affine()).collect();
+        bases[3] = G1Affine::identity();
+        let scalars: Vec<Fr> = (0..n + 5).map(|_| Fr::rand(&mut rng)).collect();
+        let want = G1Projective::msm(&bases, &scalars[..n]).unwrap();
+        assert_eq!(metal_variable_base_msm(&bases, &scalars).unwrap(), want);
+        assert_eq!(hip_variable_base_msm_packed(&bases, &scalars).unwrap(), want);
+        assert!(LAYOUT.is_some(), "G1Affine layout probe failed: the shim repacks (correct, slower)");
     }
 
     // the compressed image format is restated from ark-serialize 0.4 on the C side: this is the test that pins it

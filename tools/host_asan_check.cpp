@@ -1,0 +1,147 @@
+// tools/host_asan_check.cpp -- HOST-only AddressSanitizer + UBSan build of the parts of the host runtime that need no GPU
+// (SURVEY.md section 5 "sanitizer host build"; GPU ASan is not available on this pool): the planner (msm_planner.hpp), the thread pool
+// (msm_host_pool.hpp), the CPU finish arithmetic (host_g1.hpp), the host side of the GLV split (glv_bn254.hpp) and the shard /
+// chunk-schedule arithmetic.  Built by `make -C gpu-acceleration_amd/csrc asan`, run by tests/test_host_asan.py.
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+#define FP_HD inline
+#include "../gpu-acceleration_amd/csrc/glv_bn254.hpp"
+#include "../gpu-acceleration_amd/csrc/host_g1.hpp"
+#include "../gpu-acceleration_amd/csrc/msm_host_pool.hpp"
+#include "../gpu-acceleration_amd/csrc/msm_planner.hpp"
+
+#define REQUIRE(c)                                                              \
+    do {                                                                        \
+        if (!(c)) {                                                             \
+            std::fprintf(stderr, "FAILED: %s (%s:%d)\n", #c, __FILE__, __LINE__); \
+            return 1;                                                           \
+        }                                                                       \
+    } while (0)
+
+static int check_planner() {
+    for (uint32_t flags = 0; flags < 4; flags++)
+        for (uint32_t c = 0; c <= 20; c++) {
+            if (c == 1) continue;
+            for (size_t n : {(size_t)1, (size_t)2, (size_t)255, (size_t)1 << 10, (size_t)1 << 16, ((size_t)1 << 19) + 1, (size_t)1 << 24, (size_t)1 << 30}) {
+                msm_plan_t p;
+                int32_t rc = msmplan::make_plan(n, c, flags, &p);
+                REQUIRE(rc == MSM_OK);
+                REQUIRE(p.num_windows >= 1 && p.num_windows <= 128);
+                REQUIRE((uint64_t)p.num_windows * p.window_bits >= p.scalar_bits);  // the windows cover the scalar
+                REQUIRE(p.virtual_points == (p.glv ? 2 * n : n));
+                REQUIRE(p.num_buckets == (p.signed_digits ? 1u << (p.window_bits - 1) : 1u << p.window_bits));
+                if (c) REQUIRE(p.window_bits == c);
+            }
+        }
+    msm_plan_t p;
+    REQUIRE(msmplan::make_plan(16, 1, 0, &p) == MSM_ERR_BAD_ARG);
+    REQUIRE(msmplan::make_plan(16, 21, 0, &p) == MSM_ERR_BAD_ARG);
+    REQUIRE(msmplan::make_plan(16, 0, 8, &p) == MSM_ERR_BAD_ARG);
+    return 0;
+}
+
+static int check_pool() {
+    for (int workers : {1, 3, 7}) {
+        HostPool pool(workers);
+        for (int round = 0; round < 200; round++) {
+            const int njobs = 1 + round % 13;
+            std::vector<int> hits((size_t)njobs, 0);
+            if (round % 3 == 0) pool.arm();
+            pool.run(njobs, [&](int k) { hits[(size_t)k]++; });
+            for (int k = 0; k < njobs; k++) REQUIRE(hits[(size_t)k] == 1);
+        }
+    }  // destructor joins armed and idle workers
+    return 0;
+}
+
+static int check_g1() {
+    using namespace hostg1;
+    const Jac g{ONE, dbl(ONE), ONE};  // (1, 2)
+    Fq x, y;
+    // known answers: 2G, 3G
+    const uint64_t x2[4] = {0xd3c208c16d87cfd3ULL, 0xd97816a916871ca8ULL, 0x9b85045b68181585ULL, 0x030644e72e131a02ULL};
+    const uint64_t x3[4] = {0xf2d355961915abf0ULL, 0x9315d84715b8e679ULL, 0xf40232bcb1b6bd15ULL, 0x0769bf9ac56bea3fULL};
+    REQUIRE(!to_affine_std(jdbl(g), x, y) && std::memcmp(x.l, x2, 32) == 0);
+    REQUIRE(!to_affine_std(jadd(jdbl(g), g), x, y) && std::memcmp(x.l, x3, 32) == 0);
+    // group identities through the complete addition: P + P = 2P, P + (-P) = 0, 0 + P = P, (a+b)G by two routes
+    Jac acc = identity(), p7 = identity();
+    for (int i = 0; i < 7; i++) p7 = jadd(p7, g);
+    acc = jadd(jdbl(jdbl(g)), jadd(jdbl(g), g));  // 4G + 3G
+    Fq xa, ya, xb, yb;
+    REQUIRE(!to_affine_std(acc, xa, ya) && !to_affine_std(p7, xb, yb) && std::memcmp(xa.l, xb.l, 32) == 0 && std::memcmp(ya.l, yb.l, 32) == 0);
+    Jac neg = p7;
+    neg.y = sub(Fq{{0, 0, 0, 0}}, p7.y);
+    REQUIRE(is_identity(jadd(p7, neg)));
+    REQUIRE(!to_affine_std(jadd(p7, p7), xa, ya) && !to_affine_std(jdbl(p7), xb, yb) && std::memcmp(xa.l, xb.l, 32) == 0);
+    REQUIRE(!to_affine_std(jadd(identity(), p7), xa, ya) && !to_affine_std(p7, xb, yb) && std::memcmp(ya.l, yb.l, 32) == 0);
+    // word round trip
+    uint32_t w[24];
+    store_jac(w, p7);
+    Jac back = load_jac(w);
+    REQUIRE(std::memcmp(back.x.l, p7.x.l, 32) == 0 && std::memcmp(back.z.l, p7.z.l, 32) == 0);
+    // field: a * a^-1 = 1 for a few elements
+    std::mt19937_64 rng(5);
+    for (int i = 0; i < 20; i++) {
+        Fq a{{rng(), rng(), rng(), rng() >> 3}};
+        if (geq_mod(a)) sub_mod_inplace(a);
+        if (is_zero(a)) continue;
+        Fq one = mul(a, inv(a));
+        REQUIRE(std::memcmp(one.l, ONE.l, 32) == 0);
+    }
+    return 0;
+}
+
+static int check_glv() {
+    std::mt19937_64 rng(11);
+    for (int it = 0; it < 20000; it++) {
+        uint32_t k[8];
+        for (auto& v : k) v = (uint32_t)rng();
+        k[7] &= 0x3FFFFFFFu;
+        if (it == 0) std::memset(k, 0, sizeof k);
+        if (it == 1) std::memset(k, 0xFF, sizeof k), k[7] = 0x3FFFFFFFu;
+        uint32_t k1[4], k2[4];
+        bool n1, n2;
+        REQUIRE(glv::split(k, k1, n1, k2, n2));          // both halves below 2^127 for every scalar below 2^254
+        REQUIRE((k1[3] >> 31) == 0 && (k2[3] >> 31) == 0);
+    }
+    return 0;
+}
+
+// the shard arithmetic of msm_multi (msm_multi.inc shard_bounds) and the uniform chunk schedule (msm_hip.hip stream_schedule)
+static int check_partitions() {
+    for (size_t n : {(size_t)1, (size_t)2, (size_t)7, (size_t)1000, ((size_t)1 << 20) + 3, (size_t)1 << 30})
+        for (int G = 1; G <= 9; G++) {
+            size_t prev = 0;
+            for (int g = 0; g <= G; g++) {
+                size_t lo = (size_t)((unsigned __int128)n * (unsigned)g / (unsigned)G);
+                REQUIRE(lo >= prev && lo <= n);
+                prev = lo;
+            }
+            REQUIRE(prev == n);
+        }
+    for (size_t chunk : {(size_t)1 << 8, (size_t)1 << 18})
+        for (size_t n = 2 * chunk; n < 6 * chunk; n += chunk / 3 + 1) {
+            std::vector<size_t> sizes;
+            size_t left = n;
+            while (left >= chunk + chunk / 2) sizes.push_back(chunk), left -= chunk;
+            if (left > chunk) sizes.push_back((left / 2 + 63) & ~(size_t)63), left -= sizes.back();
+            if (left) sizes.push_back(left);
+            size_t sum = 0;
+            for (size_t s : sizes) {
+                REQUIRE(s > 0 && s < chunk + chunk / 2);
+                sum += s;
+            }
+            REQUIRE(sum == n);
+        }
+    return 0;
+}
+
+int main() {
+    if (check_planner() || check_pool() || check_g1() || check_glv() || check_partitions()) return 1;
+    std::puts("host runtime: planner, pool, host_g1, glv split, partitions clean under ASan/UBSan");
+    return 0;
+}
