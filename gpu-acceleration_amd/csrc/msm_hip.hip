@@ -404,23 +404,22 @@ int32_t enqueue_sort(msm_ctx* c, const PipeState& ps, const uint8_t* d_inf, cons
 
 // K3: bucket accumulation (the graded kernel) -- bracketed by its own events on its own stream -- and the buckets cut by chunk
 // borders.  d_bases: INTERNAL-domain records; with the GLV split 2*n_real of them, phi(P_i) at index n_real + i.
-// into = true: the buckets keep what earlier chunks of the same MSM left in them (k_accumulate<true>).
-int32_t enqueue_accumulate(msm_ctx* c, const PipeState& ps, const uint32_t* d_bases, hipStream_t st, hipEvent_t bases_ready, bool into) {
+// into = true: the buckets keep what earlier chunks of the same MSM left in them (k_accumulate<true, true>); chunked: a chunk of a
+// streamed host call (own kernel symbol).
+int32_t enqueue_accumulate(msm_ctx* c, const PipeState& ps, const uint32_t* d_bases, hipStream_t st, hipEvent_t bases_ready, bool into,
+                           bool chunked = false) {
     Range r_("msm:accumulate");
     uint32_t* flags = (uint32_t*)c->flags.p;
     uint32_t* offsets = (uint32_t*)c->offsets.p;
     const size_t tb = ps.tb;
     if (bases_ready) HIPCHK(c, hipStreamWaitEvent(st, bases_ready, 0));  // d_bases is being converted on another stream
     HIPCHK(c, hipEventRecord(c->ev[EV_ACC0], st));
-    const unsigned ab = 256;  // (64- and 128-thread workgroups: no difference at any size, tools/env_sweep.py)
-    if (into)
-        msmk::k_accumulate<true><<<grid1(ps.nchunks_max, ab), ab, 0, st>>>(d_bases, (uint32_t*)c->sorted.p, offsets, (uint32_t*)c->chunkmap.p,
-                                                                          (uint32_t*)c->buckets.p, (uint32_t*)c->heads.p, (uint32_t*)c->tails.p,
-                                                                          flags + msmk::FLAG_PAIRS, ps.chunk_len, (uint32_t)tb);
-    else
-        msmk::k_accumulate<false><<<grid1(ps.nchunks_max, ab), ab, 0, st>>>(d_bases, (uint32_t*)c->sorted.p, offsets, (uint32_t*)c->chunkmap.p,
-                                                                           (uint32_t*)c->buckets.p, (uint32_t*)c->heads.p, (uint32_t*)c->tails.p,
-                                                                           flags + msmk::FLAG_PAIRS, ps.chunk_len, (uint32_t)tb);
+    const dim3 ga = grid1(ps.nchunks_max, 256);  // (64- and 128-thread workgroups: no difference at any size, tools/env_sweep.py)
+    const uint32_t *srt = (const uint32_t*)c->sorted.p, *cm = (const uint32_t*)c->chunkmap.p, *tp = flags + msmk::FLAG_PAIRS;
+    uint32_t *bk = (uint32_t*)c->buckets.p, *hd = (uint32_t*)c->heads.p, *tl = (uint32_t*)c->tails.p;
+    if (into) msmk::k_accumulate<true, true><<<ga, 256, 0, st>>>(d_bases, srt, offsets, cm, bk, hd, tl, tp, ps.chunk_len, (uint32_t)tb);
+    else if (chunked) msmk::k_accumulate<false, true><<<ga, 256, 0, st>>>(d_bases, srt, offsets, cm, bk, hd, tl, tp, ps.chunk_len, (uint32_t)tb);
+    else msmk::k_accumulate<false, false><<<ga, 256, 0, st>>>(d_bases, srt, offsets, cm, bk, hd, tl, tp, ps.chunk_len, (uint32_t)tb);
     HIPCHK(c, hipEventRecord(c->ev[EV_ACC1], st));
     const size_t once_max = std::min(ps.nchunks_max, tb);  // a once-cut bucket owns one chunk border
     msmk::k_combine<<<dim3(msmk::MID_BLOCKS + (unsigned)((once_max + 255) / 256)), 256, 0, st>>>(
@@ -748,7 +747,7 @@ int32_t run_streamed(msm_ctx* c, const HostInput& in, size_t n, const std::vecto
         HIPCHK(c, hipStreamWaitEvent(st, c->ev_copied[s], 0));
         if ((rc = pipe_prepare(c, cnt, n, 0, st, &ps))) return rc;
         if ((rc = enqueue_sort(c, ps, d_inf, (const uint32_t*)c->sscalars[s].p, in.scalars_mont, st, j == 0))) return rc;
-        if ((rc = enqueue_accumulate(c, ps, (const uint32_t*)c->sibases[s].p, st, nullptr, j > 0))) return rc;
+        if ((rc = enqueue_accumulate(c, ps, (const uint32_t*)c->sibases[s].p, st, nullptr, j > 0, true))) return rc;
         HIPCHK(c, hipEventRecord(c->ev_free[s], st));
         lo += cnt;
     }

