@@ -341,3 +341,44 @@ def test_trace_and_roctx_switches():
     assert "stages True" in p.stdout
     line = [l for l in p.stderr.splitlines() if l.startswith("[msm_hip] host single-shot")]
     assert line and " glv 1 " in line[0] and "accumulate" in line[0] and "adds" in line[0], p.stderr[-2000:]
+
+
+def test_streamed_and_multi_randomised_fuzz():
+    """randomised net under the shared-bucket streaming (k_accumulate<INTO>: bucket read-modify-write, once/mid/long lists per chunk,
+    flag words that clean themselves between chunks) and under msm_multi's sharding: 36 random (size, chunk, window, digit form, GLV,
+    infinity mask, scalar skew) cases against the oracle, each also as a 2- or 3-shard in-process multi call"""
+    rng = np.random.default_rng(20261003)
+    nmax = 30000
+    k_all = orc.gen_scalars(777, nmax, nonzero=True)
+    bases_all = orc.gen_bases_from_logs(k_all, orc.FORM_MONT)
+    s_all = orc.gen_scalars(778, nmax)
+    for it in range(36):
+        lg = int(rng.choice([8, 9, 10, 11]))
+        n = int(rng.integers(2 << lg, min(nmax, 9 << lg)))
+        off = int(rng.integers(0, nmax - n + 1))
+        bases, s = bases_all[off:off + n].copy(), s_all[off:off + n].copy()
+        mode = int(rng.integers(0, 6))
+        if mode == 1:
+            s[:] = s[0]                      # one bucket per window holds everything: long buckets in every chunk
+        elif mode == 2:
+            s = s[np.arange(n) % 5]
+        elif mode == 3:
+            s[:, 1:] = 0                     # only the lowest windows are populated
+        elif mode == 4:
+            s[rng.random(n) < 0.7] = 0       # most digits skipped
+        elif mode == 5 and n > 1:
+            bases[1::2] = bases[0]           # P + P inside buckets and across chunks
+        inf = (rng.random(n) < rng.choice([0.002, 0.2])).astype(np.uint8) if rng.random() < 0.4 else None
+        wb = int(rng.choice([0, 0, 4, 7, 10, 13, 16]))
+        flags = (mh.FLAG_UNSIGNED_DIGITS if rng.random() < 0.2 else 0) | (mh.FLAG_NO_GLV if rng.random() < 0.4 else 0)
+        exp, einf, _ = orc.msm_pippenger(bases, s, orc.FORM_MONT, inf)
+        tag = dict(case=it, n=n, chunk_log2=lg, mode=mode, wb=wb, flags=flags, inf=inf is not None)
+        with mh.MsmContext(window_bits=wb, flags=flags, stream_chunk_log2=lg) as c:
+            for rep in range(2):             # twice: the flag words and list counters must be clean again
+                r = c.msm(bases, s, mh.FORM_MONT, inf)
+                assert r.is_infinity == bool(einf) and (r.affine_std == exp).all(), (tag, rep)
+            assert c.timings()["stream_chunks"] >= 2
+        G = 2 + it % 2
+        with mh.MsmMulti(devices=[0] * G, window_bits=wb, flags=flags, stream_chunk_log2=lg if it % 3 == 0 else 0) as m:
+            r = m.msm(bases, s, mh.FORM_MONT, inf)
+            assert r.is_infinity == bool(einf) and (r.affine_std == exp).all(), (tag, "multi", G)
