@@ -123,6 +123,7 @@ struct msm_ctx {
     bool stage_timing = false;  // record the per-stage hipEvents (each costs ~6 us of stream time); k_accumulate's pair is always on
     double acc_ms_sum = 0;
     uint64_t acc_launches = 0;
+    bool reduce_v1 = false;       // MSM_HIP_REDUCE_V1=1 at context creation: one launch per pairwise level (round 1)
     bool flags_clean = false;     // the device flag words are known to be zero (set when an MSM completes)
     uint32_t last_sort_path = 0;  // 2 = two-level LDS sort, 1 = tiled LDS histogram, 0 = global atomics (stage tests, trace)
 };
@@ -444,8 +445,20 @@ int32_t enqueue_reduce(msm_ctx* c, const PipeState& ps, hipStream_t st, uint32_t
     uint32_t* cbuf[2] = {(uint32_t*)c->rc.p + (tb / 2 + tb / 4 + 1) * msmk::XW, (uint32_t*)c->rc.p + (tb + tb / 4 + 1) * msmk::XW};
     const uint32_t *rin = bk, *cin = bk;
     size_t rn = tb, cn = tb;  // current element counts
-    uint32_t levels = kb_hi > kb_lo ? kb_hi : kb_lo;
-    for (uint32_t l = 0; l < levels; l++) {
+    const uint32_t levels = kb_hi > kb_lo ? kb_hi : kb_lo;
+    // Round 2: the first three levels (ALU-bound, most of the adds) run as ONE launch that reads every bucket once per family, the
+    // last ones (<= 16 partial sums per output left: launch- and latency-bound) as ONE launch of LDS trees; only what lies between
+    // keeps a launch per level.  MSM_HIP_REDUCE_V1=1 = one launch per level throughout (round 1; A/B knob).
+    const bool fused = !c->reduce_v1 && c->wide_max != 0;
+    const uint32_t tail_from = fused ? (kb_hi > 4 ? kb_hi - 4 : 0) : levels;  // levels [tail_from, levels) go to k_pair_tail
+    uint32_t l = 0;
+    if (fused && tail_from >= 3 && kb_lo >= 3) {
+        rn = tb / 8, cn = tb / 8;
+        msmk::k_pair_level8<<<grid1(rn + cn, 256), 256, 0, st>>>(bk, rbuf[0], cbuf[0], (uint32_t)rn, n_lo);
+        rin = rbuf[0], cin = cbuf[0];  // where level 2 would have left them
+        l = 3;
+    }
+    for (; l < tail_from; l++) {
         msmk::pair_job ja{nullptr, nullptr, 0, 1}, jb{nullptr, nullptr, 0, 1};
         if (l < kb_lo) {
             rn /= 2;
@@ -461,6 +474,13 @@ int32_t enqueue_reduce(msm_ctx* c, const PipeState& ps, hipStream_t st, uint32_t
         const size_t nadds = (size_t)ja.n_out + jb.n_out;
         if (nadds <= c->wide_max) msmk::k_pair_level_wide<<<grid1(nadds * msmk::WIDE_LANES, 256), 256, 0, st>>>(ja, jb);
         else msmk::k_pair_level<<<grid1(nadds, 256), 256, 0, st>>>(ja, jb);
+    }
+    if (l < levels) {  // the tail: m_r = n_lo >> l partial sums per row output, m_c = n_hi >> l per column output (both <= 16)
+        const uint32_t m_r = l < kb_lo ? n_lo >> l : 1u, m_c = l < kb_hi ? n_hi >> l : 1u;
+        const uint32_t n_r = m_r > 1 ? W * n_hi : 0u, n_c = m_c > 1 ? W * n_lo : 0u;
+        msmk::k_pair_tail<<<n_r + n_c, 64, 0, st>>>(rin, cin, rbuf[l & 1], cbuf[l & 1], n_r, n_c, m_r, m_c, n_lo);
+        if (n_r) rin = rbuf[l & 1];
+        if (n_c) cin = cbuf[l & 1];
     }
     // the bit sums (and the flag words) are written by the kernel straight into the caller's PINNED host buffers:
     // a D2H copy engine transfer started ~11 us after the kernel and took two launches (24 KB + 32 B)
@@ -904,6 +924,7 @@ int32_t msm_ctx_create(const msm_config_t* cfg, msm_ctx** out) {
                                  // falling (0.606 / 0.570 / 0.556 / 0.555) but 3+ threads bring 2-8 ms outliers in ~1.3 % of the calls
         if (const char* e = std::getenv("MSM_HIP_HOST_THREADS")) want = std::atoi(e) - 1;
         if (const char* e = std::getenv("MSM_HIP_WIDE_MAX")) c->wide_max = (size_t)std::max(0, std::atoi(e));
+        if (const char* e = std::getenv("MSM_HIP_REDUCE_V1")) c->reduce_v1 = *e && *e != '0';
         if (want >= 1) c->pool = new (std::nothrow) HostPool(want);
     }
     *out = c;
