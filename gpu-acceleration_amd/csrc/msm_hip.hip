@@ -446,19 +446,20 @@ int32_t enqueue_reduce(msm_ctx* c, const PipeState& ps, hipStream_t st, uint32_t
     const uint32_t *rin = bk, *cin = bk;
     size_t rn = tb, cn = tb;  // current element counts
     const uint32_t levels = kb_hi > kb_lo ? kb_hi : kb_lo;
-    // Round 2: the first three levels (ALU-bound, most of the adds) run as ONE launch that reads every bucket once per family, the
-    // last ones (<= 16 partial sums per output left: launch- and latency-bound) as ONE launch of LDS trees; only what lies between
-    // keeps a launch per level.  MSM_HIP_REDUCE_V1=1 = one launch per level throughout (round 1; A/B knob).
-    const bool fused = !c->reduce_v1 && c->wide_max != 0;
-    const uint32_t tail_from = fused ? (kb_hi > 4 ? kb_hi - 4 : 0) : levels;  // levels [tail_from, levels) go to k_pair_tail
+    // Round 2: the first three levels (ALU-bound, most of the adds) run as ONE launch that reads every bucket once per family and never
+    // writes the two intermediate levels (-14..-16 us of kernel time at every size up to 2^20).  Not above ~100 MB of buckets (c = 17,
+    // 15 x 65536 buckets: there its strided record reads lose 20-35 us to the pairwise levels).  A matching single launch for the
+    // LAST levels (one LDS tree of eight-lane additions per output) was slower than the launch-bound k_pair_level_wide levels it
+    // replaced (2^20: 52 vs 37 us: a tree's upper levels leave most lanes of its wavefront idle): profiles/NOTES_r2.md.
+    // MSM_HIP_REDUCE_V1=1 at context creation = one launch per level throughout (round 1; A/B knob).
     uint32_t l = 0;
-    if (fused && tail_from >= 3 && kb_lo >= 3) {
+    if (!c->reduce_v1 && levels >= 3 && kb_lo >= 3 && tb * XB <= ((size_t)100 << 20)) {
         rn = tb / 8, cn = tb / 8;
         msmk::k_pair_level8<<<grid1(rn + cn, 256), 256, 0, st>>>(bk, rbuf[0], cbuf[0], (uint32_t)rn, n_lo);
         rin = rbuf[0], cin = cbuf[0];  // where level 2 would have left them
         l = 3;
     }
-    for (; l < tail_from; l++) {
+    for (; l < levels; l++) {
         msmk::pair_job ja{nullptr, nullptr, 0, 1}, jb{nullptr, nullptr, 0, 1};
         if (l < kb_lo) {
             rn /= 2;
@@ -474,13 +475,6 @@ int32_t enqueue_reduce(msm_ctx* c, const PipeState& ps, hipStream_t st, uint32_t
         const size_t nadds = (size_t)ja.n_out + jb.n_out;
         if (nadds <= c->wide_max) msmk::k_pair_level_wide<<<grid1(nadds * msmk::WIDE_LANES, 256), 256, 0, st>>>(ja, jb);
         else msmk::k_pair_level<<<grid1(nadds, 256), 256, 0, st>>>(ja, jb);
-    }
-    if (l < levels) {  // the tail: m_r = n_lo >> l partial sums per row output, m_c = n_hi >> l per column output (both <= 16)
-        const uint32_t m_r = l < kb_lo ? n_lo >> l : 1u, m_c = l < kb_hi ? n_hi >> l : 1u;
-        const uint32_t n_r = m_r > 1 ? W * n_hi : 0u, n_c = m_c > 1 ? W * n_lo : 0u;
-        msmk::k_pair_tail<<<n_r + n_c, 64, 0, st>>>(rin, cin, rbuf[l & 1], cbuf[l & 1], n_r, n_c, m_r, m_c, n_lo);
-        if (n_r) rin = rbuf[l & 1];
-        if (n_c) cin = cbuf[l & 1];
     }
     // the bit sums (and the flag words) are written by the kernel straight into the caller's PINNED host buffers:
     // a D2H copy engine transfer started ~11 us after the kernel and took two launches (24 KB + 32 B)

@@ -1231,7 +1231,7 @@ __global__ void __launch_bounds__(256) k_pair_level_wide(pair_job ja, pair_job j
 // THREE pairwise levels of both families in one launch: out_r[o] = in[8o] + ... + in[8o+7] (rows: the lo dimension shrinks by 8),
 // out_c[w][a][b] = in[w][8a][b] + ... + in[w][8a+7][b] (cols: the hi dimension shrinks by 8).  One thread per output, seven dependent
 // additions; every bucket is read twice (once per family) and the two intermediate levels are never written: three launches and
-// ~2.5x the bucket array of traffic less than k_pair_level x 3 (2^20: 119 -> ~85 us, 2^17: 74 -> ~50 us).
+// ~2.5x the bucket array of traffic less than k_pair_level x 3 (measured 2^20: 119 -> 103 us, 2^17: 74 -> 60 us).
 __global__ void __launch_bounds__(256) k_pair_level8(const uint32_t* __restrict__ in, uint32_t* __restrict__ out_r, uint32_t* __restrict__ out_c,
                                                      uint32_t n_out, uint32_t n_lo) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1252,39 +1252,6 @@ __global__ void __launch_bounds__(256) k_pair_level8(const uint32_t* __restrict_
 #pragma unroll 1
     for (uint32_t j = 1; j < 8; j++) acc = xyzz_add(acc, load_xyzz(in + (i0 + j * stride) * XW));
     store_xyzz(out, acc);
-}
-
-// The LAST pairwise levels of both families in one launch: one 64-thread workgroup per final row sum R[w][hi] (m_r <= 16 partial
-// sums left, consecutive) or column sum C[w][lo] (m_c <= 16 left, n_lo apart): staged in LDS, folded by a tree of eight-lane
-// additions (log2 m dependent steps).  Replaces the 3-5 launch-bound k_pair_level_wide launches (2^20: 37 -> ~22 us).
-// n_r = W * n_hi row outputs (0 when the rows are already final), then n_c = W * n_lo column outputs.
-__global__ void __launch_bounds__(64) k_pair_tail(const uint32_t* __restrict__ in_r, const uint32_t* __restrict__ in_c,
-                                                  uint32_t* __restrict__ out_r, uint32_t* __restrict__ out_c, uint32_t n_r, uint32_t n_c,
-                                                  uint32_t m_r, uint32_t m_c, uint32_t n_lo) {
-    __shared__ uint32_t e[16 * XW];
-    uint32_t o = blockIdx.x, m;
-    const uint32_t* src;
-    size_t stride;
-    uint32_t* dst;
-    if (o < n_r) {
-        m = m_r;
-        src = in_r + (size_t)o * m_r * XW;
-        stride = 1;
-        dst = out_r + (size_t)o * XW;
-    } else {
-        o -= n_r;
-        if (o >= n_c) return;
-        m = m_c;
-        src = in_c + ((size_t)(o / n_lo) * m_c * n_lo + (o % n_lo)) * XW;
-        stride = n_lo;
-        dst = out_c + (size_t)o * XW;
-    }
-    for (uint32_t i = threadIdx.x >> 2; i < m; i += 16) {  // four lanes per record: one coordinate each
-        const uint32_t co = threadIdx.x & 3u;
-        store_coord(e + (size_t)i * XW, co, load_coord(src + (size_t)i * stride * XW, co));
-    }
-    lds_tree_wide(e, m);
-    if (threadIdx.x < 4) store_coord(dst, threadIdx.x, load_coord(e, threadIdx.x));
 }
 
 // k_reduce_bits with wide additions: one 512-thread workgroup per (window, bit); the selected elements are staged in LDS
