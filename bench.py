@@ -76,16 +76,16 @@ def valu_roofline(num_adds, acc_ms, mad_peak, fpmul_peak):
 
 
 def timed_calls(fn, reps, warm=1):
+    """(result, median ms, min ms) of `reps` calls after `warm` untimed ones"""
     for _ in range(warm):
         r = fn()
-    best, tot = 1e30, 0.0
+    ts = []
     for _ in range(reps):
         t0 = time.perf_counter()
         r = fn()
-        dt = time.perf_counter() - t0
-        tot += dt
-        best = min(best, dt)
-    return r, tot * 1e3 / reps, best * 1e3
+        ts.append((time.perf_counter() - t0) * 1e3)
+    ts.sort()
+    return r, ts[len(ts) // 2], ts[0]
 
 
 def main():
@@ -310,7 +310,7 @@ def main():
             hb_t, hs_t = d_bases[0].cpu(), d_scalars[0].cpu()
             hb = hb_t.numpy().view(np.uint32).reshape(n_local, 16)
             hs = hs_t.numpy().view(np.uint32).reshape(n_local, 8)
-            reps = 5 if n_local <= (1 << 22) else 2
+            reps = 7 if n_local <= (1 << 22) else 3
             legs = {}
             r, avg, best = timed_calls(lambda: ctx.msm(hb, hs, mh.FORM_MONT), reps)
             legs["e2e_host_pageable_ms"], legs["e2e_host_pageable_min_ms"] = round(avg, 4), round(best, 4)
@@ -332,7 +332,7 @@ def main():
             ok = ok and bool((r.affine_std == e2).all()) and r.is_infinity == bool(e2i)
             legs["bit_exact"] = ok
             legs["note"] = ("host-pointer calls on the same instance (PCIe-inclusive, 96-104 B per point); pageable = numpy arrays, "
-                            "pinned = torch pin_memory; avg and min of %d calls" % reps)
+                            "pinned = torch pin_memory; median and min of %d calls" % reps)
             out["host_pointer_legs"] = legs
             bit_exact = bit_exact and ok
 
