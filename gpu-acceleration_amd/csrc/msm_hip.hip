@@ -123,6 +123,8 @@ struct msm_ctx {
     bool stage_timing = false;  // record the per-stage hipEvents (each costs ~6 us of stream time); k_accumulate's pair is always on
     double acc_ms_sum = 0;
     uint64_t acc_launches = 0;
+    std::chrono::steady_clock::time_point t_prepare{};  // trace: when the call started preparing / enqueueing
+    float enqueue_ms = 0;         // trace: host time from there until everything was queued (what a hipGraph could shorten)
     bool reduce_v1 = false;       // MSM_HIP_REDUCE_V1=1 at context creation: one launch per pairwise level (round 1)
     bool flags_clean = false;     // the device flag words are known to be zero (set when an MSM completes)
     uint32_t last_sort_path = 0;  // 2 = two-level LDS sort, 1 = tiled LDS histogram, 0 = global atomics (stage tests, trace)
@@ -225,6 +227,7 @@ struct PipeState {
 // plan + workspace.  May reallocate buffers (hipFree synchronises the device), so with chunks in flight it must not grow
 // anything: the first chunk of a streamed MSM is the largest.
 int32_t pipe_prepare(msm_ctx* c, size_t n_real, size_t plan_n, uint32_t extra_flags, hipStream_t st, PipeState* ps) {
+    if (trace_enabled() && c->flags_clean) c->t_prepare = std::chrono::steady_clock::now();  // (flags_clean: first prepare of a call)
     if (n_real > 0x3FFFFFFFull) return fail(c, MSM_ERR_BAD_ARG, "n = %zu exceeds 2^30-1 points per context call", n_real);
     int32_t rc = make_plan(plan_n ? plan_n : n_real, c->cfg.window_bits, c->cfg.flags | extra_flags, &ps->pl);
     if (rc) return fail(c, rc, "bad window_bits/flags (%u, 0x%x)", c->cfg.window_bits, c->cfg.flags);
@@ -545,14 +548,15 @@ void trace_line(const msm_ctx* c, const char* entry, const PipeState& ps) {
     const msm_timings_t& t = c->tm;
     std::fprintf(stderr,
                  "[msm_hip] %s dev %d n %zu c %u W %u nb %u glv %u sort_path %u chunk_len %u stream_chunks %u | h2d %.3f convert %.3f "
-                 "decompose %.3f sort %.3f accumulate %.3f reduce %.3f finish %.3f total %.3f ms, %llu adds\n",
+                 "decompose %.3f sort %.3f accumulate %.3f reduce %.3f finish %.3f total %.3f ms (host enqueue %.3f ms), %llu adds\n",
                  entry, c->device, (size_t)t.num_points, ps.cbits, ps.W, ps.nb, ps.pl.glv, c->last_sort_path, ps.chunk_len, t.stream_chunks,
                  t.h2d_ms, t.convert_ms, t.decompose_ms, t.sort_ms, t.accumulate_ms, t.reduce_ms, t.finish_ms, t.total_ms,
-                 (unsigned long long)t.num_adds);
+                 c->enqueue_ms, (unsigned long long)t.num_adds);
 }
 
 // wait for the queued pipeline, finish on the CPU, fill outputs and timings
 int32_t finish_sync(msm_ctx* c, const PipeState& ps, size_t n_total, hipStream_t st, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf) {
+    if (trace_enabled()) c->enqueue_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - c->t_prepare).count();
     if (c->pool && n_total >= 256) c->pool->arm();  // workers wake up while the GPU works
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());
