@@ -633,13 +633,6 @@ struct HostInput {
     bool carries_inf() const { return kind == KIND_ARK || inf_mask != nullptr; }
 };
 
-bool is_pinned_host(const void* p) {
-    hipPointerAttribute_t a{};
-    const bool pinned = hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeHost;
-    (void)hipGetLastError();  // an unregistered pointer is not an error here
-    return pinned;
-}
-
 // host -> device copy on stream cs (hipMemcpyAsync: from pageable memory the runtime stages the data itself -- ~40 GB/s -- and the
 // call returns when the source has been consumed; from pinned memory it is fully asynchronous at the link rate, 56 GB/s).
 // Tried and dropped in round 2 (profiles/NOTES_r2.md): a pinned staging ring filled by 8 host threads (slower than the runtime's
@@ -733,9 +726,9 @@ int32_t run_single(msm_ctx* c, const HostInput& in, size_t n, uint32_t* out_jac,
 // range is cut into chunks; chunk j+1 travels host->HBM and is converted on the copy stream while chunk j is sorted and
 // accumulated on the compute stream.  MSM is linear in the points, so every chunk adds into the SAME bucket array
 // (k_accumulate<INTO>, one plan for the whole instance): ONE bucket reduction, ONE host finish and W*(kb+1) bit sums back,
-// however many chunks.  Raw and converted inputs are double-buffered.  The link is the bottleneck (96 B per point at ~55 GB/s
-// against ~1.2 ns of sort + accumulation), so what the call pays beyond the transfer is the work left when the last byte
-// has arrived: the automatic schedule ends with short chunks.
+// however many chunks.  Raw and converted inputs are double-buffered.  Transfer (96 B per point at ~56 GB/s from pinned, ~40 GB/s
+// from pageable memory) and per-chunk work (~0.47 ms per 2^18 points) are about level: the call costs the first transfer, then
+// the slower of the two per chunk, then the reduction and the host finish (2^20: 2.7-2.9 ms against 1.7 resident).
 int32_t run_streamed(msm_ctx* c, const HostInput& in, size_t n, const std::vector<size_t>& sizes, uint32_t* out_jac,
                      uint32_t* out_aff, uint8_t* out_inf) {
     int32_t rc;
