@@ -330,6 +330,16 @@ def main():
             legs["e2e_arkworks_zero_copy_ms"], legs["e2e_arkworks_zero_copy_min_ms"] = round(avg, 4), round(best, 4)
             e2, e2i = expect(dot * pow(1 << 256, -1, R_ORDER))
             ok = ok and bool((r.affine_std == e2).all()) and r.is_infinity == bool(e2i)
+            # prover shape: resident bases, a batch of host scalar vectors; single calls back to back vs
+            # msm_bn254_g1_resident_batch (two MSMs in flight inside the context).  32 B per point of PCIe in both.
+            ctx.upload_bases(hbpn, mh.FORM_MONT)
+            K = 8
+            r, avg, _ = timed_calls(lambda: [ctx.msm_resident(hspn) for _ in range(K)], 3)
+            legs["resident_single_calls_ms_per_msm"] = round(avg / K, 4)
+            ok = ok and all(bool((x.affine_std == exp).all()) for x in r)
+            r, avg, _ = timed_calls(lambda: ctx.msm_resident_batch([hspn] * K), 3)
+            legs["resident_batch_ms_per_msm"] = round(avg / K, 4)
+            ok = ok and all(bool((x.affine_std == exp).all()) for x in r)
             legs["bit_exact"] = ok
             legs["note"] = ("host-pointer calls on the same instance (PCIe-inclusive, 96-104 B per point); pageable = numpy arrays, "
                             "pinned = torch pin_memory; median and min of %d calls" % reps)

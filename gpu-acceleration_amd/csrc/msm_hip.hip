@@ -110,6 +110,12 @@ struct msm_ctx {
     // HBM workspace
     DevBuf bases, ibases, inf, scalars, digits, ranks, sorted, hist, offsets, blocksums, buckets, heads, tails, chunkmap, rc, flags,
         pow2, tilecounts, longlist, longdone, midlist, oncelist, ccounts, cregion, bigslot, big;
+    std::mutex batch_mu;           // batch on one compute stream: a whole MSM is enqueued at a time
+    bool batch_shared_stream = false;
+    std::mutex copy_mu;            // batch: the two pipelines' scalar uploads take turns (see resident_on_lane)
+    hipEvent_t last_copy = nullptr;  // ... the other pipeline's latest upload, recorded under copy_mu
+    msm_ctx* lane1 = nullptr;      // second pipeline of msm_bn254_g1_resident_batch: a context of its own (streams, workspace, pinned results)
+    HostPool* batch_pool = nullptr;  // ... and the host thread that drives it
     DevBuf rbases, rinf;  // the RESIDENT base set (msm_bn254_g1_upload_bases / _upload_compressed): never used as scratch
     bool pow2_ready = false;
     uint32_t* h_qsums = nullptr;  // pinned: W x (kb+1) Jacobian bit sums
@@ -555,10 +561,12 @@ void trace_line(const msm_ctx* c, const char* entry, const PipeState& ps) {
 }
 
 // wait for the queued pipeline, finish on the CPU, fill outputs and timings
-int32_t finish_sync(msm_ctx* c, const PipeState& ps, size_t n_total, hipStream_t st, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf) {
+int32_t finish_sync(msm_ctx* c, const PipeState& ps, size_t n_total, hipStream_t st, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf,
+                    hipEvent_t done = nullptr /* recorded after the last kernel when `st` carries other work too */) {
     if (trace_enabled()) c->enqueue_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - c->t_prepare).count();
     if (c->pool && n_total >= 256) c->pool->arm();  // workers wake up while the GPU works
-    HIPCHK(c, hipStreamSynchronize(st));
+    if (done) HIPCHK(c, hipEventSynchronize(done));
+    else HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());
     c->flags_clean = true;  // the last kernel zeroed the flag words after copying them out
     auto t_fin0 = std::chrono::steady_clock::now();
@@ -836,7 +844,11 @@ uint32_t msm_abi_version(void) { return MSM_HIP_ABI_VERSION; }
 
 const char* msm_last_error(const msm_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
-int32_t msm_ctx_create(const msm_config_t* cfg, msm_ctx** out) {
+// main_priority 1: the second pipeline of msm_bn254_g1_resident_batch.  Its main stream comes from the LOW-priority pool, so it
+// never shares a hardware queue with the first pipeline's main stream (equal-priority streams are dealt round-robin onto a few
+// HSA queues; two on one queue serialise and the batch gains nothing -- measured, profiles/NOTES_r2.md) and its kernels fill the
+// gaps of the first pipeline instead of competing with it.
+static int32_t ctx_create_impl(const msm_config_t* cfg, msm_ctx** out, int main_priority /* 0 default pool, 1 low, 2 high */) {
     if (!out) return fail(nullptr, MSM_ERR_BAD_ARG, "out == NULL");
     *out = nullptr;
     int ndev = 0;
@@ -859,7 +871,11 @@ int32_t msm_ctx_create(const msm_config_t* cfg, msm_ctx** out) {
     c->cfg = c0;
     c->stage_timing = trace_enabled();
     DeviceGuard g(dev);
-    hipError_t e = g.ok ? hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) : hipErrorInvalidDevice;
+    int least = 0, greatest = 0;
+    if (g.ok && hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
+    hipError_t e = !g.ok ? hipErrorInvalidDevice
+                   : (main_priority && least != greatest) ? hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, main_priority == 1 ? least : greatest)
+                                                              : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     for (int i = 0; i < EV_COUNT && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
     if (e == hipSuccess) {
         // The copy stream must own a HARDWARE queue of its own.  Streams of equal priority are spread over a small pool of HSA
@@ -867,8 +883,6 @@ int32_t msm_ctx_create(const msm_config_t* cfg, msm_ctx** out) {
         // one queue, the barrier packets of their cross-stream event waits executed in queue order and every chunk upload waited
         // for the PREVIOUS chunk's kernels (rocprofv3 kernel trace: one Queue_Id, profiles/NOTES_r2.md).  A stream of another
         // priority comes from another pool.
-        int least = 0, greatest = 0;
-        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
         e = least != greatest ? hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, greatest)
                               : hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
     }
@@ -922,10 +936,16 @@ int32_t msm_ctx_create(const msm_config_t* cfg, msm_ctx** out) {
     return MSM_OK;
 }
 
+int32_t msm_ctx_create(const msm_config_t* cfg, msm_ctx** out) { return ctx_create_impl(cfg, out, 0); }
+
 void msm_ctx_destroy(msm_ctx* c) {
     if (!c) return;
     delete c->pool;
     c->pool = nullptr;
+    delete c->batch_pool;
+    c->batch_pool = nullptr;
+    if (c->lane1) msm_ctx_destroy(c->lane1);
+    c->lane1 = nullptr;
     {
         DeviceGuard g(c->device);
         if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -1103,31 +1123,124 @@ int32_t msm_bn254_g1_compress(const uint32_t* bases_xy, uint32_t base_form, cons
     return MSM_OK;
 }
 
+// one MSM of `scalars` (host) against the resident set of `owner`, on the pipeline (streams, workspace, pinned results) of `w`
+// (w == owner, or owner's second lane)
+static int32_t resident_on_lane(msm_ctx* w, const msm_ctx* owner, const uint32_t* scalars, size_t n, uint32_t* out_jac, uint32_t* out_aff,
+                                uint8_t* out_inf, bool batch = false) {
+    int32_t rc;
+    if (n > owner->resident_n) n = owner->resident_n;  // unequal lengths truncate to the shorter (metal_msm.rs:652-656)
+    Range r_("msm_bn254_g1_resident");
+    auto t0 = std::chrono::steady_clock::now();
+    if (w->stage_timing) HIPCHK(w, hipEventRecord(w->ev[EV_START], w->stream));
+    if ((rc = ensure(w, w->scalars, n * 32))) return rc;
+    // the phi records sit at index resident_n + i: a call on fewer scalars (truncation) or a set uploaded without them runs unsplit
+    const uint32_t extra = (owner->resident_glv && n == owner->resident_n) ? 0u : MSM_FLAG_NO_GLV;
+    const uint32_t* rb = (const uint32_t*)owner->rbases.p;
+    const uint8_t* ri = owner->resident_has_inf ? (const uint8_t*)owner->rinf.p : nullptr;
+    PipeState ps;
+    if (!batch) {
+        HIPCHK(w, hipMemcpyAsync(w->scalars.p, scalars, n * 32, hipMemcpyHostToDevice, w->stream));
+        if (w->stage_timing) HIPCHK(w, hipEventRecord(w->ev[EV_H2D], w->stream));
+        rc = run_pipeline(w, rb, ri, (const uint32_t*)w->scalars.p, n, w->stream, out_jac, out_aff, out_inf, 0, nullptr, extra, &ps);
+        if (rc) return rc;
+    } else {
+        // Two MSMs in flight.  The pipelines must run in ANTI-phase: one uploads its scalars (DMA, 0.6 ms at 2^20) and finishes on
+        // the CPU while the other computes.  Left alone, two host threads start together and stay in lock-step -- two uploads
+        // sharing the link, then two pipelines sharing the CUs -- and kernels of two queues do not share a busy GPU fairly (a 5 us
+        // k_combine_long waited 880 us for the other pipeline's k_accumulate; rocprofv3 timelines in profiles/NOTES_r2.md).  So:
+        //   - uploads go to each pipeline's copy stream and take turns (each waits for the other pipeline's latest one);
+        //   - with owner->batch_shared_stream the kernels of BOTH pipelines go to the owner's stream, one whole MSM at a time
+        //     (enqueue under batch_mu), completion by event: the GPU runs MSM after MSM without a gap while the uploads and the
+        //     host finishes happen beside it;  without it (small sizes, where no kernel fills the GPU) each pipeline keeps its
+        //     own stream and the kernels overlap.
+        msm_ctx* o = const_cast<msm_ctx*>(owner);
+        const bool shared = o->batch_shared_stream;
+        hipStream_t cs = shared ? w->copy_stream : w->stream, st = shared ? o->stream : w->stream;
+        {
+            std::lock_guard<std::mutex> cp(o->copy_mu);
+            if (o->last_copy && o->last_copy != w->ev_fork) HIPCHK(w, hipStreamWaitEvent(cs, o->last_copy, 0));
+            HIPCHK(w, hipMemcpyAsync(w->scalars.p, scalars, n * 32, hipMemcpyHostToDevice, cs));
+            HIPCHK(w, hipEventRecord(w->ev_fork, cs));
+            o->last_copy = w->ev_fork;
+        }
+        {
+            std::unique_lock<std::mutex> q;
+            if (shared) q = std::unique_lock<std::mutex>(o->batch_mu);
+            if (w->stage_timing) HIPCHK(w, hipEventRecord(w->ev[EV_H2D], st));
+            if (shared) HIPCHK(w, hipStreamWaitEvent(st, w->ev_fork, 0));
+            if ((rc = pipe_prepare(w, n, 0, extra, st, &ps))) return rc;
+            if ((rc = enqueue_sort(w, ps, ri, (const uint32_t*)w->scalars.p, 0, st, true))) return rc;
+            if ((rc = enqueue_accumulate(w, ps, rb, st, nullptr, false))) return rc;
+            if ((rc = enqueue_reduce(w, ps, st, w->h_qsums, w->h_flags))) return rc;
+            if (shared) HIPCHK(w, hipEventRecord(w->ev_bases, st));
+        }
+        if ((rc = finish_sync(w, ps, n, st, out_jac, out_aff, out_inf, shared ? w->ev_bases : nullptr))) return rc;
+    }
+    w->tm.h2d_ms = stage_ms(w, EV_START, EV_H2D);
+    w->tm.convert_ms = 0;
+    w->tm.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    trace_line(w, "resident", ps);
+    return MSM_OK;
+}
+
 int32_t msm_bn254_g1_resident(msm_ctx* c, const uint32_t* scalars, size_t n, uint32_t out_jac[24], uint32_t out_aff[16],
                               uint8_t* out_inf) {
     int32_t rc = check_common(c, scalars, scalars, n);
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
     if (c->resident_n == 0) return fail(c, MSM_ERR_STATE, "no resident bases: call msm_bn254_g1_upload_bases first");
-    if (n > c->resident_n) n = c->resident_n;  // unequal lengths truncate to the shorter (metal_msm.rs:652-656)
     DeviceGuard g(c->device);
-    Range r_("msm_bn254_g1_resident");
-    auto t0 = std::chrono::steady_clock::now();
-    if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_START], c->stream));
-    if ((rc = ensure(c, c->scalars, n * 32))) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->scalars.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
-    if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_H2D], c->stream));
-    // the phi records sit at index resident_n + i: a call on fewer scalars (truncation) or a set uploaded without them runs unsplit
-    const uint32_t extra = (c->resident_glv && n == c->resident_n) ? 0u : MSM_FLAG_NO_GLV;
-    PipeState ps;
-    rc = run_pipeline(c, (const uint32_t*)c->rbases.p, c->resident_has_inf ? (const uint8_t*)c->rinf.p : nullptr,
-                      (const uint32_t*)c->scalars.p, n, c->stream, out_jac, out_aff, out_inf, 0, nullptr, extra, &ps);
-    if (rc) return rc;
-    c->tm.h2d_ms = stage_ms(c, EV_START, EV_H2D);
-    c->tm.convert_ms = 0;
-    c->tm.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    trace_line(c, "resident", ps);
-    return MSM_OK;
+    return resident_on_lane(c, c, scalars, n, out_jac, out_aff, out_inf);
+}
+
+// `count` MSMs against the resident bases with TWO of them in flight: a second pipeline inside the context (a context of its
+// own: streams, workspace, pinned result buffers; created on first use) is driven by a second host thread.  How provers call MSM
+// (several scalar vectors per proof against fixed bases; SURVEY.md section 8 row f2 "multiple MSMs in flight").  Measured per MSM,
+// single calls -> batch (tools/two_ctx_throughput.py, pinned host scalars): 2^14 0.40 -> 0.24 ms, 2^16 0.45 -> 0.30, 2^17 0.56 -> 0.40,
+// 2^18 0.81 -> 0.63, 2^20 2.28 -> 1.63, 2^22 8.54 -> 5.80 (= the kernel time of one MSM: upload and host finish fully hidden).
+int32_t msm_bn254_g1_resident_batch(msm_ctx* c, const uint32_t* const* scalars, size_t n, size_t count, uint32_t* out_jac,
+                                    uint32_t* out_aff, uint8_t* out_inf) {
+    if (!c) return MSM_ERR_BAD_ARG;
+    if (n == 0 || count == 0) return fail(c, MSM_ERR_EMPTY, "Empty input");
+    if (!scalars || !out_jac) return fail(c, MSM_ERR_BAD_ARG, "NULL scalars / result pointer");
+    for (size_t i = 0; i < count; i++)
+        if (!scalars[i]) return fail(c, MSM_ERR_BAD_ARG, "NULL scalar vector %zu", i);
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->resident_n == 0) return fail(c, MSM_ERR_STATE, "no resident bases: call msm_bn254_g1_upload_bases first");
+    DeviceGuard g(c->device);
+    if (count > 1 && !c->lane1) {
+        msm_config_t cfg = c->cfg;
+        cfg.device = c->device;
+        cfg.max_points = 0;
+        const char* pe = getenv("MSM_HIP_LANE_PRIORITY");  // experiment knob: low (default) | high | normal
+        int32_t rc = ctx_create_impl(&cfg, &c->lane1, pe && !strcmp(pe, "high") ? 2 : pe && !strcmp(pe, "normal") ? 0 : 1);
+        if (rc) return fail(c, rc, "second pipeline: %s", msm_last_error(nullptr));
+        c->batch_pool = new (std::nothrow) HostPool(1);
+        if (!c->batch_pool) return fail(c, MSM_ERR_OOM, "host allocation failed");
+    }
+    std::atomic<size_t> next{0};
+    std::atomic<int32_t> rcs[2] = {{MSM_OK}, {MSM_OK}};
+    auto lane = [&](int k) {
+        msm_ctx* w = k == 0 ? c : c->lane1;
+        DeviceGuard gl(c->device);  // per host thread
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= count || rcs[0] != MSM_OK || rcs[1] != MSM_OK) break;
+            const int32_t rc = resident_on_lane(w, c, scalars[i], n, out_jac + i * 24, out_aff ? out_aff + i * 16 : nullptr,
+                                                out_inf ? out_inf + i : nullptr, count > 1);
+            if (rc) rcs[k] = rc;
+        }
+    };
+    c->last_copy = nullptr;
+    {
+        // from 2^19 points the kernels fill the GPU: one compute stream; below, two (measured crossover 2^18..2^19)
+        const char* be = getenv("MSM_HIP_BATCH_MODE");  // experiment knob: shared | lanes
+        c->batch_shared_stream = be ? !strcmp(be, "shared") : n >= ((size_t)1 << 19);
+    }
+    if (count > 1) c->batch_pool->run(2, lane);
+    else lane(0);
+    if (rcs[0] == MSM_OK && rcs[1] != MSM_OK) c->err = c->lane1->err;
+    return rcs[0] != MSM_OK ? rcs[0] : rcs[1];
 }
 
 int32_t msm_bn254_g1_device(msm_ctx* c, const void* d_bases_mont, const void* d_inf_mask, const void* d_scalars, size_t n,

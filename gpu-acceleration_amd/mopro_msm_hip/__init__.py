@@ -27,7 +27,8 @@ OK, ERR_EMPTY, ERR_BAD_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_STATE, ERR_INVA
 # every symbol include/msm_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "msm_abi_version", "msm_ctx_create", "msm_ctx_destroy", "msm_last_error", "msm_bn254_g1",
-    "msm_bn254_g1_arkworks", "msm_bn254_g1_upload_bases", "msm_bn254_g1_resident", "msm_bn254_g1_device", "msm_bn254_g1_combine",
+    "msm_bn254_g1_arkworks", "msm_bn254_g1_upload_bases", "msm_bn254_g1_resident", "msm_bn254_g1_resident_batch", "msm_bn254_g1_device",
+    "msm_bn254_g1_combine",
     "msm_plan", "msm_get_timings", "msm_set_stage_timing", "msm_get_accumulate_kernel_stats", "msm_reset_kernel_stats",
     "msm_bn254_g1_decompress", "msm_bn254_g1_upload_compressed", "msm_bn254_g1_compress",
     "msm_multi_create", "msm_multi_destroy", "msm_multi_last_error", "msm_multi_num_devices", "msm_multi_exchange",
@@ -95,6 +96,7 @@ def bind_product_abi(L):
     L.msm_bn254_g1_arkworks.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _u32p, C.c_size_t, _u32p, _u32p, _u8p]
     L.msm_bn254_g1_upload_bases.argtypes = [vp, _u32p, C.c_uint32, _u8p, C.c_size_t]
     L.msm_bn254_g1_resident.argtypes = [vp, _u32p, C.c_size_t, _u32p, _u32p, _u8p]
+    L.msm_bn254_g1_resident_batch.argtypes = [vp, C.POINTER(_u32p), C.c_size_t, C.c_size_t, _u32p, _u32p, _u8p]
     L.msm_bn254_g1_device.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, _u32p, _u32p, _u8p]
     L.msm_bn254_g1_combine.argtypes = [_u32p, C.c_size_t, _u32p, _u32p, _u8p]
     L.msm_plan.argtypes = [C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(Plan)]
@@ -325,6 +327,20 @@ class MsmContext:
         self._check(self._lib.msm_bn254_g1_resident(self._h, _p32(scalars), scalars.shape[0], _p32(jac), _p32(aff),
                                                     C.byref(oi)))
         return MsmResult(jac, aff, oi.value)
+
+    def msm_resident_batch(self, scalar_vectors, want_affine=True):
+        """several scalar vectors against the resident bases, two MSMs in flight (how provers call MSM): list of MsmResult"""
+        vecs = [_words(s, 8) for s in scalar_vectors]
+        if not vecs or any(v.shape[0] == 0 for v in vecs):
+            raise MsmError(ERR_EMPTY, "Empty input")
+        n = min(v.shape[0] for v in vecs)
+        k = len(vecs)
+        ptrs = (_u32p * k)(*[_p32(v) for v in vecs])
+        jac = np.zeros((k, 24), np.uint32)
+        aff = np.zeros((k, 16), np.uint32) if want_affine else None
+        inf = np.zeros(k, np.uint8)
+        self._check(self._lib.msm_bn254_g1_resident_batch(self._h, ptrs, n, k, _p32(jac), _p32(aff), inf.ctypes.data_as(_u8p)))
+        return [MsmResult(jac[i], aff[i] if want_affine else None, inf[i]) for i in range(k)]
 
     def msm_device(self, d_bases_ptr, d_scalars_ptr, n, d_inf_ptr=None, stream=None):
         """All operands already in HBM (raw device pointers, e.g. torch.Tensor.data_ptr())."""

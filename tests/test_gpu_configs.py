@@ -7,6 +7,7 @@ pipeline, by size-independent properties (closed form (sum s_i k_i mod r) * G on
                                                                             test_automatic_streaming_* (host->HBM chunks)
   N > 1     two ranks on ONE GPU through torch.distributed (gloo)           test_two_ranks_on_one_gpu
             two/three shards in ONE process through msm_multi              test_multi_*
+  f2        msm_bn254_g1_resident_batch, two MSMs in flight                test_resident_batch_two_in_flight
   f1        msm_bn254_g1_arkworks at 2^20 with the (72, 0, 32, 64) layout  test_arkworks_entry_at_2_pow_20
 Mirrors the reference's e2e test shape (tests/cuzk/e2e.rs:14-63: random instance, compare with the CPU result)."""
 import json
@@ -231,6 +232,50 @@ def test_resident_set_survives_other_calls(ctx, inst20):
     assert (ctx.msm_resident(s).affine_std == exp).all()
     e2, _ = orc.closed_form_expected(k[:5000], s[:5000])
     assert (ctx.msm_resident(s[:5000]).affine_std == e2).all()
+
+
+def test_resident_batch_two_in_flight(ctx, inst20):
+    """msm_bn254_g1_resident_batch: several scalar vectors against the resident bases with two MSMs in flight (second pipeline
+    inside the context).  Every result equals the single-call result and the closed form; sizes on both sides of the GLV bound,
+    a truncated batch (shorter scalar vectors), a batch of one, edge scalar vectors (zeros, all r-1), and single calls after."""
+    for logn, count in ((16, 7), (20, 4)):
+        n = 1 << logn
+        if logn == 16:
+            k = orc.gen_scalars(0xB2540091, n, nonzero=True)
+            ctx.upload_bases(orc.gen_bases_from_logs(k, orc.FORM_MONT), mh.FORM_MONT)
+        else:  # the 2^20 bases made on the GPU
+            ctx.upload_bases(inst20.d_b.cpu().numpy().view(np.uint32).reshape(n, 16), mh.FORM_MONT)
+        vecs = [th.generate_scalars_host(0xB25400A0 + 16 * logn + j, n) for j in range(count)]
+        vecs[1] = np.zeros_like(vecs[1])
+        vecs[2] = np.tile(orc.int_to_words(R - 1), (n, 1)).astype(np.uint32)
+        res = ctx.msm_resident_batch(vecs)
+        assert len(res) == count and res[1].is_infinity
+        for j, (v, r) in enumerate(zip(vecs, res)):
+            one = ctx.msm_resident(v)
+            assert r.is_infinity == one.is_infinity and (r.affine_std == one.affine_std).all(), (logn, j)
+            if logn == 16 and not r.is_infinity:
+                exp, _ = orc.closed_form_expected(k, v)
+                assert (r.affine_std == exp).all(), (logn, j)
+        m = n - 4321  # shorter scalar vectors: truncation, the phi records are not used
+        short = ctx.msm_resident_batch([v[:m] for v in vecs[:3]])
+        for v, r in zip(vecs[:3], short):
+            one = ctx.msm_resident(v[:m])
+            assert r.is_infinity == one.is_infinity and (r.affine_std == one.affine_std).all()
+        assert (ctx.msm_resident_batch([vecs[0]])[0].affine_std == res[0].affine_std).all()
+    bad = vecs[3].copy()
+    bad[777, 7] = 0xFFFFFFFF  # not a canonical Fr element: the batch stops with the error of that MSM, the context stays usable
+    with pytest.raises(mh.MsmError) as e:
+        ctx.msm_resident_batch([vecs[0], vecs[3], bad, vecs[0], vecs[3]])
+    assert e.value.code == mh.ERR_BAD_ARG
+    again = ctx.msm_resident_batch([vecs[0], vecs[3]])
+    assert (again[0].affine_std == res[0].affine_std).all() and (again[1].affine_std == res[3].affine_std).all()
+    with pytest.raises(mh.MsmError):
+        ctx.msm_resident_batch([])
+    c2 = mh.MsmContext()
+    with pytest.raises(mh.MsmError) as e:
+        c2.msm_resident_batch([vecs[0][:16]])
+    assert e.value.code == mh.ERR_STATE
+    c2.close()
 
 
 # ---- N > 1 -------------------------------------------------------------------------------------------------------------------
