@@ -883,6 +883,8 @@ static int32_t ctx_create_impl(const msm_config_t* cfg, msm_ctx** out, int main_
         // one queue, the barrier packets of their cross-stream event waits executed in queue order and every chunk upload waited
         // for the PREVIOUS chunk's kernels (rocprofv3 kernel trace: one Queue_Id, profiles/NOTES_r2.md).  A stream of another
         // priority comes from another pool.
+        const char* cpe = getenv("MSM_HIP_COPY_PRIORITY");  // experiment knob: 0 = a plain stream
+        if (cpe && cpe[0] == '0') least = greatest;
         e = least != greatest ? hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, greatest)
                               : hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
     }
