@@ -596,8 +596,33 @@ int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, 
                      hipStream_t st, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf, uint32_t scalars_mont = 0,
                      hipEvent_t bases_ready = nullptr, uint32_t extra_flags = 0, PipeState* ps_out = nullptr) {
     PipeState ps;
-    int32_t rc = pipe_prepare(c, n, 0, extra_flags, st, &ps);
-    if (rc) return rc;
+    int32_t rc;
+    // From 2^23 points a (window, coarse bin) region of the sort outgrows the fine sort's LDS staging (10 coarse bits at most) and
+    // the regions take the oversized-region path: sort 2.5 ms at 2^24 where four sorts of 2^22 take 1.5.  Such an instance is
+    // cut into point ranges of 2^22 that accumulate INTO the shared bucket array, like the chunks of a streamed host call:
+    // 2^23 11.42 -> 11.0-11.1 ms, 2^24 22.76 -> 21.90 (tools/device_chunk_ab.py; every further cut costs ~0.1 ms: 2^22 in ranges of
+    // 2^20 loses 0.5 ms, so smaller instances stay whole).
+    static const uint32_t dev_chunk_log2 = [] {
+        const char* e = getenv("MSM_HIP_DEVICE_CHUNK_LOG2");  // experiment knob; 0 = never cut
+        return e ? (uint32_t)atoi(e) : 22u;
+    }();
+    const size_t dchunk = dev_chunk_log2 ? (size_t)1 << dev_chunk_log2 : 0;
+    if (dchunk && n >= 2 * dchunk && !plan_glv(c, n, extra_flags)) {
+        if ((rc = pipe_prepare(c, dchunk, n, extra_flags, st, &ps))) return rc;
+        uint32_t nch = 0;
+        for (size_t lo = 0; lo < n; lo += dchunk, nch++) {
+            const size_t cnt = std::min(dchunk, n - lo);
+            if ((rc = pipe_prepare(c, cnt, n, extra_flags, st, &ps))) return rc;
+            if ((rc = enqueue_sort(c, ps, d_inf ? d_inf + lo : nullptr, d_scalars + lo * 8, scalars_mont, st, lo == 0))) return rc;
+            if ((rc = enqueue_accumulate(c, ps, d_bases + lo * 16, st, lo == 0 ? bases_ready : nullptr, lo > 0, true))) return rc;
+        }
+        if ((rc = enqueue_reduce(c, ps, st, c->h_qsums, c->h_flags))) return rc;
+        if (ps_out) *ps_out = ps;
+        if ((rc = finish_sync(c, ps, n, st, out_jac, out_aff, out_inf))) return rc;
+        c->tm.stream_chunks = nch;
+        return MSM_OK;
+    }
+    if ((rc = pipe_prepare(c, n, 0, extra_flags, st, &ps))) return rc;
     if ((rc = enqueue_sort(c, ps, d_inf, d_scalars, scalars_mont, st, true))) return rc;
     if ((rc = enqueue_accumulate(c, ps, d_bases, st, bases_ready, false))) return rc;
     if ((rc = enqueue_reduce(c, ps, st, c->h_qsums, c->h_flags))) return rc;

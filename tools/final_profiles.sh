@@ -8,9 +8,9 @@ R="$GRAFT_REPO_ROOT"
 O="$R/gpurun_out/final"
 rm -rf "$O"; mkdir -p "$O"
 cd "$R"
-python3 bench.py --steps 20 --warmup 3 > $O/bench_line.json 2> $O/bench.err; echo "bench rc $?"
+python3 bench.py > $O/bench_line.json 2> $O/bench.err; echo "bench rc $?"
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o p -- python3 $R/bench.py --steps 20 --warmup 3 > $O/bench_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o p -- python3 $R/bench.py > $O/bench_under_rocprof.json 2>/dev/null
 cp $O/stats/p_kernel_stats.csv $O/kernel_stats.csv
 cd "$R"
 python3 tools/sweep.py 10 12 14 16 17 18 19 20 21 22 23 24 > $O/sweep.txt 2>&1

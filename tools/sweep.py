@@ -3,7 +3,7 @@
 import json, subprocess, sys
 sizes = [int(x) for x in (sys.argv[1:] or "10 12 14 16 18 20 22 23 24".split())]
 for n in sizes:
-    p = subprocess.run([sys.executable, "bench.py", "--log-n", str(n), "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-host-legs"],
+    p = subprocess.run([sys.executable, "bench.py", "--log-n", str(n), "--steps", "30", "--warmup", "5", "--no-cpu-baseline", "--no-host-legs"],
                        capture_output=True, text=True)
     try:
         j = json.loads(p.stdout.strip().splitlines()[-1])
