@@ -7,7 +7,7 @@ cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/pmc_acc
 mkdir -p $O
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/bench_$c -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-legs > $O/bench_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/bench_$c -- python3 bench.py --steps 3 --warmup 1 --pre-warm-ms 0 --no-cpu-baseline --no-host-legs > $O/bench_$c.log 2>&1
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/calib_$c -- ./tools/calib_gather > $O/calib_$c.log 2>&1
 done
 python3 tools/pmc_summarize.py $O

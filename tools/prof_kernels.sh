@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 for n in "$@"; do
   out=$GRAFT_REPO_ROOT/gpurun_out/prof$n
   rm -rf $out; mkdir -p $out
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out -o p -- python3 $GRAFT_REPO_ROOT/bench.py --log-n $n --steps 20 --warmup 3 --no-cpu-baseline --no-host-legs > $out/bench.json 2>/dev/null
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out -o p -- python3 $GRAFT_REPO_ROOT/bench.py --log-n $n --no-cpu-baseline --no-host-legs > $out/bench.json 2>/dev/null
   echo "== N=2^$n: $(python3 -c "import json,sys; j=json.loads(open('$out/bench.json').read().strip().splitlines()[-1]); print(j['value'],'ms exact',j['bit_exact'])")"
   python3 $GRAFT_REPO_ROOT/tools/kstats.py $out | grep -v "^#" | head -${TOPK:-14}
 done
