@@ -62,33 +62,56 @@ FP_HD xyzz xyzz_dbl(const xyzz& p) {
     return xyzz{x3, y3, fp_mul(v, p.zz), fp_mul(w, p.zzz)};
 }
 
-// acc += (x2,y2)   madd-2008-s, 8M+2S, complete.
-FP_HD void xyzz_madd(xyzz& acc, const affine& q) {
+// acc += (x2,y2) with every intermediate normalised: what xyzz_madd below is checked against (tools/fp_bounds_check.cpp)
+FP_HD void xyzz_madd_plain(xyzz& acc, const affine& q) {
     if (xyzz_is_identity(acc)) {
         acc = xyzz_from_affine(q);
         return;
     }
+    fp u2 = fp_mul(q.x, acc.zz), s2 = fp_mul(q.y, acc.zzz);
+    fp pp_ = fp_sub<8>(u2, acc.x), r = fp_sub<6>(s2, acc.y), pp = fp_sqr(pp_);
+    if (fp_is_zero_lt2p(pp)) {
+        if (fp_is_zero_lt2p(fp_sqr(r))) acc = xyzz_dbl_affine(q);
+        else acc = xyzz_identity();
+        return;
+    }
+    fp ppp = fp_mul(pp_, pp), qv = fp_mul(acc.x, pp);
+    fp x3 = fp_sub<5>(fp_sqr(r), fp_add(ppp, fp_dbl(qv)));
+    fp y3 = fp_mul_add(r, fp_sub<8>(qv, x3), fp_neg<6>(acc.y), ppp);
+    acc = xyzz{x3, y3, fp_mul(acc.zz, pp), fp_mul(acc.zzz, ppp)};
+}
+
+// acc += (x2,y2)   madd-2008-s, 8M+2S, complete.  q.y may be RAW (fp_neg_raw<2>: the sign of a digit is applied without a carry
+// ripple); three more ripples are saved inside: X3 takes one (fp_sub_b_2c) instead of three, and the two subtractions that only
+// feed Y3's fused multiply-add stay raw.  120 of the ~2250 instructions of a mixed addition.
+FP_HD void xyzz_madd(xyzz& acc, const affine& q) {
+#ifdef FP_PLAIN_MADD  // A/B switch (tools/build_ab.sh)
+    xyzz_madd_plain(acc, affine{q.x, fp_normalize(q.y)});
+    return;
+#endif
+    if (xyzz_is_identity(acc)) {
+        acc = xyzz{q.x, fp_normalize(q.y), fp_one(), fp_one()};
+        return;
+    }
     fp u2 = fp_mul(q.x, acc.zz);       // < 1.02
-    fp s2 = fp_mul(q.y, acc.zzz);      // < 1.03
+    fp s2 = fp_mul(q.y, acc.zzz);      // q.y raw, value < 2: < 1.03
     fp pp_ = fp_sub<8>(u2, acc.x);     // P: acc.x < 7;  P < 9.02
     fp r = fp_sub<6>(s2, acc.y);       // R: acc.y < 5;  R < 7.03
     fp pp = fp_sqr(pp_);               // < 1.49
     if (fp_is_zero_lt2p(pp)) {         // P == 0 (mod p): same x
-        if (fp_is_zero_lt2p(fp_sqr(r))) acc = xyzz_dbl_affine(q);  // same point
-        else acc = xyzz_identity();                                // opposite points
+        if (fp_is_zero_lt2p(fp_sqr(r))) acc = xyzz_dbl_affine(affine{q.x, fp_normalize(q.y)});  // same point
+        else acc = xyzz_identity();                                                             // opposite points
         return;
     }
     fp ppp = fp_mul(pp_, pp);          // < 1.08
     fp qv = fp_mul(acc.x, pp);         // < 1.07
-    fp t = fp_add(ppp, fp_dbl(qv));    // < 3.22
-    fp x3 = fp_sub<5>(fp_sqr(r), t);   // r^2 < 1.3;  x3 < 6.3
-    fp y3 = fp_mul_add(r, fp_sub<8>(qv, x3), fp_neg<6>(acc.y), ppp);  // r*(qv - x3) + (6p - y)*ppp: (7.03*9.07 + 6*1.08)k + 1 < 1.42
+    fp x3 = fp_sub_b_2c(fp_sqr(r), ppp, qv);  // r^2 < 1.3, ppp + 2 qv < 3.22;  x3 < 6.3
+    fp y3 = fp_mul_add(r, fp_sub_raw<8>(qv, x3), fp_neg_raw<6>(acc.y), ppp);  // r*(qv - x3) + (6p - y)*ppp: (7.03*9.07 + 6*1.08)k + 1 < 1.42
     acc.x = x3;
     acc.y = y3;
     acc.zz = fp_mul(acc.zz, pp);       // < 1.02
     acc.zzz = fp_mul(acc.zzz, ppp);    // < 1.02
 }
-
 // a + b, add-2008-s, 12M+2S, complete.
 FP_HD xyzz xyzz_add(const xyzz& a, const xyzz& b) {
     if (xyzz_is_identity(a)) return b;

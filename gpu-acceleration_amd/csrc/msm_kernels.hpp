@@ -1044,7 +1044,7 @@ __global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__
             q.x = fp_unpack(wx);
             q.y = fp_unpack(wy);
         }
-        if (e_cur & SIGN_BIT) q.y = fp_neg<2>(q.y);
+        if (e_cur & SIGN_BIT) q.y = fp_neg_raw<2>(q.y);  // raw: only ever a multiplier in xyzz_madd
         uint32_t e_nn = 0;
         if (j + 1 < j1) {
             const uint4* bp = reinterpret_cast<const uint4*>(bases + (size_t)(e_nxt & ~SIGN_BIT) * 16);

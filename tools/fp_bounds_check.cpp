@@ -73,8 +73,17 @@ int main() {
             rand_words(wx, s % 31 == 0 ? 1 : s % 37 == 0 ? 2 : 0);
             rand_words(wy, s % 29 == 0 ? 1 : 0);
             affine p2{fp_from_mont256(wx), fp_from_mont256(wy)};
-            if (rng() & 1) p2.y = fp_neg<2>(p2.y);
-            xyzz_madd(acc, p2);
+            const bool ng = rng() & 1;
+            affine p2n = p2, p2r = p2;
+            if (ng) p2n.y = fp_neg<2>(p2.y), p2r.y = fp_neg_raw<2>(p2.y);
+            p2 = p2n;
+            {   // the lazily normalised mixed addition (raw negated y) against the fully normalised one
+                xyzz a1 = acc, a2 = acc;
+                xyzz_madd(a1, p2r);
+                xyzz_madd_plain(a2, p2n);
+                if (!same_xyzz(a1, a2) || xyzz_is_identity(a1) != xyzz_is_identity(a2)) { printf("madd: lazy and plain differ (chain %d step %d)\n", chain, s); return 1; }
+            }
+            xyzz_madd(acc, p2r);
             if (s % 5 == 0) { xyzz_madd(other, p2); other = xyzz_add(other, acc); }
             if (s % 7 == 0) acc = xyzz_dbl(acc);
             if (s % 97 == 0) acc = xyzz_add(acc, acc);  // takes the doubling branch
@@ -97,8 +106,13 @@ int main() {
         affine q{fp_from_mont256(w[4]), fp_from_mont256(w[5])};
         affine qi{q.x, add_kp(q.y, 1)};
         xyzz r1 = a, r2 = ai;
-        xyzz_madd(r1, q);
-        xyzz_madd(r2, qi);
+        if (it & 1) {  // negated y: normalised on the reduced operands, RAW (no carry ripple) on the inflated ones
+            xyzz_madd(r1, affine{q.x, fp_neg<2>(q.y)});
+            xyzz_madd(r2, affine{q.x, fp_neg_raw<2>(q.y)});
+        } else {
+            xyzz_madd(r1, q);
+            xyzz_madd(r2, qi);
+        }
         if (!same_xyzz(r1, r2)) { printf("madd: inflated operands change the residues (it=%d)\n", it); return 1; }
         if (!same_xyzz(xyzz_dbl(a), xyzz_dbl(ai))) { printf("dbl: inflated operands change the residues\n"); return 1; }
         xyzz b{fp_from_mont256(w[4]), fp_from_mont256(w[5]), fp_from_mont256(w[1]), fp_from_mont256(w[0])};
