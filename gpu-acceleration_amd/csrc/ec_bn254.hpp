@@ -129,9 +129,8 @@ FP_HD xyzz xyzz_add(const xyzz& a, const xyzz& b) {
     }
     fp ppp = fp_mul(pp_, pp);          // < 1.03
     fp qv = fp_mul(u1, pp);            // < 1.01
-    fp t = fp_add(ppp, fp_dbl(qv));    // < 3.05
-    fp x3 = fp_sub<5>(fp_sqr(r), t);   // r^2 < 1.1;  x3 < 6.1
-    fp y3 = fp_mul_add(r, fp_sub<8>(qv, x3), fp_neg<3>(s1), ppp);  // r*(qv - x3) + (3p - s1)*ppp: (4.06*9.01 + 3*1.03)k + 1 < 1.24
+    fp x3 = fp_sub_b_2c(fp_sqr(r), ppp, qv);  // r^2 < 1.1, ppp + 2 qv < 3.05;  x3 < 6.1   (one carry ripple, see xyzz_madd)
+    fp y3 = fp_mul_add(r, fp_sub_raw<8>(qv, x3), fp_neg_raw<3>(s1), ppp);  // r*(qv - x3) + (3p - s1)*ppp: (4.06*9.01 + 3*1.03)k + 1 < 1.24
     fp zz3 = fp_mul(fp_mul(a.zz, b.zz), pp);
     fp zzz3 = fp_mul(fp_mul(a.zzz, b.zzz), ppp);
     return xyzz{x3, y3, zz3, zzz3};

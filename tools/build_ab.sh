@@ -4,7 +4,7 @@
 cd "$GRAFT_REPO_ROOT"
 FLAGS="$1"; shift
 SIZES="${*:-17 20 20 22}"
-line() { python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', 'logN', '$2', 'ms', d['value'], 'acc', d['roofline']['avg_kernel_ms'], 'fp_mul peak', d['roofline_valu']['peak'], 'exact', d['bit_exact'])"; }
+line() { python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', 'logN', '$2', 'ms', d['value'], 'acc', d['roofline']['avg_kernel_ms'], 'fp_mul peak', d['roofline_valu']['peak'], 'finish', d['stage_ms_untimed_diagnostic_step'].get('finish_ms'), 'reduce', d['stage_ms_untimed_diagnostic_step'].get('reduce_ms'), 'exact', d['bit_exact'])"; }
 run() { for n in $SIZES; do python3 bench.py --log-n $n --no-cpu-baseline --no-host-legs 2>/dev/null | line "$1" $n; done; }
 run "as built      "
 cp gpu-acceleration_amd/libmsm_hip.so /tmp/a.so; cp gpu-acceleration_amd/libmsm_hip_hooks.so /tmp/a_hooks.so
