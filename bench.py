@@ -218,8 +218,13 @@ def main():
     elapsed = time.perf_counter() - t0
     if ctx is not None:
         acc_avg_ms, acc_launches = ctx.accumulate_kernel_stats()
+        # instances cut into point ranges (device inputs from 2^23 points, streamed host inputs) launch k_accumulate once per range:
+        # the roofline prices the MSM's accumulation = all of a step's launches together, against the whole instance's bytes
+        # (the context's statistic holds the LAST range's launch of every call; the ranges are equal: 2^22 points each)
+        launches_per_step = 1 if args.streamed else max(1, int(ctx.timings().get("stream_chunks", 0)))
+        acc_avg_ms *= launches_per_step
     else:
-        acc_avg_ms, acc_launches = multi.timings(0)["accumulate_ms"], 1
+        acc_avg_ms, acc_launches, launches_per_step = multi.timings(0)["accumulate_ms"], 1, 1
     mad_peak, fpmul_peak = (0.0, 0.0)
     if rank == 0:  # two ~1 ms micro-kernels, outside the timed region
         with th.HooksContext(device=devs[my_shards[0]].index) as cal:
@@ -312,7 +317,7 @@ def main():
             "bit_exact": bit_exact,
             "roofline": {"bound": "hbm", "kernel": "k_accumulate", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_ms": round(acc_avg_ms, 4),
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_ms": round(acc_avg_ms, 4), "launches_per_step": launches_per_step,
                          "launches_timed": int(acc_launches),
                          "note": "integer-multiply (VALU) bound kernel; HBM fraction reported because BASELINE.json asks for it; "
                                  "the multiplier roofline is in roofline_valu"},

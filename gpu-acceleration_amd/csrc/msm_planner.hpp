@@ -44,7 +44,10 @@ inline uint32_t plan_window_bits_glv(size_t n, bool is_signed) {
     // measured (tools/sweep_c.py, split on): 2^10 c = 9/10 0.247/0.249 ms; 2^12 10/11 0.286/0.281; 2^13 10 0.308 (16: 0.364);
     // 2^14 10 0.330 (16: 0.440); 2^15 12 0.365 (16: 0.435); 2^16 16 0.420 (13: 0.439); 2^17 16 0.504 (13: 0.541); 2^18 16 0.671
     // (15: 1.06); 2^20 16 1.681.  127 = 7*16 + 15: eight windows, the top one 15 bits wide -- no degenerate window.
-    uint32_t c = n <= ((size_t)1 << 14) ? 10u : n <= ((size_t)1 << 15) ? 12u : 16u;
+    // Re-measured after k_accumulate lost 11 % of its instructions (round 2, tools/sweep_c.py, ramped-up clock, ms): 2^13 c = 10 0.337,
+    // 13 0.327, 16 0.331; 2^14 10 0.362-0.369, 13 0.363, 16 0.331; 2^15 12 0.406-0.409, 15 0.390, 16 0.336-0.346; 2^16 16 0.378-0.382
+    // (15: 0.446); 2^17 16 0.451 (13: 0.552); 2^18 16 0.613 (13: 0.760); 2^19 16 0.937 (13: 1.201)  => 16 from 2^14 points on.
+    uint32_t c = n < ((size_t)1 << 14) ? 10u : 16u;
     if (!is_signed && c > 15u) c = 15u;
     return c;
 }

@@ -4,10 +4,10 @@ import json, os, subprocess, sys
 sizes = [int(x) for x in (sys.argv[1:] or "10 12 14 15 16".split())]
 for n in sizes:
     row = []
-    for c in (0, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16):
+    for c in [int(x) for x in (os.environ.get("CS") or "0,7,8,9,10,11,12,13,14,15,16").split(",")]:
         if c and (1 << (c - 1)) > (1 << n) * 4:
             continue
-        p = subprocess.run([sys.executable, "bench.py", "--log-n", str(n), "--steps", "30", "--warmup", "3", "--no-cpu-baseline",
+        p = subprocess.run([sys.executable, "bench.py", "--log-n", str(n), "--steps", "60", "--warmup", "5", "--no-cpu-baseline", "--no-host-legs",
                             "--window-bits", str(c)], capture_output=True, text=True)
         try:
             j = json.loads(p.stdout.strip().splitlines()[-1])
