@@ -256,7 +256,9 @@ int32_t pipe_prepare(msm_ctx* c, size_t n_real, size_t plan_n, uint32_t extra_fl
     // 2^16 0.403 vs 0.425 ms, 2^17 0.490 vs 0.509; from 2^22 entries on 16 wins because the buckets cut three and more times
     // cost k_combine more than the finer granularity saves in k_accumulate)
     // -- only where buckets are short, though: 2^14 points on c = 10 windows (64 entries per bucket) turn every bucket into a long one)
-    uint32_t chunk_len = (pairs <= ((size_t)1 << 17) || (pairs <= ((size_t)1 << 21) && n / nb <= 8)) ? 8 : 16;
+    // (round 2, after the planner moved 2^14 and 2^15 points to c = 16: one or two entries per bucket there, and L = 4 fills
+    // twice the lanes: 2^14 0.329 -> 0.307 ms, 2^15 0.347 -> 0.341)
+    uint32_t chunk_len = (pairs <= ((size_t)1 << 17) || (pairs <= ((size_t)1 << 21) && n / nb <= 8)) ? (n / nb <= 2 && pairs > ((size_t)1 << 17) ? 4 : 8) : 16;
     // ... and from there the chunk follows the mean bucket occupancy n/nb (32 at 2^20 unsplit, 64 with the GLV split: measured
     // 1.728 ms at L = 32 against 1.698 at 64), as long as ~2^17 chunks remain to fill the chip
     while (chunk_len < 1024 && chunk_len < n / nb && pairs / (chunk_len * 2) >= 131072) chunk_len *= 2;

@@ -5,7 +5,8 @@ for n in [int(x) for x in (sys.argv[1:] or "16 17 18 19 20 21 22".split())]:
     res = {"glv": [], "plain": []}
     for rnd in range(3):
         for name, extra in (("glv", []), ("plain", ["--no-glv"])):
-            p = subprocess.run([sys.executable, "bench.py", "--log-n", str(n), "--steps", "20", "--warmup", "3", "--no-cpu-baseline"] + extra,
+            p = subprocess.run([sys.executable, "bench.py", "--log-n", str(n), "--steps", "40", "--warmup", "5", "--no-cpu-baseline", "--no-host-legs"] + extra,
+                               env=dict(os.environ, MSM_HIP_GLV_MAX_LOG2="23"),
                                capture_output=True, text=True)
             j = json.loads(p.stdout.strip().splitlines()[-1])
             assert j["bit_exact"]
