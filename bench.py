@@ -225,6 +225,13 @@ def main():
         acc_avg_ms *= launches_per_step
     else:
         acc_avg_ms, acc_launches, launches_per_step = multi.timings(0)["accumulate_ms"], 1, 1
+    # what a caller sees who does NOT keep the GPU busy: one step after 0.2 s without work (the clock has dropped)
+    after_idle_ms = None
+    if world == 1 and not in_proc:
+        time.sleep(0.2)
+        t_i = time.perf_counter()
+        step()
+        after_idle_ms = (time.perf_counter() - t_i) * 1e3
     mad_peak, fpmul_peak = (0.0, 0.0)
     if rank == 0:  # two ~1 ms micro-kernels, outside the timed region
         with th.HooksContext(device=devs[my_shards[0]].index) as cal:
@@ -301,6 +308,7 @@ def main():
         out = {
             "metric": "BN254 G1 MSM latency (ms) at N=2^%d, bit-exact vs arkworks-equivalent oracle" % args.log_n,
             "value": round(ms_per_step, 4), "unit": "ms", "n_gpus": nshards, "steps": args.steps, "warmup": args.warmup, "pre_warm_steps": pre_warm_steps,
+            "step_after_0.2s_idle_ms": round(after_idle_ms, 4) if after_idle_ms is not None else None,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": "BN254 G1 variable-base MSM, N=2^%d, dynamic window + signed-digit buckets "
