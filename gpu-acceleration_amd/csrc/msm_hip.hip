@@ -1184,7 +1184,11 @@ static int32_t resident_on_lane(msm_ctx* w, const msm_ctx* owner, const uint32_t
         //     own stream and the kernels overlap.
         msm_ctx* o = const_cast<msm_ctx*>(owner);
         const bool shared = o->batch_shared_stream;
-        hipStream_t cs = shared ? w->copy_stream : w->stream, st = shared ? o->stream : w->stream;
+        // (shared: BOTH pipelines upload through the owner's copy stream.  Uploads queued on the second pipeline's own copy stream
+        // slowed the kernels running beside them 1.4-4.6x -- k_coarse_scatter 33 -> 47 us, k_fine_sort 42 -> 85, k_chunk_map 18 -> 84 --
+        // while the owner's did not: 1.61-1.62 -> 1.51-1.58 ms per MSM at 2^20, NOTES_r2.md section 7)
+        const char* cse = getenv("MSM_HIP_BATCH_COPY");  // A/B knob (per call): 0 = each pipeline's own copy stream
+        hipStream_t cs = shared ? (cse && cse[0] == '0' ? w->copy_stream : o->copy_stream) : w->stream, st = shared ? o->stream : w->stream;
         {
             std::lock_guard<std::mutex> cp(o->copy_mu);
             if (o->last_copy && o->last_copy != w->ev_fork) HIPCHK(w, hipStreamWaitEvent(cs, o->last_copy, 0));
