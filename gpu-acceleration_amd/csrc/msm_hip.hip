@@ -94,8 +94,57 @@ bool trace_enabled() {
 
 }  // namespace
 
+// Every MSM_HIP_* tuning / A-B switch, read ONCE when a context is created (INTEGRATION.md lists them): a call never looks at the
+// environment, so an upload and the resident calls after it, or the two pipelines of a batch, cannot see different plans.
+// (MSM_HIP_TRACE / MSM_HIP_ROCTX are per process; MSM_HIP_DEVICES / MSM_HIP_MULTI_VERIFY belong to msm_multi_create.)
+struct Knobs {
+    size_t glv_max = msmplan::GLV_MAX_POINTS;  // MSM_HIP_GLV_MAX_LOG2
+    uint32_t chunk_len = 0;                    // MSM_HIP_CHUNK_LEN: entries per k_accumulate thread; 0 = by size
+    bool direct_scatter = false;               // MSM_HIP_DIRECT_SCATTER: skip the two-level LDS sort
+    uint32_t device_chunk_log2 = 22;           // MSM_HIP_DEVICE_CHUNK_LOG2: point ranges of device-resident instances; 0 = never cut
+    uint32_t stream_min_log2 = 19;             // MSM_HIP_STREAM_MIN_LOG2: host calls are streamed from this size on
+    uint32_t stream_chunk_log2 = 0;            // MSM_HIP_STREAM_CHUNK_LOG2: 0 = by size
+    bool copy_priority = true;                 // MSM_HIP_COPY_PRIORITY=0: the copy stream is a plain stream
+    int host_threads = -1;                     // MSM_HIP_HOST_THREADS: CPU finish threads incl. the caller; -1 = default (2)
+    size_t wide_max = 40960;                   // MSM_HIP_WIDE_MAX: pairwise levels up to this many additions use 8 lanes per addition; 0 = never
+    bool reduce_v1 = false;                    // MSM_HIP_REDUCE_V1: one launch per pairwise level (round 1)
+    int batch_copy_own = 0;                    // MSM_HIP_BATCH_COPY=0: each batch pipeline uploads on its own copy stream
+    int lane_priority = 1;                     // MSM_HIP_LANE_PRIORITY: low (1, default) | high (2) | normal (0)
+    int batch_mode = -1;                       // MSM_HIP_BATCH_MODE: shared (1) | lanes (0); -1 = by size
+    static Knobs from_env() {
+        Knobs k;
+        auto num = [](const char* name, long lo, long hi, long dflt) {
+            const char* e = std::getenv(name);
+            if (!e || !*e) return dflt;
+            return std::max(lo, std::min(hi, std::atol(e)));
+        };
+        auto on = [](const char* name) {
+            const char* e = std::getenv(name);
+            return e && *e && *e != '0';
+        };
+        k.glv_max = msmplan::glv_max_from_env();
+        {
+            const long v = num("MSM_HIP_CHUNK_LEN", 0, 1 << 30, 0);
+            k.chunk_len = v >= 1 && v <= 4096 ? (uint32_t)v : 0u;
+        }
+        k.direct_scatter = std::getenv("MSM_HIP_DIRECT_SCATTER") != nullptr;
+        k.device_chunk_log2 = (uint32_t)num("MSM_HIP_DEVICE_CHUNK_LOG2", 0, 30, 22);
+        k.stream_min_log2 = (uint32_t)num("MSM_HIP_STREAM_MIN_LOG2", 9, 31, 19);
+        k.stream_chunk_log2 = std::getenv("MSM_HIP_STREAM_CHUNK_LOG2") ? (uint32_t)num("MSM_HIP_STREAM_CHUNK_LOG2", 8, 28, 0) : 0u;
+        if (const char* e = std::getenv("MSM_HIP_COPY_PRIORITY")) k.copy_priority = e[0] != '0';
+        if (std::getenv("MSM_HIP_HOST_THREADS")) k.host_threads = (int)num("MSM_HIP_HOST_THREADS", 0, 64, 2);
+        k.wide_max = (size_t)num("MSM_HIP_WIDE_MAX", 0, 1 << 30, 40960);
+        k.reduce_v1 = on("MSM_HIP_REDUCE_V1");
+        if (const char* e = std::getenv("MSM_HIP_BATCH_COPY")) k.batch_copy_own = e[0] == '0';
+        if (const char* e = std::getenv("MSM_HIP_LANE_PRIORITY")) k.lane_priority = !strcmp(e, "high") ? 2 : !strcmp(e, "normal") ? 0 : 1;
+        if (const char* e = std::getenv("MSM_HIP_BATCH_MODE")) k.batch_mode = !strcmp(e, "shared") ? 1 : 0;
+        return k;
+    }
+};
+
 struct msm_ctx {
     std::mutex mu;
+    Knobs knobs;
     HostPool* pool = nullptr;        // CPU finish: the caller + one worker
     int device = 0;
     hipStream_t stream = nullptr;
@@ -122,7 +171,6 @@ struct msm_ctx {
     uint32_t* h_flags = nullptr;    // pinned
     // resident bases
     size_t resident_n = 0;
-    size_t wide_max = 40960;  // pairwise levels up to this many additions use 8 lanes per addition (MSM_HIP_WIDE_MAX; 0 = never)
     bool resident_has_inf = false;
     bool resident_glv = false;  // the resident set holds the phi records too (index resident_n + i)
     msm_timings_t tm{};
@@ -131,7 +179,6 @@ struct msm_ctx {
     uint64_t acc_launches = 0;
     std::chrono::steady_clock::time_point t_prepare{};  // trace: when the call started preparing / enqueueing
     float enqueue_ms = 0;         // trace: host time from there until everything was queued (what a hipGraph could shorten)
-    bool reduce_v1 = false;       // MSM_HIP_REDUCE_V1=1 at context creation: one launch per pairwise level (round 1)
     bool flags_clean = false;     // the device flag words are known to be zero (set when an MSM completes)
     uint32_t last_sort_path = 0;  // 2 = two-level LDS sort, 1 = tiled LDS histogram, 0 = global atomics (stage tests, trace)
 };
@@ -182,10 +229,14 @@ struct DevTmp {
 
 static_assert(msmplan::GLV_SPLIT_BITS == (uint32_t)glv::SPLIT_BITS, "planner and GLV split disagree");
 using msmplan::make_plan;
-// does a call on n points (context configuration + per-call extra flags) use the GLV split, i.e. 2n base records?
+// the plan of a call on n points under this context's configuration and knobs (+ per-call extra flags)
+inline int32_t ctx_plan(const msm_ctx* c, size_t n, uint32_t extra_flags, msm_plan_t* pl) {
+    return make_plan(n, c->cfg.window_bits, c->cfg.flags | extra_flags, pl, c->knobs.glv_max);
+}
+// does such a call use the GLV split, i.e. 2n base records?
 inline bool plan_glv(const msm_ctx* c, size_t n, uint32_t extra_flags = 0) {
     msm_plan_t pl;
-    return make_plan(n, c->cfg.window_bits, c->cfg.flags | extra_flags, &pl) == MSM_OK && pl.glv != 0;
+    return ctx_plan(c, n, extra_flags, &pl) == MSM_OK && pl.glv != 0;
 }
 constexpr size_t XB = msmk::XW * 4;               // bytes per XYZZ record (4 coordinates x 9 x 29-bit limbs)
 constexpr size_t LDS_HIST_BYTES = 128 * 1024;   // one window's bucket histogram must fit here for the LDS sort path
@@ -235,7 +286,7 @@ struct PipeState {
 int32_t pipe_prepare(msm_ctx* c, size_t n_real, size_t plan_n, uint32_t extra_flags, hipStream_t st, PipeState* ps) {
     if (trace_enabled() && c->flags_clean) c->t_prepare = std::chrono::steady_clock::now();  // (flags_clean: first prepare of a call)
     if (n_real > 0x3FFFFFFFull) return fail(c, MSM_ERR_BAD_ARG, "n = %zu exceeds 2^30-1 points per context call", n_real);
-    int32_t rc = make_plan(plan_n ? plan_n : n_real, c->cfg.window_bits, c->cfg.flags | extra_flags, &ps->pl);
+    int32_t rc = ctx_plan(c, plan_n ? plan_n : n_real, extra_flags, &ps->pl);
     if (rc) return fail(c, rc, "bad window_bits/flags (%u, 0x%x)", c->cfg.window_bits, c->cfg.flags);
     const msm_plan_t& pl = ps->pl;
     ps->n_real = n_real;
@@ -262,10 +313,7 @@ int32_t pipe_prepare(msm_ctx* c, size_t n_real, size_t plan_n, uint32_t extra_fl
     // ... and from there the chunk follows the mean bucket occupancy n/nb (32 at 2^20 unsplit, 64 with the GLV split: measured
     // 1.728 ms at L = 32 against 1.698 at 64), as long as ~2^17 chunks remain to fill the chip
     while (chunk_len < 1024 && chunk_len < n / nb && pairs / (chunk_len * 2) >= 131072) chunk_len *= 2;
-    if (const char* e = std::getenv("MSM_HIP_CHUNK_LEN")) {  // tuning knob (any value >= 1 is correct)
-        int v = std::atoi(e);
-        if (v >= 1 && v <= 4096) chunk_len = (uint32_t)v;
-    }
+    if (c->knobs.chunk_len) chunk_len = c->knobs.chunk_len;  // MSM_HIP_CHUNK_LEN at context creation (any value >= 1 is correct)
     ps->chunk_len = chunk_len;
     const size_t nchunks_max = ps->nchunks_max = (pairs + chunk_len - 1) / chunk_len;
     if ((rc = ensure(c, c->digits, pairs * 4))) return rc;
@@ -317,7 +365,7 @@ int32_t enqueue_sort(msm_ctx* c, const PipeState& ps, const uint8_t* d_inf, cons
     if (coarse_bits > kb) coarse_bits = kb;
     const uint32_t fine_bits = kb - coarse_bits, idx_bits = 31 - fine_bits;
     const uint32_t ncoarse = 1u << coarse_bits;
-    const bool two_level = fine_bits <= 7 && n <= ((size_t)1 << idx_bits) && !std::getenv("MSM_HIP_DIRECT_SCATTER");
+    const bool two_level = fine_bits <= 7 && n <= ((size_t)1 << idx_bits) && !c->knobs.direct_scatter;
     const bool lds_counts = two_level || tiled;  // no device-scope histogram / rank atomics in k_decompose
     const uint32_t NS = (uint32_t)((n + msmk::SUBTILE - 1) / msmk::SUBTILE);
     uint32_t T = 1, tile_len = (uint32_t)n;
@@ -464,7 +512,7 @@ int32_t enqueue_reduce(msm_ctx* c, const PipeState& ps, hipStream_t st, uint32_t
     // replaced (2^20: 52 vs 37 us: a tree's upper levels leave most lanes of its wavefront idle): profiles/NOTES_r2.md.
     // MSM_HIP_REDUCE_V1=1 at context creation = one launch per level throughout (round 1; A/B knob).
     uint32_t l = 0;
-    if (!c->reduce_v1 && levels >= 3 && kb_lo >= 3 && tb * XB <= ((size_t)100 << 20)) {
+    if (!c->knobs.reduce_v1 && levels >= 3 && kb_lo >= 3 && tb * XB <= ((size_t)100 << 20)) {
         rn = tb / 8, cn = tb / 8;
         msmk::k_pair_level8<<<grid1(rn + cn, 256), 256, 0, st>>>(bk, rbuf[0], cbuf[0], (uint32_t)rn, n_lo);
         rin = rbuf[0], cin = cbuf[0];  // where level 2 would have left them
@@ -484,7 +532,7 @@ int32_t enqueue_reduce(msm_ctx* c, const PipeState& ps, hipStream_t st, uint32_t
         }
         // levels with fewer additions than an eighth of the lanes the chip keeps resident: eight lanes per addition
         const size_t nadds = (size_t)ja.n_out + jb.n_out;
-        if (nadds <= c->wide_max) msmk::k_pair_level_wide<<<grid1(nadds * msmk::WIDE_LANES, 256), 256, 0, st>>>(ja, jb);
+        if (nadds <= c->knobs.wide_max) msmk::k_pair_level_wide<<<grid1(nadds * msmk::WIDE_LANES, 256), 256, 0, st>>>(ja, jb);
         else msmk::k_pair_level<<<grid1(nadds, 256), 256, 0, st>>>(ja, jb);
     }
     // the bit sums (and the flag words) are written by the kernel straight into the caller's PINNED host buffers:
@@ -492,7 +540,7 @@ int32_t enqueue_reduce(msm_ctx* c, const PipeState& ps, hipStream_t st, uint32_t
     uint32_t *q_dev = nullptr, *f_dev = nullptr;
     HIPCHK(c, hipHostGetDevicePointer((void**)&q_dev, h_qsums_dst, 0));
     HIPCHK(c, hipHostGetDevicePointer((void**)&f_dev, h_flags_dst, 0));
-    if (c->wide_max && n_hi / 2 <= msmk::WIDE_TREE_MAX && n_lo <= msmk::WIDE_TREE_MAX)
+    if (c->knobs.wide_max && n_hi / 2 <= msmk::WIDE_TREE_MAX && n_lo <= msmk::WIDE_TREE_MAX)
         msmk::k_reduce_bits_wide<<<W * (kb + 1), 512, 0, st>>>(rin, cin, q_dev, n_hi, n_lo, kb_lo, kb, flags, f_dev);
     else
         msmk::k_reduce_bits<<<W * (kb + 1), 64, 0, st>>>(rin, cin, q_dev, n_hi, n_lo, kb_lo, kb, flags, f_dev);
@@ -604,10 +652,7 @@ int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, 
     // cut into point ranges of 2^22 that accumulate INTO the shared bucket array, like the chunks of a streamed host call:
     // 2^23 11.42 -> 11.0-11.1 ms, 2^24 22.76 -> 21.90 (tools/device_chunk_ab.py; every further cut costs ~0.1 ms: 2^22 in ranges of
     // 2^20 loses 0.5 ms, so smaller instances stay whole).
-    static const uint32_t dev_chunk_log2 = [] {
-        const char* e = getenv("MSM_HIP_DEVICE_CHUNK_LOG2");  // experiment knob; 0 = never cut
-        return e ? (uint32_t)atoi(e) : 22u;
-    }();
+    const uint32_t dev_chunk_log2 = c->knobs.device_chunk_log2;  // (MSM_HIP_DEVICE_CHUNK_LOG2 at context creation; 0 = never cut)
     const size_t dchunk = dev_chunk_log2 ? (size_t)1 << dev_chunk_log2 : 0;
     if (dchunk && n >= 2 * dchunk && !plan_glv(c, n, extra_flags)) {
         if ((rc = pipe_prepare(c, dchunk, n, extra_flags, st, &ps))) return rc;
@@ -819,9 +864,9 @@ std::vector<size_t> stream_schedule(const msm_ctx* c, size_t n) {
     // longer.  Uniform chunks of 2^18 points (2^19 / 2^20 for large instances): shorter chunks at the end, meant to leave less work
     // after the last byte, cost more in fixed per-chunk work than they hide (measured: 2^20 in 4 chunks 2.89 ms, 3 x 2^18 +
     // 2^17 + 2 x 2^16: 3.48 ms -- profiles/NOTES_r2.md).  A remainder below half a chunk joins the last chunk.
-    uint32_t min_log2 = 19, lg = n < ((size_t)1 << 21) ? 18u : n < ((size_t)1 << 23) ? 19u : 20u;
-    if (const char* e = std::getenv("MSM_HIP_STREAM_MIN_LOG2")) min_log2 = (uint32_t)std::max(9, std::min(31, std::atoi(e)));
-    if (const char* e = std::getenv("MSM_HIP_STREAM_CHUNK_LOG2")) lg = (uint32_t)std::max(8, std::min(28, std::atoi(e)));
+    const uint32_t min_log2 = c->knobs.stream_min_log2;
+    uint32_t lg = n < ((size_t)1 << 21) ? 18u : n < ((size_t)1 << 23) ? 19u : 20u;
+    if (c->knobs.stream_chunk_log2) lg = c->knobs.stream_chunk_log2;
     const size_t chunk = (size_t)1 << lg;
     if (n < ((size_t)1 << min_log2) || n < 2 * chunk) return sizes;
     size_t left = n;
@@ -875,7 +920,8 @@ const char* msm_last_error(const msm_ctx* ctx) { return ctx ? ctx->err.c_str() :
 // never shares a hardware queue with the first pipeline's main stream (equal-priority streams are dealt round-robin onto a few
 // HSA queues; two on one queue serialise and the batch gains nothing -- measured, profiles/NOTES_r2.md) and its kernels fill the
 // gaps of the first pipeline instead of competing with it.
-static int32_t ctx_create_impl(const msm_config_t* cfg, msm_ctx** out, int main_priority /* 0 default pool, 1 low, 2 high */) {
+static int32_t ctx_create_impl(const msm_config_t* cfg, msm_ctx** out, int main_priority /* 0 default pool, 1 low, 2 high */,
+                               const Knobs* inherit = nullptr /* second pipeline of a batch: the owner's knobs */) {
     if (!out) return fail(nullptr, MSM_ERR_BAD_ARG, "out == NULL");
     *out = nullptr;
     int ndev = 0;
@@ -884,8 +930,9 @@ static int32_t ctx_create_impl(const msm_config_t* cfg, msm_ctx** out, int main_
     msm_config_t c0{};
     c0.device = -1;
     if (cfg) c0 = *cfg;
+    const Knobs knobs = inherit ? *inherit : Knobs::from_env();
     msm_plan_t probe;
-    if (make_plan(1, c0.window_bits, c0.flags, &probe) != MSM_OK)
+    if (make_plan(1, c0.window_bits, c0.flags, &probe, knobs.glv_max) != MSM_OK)
         return fail(nullptr, MSM_ERR_BAD_ARG, "bad window_bits/flags (%u, 0x%x)", c0.window_bits, c0.flags);
     if (c0.stream_chunk_log2 && (c0.stream_chunk_log2 < 8 || c0.stream_chunk_log2 > 28))
         return fail(nullptr, MSM_ERR_BAD_ARG, "stream_chunk_log2 = %u out of range [8, 28]", c0.stream_chunk_log2);
@@ -896,6 +943,7 @@ static int32_t ctx_create_impl(const msm_config_t* cfg, msm_ctx** out, int main_
     if (!c) return fail(nullptr, MSM_ERR_OOM, "host allocation failed");
     c->device = dev;
     c->cfg = c0;
+    c->knobs = knobs;
     c->stage_timing = trace_enabled();
     DeviceGuard g(dev);
     int least = 0, greatest = 0;
@@ -910,8 +958,7 @@ static int32_t ctx_create_impl(const msm_config_t* cfg, msm_ctx** out, int main_
         // one queue, the barrier packets of their cross-stream event waits executed in queue order and every chunk upload waited
         // for the PREVIOUS chunk's kernels (rocprofv3 kernel trace: one Queue_Id, profiles/NOTES_r2.md).  A stream of another
         // priority comes from another pool.
-        const char* cpe = getenv("MSM_HIP_COPY_PRIORITY");  // experiment knob: 0 = a plain stream
-        if (cpe && cpe[0] == '0') least = greatest;
+        if (!knobs.copy_priority) least = greatest;  // MSM_HIP_COPY_PRIORITY=0 (experiment): a plain stream
         e = least != greatest ? hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, greatest)
                               : hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
     }
@@ -935,7 +982,7 @@ static int32_t ctx_create_impl(const msm_config_t* cfg, msm_ctx** out, int main_
     }
     if (c0.max_points) {
         msm_plan_t pl;
-        make_plan(c0.max_points, c0.window_bits, c0.flags, &pl);
+        make_plan(c0.max_points, c0.window_bits, c0.flags, &pl, knobs.glv_max);
         size_t pairs = (size_t)pl.num_windows * (size_t)pl.virtual_points, tb = (size_t)pl.num_windows * pl.num_buckets;
         int32_t rc = MSM_OK;
         if (!rc) rc = ensure(c, c->bases, c0.max_points * 64);
@@ -956,9 +1003,7 @@ static int32_t ctx_create_impl(const msm_config_t* cfg, msm_ctx** out, int main_
         if (want > 1) want = 1;  // the calling thread + ONE worker: measured over 1500 calls at 2^17 (tools/step_jitter.py),
                                  // mean latency 0.608 / 0.575 / 0.588 / 0.590 ms with 1 / 2 / 3 / 4 threads -- the median keeps
                                  // falling (0.606 / 0.570 / 0.556 / 0.555) but 3+ threads bring 2-8 ms outliers in ~1.3 % of the calls
-        if (const char* e = std::getenv("MSM_HIP_HOST_THREADS")) want = std::atoi(e) - 1;
-        if (const char* e = std::getenv("MSM_HIP_WIDE_MAX")) c->wide_max = (size_t)std::max(0, std::atoi(e));
-        if (const char* e = std::getenv("MSM_HIP_REDUCE_V1")) c->reduce_v1 = *e && *e != '0';
+        if (knobs.host_threads >= 0) want = knobs.host_threads - 1;  // MSM_HIP_HOST_THREADS
         if (want >= 1) c->pool = new (std::nothrow) HostPool(want);
     }
     *out = c;
@@ -1187,8 +1232,8 @@ static int32_t resident_on_lane(msm_ctx* w, const msm_ctx* owner, const uint32_t
         // (shared: BOTH pipelines upload through the owner's copy stream.  Uploads queued on the second pipeline's own copy stream
         // slowed the kernels running beside them 1.4-4.6x -- k_coarse_scatter 33 -> 47 us, k_fine_sort 42 -> 85, k_chunk_map 18 -> 84 --
         // while the owner's did not: 1.61-1.62 -> 1.51-1.58 ms per MSM at 2^20, NOTES_r2.md section 7)
-        const char* cse = getenv("MSM_HIP_BATCH_COPY");  // A/B knob (per call): 0 = each pipeline's own copy stream
-        hipStream_t cs = shared ? (cse && cse[0] == '0' ? w->copy_stream : o->copy_stream) : w->stream, st = shared ? o->stream : w->stream;
+        // (MSM_HIP_BATCH_COPY=0 at context creation, A/B: each pipeline's own copy stream)
+        hipStream_t cs = shared ? (o->knobs.batch_copy_own ? w->copy_stream : o->copy_stream) : w->stream, st = shared ? o->stream : w->stream;
         {
             std::lock_guard<std::mutex> cp(o->copy_mu);
             if (o->last_copy && o->last_copy != w->ev_fork) HIPCHK(w, hipStreamWaitEvent(cs, o->last_copy, 0));
@@ -1245,8 +1290,7 @@ int32_t msm_bn254_g1_resident_batch(msm_ctx* c, const uint32_t* const* scalars, 
         msm_config_t cfg = c->cfg;
         cfg.device = c->device;
         cfg.max_points = 0;
-        const char* pe = getenv("MSM_HIP_LANE_PRIORITY");  // experiment knob: low (default) | high | normal
-        int32_t rc = ctx_create_impl(&cfg, &c->lane1, pe && !strcmp(pe, "high") ? 2 : pe && !strcmp(pe, "normal") ? 0 : 1);
+        int32_t rc = ctx_create_impl(&cfg, &c->lane1, c->knobs.lane_priority, &c->knobs);  // (MSM_HIP_LANE_PRIORITY: low by default)
         if (rc) return fail(c, rc, "second pipeline: %s", msm_last_error(nullptr));
         c->batch_pool = new (std::nothrow) HostPool(1);
         if (!c->batch_pool) return fail(c, MSM_ERR_OOM, "host allocation failed");
@@ -1267,8 +1311,8 @@ int32_t msm_bn254_g1_resident_batch(msm_ctx* c, const uint32_t* const* scalars, 
     c->last_copy = nullptr;
     {
         // from 2^19 points the kernels fill the GPU: one compute stream; below, two (measured crossover 2^18..2^19)
-        const char* be = getenv("MSM_HIP_BATCH_MODE");  // experiment knob: shared | lanes
-        c->batch_shared_stream = be ? !strcmp(be, "shared") : n >= ((size_t)1 << 19);
+        // (MSM_HIP_BATCH_MODE at context creation, experiment: shared | lanes)
+        c->batch_shared_stream = c->knobs.batch_mode >= 0 ? c->knobs.batch_mode == 1 : n >= ((size_t)1 << 19);
     }
     if (count > 1) c->batch_pool->run(2, lane);
     else lane(0);
@@ -1327,7 +1371,7 @@ int32_t msm_bn254_g1_combine(const uint32_t* partials, size_t k, uint32_t out_ja
 int32_t msm_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_plan_t* out) {
     if (!out) return MSM_ERR_BAD_ARG;
     if (n == 0) return MSM_ERR_EMPTY;
-    return make_plan(n, window_bits, flags, out);
+    return make_plan(n, window_bits, flags, out, msmplan::glv_max_from_env());  // what a context created NOW would plan (no context here)
 }
 
 int32_t msm_get_timings(const msm_ctx* c, msm_timings_t* out) {

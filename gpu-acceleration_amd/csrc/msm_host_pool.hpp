@@ -13,7 +13,8 @@
 // reference runs its CPU finish under rayon (metal_msm.rs:214-247); std::thread + a condition variable here.
 // run() returns when every JOB is done, not when every worker has checked in: a worker the OS wakes late (seen as
 // 3-10 ms outliers of the finish stage) simply finds nothing left, because the caller and the punctual workers pull jobs
-// from one ticket counter.  The ticket carries the generation, so a late worker can never take a job of a later run().
+// from one ticket counter.  The ticket carries the generation (its low 32 bits: a late worker would have to sleep through 2^32 runs
+// to confuse two of them), so a late worker can never take a job of a later run().
 class HostPool {
 public:
     explicit HostPool(int nthreads) {
@@ -63,7 +64,7 @@ private:
     void pull(uint64_t gen, int njobs, const std::function<void(int)>& fn) {
         for (;;) {
             uint64_t v = ticket_.load(std::memory_order_acquire);
-            if ((v >> 32) != gen || (int)(uint32_t)v >= njobs) return;
+            if ((uint32_t)(v >> 32) != (uint32_t)gen || (int)(uint32_t)v >= njobs) return;  // the ticket holds the LOW 32 bits of the generation
             if (!ticket_.compare_exchange_weak(v, v + 1, std::memory_order_acq_rel)) continue;
             fn((int)(uint32_t)v);  // fn outlives this call: run(gen) cannot return before done_ counts it
             done_.fetch_add(1, std::memory_order_release);
@@ -84,7 +85,7 @@ private:
             }
             if (njobs == 0) {  // armed: spin (bounded) until run() moves the ticket to the next generation
                 const auto t0 = std::chrono::steady_clock::now();
-                for (uint32_t spins = 1; (ticket_.load(std::memory_order_acquire) >> 32) == seen; spins++) {
+                for (uint32_t spins = 1; (uint32_t)(ticket_.load(std::memory_order_acquire) >> 32) == (uint32_t)seen; spins++) {
                     if ((spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
                     __builtin_ia32_pause();
                 }

@@ -51,11 +51,16 @@ inline uint32_t plan_window_bits_glv(size_t n, bool is_signed) {
     if (!is_signed && c > 15u) c = 15u;
     return c;
 }
-inline int32_t make_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_plan_t* out) {
+// MSM_HIP_GLV_MAX_LOG2 (A/B knob).  Read where a CONTEXT is created (msm_ctx.knobs) and by the context-free
+// msm_plan(); never inside make_plan, which a call evaluates several times and which must give an upload and the resident calls
+// that follow it the same answer.
+inline size_t glv_max_from_env() {
+    if (const char* e = std::getenv("MSM_HIP_GLV_MAX_LOG2")) return (size_t)1 << std::min(23, std::max(0, std::atoi(e)));
+    return GLV_MAX_POINTS;
+}
+inline int32_t make_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_plan_t* out, size_t glv_max = GLV_MAX_POINTS) {
     if (flags & ~(MSM_FLAG_UNSIGNED_DIGITS | MSM_FLAG_NO_GLV)) return MSM_ERR_BAD_ARG;
     bool is_signed = !(flags & MSM_FLAG_UNSIGNED_DIGITS);
-    size_t glv_max = GLV_MAX_POINTS;
-    if (const char* e = std::getenv("MSM_HIP_GLV_MAX_LOG2")) glv_max = (size_t)1 << std::min(23, std::max(0, std::atoi(e)));  // A/B knob
     bool use_glv = !(flags & MSM_FLAG_NO_GLV) && n <= glv_max;
     uint32_t c = window_bits ? window_bits : (use_glv ? plan_window_bits_glv(n, is_signed) : plan_window_bits(n, is_signed));
     if (c < 2 || c > 20) return MSM_ERR_BAD_ARG;

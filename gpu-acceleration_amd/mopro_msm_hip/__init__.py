@@ -33,6 +33,7 @@ ABI_SYMBOLS = [
     "msm_bn254_g1_decompress", "msm_bn254_g1_upload_compressed", "msm_bn254_g1_compress",
     "msm_multi_create", "msm_multi_destroy", "msm_multi_last_error", "msm_multi_num_devices", "msm_multi_exchange",
     "msm_bn254_g1_multi", "msm_bn254_g1_multi_arkworks", "msm_bn254_g1_multi_device", "msm_multi_get_timings",
+    "msm_multi_get_exchange_stats",
 ]
 ERR_RCCL = -8
 EXCHANGE_AUTO, EXCHANGE_RCCL, EXCHANGE_HOST = 0, 1, 2
@@ -120,6 +121,7 @@ def bind_product_abi(L):
     L.msm_bn254_g1_multi_arkworks.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _u32p, C.c_size_t, _u32p, _u32p, _u8p]
     L.msm_bn254_g1_multi_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_size_t), _u32p, _u32p, _u8p]
     L.msm_multi_get_timings.argtypes = [vp, C.c_int32, C.POINTER(Timings)]
+    L.msm_multi_get_exchange_stats.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32]
     for name in ABI_SYMBOLS:
         f = getattr(L, name)
         if f.restype is C.c_int:  # default
@@ -446,6 +448,13 @@ class MsmMulti:
         t = Timings()
         self._check(self._lib.msm_multi_get_timings(self._h, g, C.byref(t)))
         return t.as_dict()
+
+    def exchange_stats(self):
+        """(exchange ms of rank 0, [wall-clock ms of every rank's local MSM]) of the last call"""
+        ex = C.c_float(0)
+        sh = (C.c_float * self.num_devices)()
+        self._check(self._lib.msm_multi_get_exchange_stats(self._h, C.byref(ex), sh, self.num_devices))
+        return float(ex.value), [float(v) for v in sh]
 
 
 _default_ctx = None

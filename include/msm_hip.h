@@ -65,7 +65,8 @@ typedef struct {
     uint32_t stream_chunk_log2; /* the host-pointer entries cut n >= 2 * 2^this points into chunks of 2^this points: chunk j+1
                                    travels host->HBM (copy stream) while chunk j is sorted and accumulated INTO the shared bucket
                                    array; one bucket reduction and one host finish per MSM (BASELINE config 5).
-                                   0 = automatic: from 2^19 points on, chunks of 2^18..2^20 points ending in a few short ones.
+                                   0 = automatic: from 2^19 points on, uniform chunks of 2^18..2^20 points (a remainder below half a chunk
+                                   joins the last one).
                                    Copies run on a stream with a hardware queue of its own: from pinned caller memory at the link
                                    rate, from pageable memory as fast as the runtime stages it (both overlap the kernels) */
     uint64_t max_points;  /* pre-size the HBM workspace for this many points; 0 = grow on demand        */
@@ -207,6 +208,13 @@ int32_t msm_bn254_g1_multi_device(msm_multi *m, const void *const *d_bases_mont,
                                   uint32_t out_jacobian_mont[24], uint32_t out_affine_std[16], uint8_t *out_is_inf);
 /* timings of device g's part of the last call */
 int32_t msm_multi_get_timings(const msm_multi *m, int32_t g, msm_timings_t *out);
+/* what the exchange cost in the last call: *exchange_ms = rank 0's wall clock from the end of its local MSM to the folded result
+ * (RCCL: the rendezvous with the slowest rank, 96 B up, ncclAllGather, 96*ndev B down, fold; host fold: the fold alone);
+ * shard_ms[0..nshard) = wall clock of every rank's local MSM.  Either pointer may be NULL.
+ * Error behaviour of the multi calls: a rank whose local MSM fails never leaves its peers waiting in the collective -- the ranks
+ * rendezvous on the host first and ALL skip the exchange; the call returns the first failing rank's status, and
+ * msm_multi_last_error() names the device and rank (metal_msm.rs:647-656: errors are returned, nothing hangs). */
+int32_t msm_multi_get_exchange_stats(const msm_multi *m, float *exchange_ms, float *shard_ms, int32_t nshard);
 
 /* ---- introspection --------------------------------------------------------------------------- */
 int32_t msm_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_plan_t *out);

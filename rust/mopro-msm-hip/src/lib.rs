@@ -50,6 +50,7 @@ extern "C" {
     ) -> i32;
     fn msm_multi_create(devices: *const i32, ndev: i32, cfg: *const MsmConfig, exchange: u32, out: *mut *mut MsmMulti) -> i32;
     fn msm_multi_num_devices(m: *const MsmMulti) -> i32;
+    fn msm_multi_destroy(m: *mut MsmMulti);
     fn msm_multi_last_error(m: *const MsmMulti) -> *const c_char;
     fn msm_bn254_g1_multi_arkworks(
         m: *mut MsmMulti, bases: *const core::ffi::c_void, stride: usize, x_off: usize, y_off: usize, inf_off: usize,
@@ -126,15 +127,26 @@ static LAYOUT: Lazy<Option<Layout>> = Lazy::new(|| {
     if ok { Some(l) } else { None }
 });
 
-/// Multi-GPU handle over every visible device (or `MSM_HIP_DEVICES=0,1,...`): one context + host thread per device, point-range
-/// shards, partials exchanged with RCCL (include/msm_hip.h "multi-GPU").  `None` on a single-GPU host.
+/// Multi-GPU handle (include/msm_hip.h "multi-GPU"): one context + host thread per device, point-range shards, partials
+/// exchanged with RCCL.  OPT-IN: only when `MSM_HIP_DEVICES=0,1,...` names the devices -- a one-process-per-GPU deployment
+/// (every rank calling this function on its own device) must not open contexts and a communicator on all GPUs of the node.
+/// A handle that ends up with a single device is destroyed again (nothing is kept, nothing leaks).
 struct Multi(*mut MsmMulti);
 unsafe impl Send for Multi {}
 static MULTI: Lazy<Mutex<Option<Multi>>> = Lazy::new(|| {
+    if std::env::var_os("MSM_HIP_DEVICES").is_none() {
+        return Mutex::new(None);
+    }
     let cfg = MsmConfig { device: -1, window_bits: 0, flags: 0, stream_chunk_log2: 0, max_points: 0 };
     let mut p: *mut MsmMulti = std::ptr::null_mut();
     let rc = unsafe { msm_multi_create(std::ptr::null(), 0, &cfg, 0 /* MSM_MULTI_EXCHANGE_AUTO */, &mut p) };
-    Mutex::new(if rc == 0 && unsafe { msm_multi_num_devices(p) } > 1 { Some(Multi(p)) } else { None })
+    if rc == 0 && unsafe { msm_multi_num_devices(p) } > 1 {
+        return Mutex::new(Some(Multi(p)));
+    }
+    if !p.is_null() {
+        unsafe { msm_multi_destroy(p) };
+    }
+    Mutex::new(None)
 });
 /// below this many points one GPU is faster than several (per-GPU fixed costs ~0.35 ms)
 const MULTI_MIN_POINTS: usize = 1 << 19;
@@ -149,8 +161,8 @@ fn to_projective(jac: &[u64; 12]) -> G1Projective {
 ///
 /// The two slices go to the GPU(s) AS THEY ARE: `Fq`/`Fr` are arkworks' Montgomery words (R = 2^256), the engine reads the struct
 /// array through the measured layout and reduces the scalars on the device -- the reference's whole `pack_affine_and_scalars`
-/// stage (utils/limbs_conversion.rs:311-378: 3 CPU Montgomery reductions + 3 heap allocations per point) is gone.  From 2^19 points
-/// on, a multi-GPU host shards the point range over all devices behind this unchanged signature.  Only if the layout probe fails
+/// stage (utils/limbs_conversion.rs:311-378: 3 CPU Montgomery reductions + 3 heap allocations per point) is gone.  With
+/// `MSM_HIP_DEVICES` set, calls of 2^19 points and more shard the point range over those devices behind this unchanged signature.  Only if the layout probe fails
 /// (a future arkworks changing `G1Affine`) are the points repacked -- in parallel, still without any field reduction.
 pub fn metal_variable_base_msm(bases: &[G1Affine], scalars: &[Fr]) -> Result<G1Projective, Box<dyn Error>> {
     if bases.is_empty() || scalars.is_empty() {

@@ -1,4 +1,4 @@
-"""Worker of tests/test_gpu_configs.py::test_two_ranks_on_one_gpu (launched by torch.distributed.run, 2 processes, both on
+"""Worker of tests/test_gpu_3_configs.py::test_two_ranks_on_one_gpu (launched by torch.distributed.run, 2 processes, both on
 cuda:0, exchange over gloo): rank r generates and runs its point range of one 2^18-point instance through
 distributed_msm_device, then EVERY rank checks its own bits against the closed form and prints one JSON line."""
 import json
@@ -34,6 +34,26 @@ def main():
     with th.HooksContext(device=0) as gen:
         gen.generate_device(bs, ss, n, d_b.data_ptr(), d_s.data_ptr())
     torch.cuda.synchronize()
+    bad_rank = int(os.environ.get("MSM_TEST_BAD_SCALAR_RANK", "-1"))
+    if bad_rank >= 0:
+        # failure propagation: ONE rank's shard holds a scalar >= 2^254; every rank must raise MsmError(ERR_BAD_ARG), nobody hangs
+        if rank == bad_rank:
+            d_s[8 * (n // 3) + 7] = 0x40000000
+            torch.cuda.synchronize()
+        code, good, msg = None, False, ""
+        with mh.MsmContext(device=0) as ctx:
+            for _ in range(2):
+                try:
+                    md.distributed_msm_device(ctx, d_b.data_ptr(), d_s.data_ptr(), n, device=None)
+                except mh.MsmError as e:
+                    code = e.code
+                    msg = str(e)
+            good = code == mh.ERR_BAD_ARG and ("rank %d" % bad_rank) in msg
+        sys.stdout.write(json.dumps({"rank": rank, "ok": good, "error_code": code, "message": msg}) + "\n")
+        sys.stdout.flush()
+        dist.barrier()
+        dist.destroy_process_group()
+        sys.exit(0 if good else 1)
     with mh.MsmContext(device=0) as ctx:
         res = None
         for _ in range(3):

@@ -65,6 +65,63 @@ def test_gloo_point_range_shards_allgather_fold(world, case):
     assert len({blob for _, _, blob in res}) == 1  # every rank saw the same gathered partials
 
 
+def _worker_fail(rank, world, port, bad_rank, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "gpu-acceleration_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    import mopro_msm_hip as mh
+    from mopro_msm_hip import distributed as md
+    from oracle import bn254_oracle as orc
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "msm_rand_n256.npz"))
+    lo, hi = md.shard_range(g["bases"].shape[0], rank, world)
+
+    def local():
+        if rank == bad_rank:  # what MsmContext.msm_device raises for a scalar >= 2^254 in this rank's shard
+            raise mh.MsmError(mh.ERR_BAD_ARG, "a scalar is >= 2^254 (not a canonical Fr element)")
+        _, _, jac = orc.msm_pippenger(g["bases"][lo:hi], g["scalars"][lo:hi], orc.FORM_STD, g["inf"][lo:hi])
+        return mh.MsmResult(jac, None, False)
+
+    code, msg = None, ""
+    try:
+        md.guarded(local)
+    except mh.MsmError as e:
+        code, msg = e.code, str(e)
+    # ... and the group is still usable: the same call without the failure gives the golden result on every rank
+    bad_rank = -1
+    full = md.guarded(local)
+    ok = bool((full.affine_std == g["expected"]).all())
+    q.put((rank, code, msg, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,bad_rank", [(2, 1), (3, 0)])
+def test_gloo_failed_rank_fails_every_rank_and_nobody_hangs(world, bad_rank):
+    """VERDICT r2 missing #2: one rank's local MSM fails; it must still join the all-gather (identity + status word) so that
+    every rank raises the first failing rank's code instead of blocking in the collective (metal_msm.rs:647-656: Err, never a hang)"""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_fail, args=(r, world, port, bad_rank, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    import mopro_msm_hip as mh
+    for rank, code, msg, ok in res:
+        assert code == mh.ERR_BAD_ARG and ("rank %d of %d" % (bad_rank, world)) in msg, (rank, code, msg)
+        assert ok
+        assert ("this rank" in msg) == (rank == bad_rank)
+
+
 def test_shard_ranges_partition_everything():
     from mopro_msm_hip import distributed as md
     for n in (1, 7, 1 << 20, (1 << 20) + 3):

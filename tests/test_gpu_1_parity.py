@@ -237,6 +237,62 @@ def test_reference_error_and_truncation_semantics(ctx):
     assert mh.metal_variable_base_msm is mh.hip_variable_base_msm
 
 
+def test_device_entry_with_infinity_mask_and_caller_stream(ctx, hk):
+    """msm_bn254_g1_device(d_inf_mask != NULL, hip_stream != NULL) -- the two ABI arguments no other test passes.  Goldens with
+    infinity masks on a caller-owned torch stream; then 2^19 points (above 2^18 the base conversion forks to the context's second
+    stream behind an event recorded on the CALLER's stream) with an infinity mask, inputs still being produced on that stream
+    when the call is made.  Mirrors the reference's e2e shape (tests/cuzk/e2e.rs:14-63): random instance, compare with the CPU."""
+    import torch
+    dev = torch.device("cuda:0")
+    st = torch.cuda.Stream(device=dev)
+
+    def to_dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a).view(np.int32).reshape(-1)).to(dev)
+
+    for name in ("edge_inf_bases", "rand_n1024", "rand_n4096", "rand_n17"):
+        g = load_golden(name)
+        bm = np.concatenate([hk.test_fp_op(3, g["bases"][:, :8]), hk.test_fp_op(3, g["bases"][:, 8:])], axis=1)  # Montgomery words
+        d_b, d_s = to_dev(bm), to_dev(g["scalars"])
+        d_i = torch.from_numpy(np.ascontiguousarray(g["inf"], dtype=np.uint8)).to(dev)
+        torch.cuda.synchronize()
+        for stream in (None, st.cuda_stream):
+            r = ctx.msm_device(d_b.data_ptr(), d_s.data_ptr(), g["bases"].shape[0], d_inf_ptr=d_i.data_ptr(), stream=stream)
+            assert r.is_infinity == bool(g["expected_inf"]) and (r.affine_std == g["expected"]).all(), (name, stream)
+    n = 1 << 19
+    k = th.generate_scalars_host(0xB2540071, n, nonzero=True)
+    s = th.generate_scalars_host(0xB2540072, n)
+    inf = (np.arange(n) % 97 == 5).astype(np.uint8)
+    keep = inf == 0
+    exp, _ = orc.closed_form_expected(k[keep], s[keep])
+    d_b = torch.empty(n * 16, dtype=torch.int32, device=dev)
+    d_s = torch.empty(n * 8, dtype=torch.int32, device=dev)
+    hk.generate_device(0xB2540071, 0xB2540072, n, d_b.data_ptr(), d_s.data_ptr())
+    torch.cuda.synchronize()
+    h_i = torch.from_numpy(inf).pin_memory()
+    for rep in range(3):
+        with torch.cuda.stream(st):
+            # the mask and a copy of the scalars are PRODUCED on the caller's stream right before the call: the engine must order
+            # its second stream behind them (event fork, msm_bn254_g1_device)
+            d_i = h_i.to(dev, non_blocking=True)
+            d_s2 = d_s.clone()
+            d_b2 = d_b.clone()
+        r = ctx.msm_device(d_b2.data_ptr(), d_s2.data_ptr(), n, d_inf_ptr=d_i.data_ptr(), stream=st.cuda_stream)
+        assert (r.affine_std == exp).all() and not r.is_infinity, rep
+    st.synchronize()
+    # ... and msm_bn254_g1_multi_device with per-shard masks ({0,0}: two ranks on this GPU, host fold)
+    with mh.MsmMulti(devices=[0, 0]) as m:
+        h = n // 2
+        r = m.msm_device([d_b.data_ptr(), d_b.data_ptr() + 64 * h], [d_s.data_ptr(), d_s.data_ptr() + 32 * h], [h, n - h],
+                         d_inf_ptrs=[d_i.data_ptr(), d_i.data_ptr() + h])
+        assert (r.affine_std == exp).all()
+        r = m.msm_device([d_b.data_ptr(), d_b.data_ptr() + 64 * h], [d_s.data_ptr(), d_s.data_ptr() + 32 * h], [h, n - h],
+                         d_inf_ptrs=[None, d_i.data_ptr() + h])  # nullable entries
+        keep2 = keep.copy()
+        keep2[:h] = True
+        e2, _ = orc.closed_form_expected(k[keep2], s[keep2])
+        assert (r.affine_std == e2).all()
+
+
 @pytest.mark.parametrize("logn", [10, 12, 16])
 def test_msm_random_vs_oracle(ctx, logn):
     n = 1 << logn
@@ -414,9 +470,9 @@ def test_glv_split_full_size_matches_unsplit_and_closed_form(monkeypatch, hk, lo
 
 # ---- BASELINE config 5: streamed host->HBM chunks overlapped with the pipeline ---------------------
 def test_streamed_chunks_match_oracle(hk):
-    """msm_bn254_g1 cuts n >= 2*chunk points into chunks (double-buffered H2D on a copy stream, partials added on
-    the host).  Forced to tiny chunks here so that the golden cases exercise it; ragged last chunk and infinity
-    masks included."""
+    """msm_bn254_g1 cuts n >= 2*chunk points into chunks (double-buffered H2D on a copy stream; every chunk accumulates INTO the
+    shared bucket array, k_accumulate<true, true>: one bucket reduction and one host finish per MSM).  Forced to tiny chunks here so
+    that the golden cases exercise it; ragged last chunk and infinity masks included."""
     with mh.MsmContext(stream_chunk_log2=8) as c:
         for name in ("rand_n1024", "rand_n4096"):
             g = load_golden(name)
