@@ -111,6 +111,7 @@ struct Knobs {
     int batch_copy_own = 0;                    // MSM_HIP_BATCH_COPY=0: each batch pipeline uploads on its own copy stream
     int lane_priority = 1;                     // MSM_HIP_LANE_PRIORITY: low (1, default) | high (2) | normal (0)
     int batch_mode = -1;                       // MSM_HIP_BATCH_MODE: shared (1) | lanes (0); -1 = by size
+    msmplan::table_knobs table;                // MSM_HIP_TABLE_C / MSM_HIP_TABLE_F / MSM_HIP_TABLE_MAX_GB (window table of a resident set)
     static Knobs from_env() {
         Knobs k;
         auto num = [](const char* name, long lo, long hi, long dflt) {
@@ -138,6 +139,9 @@ struct Knobs {
         if (const char* e = std::getenv("MSM_HIP_BATCH_COPY")) k.batch_copy_own = e[0] == '0';
         if (const char* e = std::getenv("MSM_HIP_LANE_PRIORITY")) k.lane_priority = !strcmp(e, "high") ? 2 : !strcmp(e, "normal") ? 0 : 1;
         if (const char* e = std::getenv("MSM_HIP_BATCH_MODE")) k.batch_mode = !strcmp(e, "shared") ? 1 : 0;
+        k.table.c = (uint32_t)num("MSM_HIP_TABLE_C", 0, 20, 0);
+        k.table.f = (uint32_t)num("MSM_HIP_TABLE_F", 0, 128, 0);
+        k.table.max_bytes = (size_t)num("MSM_HIP_TABLE_MAX_GB", 0, 1024, 64) << 30;
         return k;
     }
 };
@@ -173,6 +177,8 @@ struct msm_ctx {
     size_t resident_n = 0;
     bool resident_has_inf = false;
     bool resident_glv = false;  // the resident set holds the phi records too (index resident_n + i)
+    // window table of the resident set (MSM_FLAG_WINDOW_TABLE): rbases holds table_f levels of nv records, level j = 2^(table_c * j) * level 0
+    uint32_t table_c = 0, table_f = 1;
     msm_timings_t tm{};
     bool stage_timing = false;  // record the per-stage hipEvents (each costs ~6 us of stream time); k_accumulate's pair is always on
     double acc_ms_sum = 0;
@@ -229,6 +235,15 @@ struct DevTmp {
 
 static_assert(msmplan::GLV_SPLIT_BITS == (uint32_t)glv::SPLIT_BITS, "planner and GLV split disagree");
 using msmplan::make_plan;
+// Window table with ONE shared bucket array (table factor == number of windows): the top window only holds
+// scalar_bits - c*(W-1) bits (14 of 20 at c = 20), so its digits would all land in the lowest buckets -- a few regions of the sort and
+// a few hundred chunks of k_accumulate would carry a whole window.  Its table level is built as 2^(c*(W-1) - s) P and the digit d enters
+// as d * 2^s instead (same group element, every 2^s-th bucket): s = (c - 1) - top bits, so that d * 2^s <= 2^(c-1) still holds.
+inline uint32_t table_top_shift(const msm_plan_t& pl, uint32_t tf) {
+    if (tf <= 1 || tf != pl.num_windows || !pl.signed_digits) return 0;
+    const uint32_t top_bits = pl.scalar_bits - pl.window_bits * (pl.num_windows - 1);  // max top digit 2^top_bits (carry included)
+    return top_bits < pl.window_bits - 1 ? pl.window_bits - 1 - top_bits : 0u;
+}
 // the plan of a call on n points under this context's configuration and knobs (+ per-call extra flags)
 inline int32_t ctx_plan(const msm_ctx* c, size_t n, uint32_t extra_flags, msm_plan_t* pl) {
     return make_plan(n, c->cfg.window_bits, c->cfg.flags | extra_flags, pl, c->knobs.glv_max);
@@ -240,7 +255,7 @@ inline bool plan_glv(const msm_ctx* c, size_t n, uint32_t extra_flags = 0) {
 }
 constexpr size_t XB = msmk::XW * 4;               // bytes per XYZZ record (4 coordinates x 9 x 29-bit limbs)
 constexpr size_t LDS_HIST_BYTES = 128 * 1024;   // one window's bucket histogram must fit here for the LDS sort path
-constexpr size_t MAX_QSUM_POINTS = 128 * 21;  // W <= 128 windows (c >= 2), kb + 1 <= 21 bit sums each
+constexpr size_t MAX_QSUM_POINTS = 4096;  // (pseudo-)windows x (rkb + 1) bit sums: c = 2: 128 x 2; c = 20 unsigned: 13 x 16 slices x 17 = 3536
 
 uint32_t ilog2(uint32_t v) {
     uint32_t l = 0;
@@ -274,28 +289,51 @@ void finish_outputs(const hostg1::Jac& r, uint32_t* out_jac, uint32_t* out_aff, 
 // accumulated -- the sort geometry follows the points at hand.
 struct PipeState {
     msm_plan_t pl{};
-    size_t n_real = 0, n = 0;  // real / virtual (x2 with the GLV split) points of this chunk
-    uint32_t W = 0, nb = 0, cbits = 0, kb = 0, kb_lo = 0, kb_hi = 0, n_lo = 0, n_hi = 0;
-    size_t pairs = 0, tb = 0;
+    size_t n_real = 0, n = 0;  // real / virtual (x2 with the GLV split) points of this chunk: what k_decompose sees
+    uint32_t W = 0, nb = 0, cbits = 0, kb = 0;  // decomposition: W windows of cbits bits, nb = 2^kb buckets per bucket array
+    // SORT / ACCUMULATE view.  Without a window table every window has its own bucket array: sW = W sort windows of sn = n entries.
+    // With the window table of a resident base set (factor tf: T_j = 2^(c*j) P, j < tf; k_table_next) the tf windows of a group share
+    // one array: sW = W / tf sort windows of sn = tf * n entries each, and a sorted entry is the TABLE index j * n + i.
+    uint32_t tf = 1, sW = 0;
+    size_t sn = 0;
+    uint32_t top_shift = 0;  // full table (tf == W): the short top window's digits enter as d * 2^top_shift (table_top_shift)
+    size_t digit_off = 0;  // first entry of this sort in the digits array (window ranges of a table MSM)
+    // REDUCTION view: arrays of more than 2^17 buckets are reduced as 2^pw_bits PSEUDO-windows of 2^rkb buckets each (bucket index
+    // b = q * 2^rkb + b'); the host adds q * 2^rkb * (plain sum of pseudo-window q) back in (host_finish).  rW = sW << pw_bits.
+    uint32_t rW = 0, rkb = 0, pw_bits = 0, kb_lo = 0, kb_hi = 0, n_lo = 0, n_hi = 0;
+    size_t pairs = 0, tb = 0;  // sorted entries at most (= W * n = sW * sn), buckets in all (= sW * nb)
     uint32_t chunk_len = 0;
     size_t nchunks_max = 0;
 };
 
 // plan + workspace.  May reallocate buffers (hipFree synchronises the device), so with chunks in flight it must not grow
 // anything: the first chunk of a streamed MSM is the largest.
-int32_t pipe_prepare(msm_ctx* c, size_t n_real, size_t plan_n, uint32_t extra_flags, hipStream_t st, PipeState* ps) {
+int32_t pipe_prepare(msm_ctx* c, size_t n_real, size_t plan_n, uint32_t extra_flags, hipStream_t st, PipeState* ps, uint32_t table_c = 0,
+                     uint32_t table_f = 1) {
     if (trace_enabled() && c->flags_clean) c->t_prepare = std::chrono::steady_clock::now();  // (flags_clean: first prepare of a call)
     if (n_real > 0x3FFFFFFFull) return fail(c, MSM_ERR_BAD_ARG, "n = %zu exceeds 2^30-1 points per context call", n_real);
-    int32_t rc = ctx_plan(c, plan_n ? plan_n : n_real, extra_flags, &ps->pl);
-    if (rc) return fail(c, rc, "bad window_bits/flags (%u, 0x%x)", c->cfg.window_bits, c->cfg.flags);
+    int32_t rc = table_c ? make_plan(plan_n ? plan_n : n_real, table_c, c->cfg.flags | extra_flags, &ps->pl, c->knobs.glv_max)
+                         : ctx_plan(c, plan_n ? plan_n : n_real, extra_flags, &ps->pl);
+    if (rc) return fail(c, rc, "bad window_bits/flags (%u, 0x%x)", table_c ? table_c : c->cfg.window_bits, c->cfg.flags);
     const msm_plan_t& pl = ps->pl;
     ps->n_real = n_real;
     const size_t n = ps->n = pl.glv ? 2 * n_real : n_real;  // what the sort, the accumulation and the reduction see
     const uint32_t W = ps->W = pl.num_windows, nb = ps->nb = pl.num_buckets;
     ps->cbits = pl.window_bits;
-    const size_t pairs = ps->pairs = (size_t)W * n, tb = ps->tb = (size_t)W * nb;
+    ps->tf = table_f ? table_f : 1u;
+    if (W % ps->tf) return fail(c, MSM_ERR_BAD_ARG, "internal: table factor %u does not divide %u windows", ps->tf, W);
+    ps->sW = W / ps->tf;
+    ps->sn = (size_t)ps->tf * n;
+    ps->top_shift = table_top_shift(pl, ps->tf);
+    ps->digit_off = 0;
+    const size_t pairs = ps->pairs = (size_t)W * n, tb = ps->tb = (size_t)ps->sW * nb;
     if (pairs > 0xFFFFFFFFull) return fail(c, MSM_ERR_BAD_ARG, "n*W = %zu does not fit 32-bit offsets", pairs);
-    ps->kb = ilog2(nb), ps->kb_lo = ps->kb / 2, ps->kb_hi = ps->kb - ps->kb_lo;  // bucket index = hi * n_lo + lo
+    ps->kb = ilog2(nb);
+    ps->pw_bits = ps->kb > 17 ? ps->kb - 16 : 0;  // up to 2^17 buckets the reduction kernels take an array whole
+    ps->rkb = ps->kb - ps->pw_bits;
+    ps->rW = ps->sW << ps->pw_bits;
+    if ((size_t)ps->rW * (ps->rkb + 1) > MAX_QSUM_POINTS) return fail(c, MSM_ERR_BAD_ARG, "window_bits %u: too many bit sums for the result buffer", ps->cbits);
+    ps->kb_lo = ps->rkb / 2, ps->kb_hi = ps->rkb - ps->kb_lo;  // bucket index inside a (pseudo-)window = hi * n_lo + lo
     ps->n_lo = 1u << ps->kb_lo, ps->n_hi = 1u << ps->kb_hi;
     const uint32_t ntiles = (uint32_t)((tb + msmk::SCAN_TILE - 1) / msmk::SCAN_TILE);
     // sorted entries folded by one k_accumulate thread: ~2^19 chunks per call (2.7 rounds of the 196608 threads that
@@ -309,10 +347,11 @@ int32_t pipe_prepare(msm_ctx* c, size_t n_real, size_t plan_n, uint32_t extra_fl
     // -- only where buckets are short, though: 2^14 points on c = 10 windows (64 entries per bucket) turn every bucket into a long one)
     // (round 2, after the planner moved 2^14 and 2^15 points to c = 16: one or two entries per bucket there, and L = 4 fills
     // twice the lanes: 2^14 0.329 -> 0.307 ms, 2^15 0.347 -> 0.341)
-    uint32_t chunk_len = (pairs <= ((size_t)1 << 17) || (pairs <= ((size_t)1 << 21) && n / nb <= 8)) ? (n / nb <= 2 && pairs > ((size_t)1 << 17) ? 4 : 8) : 16;
+    const size_t occ = ps->sn / nb;  // mean entries per bucket
+    uint32_t chunk_len = (pairs <= ((size_t)1 << 17) || (pairs <= ((size_t)1 << 21) && occ <= 8)) ? (occ <= 2 && pairs > ((size_t)1 << 17) ? 4 : 8) : 16;
     // ... and from there the chunk follows the mean bucket occupancy n/nb (32 at 2^20 unsplit, 64 with the GLV split: measured
     // 1.728 ms at L = 32 against 1.698 at 64), as long as ~2^17 chunks remain to fill the chip
-    while (chunk_len < 1024 && chunk_len < n / nb && pairs / (chunk_len * 2) >= 131072) chunk_len *= 2;
+    while (chunk_len < 1024 && chunk_len < occ && pairs / (chunk_len * 2) >= 131072) chunk_len *= 2;
     if (c->knobs.chunk_len) chunk_len = c->knobs.chunk_len;  // MSM_HIP_CHUNK_LEN at context creation (any value >= 1 is correct)
     ps->chunk_len = chunk_len;
     const size_t nchunks_max = ps->nchunks_max = (pairs + chunk_len - 1) / chunk_len;
@@ -339,107 +378,134 @@ int32_t pipe_prepare(msm_ctx* c, size_t n_real, size_t plan_n, uint32_t extra_fl
     return MSM_OK;
 }
 
-// K1b + K2 + chunk map of one (chunk of an) MSM on stream st: digits -> offsets / sorted / chunk owners.  Needs the scalars
-// (and the infinity mask), NOT the bases.  first = false: a later chunk of a streamed MSM (error bits and the running count
-// of additions survive).
-int32_t enqueue_sort(msm_ctx* c, const PipeState& ps, const uint8_t* d_inf, const uint32_t* d_scalars, uint32_t scalars_mont,
-                     hipStream_t st, bool first) {
-    Range r_("msm:decompose+sort");
-    int32_t rc;
-    const msm_plan_t& pl = ps.pl;
-    const size_t n = ps.n, n_real = ps.n_real, pairs = ps.pairs, tb = ps.tb;
-    const uint32_t W = ps.W, nb = ps.nb, cbits = ps.cbits, kb = ps.kb;
-    const uint32_t ntiles = (uint32_t)((tb + msmk::SCAN_TILE - 1) / msmk::SCAN_TILE);
-    uint32_t* hist = (uint32_t*)c->hist.p;
-    uint32_t* offsets = (uint32_t*)c->offsets.p;
-    uint32_t* flags = (uint32_t*)c->flags.p;
+// K1b: digits + signed recode of one (chunk of an) MSM on stream st (with the GLV split: two 127-bit halves per scalar, 2*n_real digit
+// columns).  Needs the scalars (and the infinity mask), NOT the bases.  first = false: a later chunk of a streamed MSM (error bits and
+// the running count of additions survive).
+struct SortGeom {  // counting-sort plan of (sW sort windows, sn entries each, nb buckets per window)
+    bool tiled = false, two_level = false, lds_counts = false;
+    uint32_t coarse_bits = 0, fine_bits = 0, idx_bits = 0, ncoarse = 0, NS = 0, nsuper = 1;
+};
+SortGeom sort_geometry(const msm_ctx* c, const PipeState& ps) {
+    SortGeom g;
+    const size_t sn = ps.sn;
+    const uint32_t kb = ps.kb;
     // Counting-sort plan: when one window's histogram fits LDS (nb <= 32768) the bucket counts and arrival
     // ranks come from per-tile LDS histograms, otherwise from device-scope atomics in k_decompose.
-    const bool tiled = (size_t)nb * 4 <= LDS_HIST_BYTES;
-    // two-level LDS sort: coarse = top bits of the bucket index, fine = the rest (<= 7 bits)
+    g.tiled = (size_t)ps.nb * 4 <= LDS_HIST_BYTES;
+    // two-level LDS sort: coarse = top bits of the bucket index, fine = the rest (<= 7 bits; up to 9 for windows of 2^18 and 2^19 buckets)
     // (8 coarse bits up to n = 2^21, then 9 and 10, so that a (window, coarse bin) region stays ~8192 elements and
     // fits the fine sort's LDS staging)
     uint32_t coarse_bits = 8;
-    while (coarse_bits < 10 && (n >> coarse_bits) > 8192) coarse_bits++;
-    if (kb > coarse_bits + 7) coarse_bits = std::min(10u, kb - 7);  // wide windows (up to 2^17 buckets): the fine part stays 7 bits
+    while (coarse_bits < 10 && (sn >> coarse_bits) > 8192) coarse_bits++;
+    if (kb > coarse_bits + 7) coarse_bits = std::min(10u, kb - 7);  // wide windows: the fine part stays 7 bits up to 2^17 buckets
     if (coarse_bits > kb) coarse_bits = kb;
-    const uint32_t fine_bits = kb - coarse_bits, idx_bits = 31 - fine_bits;
-    const uint32_t ncoarse = 1u << coarse_bits;
-    const bool two_level = fine_bits <= 7 && n <= ((size_t)1 << idx_bits) && !c->knobs.direct_scatter;
-    const bool lds_counts = two_level || tiled;  // no device-scope histogram / rank atomics in k_decompose
-    const uint32_t NS = (uint32_t)((n + msmk::SUBTILE - 1) / msmk::SUBTILE);
-    uint32_t T = 1, tile_len = (uint32_t)n;
-    c->last_sort_path = two_level ? 2u : tiled ? 1u : 0u;
-    if (!lds_counts && (rc = ensure(c, c->ranks, pairs * 4))) return rc;
-    if (two_level) {
-        if ((rc = ensure(c, c->bigslot, (size_t)W * ncoarse * 4))) return rc;
-        if ((rc = ensure(c, c->big, msmk::BIG_WORDS * 4))) return rc;
-        if ((rc = ensure(c, c->ccounts, (size_t)W * ncoarse * NS * 4))) return rc;
-        if ((rc = ensure(c, c->cregion, ((size_t)W * ncoarse * 2 + 2) * 4))) return rc;
-    } else if (tiled) {
-        T = (uint32_t)((n + 65535) / 65536);
-        if (T > 64) T = 64;
-        tile_len = (uint32_t)((n + T - 1) / T);
-        if ((rc = ensure(c, c->tilecounts, (size_t)W * T * nb * 4))) return rc;
-    } else {
-        HIPCHK(c, hipMemsetAsync(hist, 0, tb * 4, st));
-    }
+    g.coarse_bits = coarse_bits;
+    g.fine_bits = kb - coarse_bits;
+    g.idx_bits = 31 - g.fine_bits;
+    g.ncoarse = 1u << coarse_bits;
+    // a sort window longer than 2^idx_bits entries is cut into super-tiles whose number is recovered from an element's position (sort_hi)
+    g.nsuper = (uint32_t)((sn + ((size_t)1 << g.idx_bits) - 1) >> g.idx_bits);
+    if (g.nsuper == 0) g.nsuper = 1;
+    g.two_level = g.fine_bits <= 9 && g.nsuper <= msmk::SUPER_MAX && !c->knobs.direct_scatter;
+    g.lds_counts = g.two_level || g.tiled;  // no device-scope histogram / rank atomics in k_decompose
+    g.NS = (uint32_t)((sn + msmk::SUBTILE - 1) / msmk::SUBTILE);
+    return g;
+}
+
+int32_t enqueue_decompose(msm_ctx* c, const PipeState& ps, const uint8_t* d_inf, const uint32_t* d_scalars, uint32_t scalars_mont,
+                          hipStream_t st, bool first) {
+    Range r_("msm:decompose");
+    int32_t rc;
+    const msm_plan_t& pl = ps.pl;
+    const size_t n_real = ps.n_real, pairs = ps.pairs, tb = ps.tb;
+    const uint32_t W = ps.W, nb = ps.nb, cbits = ps.cbits;
+    uint32_t* hist = (uint32_t*)c->hist.p;
+    uint32_t* flags = (uint32_t*)c->flags.p;
+    const SortGeom sg = sort_geometry(c, ps);
+    if (!sg.lds_counts && ps.tf > 1) return fail(c, MSM_ERR_BAD_ARG, "window_bits %u: the window table needs the LDS sort paths", cbits);
+    if (!sg.lds_counts && (rc = ensure(c, c->ranks, pairs * 4))) return rc;
+    if (!sg.lds_counts) HIPCHK(c, hipMemsetAsync(hist, 0, tb * 4, st));
     // The flag words clean themselves (a hipMemsetAsync is its own dispatch: ~5 us + a ~12 us bubble in front of it, per call and per
     // streamed chunk): k_decompose zeroes the list counters of the chunk, the kernel that ends an MSM zeroes the error and count
     // words after copying them out.  Only a context whose last call did not complete (error paths) is cleaned from the host.
     if (first && !c->flags_clean) HIPCHK(c, hipMemsetAsync(flags, 0, 64, st));
     if (first) c->flags_clean = false;
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_CONVERT], st));
-    // K1b: digits + signed recode (with the GLV split: two 127-bit halves per scalar, 2*n_real digit columns)
-    {
-        uint32_t *dg = (uint32_t*)c->digits.p, *rk = (uint32_t*)c->ranks.p;
-        dim3 g = grid1(n_real, 256);
-        const uint32_t nr = (uint32_t)n_real;
-        if (pl.glv) {
-            if (!lds_counts) return fail(c, MSM_ERR_BAD_ARG, "window_bits %u needs the non-GLV path (MSM_FLAG_NO_GLV)", cbits);
-            if (pl.signed_digits) msmk::k_decompose_glv<true><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, dg, flags, scalars_mont);
-            else msmk::k_decompose_glv<false><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, dg, flags, scalars_mont);
-        } else if (pl.signed_digits && lds_counts) msmk::k_decompose<true, false><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, nb, hist, dg, rk, flags, scalars_mont);
-        else if (pl.signed_digits) msmk::k_decompose<true, true><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, nb, hist, dg, rk, flags, scalars_mont);
-        else if (lds_counts) msmk::k_decompose<false, false><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, nb, hist, dg, rk, flags, scalars_mont);
-        else msmk::k_decompose<false, true><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, nb, hist, dg, rk, flags, scalars_mont);
-    }
+    uint32_t *dg = (uint32_t*)c->digits.p, *rk = (uint32_t*)c->ranks.p;
+    dim3 g = grid1(n_real, 256);
+    const uint32_t nr = (uint32_t)n_real;
+    if (pl.glv) {
+        if (!sg.lds_counts) return fail(c, MSM_ERR_BAD_ARG, "window_bits %u needs the non-GLV path (MSM_FLAG_NO_GLV)", cbits);
+        if (pl.signed_digits) msmk::k_decompose_glv<true><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, dg, flags, scalars_mont, ps.top_shift);
+        else msmk::k_decompose_glv<false><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, dg, flags, scalars_mont, ps.top_shift);
+    } else if (pl.signed_digits && sg.lds_counts) msmk::k_decompose<true, false><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, nb, hist, dg, rk, flags, scalars_mont, ps.top_shift);
+    else if (pl.signed_digits) msmk::k_decompose<true, true><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, nb, hist, dg, rk, flags, scalars_mont, ps.top_shift);
+    else if (sg.lds_counts) msmk::k_decompose<false, false><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, nb, hist, dg, rk, flags, scalars_mont, ps.top_shift);
+    else msmk::k_decompose<false, true><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, nb, hist, dg, rk, flags, scalars_mont, ps.top_shift);
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_DECOMP], st));
-    if (two_level) {
-        const uint32_t nregions = W * ncoarse;
+    return MSM_OK;
+}
+
+// K2 + chunk map on stream st: the digits of ps.sW sort windows x ps.sn entries (from digits + ps.digit_off) -> offsets / sorted /
+// chunk owners.  into = true: the bucket array keeps what earlier chunks / window ranges of the same MSM left in it.
+int32_t enqueue_sort(msm_ctx* c, const PipeState& ps, hipStream_t st, bool into) {
+    Range r_("msm:sort");
+    int32_t rc;
+    const size_t sn = ps.sn, tb = ps.tb;
+    const uint32_t sW = ps.sW, nb = ps.nb;
+    const uint32_t ntiles = (uint32_t)((tb + msmk::SCAN_TILE - 1) / msmk::SCAN_TILE);
+    uint32_t* hist = (uint32_t*)c->hist.p;
+    uint32_t* offsets = (uint32_t*)c->offsets.p;
+    uint32_t* flags = (uint32_t*)c->flags.p;
+    const uint32_t* digits = (const uint32_t*)c->digits.p + ps.digit_off;
+    const SortGeom sg = sort_geometry(c, ps);
+    const uint32_t coarse_bits = sg.coarse_bits, fine_bits = sg.fine_bits, idx_bits = sg.idx_bits, ncoarse = sg.ncoarse, NS = sg.NS;
+    uint32_t T = 1, tile_len = (uint32_t)sn;
+    c->last_sort_path = sg.two_level ? 2u : sg.tiled ? 1u : 0u;
+    if (sg.two_level) {
+        if ((rc = ensure(c, c->bigslot, (size_t)sW * ncoarse * 4))) return rc;
+        if ((rc = ensure(c, c->big, msmk::BIG_WORDS * 4))) return rc;
+        if ((rc = ensure(c, c->ccounts, (size_t)sW * ncoarse * NS * 4))) return rc;
+        if ((rc = ensure(c, c->cregion, ((size_t)sW * ncoarse * 2 + 2) * 4))) return rc;
+        const uint32_t nregions = sW * ncoarse;
         uint32_t* counts = (uint32_t*)c->ccounts.p;
         uint32_t* rtotal = (uint32_t*)c->cregion.p;
         uint32_t* rstart = rtotal + nregions;
         uint32_t* tmp = (uint32_t*)c->heads.p;  // staging copy; k_accumulate only writes heads later
-        msmk::k_coarse_hist<<<dim3(NS, W), msmk::TILE_BLOCK, 0, st>>>((uint32_t*)c->digits.p, counts, (uint32_t)n, fine_bits, ncoarse, NS);
-        msmk::k_coarse_prefix<<<grid1(nregions, 256), 256, 0, st>>>(counts, rtotal, NS, ncoarse, nregions);
+        msmk::k_coarse_hist<<<dim3(NS, sW), msmk::TILE_BLOCK, 0, st>>>(digits, counts, (uint32_t)sn, fine_bits, ncoarse, NS, flags);
+        msmk::k_coarse_prefix<<<grid1(nregions, msmk::PREFIX_REGIONS), 1024, 0, st>>>(counts, rtotal, NS, ncoarse, nregions);
         // regions too large for one workgroup's staging area are cut into batches that worker blocks share (skewed scalars)
-        const uint32_t fine_block = (n >> coarse_bits) <= 1024 ? 256u : (n >> coarse_bits) <= 2048 ? 512u : 1024u;
+        uint32_t fine_block = (sn >> coarse_bits) <= 1024 ? 256u : (sn >> coarse_bits) <= 2048 ? 512u : 1024u;
+        if (fine_block < (1u << fine_bits)) fine_block = 512u;  // one thread per fine bin in the scans (8 and 9 fine bits)
         const uint32_t fine_cap = fine_block * 16u;
         uint32_t* bigslot = (uint32_t*)c->bigslot.p;
         uint32_t* big = (uint32_t*)c->big.p;
         msmk::k_coarse_starts<<<1, msmk::SCAN_BLOCK, 0, st>>>(rtotal, rstart, nregions, flags + msmk::FLAG_PAIRS, offsets + tb, bigslot, big, fine_cap);
-        msmk::k_coarse_scatter<<<dim3(NS, W), msmk::TILE_BLOCK, 0, st>>>((uint32_t*)c->digits.p, counts, rstart, tmp, (uint32_t)n, fine_bits,
-                                                                       idx_bits, ncoarse, NS);
+        msmk::k_coarse_scatter<<<dim3(NS, sW), msmk::TILE_BLOCK, 0, st>>>(digits, counts, rstart, tmp, (uint32_t)sn, fine_bits, idx_bits, ncoarse, NS);
         // workgroup size by mean region size (a workgroup stages up to 16 elements per thread); grid.x = the window's regions +
         // BIG_WORKERS_X worker blocks for the batches of oversized regions, which k_big_place then places
-        const dim3 gf(ncoarse + msmk::BIG_WORKERS_X, W), gp(msmk::BIG_WORKERS_X, W);
+        const uint32_t wx = std::max(msmk::BIG_WORKERS_X, (msmk::BIG_WORKERS_MIN + sW - 1) / sW);  // worker blocks per sort window
+        const dim3 gf(ncoarse + wx, sW), gp(wx, sW);
         uint32_t* srt = (uint32_t*)c->sorted.p;
+        const msmk::sort_hi hi{counts, NS, sg.nsuper, (uint32_t)(((size_t)1 << idx_bits) / msmk::SUBTILE)};
         if (fine_block == 256) {
-            msmk::k_fine_sort<256><<<gf, 256, 0, st>>>(tmp, rstart, offsets, srt, nb, fine_bits, idx_bits, ncoarse, bigslot, big);
-            msmk::k_big_place<256><<<gp, 256, 0, st>>>(tmp, rstart, offsets, srt, nb, fine_bits, idx_bits, ncoarse, bigslot, big);
+            msmk::k_fine_sort<256><<<gf, 256, 0, st>>>(tmp, rstart, offsets, srt, nb, fine_bits, idx_bits, ncoarse, bigslot, big, hi);
+            msmk::k_big_place<256><<<gp, 256, 0, st>>>(tmp, rstart, offsets, srt, nb, fine_bits, idx_bits, ncoarse, bigslot, big, hi);
         } else if (fine_block == 512) {  // (up to a mean of 2048: at 4096 the 512-thread variant is 1.5 us faster on uniform scalars only)
-            msmk::k_fine_sort<512><<<gf, 512, 0, st>>>(tmp, rstart, offsets, srt, nb, fine_bits, idx_bits, ncoarse, bigslot, big);
-            msmk::k_big_place<512><<<gp, 512, 0, st>>>(tmp, rstart, offsets, srt, nb, fine_bits, idx_bits, ncoarse, bigslot, big);
+            msmk::k_fine_sort<512><<<gf, 512, 0, st>>>(tmp, rstart, offsets, srt, nb, fine_bits, idx_bits, ncoarse, bigslot, big, hi);
+            msmk::k_big_place<512><<<gp, 512, 0, st>>>(tmp, rstart, offsets, srt, nb, fine_bits, idx_bits, ncoarse, bigslot, big, hi);
         } else {
-            msmk::k_fine_sort<1024><<<gf, 1024, 0, st>>>(tmp, rstart, offsets, srt, nb, fine_bits, idx_bits, ncoarse, bigslot, big);
-            msmk::k_big_place<1024><<<gp, 1024, 0, st>>>(tmp, rstart, offsets, srt, nb, fine_bits, idx_bits, ncoarse, bigslot, big);
+            msmk::k_fine_sort<1024><<<gf, 1024, 0, st>>>(tmp, rstart, offsets, srt, nb, fine_bits, idx_bits, ncoarse, bigslot, big, hi);
+            msmk::k_big_place<1024><<<gp, 1024, 0, st>>>(tmp, rstart, offsets, srt, nb, fine_bits, idx_bits, ncoarse, bigslot, big, hi);
         }
     } else {
         // K2/1: per-tile LDS histograms, then per-bucket prefix over tiles
-        if (tiled) {
-            msmk::k_tile_hist<<<dim3(T, W), msmk::TILE_BLOCK, (size_t)nb * 4, st>>>((uint32_t*)c->digits.p, (uint32_t*)c->tilecounts.p,
-                                                                                  (uint32_t)n, nb, tile_len, T);
+        if (sg.tiled) {
+            T = (uint32_t)((sn + 65535) / 65536);
+            if (T > 64) T = 64;
+            tile_len = (uint32_t)((sn + T - 1) / T);
+            if ((rc = ensure(c, c->tilecounts, (size_t)sW * T * nb * 4))) return rc;
+            msmk::k_tile_hist<<<dim3(T, sW), msmk::TILE_BLOCK, (size_t)nb * 4, st>>>(digits, (uint32_t*)c->tilecounts.p, (uint32_t)sn, nb, tile_len, T);
             msmk::k_tile_prefix<<<grid1(tb, 256), 256, 0, st>>>((uint32_t*)c->tilecounts.p, hist, nb, T, (uint32_t)tb);
         }
         // K2/2: bucket offsets
@@ -447,19 +513,27 @@ int32_t enqueue_sort(msm_ctx* c, const PipeState& ps, const uint8_t* d_inf, cons
         msmk::k_scan_block_sums<<<1, msmk::SCAN_BLOCK, 0, st>>>((uint32_t*)c->blocksums.p, ntiles, flags + msmk::FLAG_PAIRS);
         msmk::k_scan_add<<<grid1(tb, 256), 256, 0, st>>>(offsets, (uint32_t*)c->blocksums.p, (uint32_t)tb, flags + msmk::FLAG_PAIRS);
         // K2/3: scatter
-        if (tiled) {
-            msmk::k_tile_scatter<<<dim3(T, W), msmk::TILE_BLOCK, (size_t)nb * 4, st>>>((uint32_t*)c->digits.p, offsets, (uint32_t*)c->tilecounts.p,
-                                                                                     (uint32_t*)c->sorted.p, (uint32_t)n, nb, tile_len, T);
+        if (sg.tiled) {
+            msmk::k_tile_scatter<<<dim3(T, sW), msmk::TILE_BLOCK, (size_t)nb * 4, st>>>(digits, offsets, (uint32_t*)c->tilecounts.p,
+                                                                                      (uint32_t*)c->sorted.p, (uint32_t)sn, nb, tile_len, T);
         } else {
-            dim3 g((unsigned)((n + 255) / 256), W);
-            msmk::k_scatter<<<g, 256, 0, st>>>((uint32_t*)c->digits.p, (uint32_t*)c->ranks.p, offsets, (uint32_t*)c->sorted.p, (uint32_t)n, nb);
+            dim3 g((unsigned)((sn + 255) / 256), sW);
+            msmk::k_scatter<<<g, 256, 0, st>>>(digits, (uint32_t*)c->ranks.p, offsets, (uint32_t*)c->sorted.p, (uint32_t)sn, nb);
         }
     }
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_SORT], st));
     msmk::k_chunk_map<<<grid1(tb, 1024), 1024, 0, st>>>(offsets, (uint32_t*)c->chunkmap.p, (uint32_t)tb, ps.chunk_len, flags,
                                                       (uint32_t*)c->longlist.p, (uint32_t*)c->midlist.p, (uint32_t*)c->oncelist.p,
-                                                      (uint32_t*)c->buckets.p, first ? 0u : 1u);  // not the first chunk: accumulating INTO the buckets
+                                                      (uint32_t*)c->buckets.p, into ? 1u : 0u);  // accumulating INTO the buckets
     return MSM_OK;
+}
+
+// K1b + K2 of one (chunk of an) MSM: what every path without a window table queues before its accumulation
+int32_t enqueue_digits_sort(msm_ctx* c, const PipeState& ps, const uint8_t* d_inf, const uint32_t* d_scalars, uint32_t scalars_mont,
+                            hipStream_t st, bool first) {
+    int32_t rc = enqueue_decompose(c, ps, d_inf, d_scalars, scalars_mont, st, first);
+    if (rc) return rc;
+    return enqueue_sort(c, ps, st, !first);
 }
 
 // K3: bucket accumulation (the graded kernel) -- bracketed by its own events on its own stream -- and the buckets cut by chunk
@@ -496,7 +570,8 @@ int32_t enqueue_accumulate(msm_ctx* c, const PipeState& ps, const uint32_t* d_ba
 int32_t enqueue_reduce(msm_ctx* c, const PipeState& ps, hipStream_t st, uint32_t* h_qsums_dst, uint32_t* h_flags_dst) {
     Range r_("msm:reduce");
     const size_t tb = ps.tb;
-    const uint32_t W = ps.W, kb = ps.kb, kb_lo = ps.kb_lo, kb_hi = ps.kb_hi, n_lo = ps.n_lo, n_hi = ps.n_hi;
+    // (pseudo-)windows of 2^kb buckets: the whole bucket array of a window up to 2^17 buckets, 2^16-bucket slices of it above
+    const uint32_t W = ps.rW, kb = ps.rkb, kb_lo = ps.kb_lo, kb_hi = ps.kb_hi, n_lo = ps.n_lo, n_hi = ps.n_hi;
     uint32_t* flags = (uint32_t*)c->flags.p;
     const uint32_t* bk = (const uint32_t*)c->buckets.p;
     // ping-pong buffers per family: [0, tb/2) and [tb/2, tb/2 + tb/4) elements
@@ -548,32 +623,41 @@ int32_t enqueue_reduce(msm_ctx* c, const PipeState& ps, hipStream_t st, uint32_t
     return MSM_OK;
 }
 
-// final_reduction (metal_msm.rs:204-261) on the CPU.  With S_w = Q_all,w + sum_u 2^u Q_w,u the result is
-//     sum_w 2^(c*w) S_w = sum over bit positions p = c*w + u of 2^p * (Q_w,u  [+ Q_all,w when u == 0]),
-// ONE Horner chain over the ~254 positions (one doubling and about one addition per position) instead of the reference's
-// chain per window plus c doublings between windows (metal_msm.rs:249-258).  The chain is cut into a few segments of
-// geometrically shrinking length (a segment starting at position lo pays lo extra doublings to shift its sum), one per
-// host thread: 2 threads reach ~60 % of the serial time, 4 threads ~45 %, more add nothing because the shift of the top
-// segment is serial.  TWO threads by default: every further worker lowers the median by a few microseconds and raises the
-// MEAN through 2-8 ms outliers in ~1.3 % of the calls (busy hosts; a pool of 15: 2.5 %) -- tools/step_jitter.py.
+// final_reduction (metal_msm.rs:204-261) on the CPU.  The device returns, for every (pseudo-)window q of every bucket array v, the bit
+// sums Q_u (u < rkb: buckets whose index has bit u set) and the plain sum A.  With S_v = sum_b (b + 1) * B[v][b] and b = q * 2^rkb + b'
+//     S_v = sum_q [ A_q + sum_u 2^u Q_q,u ]  +  2^rkb * sum_q q * A_q          (second term: arrays cut into pseudo-windows only)
+// and the result is sum_v 2^(cbits * tf * v) S_v (tf windows share an array with a window table, tf = 1 without): ONE Horner chain
+// over the bit positions p = cbits*tf*v + u with the terms
+//     u < rkb:  sum_q Q_q,u   (+ sum_q A_q at u == 0);      rkb <= u < kb:  sum over {q : bit u-rkb of q set} of A_q
+// (one doubling and about one addition per position) instead of the reference's chain per window plus c doublings between windows
+// (metal_msm.rs:249-258).  The chain is cut into a few segments of geometrically shrinking length (a segment starting at position
+// lo pays lo extra doublings to shift its sum), one per host thread: 2 threads reach ~60 % of the serial time, 4 threads ~45 %, more
+// add nothing because the shift of the top segment is serial.  TWO threads by default: every further worker lowers the median by a
+// few microseconds and raises the MEAN through 2-8 ms outliers in ~1.3 % of the calls (busy hosts; a pool of 15: 2.5 %) --
+// tools/step_jitter.py.  With one shared bucket array (full window table) the chain is cbits - 1 positions long instead of 254.
 hostg1::Jac host_finish(msm_ctx* c, const uint32_t* h_qsums, const PipeState& g) {
     Range r_("msm:host_finish");
-    const uint32_t W = g.W, kb = g.kb, cbits = g.cbits;
-    const uint32_t npos = cbits * (W - 1) + (kb > 0 ? kb : 1);  // positions 0 .. npos-1 carry terms
+    const uint32_t V = g.sW, kb = g.kb, rkb = g.rkb, PW = 1u << g.pw_bits, spacing = g.cbits * g.tf;
+    const uint32_t npos = spacing * (V - 1) + (kb > 0 ? kb : 1);  // positions 0 .. npos-1 carry terms
+    auto qsum = [&](uint32_t v, uint32_t q, uint32_t u) { return hostg1::load_jac(h_qsums + ((size_t)(v * PW + q) * (rkb + 1) + u) * 24); };
     auto segment = [&](uint32_t lo, uint32_t hi) {             // sum over p in [lo, hi) of 2^p * term(p)
         hostg1::Jac acc = hostg1::identity();
         for (uint32_t p = hi; p-- > lo;) {
             acc = hostg1::jdbl(acc);
-            const uint32_t w = p / cbits, u = p % cbits;
-            const uint32_t* qw = h_qsums + (size_t)w * (kb + 1) * 24;
-            if (u < kb) acc = hostg1::jadd(acc, hostg1::load_jac(qw + (size_t)u * 24));
-            if (u == 0) acc = hostg1::jadd(acc, hostg1::load_jac(qw + (size_t)kb * 24));
+            const uint32_t v = p / spacing, u = p % spacing;
+            if (u < rkb)
+                for (uint32_t q = 0; q < PW; q++) acc = hostg1::jadd(acc, qsum(v, q, u));
+            else if (u < kb)
+                for (uint32_t q = 0; q < PW; q++)
+                    if ((q >> (u - rkb)) & 1u) acc = hostg1::jadd(acc, qsum(v, q, rkb));
+            if (u == 0)
+                for (uint32_t q = 0; q < PW; q++) acc = hostg1::jadd(acc, qsum(v, q, rkb));
         }
         for (uint32_t k = 0; k < lo; k++) acc = hostg1::jdbl(acc);
         return acc;
     };
     const int nseg = c->pool ? std::min<int>(c->pool->size() + 1, 8) : 1;
-    if (nseg == 1 || npos < 32) return segment(0, npos);
+    if (nseg == 1 || npos < 16) return segment(0, npos);
     // segment k has length proportional to 0.7^k (a doubling costs ~0.3 of a position's doubling + addition)
     uint32_t bound[9];
     double tot = 0, wgt = 1;
@@ -641,10 +725,40 @@ int32_t finish_sync(msm_ctx* c, const PipeState& ps, size_t n_total, hipStream_t
     return MSM_OK;
 }
 
-// The pipeline proper: everything in HBM, one stream.  d_bases: INTERNAL-domain packed coordinates.
+// K1b + K2 + K3 of a whole MSM whose inputs are in HBM, on stream st.  d_bases: INTERNAL-domain records (with a window table: the
+// table, record j * n + i = 2^(c*j) P_i).
+// A table MSM whose ONE shared bucket array would see more than ~2^24 entries in a single sort -- the regions of the fine sort hold
+// sn / 1024 entries and stage 16384 -- is cut into WINDOW RANGES: the digits are made once, then windows [j0, j1) are sorted and
+// accumulated INTO the shared array range after range (the entries of a window range are contiguous in the digits array and their
+// table records start at j0 * n: no kernel knows about it).
+constexpr size_t TABLE_SORT_MAX = (size_t)15 << 20;
+int32_t enqueue_body(msm_ctx* c, const PipeState& ps, const uint32_t* d_bases, const uint8_t* d_inf, const uint32_t* d_scalars,
+                     uint32_t scalars_mont, hipStream_t st, hipEvent_t bases_ready) {
+    int32_t rc;
+    if ((rc = enqueue_decompose(c, ps, d_inf, d_scalars, scalars_mont, st, true))) return rc;
+    if (ps.tf > 1 && ps.sW == 1 && ps.sn > TABLE_SORT_MAX && ps.n <= TABLE_SORT_MAX) {
+        const uint32_t per = (uint32_t)std::max<size_t>(1, TABLE_SORT_MAX / ps.n);  // windows per range
+        for (uint32_t j0 = 0; j0 < ps.tf; j0 += per) {
+            PipeState r = ps;
+            const uint32_t cnt = std::min(per, ps.tf - j0);
+            r.sn = (size_t)cnt * ps.n;
+            r.digit_off = (size_t)j0 * ps.n;
+            r.nchunks_max = (r.sn + r.chunk_len - 1) / r.chunk_len;
+            if ((rc = enqueue_sort(c, r, st, j0 > 0))) return rc;
+            if ((rc = enqueue_accumulate(c, r, d_bases + (size_t)j0 * ps.n * 16, st, j0 == 0 ? bases_ready : nullptr, j0 > 0, true))) return rc;
+        }
+        return MSM_OK;
+    }
+    if ((rc = enqueue_sort(c, ps, st, false))) return rc;
+    return enqueue_accumulate(c, ps, d_bases, st, bases_ready, false);
+}
+
+// The pipeline proper: everything in HBM, one stream.  d_bases: INTERNAL-domain packed coordinates (or the window table of the
+// resident set, table_f > 1: planned with table_c bits per window).
 int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, const uint32_t* d_scalars, size_t n,
                      hipStream_t st, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf, uint32_t scalars_mont = 0,
-                     hipEvent_t bases_ready = nullptr, uint32_t extra_flags = 0, PipeState* ps_out = nullptr) {
+                     hipEvent_t bases_ready = nullptr, uint32_t extra_flags = 0, PipeState* ps_out = nullptr, uint32_t table_c = 0,
+                     uint32_t table_f = 1) {
     PipeState ps;
     int32_t rc;
     // From 2^23 points a (window, coarse bin) region of the sort outgrows the fine sort's LDS staging (10 coarse bits at most) and
@@ -654,13 +768,13 @@ int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, 
     // 2^20 loses 0.5 ms, so smaller instances stay whole).
     const uint32_t dev_chunk_log2 = c->knobs.device_chunk_log2;  // (MSM_HIP_DEVICE_CHUNK_LOG2 at context creation; 0 = never cut)
     const size_t dchunk = dev_chunk_log2 ? (size_t)1 << dev_chunk_log2 : 0;
-    if (dchunk && n >= 2 * dchunk && !plan_glv(c, n, extra_flags)) {
+    if (table_f <= 1 && dchunk && n >= 2 * dchunk && !plan_glv(c, n, extra_flags)) {
         if ((rc = pipe_prepare(c, dchunk, n, extra_flags, st, &ps))) return rc;
         uint32_t nch = 0;
         for (size_t lo = 0; lo < n; lo += dchunk, nch++) {
             const size_t cnt = std::min(dchunk, n - lo);
             if ((rc = pipe_prepare(c, cnt, n, extra_flags, st, &ps))) return rc;
-            if ((rc = enqueue_sort(c, ps, d_inf ? d_inf + lo : nullptr, d_scalars + lo * 8, scalars_mont, st, lo == 0))) return rc;
+            if ((rc = enqueue_digits_sort(c, ps, d_inf ? d_inf + lo : nullptr, d_scalars + lo * 8, scalars_mont, st, lo == 0))) return rc;
             if ((rc = enqueue_accumulate(c, ps, d_bases + lo * 16, st, lo == 0 ? bases_ready : nullptr, lo > 0, true))) return rc;
         }
         if ((rc = enqueue_reduce(c, ps, st, c->h_qsums, c->h_flags))) return rc;
@@ -669,9 +783,8 @@ int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, 
         c->tm.stream_chunks = nch;
         return MSM_OK;
     }
-    if ((rc = pipe_prepare(c, n, 0, extra_flags, st, &ps))) return rc;
-    if ((rc = enqueue_sort(c, ps, d_inf, d_scalars, scalars_mont, st, true))) return rc;
-    if ((rc = enqueue_accumulate(c, ps, d_bases, st, bases_ready, false))) return rc;
+    if ((rc = pipe_prepare(c, n, 0, extra_flags, st, &ps, table_c, table_f))) return rc;
+    if ((rc = enqueue_body(c, ps, d_bases, d_inf, d_scalars, scalars_mont, st, bases_ready))) return rc;
     if ((rc = enqueue_reduce(c, ps, st, c->h_qsums, c->h_flags))) return rc;
     if (ps_out) *ps_out = ps;
     return finish_sync(c, ps, n, st, out_jac, out_aff, out_inf);
@@ -776,20 +889,20 @@ int32_t run_single(msm_ctx* c, const HostInput& in, size_t n, uint32_t* out_jac,
             if ((rc = feed_scalars(c, in, 0, n, c->scalars.p, nullptr, st))) return rc;
             if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_H2D], st));
             if (overlap) HIPCHK(c, hipStreamWaitEvent(st, c->ev_bases, 0));  // k_decompose reads the infinity bytes
-            if ((rc = enqueue_sort(c, ps, d_inf, (const uint32_t*)c->scalars.p, in.scalars_mont, st, true))) return rc;
+            if ((rc = enqueue_digits_sort(c, ps, d_inf, (const uint32_t*)c->scalars.p, in.scalars_mont, st, true))) return rc;
             if ((rc = enqueue_accumulate(c, ps, ib, st, nullptr, false))) return rc;
         } else {
             if ((rc = feed_scalars(c, in, 0, n, c->scalars.p, c->inf.p, st))) return rc;
             if (overlap) {
                 // queue the sort BEFORE the bases are touched: a copy from pageable memory blocks the host, the GPU sorts meanwhile
-                if ((rc = enqueue_sort(c, ps, d_inf, (const uint32_t*)c->scalars.p, in.scalars_mont, st, true))) return rc;
+                if ((rc = enqueue_digits_sort(c, ps, d_inf, (const uint32_t*)c->scalars.p, in.scalars_mont, st, true))) return rc;
                 if ((rc = feed_bases(c, in, 0, n, c->bases.p, ib, nullptr, glv, bs))) return rc;
                 HIPCHK(c, hipEventRecord(c->ev_bases, bs));
                 if ((rc = enqueue_accumulate(c, ps, ib, st, c->ev_bases, false))) return rc;
             } else {
                 if ((rc = feed_bases(c, in, 0, n, c->bases.p, ib, nullptr, glv, st))) return rc;
                 if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_H2D], st));
-                if ((rc = enqueue_sort(c, ps, d_inf, (const uint32_t*)c->scalars.p, in.scalars_mont, st, true))) return rc;
+                if ((rc = enqueue_digits_sort(c, ps, d_inf, (const uint32_t*)c->scalars.p, in.scalars_mont, st, true))) return rc;
                 if ((rc = enqueue_accumulate(c, ps, ib, st, nullptr, false))) return rc;
             }
         }
@@ -837,7 +950,7 @@ int32_t run_streamed(msm_ctx* c, const HostInput& in, size_t n, const std::vecto
         }
         HIPCHK(c, hipStreamWaitEvent(st, c->ev_copied[s], 0));
         if ((rc = pipe_prepare(c, cnt, n, 0, st, &ps))) return rc;
-        if ((rc = enqueue_sort(c, ps, d_inf, (const uint32_t*)c->sscalars[s].p, in.scalars_mont, st, j == 0))) return rc;
+        if ((rc = enqueue_digits_sort(c, ps, d_inf, (const uint32_t*)c->sscalars[s].p, in.scalars_mont, st, j == 0))) return rc;
         if ((rc = enqueue_accumulate(c, ps, (const uint32_t*)c->sibases[s].p, st, nullptr, j > 0, true))) return rc;
         HIPCHK(c, hipEventRecord(c->ev_free[s], st));
         lo += cnt;
@@ -891,13 +1004,34 @@ int32_t run_host_input(msm_ctx* c, const HostInput& in, size_t n, uint32_t* out_
     return MSM_OK;
 }
 
-// raw caller coordinates (host) -> c->bases (staging) -> the RESIDENT set c->rbases (internal domain)
+// The plan of resident calls on a set of n bases under this context: GLV split or not, and the window table (table_factor > 1 with
+// MSM_FLAG_WINDOW_TABLE).  Decided ONCE per upload; the calls that follow use what the upload stored.
+int32_t resident_plan(const msm_ctx* c, size_t n, msm_plan_t* pl) {
+    return msmplan::make_table_plan(n, c->cfg.window_bits, c->cfg.flags, pl, c->knobs.glv_max, c->knobs.table);
+}
+// levels 1 .. f-1 of the window table behind level 0 (the converted bases, nv records) in c->rbases, on the context's stream
+int32_t build_table_locked(msm_ctx* c, const msm_plan_t& pl) {
+    c->table_c = 0, c->table_f = 1;
+    if (pl.table_factor <= 1) return MSM_OK;
+    Range r_("msm:window_table");
+    const size_t nv = (size_t)pl.virtual_points;
+    uint32_t* t = (uint32_t*)c->rbases.p;
+    const uint32_t top_shift = table_top_shift(pl, pl.table_factor);
+    for (uint32_t j = 1; j < pl.table_factor; j++)  // (the top level of a full table: top_shift doublings fewer, see table_top_shift)
+        msmk::k_table_next<<<grid1(nv, 256), 256, 0, c->stream>>>(t + (size_t)(j - 1) * nv * 16, t + (size_t)j * nv * 16, (uint32_t)nv,
+                                                                 pl.window_bits - (j + 1 == pl.table_factor ? top_shift : 0u));
+    c->table_c = pl.window_bits, c->table_f = pl.table_factor;
+    return MSM_OK;
+}
+// raw caller coordinates (host) -> c->bases (staging) -> the RESIDENT set c->rbases (internal domain; + the window table)
 int32_t upload_resident_locked(msm_ctx* c, const uint32_t* bases_xy, uint32_t form, const uint8_t* inf_mask, size_t n) {
     if (form != MSM_FORM_STD && form != MSM_FORM_MONT) return fail(c, MSM_ERR_BAD_ARG, "unknown base_form %u", form);
     int32_t rc;
-    const bool glv = plan_glv(c, n);
+    msm_plan_t pl;
+    if ((rc = resident_plan(c, n, &pl))) return fail(c, rc, "bad window_bits/flags (%u, 0x%x)", c->cfg.window_bits, c->cfg.flags);
+    const bool glv = pl.glv != 0;
     if ((rc = ensure(c, c->bases, n * 64))) return rc;
-    if ((rc = ensure(c, c->rbases, (glv ? 2 : 1) * n * 64))) return rc;
+    if ((rc = ensure(c, c->rbases, (size_t)pl.table_factor * (glv ? 2 : 1) * n * 64))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->bases.p, bases_xy, n * 64, hipMemcpyHostToDevice, c->stream));
     if (inf_mask) {
         if ((rc = ensure(c, c->rinf, n))) return rc;
@@ -905,6 +1039,8 @@ int32_t upload_resident_locked(msm_ctx* c, const uint32_t* bases_xy, uint32_t fo
     }
     msmk::k_convert_bases<<<grid1(2 * n, 256), 256, 0, c->stream>>>((const uint32_t*)c->bases.p, (uint32_t*)c->rbases.p, (uint32_t)n,
                                                                   form == MSM_FORM_MONT ? 1u : 0u, glv ? 1u : 0u);
+    if ((rc = build_table_locked(c, pl))) return rc;
+    c->resident_glv = glv;
     return MSM_OK;
 }
 
@@ -1099,7 +1235,6 @@ int32_t msm_bn254_g1_upload_bases(msm_ctx* c, const uint32_t* bases_xy, uint32_t
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
     c->resident_n = n;
-    c->resident_glv = plan_glv(c, n);
     c->resident_has_inf = inf_mask != nullptr;
     return MSM_OK;
 }
@@ -1151,10 +1286,15 @@ int32_t msm_bn254_g1_upload_compressed(msm_ctx* c, const uint8_t* compressed, si
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
     c->resident_n = 0;
-    const bool glv = plan_glv(c, n);
-    if ((rc = ensure(c, c->rbases, (glv ? 2 : 1) * n * 64))) return rc;
+    msm_plan_t pl;
+    if ((rc = resident_plan(c, n, &pl))) return fail(c, rc, "bad window_bits/flags (%u, 0x%x)", c->cfg.window_bits, c->cfg.flags);
+    const bool glv = pl.glv != 0;
+    if ((rc = ensure(c, c->rbases, (size_t)pl.table_factor * (glv ? 2 : 1) * n * 64))) return rc;
     if ((rc = ensure(c, c->rinf, n))) return rc;
     if ((rc = decompress_locked(c, compressed, n, 0u, glv, (uint32_t*)c->rbases.p, (uint8_t*)c->rinf.p, first_invalid))) return rc;
+    if ((rc = build_table_locked(c, pl))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
     c->resident_n = n;
     c->resident_glv = glv;
     c->resident_has_inf = true;
@@ -1209,13 +1349,17 @@ static int32_t resident_on_lane(msm_ctx* w, const msm_ctx* owner, const uint32_t
     if ((rc = ensure(w, w->scalars, n * 32))) return rc;
     // the phi records sit at index resident_n + i: a call on fewer scalars (truncation) or a set uploaded without them runs unsplit
     const uint32_t extra = (owner->resident_glv && n == owner->resident_n) ? 0u : MSM_FLAG_NO_GLV;
+    // the window table (MSM_FLAG_WINDOW_TABLE) serves calls on the WHOLE resident set; a call on fewer scalars runs the plain pipeline
+    // on the first n records of T_0, which are the bases themselves
+    const bool use_table = owner->table_f > 1 && n == owner->resident_n;
+    const uint32_t tab_c = use_table ? owner->table_c : 0u, tab_f = use_table ? owner->table_f : 1u;
     const uint32_t* rb = (const uint32_t*)owner->rbases.p;
     const uint8_t* ri = owner->resident_has_inf ? (const uint8_t*)owner->rinf.p : nullptr;
     PipeState ps;
     if (!batch) {
         HIPCHK(w, hipMemcpyAsync(w->scalars.p, scalars, n * 32, hipMemcpyHostToDevice, w->stream));
         if (w->stage_timing) HIPCHK(w, hipEventRecord(w->ev[EV_H2D], w->stream));
-        rc = run_pipeline(w, rb, ri, (const uint32_t*)w->scalars.p, n, w->stream, out_jac, out_aff, out_inf, 0, nullptr, extra, &ps);
+        rc = run_pipeline(w, rb, ri, (const uint32_t*)w->scalars.p, n, w->stream, out_jac, out_aff, out_inf, 0, nullptr, extra, &ps, tab_c, tab_f);
         if (rc) return rc;
     } else {
         // Two MSMs in flight.  The pipelines must run in ANTI-phase: one uploads its scalars (DMA, 0.6 ms at 2^20) and finishes on
@@ -1246,9 +1390,8 @@ static int32_t resident_on_lane(msm_ctx* w, const msm_ctx* owner, const uint32_t
             if (shared) q = std::unique_lock<std::mutex>(o->batch_mu);
             if (w->stage_timing) HIPCHK(w, hipEventRecord(w->ev[EV_H2D], st));
             if (shared) HIPCHK(w, hipStreamWaitEvent(st, w->ev_fork, 0));
-            if ((rc = pipe_prepare(w, n, 0, extra, st, &ps))) return rc;
-            if ((rc = enqueue_sort(w, ps, ri, (const uint32_t*)w->scalars.p, 0, st, true))) return rc;
-            if ((rc = enqueue_accumulate(w, ps, rb, st, nullptr, false))) return rc;
+            if ((rc = pipe_prepare(w, n, 0, extra, st, &ps, tab_c, tab_f))) return rc;
+            if ((rc = enqueue_body(w, ps, rb, ri, (const uint32_t*)w->scalars.p, 0, st, nullptr))) return rc;
             if ((rc = enqueue_reduce(w, ps, st, w->h_qsums, w->h_flags))) return rc;
             if (shared) HIPCHK(w, hipEventRecord(w->ev_bases, st));
         }
@@ -1371,7 +1514,9 @@ int32_t msm_bn254_g1_combine(const uint32_t* partials, size_t k, uint32_t out_ja
 int32_t msm_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_plan_t* out) {
     if (!out) return MSM_ERR_BAD_ARG;
     if (n == 0) return MSM_ERR_EMPTY;
-    return make_plan(n, window_bits, flags, out, msmplan::glv_max_from_env());  // what a context created NOW would plan (no context here)
+    // what a context created NOW would plan (no context here)
+    if (flags & MSM_FLAG_WINDOW_TABLE) return msmplan::make_table_plan(n, window_bits, flags, out, msmplan::glv_max_from_env(), Knobs::from_env().table);
+    return make_plan(n, window_bits, flags, out, msmplan::glv_max_from_env());
 }
 
 int32_t msm_get_timings(const msm_ctx* c, msm_timings_t* out) {

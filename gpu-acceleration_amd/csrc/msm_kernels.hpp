@@ -286,6 +286,30 @@ __global__ void k_decompress(const uint32_t* __restrict__ rec, uint32_t n, uint3
 }
 
 // ---------------------------------------------------------------------------------------------
+// Row f4: the WINDOW TABLE of a resident base set.  T_0 = the bases, T_j[i] = 2^(c*j) * P_i for j < f.
+// A digit of window w = v*f + j then adds  +-T_j[i]  into bucket array v, whose weight is 2^(c*f*v): the f windows of a group share
+// ONE bucket array, and with f = W every window shares the same one -- which is what allows windows of 20 bits (2^19 buckets) at
+// 2^20 points: 13 windows instead of 16, 19 % fewer mixed additions, one array of buckets to reduce.  The reference names this
+// family of techniques under "advanced algorithms" (README.md:192-196); its cost model (utils/window_size_optimizer.rs:38-51,
+// (n + 2^(s+1)) * ceil(lambda/s)) is what the table changes: the 2^(s+1) term is paid once, not once per window.
+// One thread per record: c doublings (XYZZ, dbl-2008-s-1) and one inversion back to affine; run once per upload and level.
+__global__ void __launch_bounds__(256) k_table_next(const uint32_t* __restrict__ prev, uint32_t* __restrict__ next, uint32_t nv, uint32_t c) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nv) return;
+    const affine a = load_affine(prev + (size_t)i * 16);
+    xyzz t = xyzz_dbl_affine(a);
+#pragma unroll 1
+    for (uint32_t k = 1; k < c; k++) t = xyzz_dbl(t);
+    affine r;
+    (void)xyzz_to_affine(t, r);  // a base at infinity (masked out by its digits) or a garbage record gives (0, 0): never read
+    uint32_t w[8];
+    fp_pack(w, fp_reduce_lt2p(r.x));
+    store_words8(next + (size_t)i * 16, w);
+    fp_pack(w, fp_reduce_lt2p(r.y));
+    store_words8(next + (size_t)i * 16 + 8, w);
+}
+
+// ---------------------------------------------------------------------------------------------
 // K1 scalar half + K2 phase 1.  One thread per point: slice the scalar into W radix-2^c digits,
 // recode to signed digits d in [-(H-1), H] (v > H  =>  d = v - 2H, carry 1), and count the bucket.
 // bits [off, off+c) of a 256-bit little-endian scalar
@@ -339,7 +363,7 @@ template <bool SIGNED, bool HIST>
 __global__ void k_decompose(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_mask, uint32_t n,
                             uint32_t c, uint32_t W, uint32_t nb, uint32_t* __restrict__ hist,
                             uint32_t* __restrict__ digits, uint32_t* __restrict__ ranks, uint32_t* __restrict__ err,
-                            uint32_t scalars_mont) {
+                            uint32_t scalars_mont, uint32_t top_shift) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) err[FLAG_LONG] = 0, err[FLAG_MID] = 0, err[FLAG_ONCE] = 0;  // list counters of this (chunk of an) MSM: k_chunk_map fills them later in the stream
     if (i >= n) return;
@@ -364,6 +388,10 @@ __global__ void k_decompose(const uint32_t* __restrict__ scalars, const uint8_t*
             }
         }
         size_t o = (size_t)w * n + i;
+        // window table with one shared bucket array: the short top window (14 bits of 20 at c = 20) would pile its digits into the
+        // lowest buckets -- 32 of the sort's 1024 regions.  Its table level is 2^(c*(W-1) - top_shift) P instead, and the digit goes in
+        // as d * 2^top_shift: the same group element, spread over every 2^top_shift-th bucket
+        if (w == W - 1) mag <<= top_shift;
         if (mag == 0 || skip) {
             digits[o] = DIGIT_SKIP;
         } else {
@@ -388,7 +416,8 @@ __device__ __forceinline__ uint32_t window128(const uint32_t s[4], uint32_t off,
 // digits: W x 2n, window-major.
 template <bool SIGNED>
 __global__ void k_decompose_glv(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_mask, uint32_t n, uint32_t c,
-                                uint32_t W, uint32_t* __restrict__ digits, uint32_t* __restrict__ err, uint32_t scalars_mont) {
+                                uint32_t W, uint32_t* __restrict__ digits, uint32_t* __restrict__ err, uint32_t scalars_mont,
+                                uint32_t top_shift) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) err[FLAG_LONG] = 0, err[FLAG_MID] = 0, err[FLAG_ONCE] = 0;  // list counters of this (chunk of an) MSM: k_chunk_map fills them later in the stream
     if (i >= n) return;
@@ -419,6 +448,7 @@ __global__ void k_decompose_glv(const uint32_t* __restrict__ scalars, const uint
                     carry = 0;
                 }
             }
+            if (w == W - 1) mag <<= top_shift;  // (window table, shared bucket array: see k_decompose)
             digits[(size_t)w * row + (size_t)h * n + i] = (mag == 0 || skip) ? DIGIT_SKIP : ((mag - 1) | (neg ? SIGN_BIT : 0u));
         }
         if (SIGNED && carry) atomicOr(err, 2u);
@@ -586,9 +616,13 @@ __device__ __forceinline__ uint32_t lds_inc(uint32_t* ctr, uint32_t key) {
 }
 
 __global__ void __launch_bounds__(TILE_BLOCK) k_coarse_hist(const uint32_t* __restrict__ digits, uint32_t* __restrict__ counts,
-                                                            uint32_t n, uint32_t fine_bits, uint32_t ncoarse, uint32_t NS) {
+                                                            uint32_t n, uint32_t fine_bits, uint32_t ncoarse, uint32_t NS,
+                                                            uint32_t* __restrict__ flags) {
     __shared__ uint32_t s_h[COARSE_BINS_MAX];
     const uint32_t st = blockIdx.x, w = blockIdx.y;
+    // list counters of THIS sort call (k_chunk_map fills them later in the stream): k_decompose zeroes them too, but a window-table MSM
+    // cut into window ranges decomposes once and sorts several times
+    if (st == 0 && w == 0 && threadIdx.x == 0) flags[FLAG_LONG] = 0, flags[FLAG_MID] = 0, flags[FLAG_ONCE] = 0;
     if (threadIdx.x < COARSE_BINS_MAX) s_h[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t i0 = st * SUBTILE, i1 = min(n, i0 + SUBTILE);
@@ -606,21 +640,41 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_coarse_hist(const uint32_t* __re
     __syncthreads();
     if (threadIdx.x < ncoarse) counts[((size_t)w * NS + st) * ncoarse + threadIdx.x] = s_h[threadIdx.x];  // [w][sub-tile][bin]
 }
-// per (window, bin): exclusive prefix over the sub-tiles in place; total of the region.  Threads of a wavefront own
-// consecutive bins, so every step reads one coalesced row of counts[w][sub-tile][*]
-__global__ void k_coarse_prefix(uint32_t* __restrict__ counts, uint32_t* __restrict__ region_total, uint32_t NS, uint32_t ncoarse,
-                                uint32_t nregions) {
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nregions) return;
-    const uint32_t w = r / ncoarse, b = r % ncoarse;
+// per (window, bin): exclusive prefix over the sub-tiles in place; total of the region.  One 1024-thread workgroup per PREFIX_REGIONS
+// consecutive regions: thread (segment, region) sums its SEGMENT of the sub-tiles (consecutive threads own consecutive regions: every
+// step reads 64-byte runs of counts[w][sub-tile][*]), the segment totals meet in LDS, a second pass writes the prefixes.  (Round 2:
+// one thread per region walked all NS sub-tiles alone -- 64 dependent steps at 2^20 points, 832 with the 13 x 2^20 entries of a
+// window-table MSM: 0.3 ms of latency on four workgroups.)
+constexpr uint32_t PREFIX_REGIONS = 16, PREFIX_SEGS = 1024 / PREFIX_REGIONS;
+__global__ void __launch_bounds__(1024) k_coarse_prefix(uint32_t* __restrict__ counts, uint32_t* __restrict__ region_total, uint32_t NS,
+                                                        uint32_t ncoarse, uint32_t nregions) {
+    __shared__ uint32_t s_seg[PREFIX_SEGS][PREFIX_REGIONS + 1];
+    const uint32_t rl = threadIdx.x % PREFIX_REGIONS, sg = threadIdx.x / PREFIX_REGIONS;
+    const uint32_t r = blockIdx.x * PREFIX_REGIONS + rl;
+    const bool live = r < nregions;
+    const uint32_t w = live ? r / ncoarse : 0u, b = live ? r % ncoarse : 0u;
     uint32_t* p = counts + (size_t)w * NS * ncoarse + b;
-    uint32_t run = 0;
-    for (uint32_t s = 0; s < NS; s++) {
-        uint32_t v = p[(size_t)s * ncoarse];
-        p[(size_t)s * ncoarse] = run;
-        run += v;
+    const uint32_t per = (NS + PREFIX_SEGS - 1) / PREFIX_SEGS;
+    const uint32_t s0 = min(NS, sg * per), s1 = min(NS, s0 + per);
+    uint32_t sum = 0;
+    if (live)
+        for (uint32_t s = s0; s < s1; s++) sum += p[(size_t)s * ncoarse];
+    s_seg[sg][rl] = sum;
+    __syncthreads();
+    uint32_t run = 0, tot = 0;
+    for (uint32_t k = 0; k < PREFIX_SEGS; k++) {
+        const uint32_t v = s_seg[k][rl];
+        if (k < sg) run += v;
+        tot += v;
     }
-    region_total[r] = run;
+    if (live) {
+        for (uint32_t s = s0; s < s1; s++) {
+            const uint32_t v = p[(size_t)s * ncoarse];
+            p[(size_t)s * ncoarse] = run;
+            run += v;
+        }
+        if (sg == 0) region_total[r] = tot;
+    }
 }
 // single workgroup: exclusive scan of the region totals (any count) -> region_start[0..nregions], grand total
 // OVERSIZED regions (skewed scalars: one bucket holds a large share of a window, e.g. the ones of a witness vector) used to be
@@ -628,12 +682,14 @@ __global__ void k_coarse_prefix(uint32_t* __restrict__ counts, uint32_t* __restr
 // that extra workgroups share: k_coarse_starts lists them, the worker blocks of k_fine_sort count every batch into the region's
 // global fine histogram, k_big_place turns the histogram into bucket offsets and places every batch (one global cursor add per
 // bucket and batch).  `big` layout (u32): [0] items listed (may exceed BIG_MAX_ITEMS: regions that did not fit keep their owner),
-// [1] table slots used, [16 ..) BIG_MAX_ITEMS x (region, batch), then per slot 128 counts + 128 cursors.
+// [1] table slots used, [16 ..) BIG_MAX_ITEMS x (region, batch), then per slot BIG_SLOT_WORDS = 512 counts + 512 cursors.
 constexpr uint32_t BIG_NONE = 0xFFFFFFFFu;
 constexpr uint32_t BIG_MAX_ITEMS = 4096;
-constexpr uint32_t BIG_WORKERS_X = 16;  // worker blocks per window row (grid.y = W)
+constexpr uint32_t BIG_WORKERS_X = 16;  // worker blocks per window row (grid.y = sort windows), at least BIG_WORKERS_MIN in all
+constexpr uint32_t BIG_WORKERS_MIN = 128;
 constexpr uint32_t BIG_ITEMS_OFF = 16, BIG_TAB_OFF = BIG_ITEMS_OFF + 2 * BIG_MAX_ITEMS;
-constexpr size_t BIG_WORDS = (size_t)BIG_TAB_OFF + (size_t)BIG_MAX_ITEMS * 256;
+constexpr uint32_t BIG_SLOT_WORDS = 1024;  // == 2 * FINE_BINS_MAX: counts, then cursors, of up to 512 fine bins
+constexpr size_t BIG_WORDS = (size_t)BIG_TAB_OFF + (size_t)BIG_MAX_ITEMS * BIG_SLOT_WORDS;
 
 __global__ void k_coarse_starts(const uint32_t* __restrict__ region_total, uint32_t* __restrict__ region_start, uint32_t nregions,
                                 uint32_t* __restrict__ total_out, uint32_t* __restrict__ offsets_end, uint32_t* __restrict__ bigslot,
@@ -665,7 +721,6 @@ __global__ void k_coarse_starts(const uint32_t* __restrict__ region_total, uint3
                             big[BIG_ITEMS_OFF + 2 * (ib + z)] = base + k;
                             big[BIG_ITEMS_OFF + 2 * (ib + z) + 1] = z;
                         }
-                        for (uint32_t q = 0; q < 256; q++) big[BIG_TAB_OFF + (size_t)slot * 256 + q] = 0;
                     }
                 }
                 bigslot[base + k] = slot;
@@ -679,6 +734,9 @@ __global__ void k_coarse_starts(const uint32_t* __restrict__ region_total, uint3
         *total_out = running;    // number of sorted entries (non-zero digits)
         *offsets_end = running;  // offsets[W * nb]
     }
+    __syncthreads();  // big[1] is final: the whole workgroup clears the count / cursor tables of the slots in use
+    const uint32_t nslots = min(big[1], BIG_MAX_ITEMS);
+    for (size_t q = threadIdx.x; q < (size_t)nslots * BIG_SLOT_WORDS; q += blockDim.x) big[BIG_TAB_OFF + q] = 0;
 }
 __global__ void __launch_bounds__(TILE_BLOCK) k_coarse_scatter(const uint32_t* __restrict__ digits, const uint32_t* __restrict__ counts,
                                                                const uint32_t* __restrict__ region_start, uint32_t* __restrict__ tmp,
@@ -739,36 +797,87 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_coarse_scatter(const uint32_t* _
         const uint32_t i = i0 + threadIdx.x + k * TILE_BLOCK;
         uint32_t bkt = d & ~SIGN_BIT;
         uint32_t pos = lds_inc(s_cur, bkt >> fine_bits);
-        s_stage[pos] = i | ((bkt & fine_mask) << idx_bits) | (d & SIGN_BIT);
+        s_stage[pos] = (i & ((1u << idx_bits) - 1u)) | ((bkt & fine_mask) << idx_bits) | (d & SIGN_BIT);
     }
     __syncthreads();
-    // copy-out: a wavefront takes a bin at a time and writes its run with consecutive lanes on consecutive words
-    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (uint32_t b = wv; b < ncoarse; b += TILE_BLOCK / 64) {
+    // copy-out: a group of gw lanes takes a bin at a time and writes its run with consecutive lanes on consecutive words.  gw follows
+    // the mean run length SUBTILE / ncoarse: a whole wavefront per bin with 256 bins (runs of 64), 16 lanes with 1024 bins (runs of
+    // 16: a wavefront per bin left three quarters of its lanes idle through 64 trips -- 52 us for the 13.6 M entries of a table MSM)
+    const uint32_t gw = ncoarse <= 256 ? 64u : ncoarse <= 512 ? 32u : 16u;
+    const uint32_t gl = threadIdx.x % gw, grp = threadIdx.x / gw, ngrp = TILE_BLOCK / gw;
+    for (uint32_t b = grp; b < ncoarse; b += ngrp) {
         const uint32_t ls = s_lstart[b], le = s_lstart[b + 1], gb = s_gbase[b];
-        for (uint32_t k = ls + lane; k < le; k += 64) tmp[gb + (k - ls)] = s_stage[k];
+        for (uint32_t k = ls + gl; k < le; k += gw) tmp[gb + (k - ls)] = s_stage[k];
     }
 }
 constexpr int FINE_PER_THREAD = 16;  // elements that live in registers between the two phases
+constexpr uint32_t FINE_BINS_MAX = 512;  // fine part of the bucket index: up to 9 bits (windows of 2^19 buckets: 10 coarse + 9 fine)
+constexpr uint32_t SUPER_MAX = 16;       // super-tiles of 2^idx_bits elements a sort window may span
+static_assert(BIG_SLOT_WORDS == 2 * FINE_BINS_MAX, "oversized-region tables hold counts + cursors of every fine bin");
+// An element travels through the staging array as  (position in its sort window) mod 2^idx_bits | fine << idx_bits | sign << 31 with
+// idx_bits = 31 - fine_bits.  A sort window longer than 2^idx_bits elements (the shared bucket array of a window table: 13 x 2^20
+// entries with 9 fine bits) is cut into SUPER-TILES of 2^idx_bits elements; the dropped high bits of the position are recovered from
+// where the element sits in its region: k_coarse_scatter lays a region out sub-tile after sub-tile, so the region's elements of
+// super-tile h are exactly the positions [bnd[h-1], bnd[h]) with bnd[h] = counts[w][(h+1) * sub_per_super][bin] -- the exclusive prefix
+// k_coarse_prefix left there.  nsuper - 1 <= 15 comparisons per element, no extra bytes.
+struct sort_hi {
+    const uint32_t* counts;  // [w][sub-tile][bin] prefixes (k_coarse_prefix)
+    uint32_t NS;             // sub-tiles per sort window
+    uint32_t nsuper;         // super-tiles per sort window (1 = positions fit idx_bits: nothing to recover)
+    uint32_t sub_per_super;  // 2^idx_bits / SUBTILE
+};
+// called by the whole workgroup (barrier inside): boundaries of region (w, cb) into s_bnd
+__device__ __forceinline__ void sort_hi_load(const sort_hi& hi, uint32_t w, uint32_t cb, uint32_t ncoarse, uint32_t* s_bnd) {
+    if (hi.nsuper <= 1) return;  // uniform
+    __syncthreads();
+    if (threadIdx.x + 1 < hi.nsuper) s_bnd[threadIdx.x] = hi.counts[((size_t)w * hi.NS + (size_t)(threadIdx.x + 1) * hi.sub_per_super) * ncoarse + cb];
+    __syncthreads();
+}
+__device__ __forceinline__ uint32_t sort_hi_of(const sort_hi& hi, const uint32_t* s_bnd, uint32_t pos, uint32_t idx_bits) {
+    uint32_t h = 0;
+    for (uint32_t k = 0; k + 1 < hi.nsuper; k++) h += pos >= s_bnd[k] ? 1u : 0u;  // uniform trip count
+    return h << idx_bits;
+}
+// exclusive prefix over the first nfine <= FINE_BINS_MAX threads' values (the rest pass 0); whole workgroup, blockDim >= nfine
+__device__ __forceinline__ uint32_t fine_scan(uint32_t cnt, uint32_t* s_wtot /* [FINE_BINS_MAX / 64] */) {
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    uint32_t x = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t y = __shfl_up(x, d, 64);
+        if (lane >= (uint32_t)d) x += y;
+    }
+    if (lane == 63 && wv < FINE_BINS_MAX / 64) s_wtot[wv] = x;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t k = 0; k < wv && k < FINE_BINS_MAX / 64; k++) base += s_wtot[k];
+    __syncthreads();
+    return base + x - cnt;
+}
 // FINE_BLOCK threads stage up to FINE_BLOCK * 16 elements: 1024 threads (16384 elements, 64 KB of LDS) for the regions of a
 // large instance, 256 threads (4096 elements) when regions only hold a few hundred elements -- a 1024-thread workgroup
-// costs its dispatch and barriers whatever it sorts, and below 2^18 points those were most of this kernel's time
+// costs its dispatch and barriers whatever it sorts, and below 2^18 points those were most of this kernel's time.
+// nfine = 2^fine_bits <= FINE_BINS_MAX fine bins; FINE_BLOCK >= nfine (the host picks the block).
 template <int FINE_BLOCK>
 __global__ void __launch_bounds__(FINE_BLOCK) k_fine_sort(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ region_start,
                                                           uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted, uint32_t nb,
                                                           uint32_t fine_bits, uint32_t idx_bits, uint32_t ncoarse,
-                                                          const uint32_t* __restrict__ bigslot, uint32_t* __restrict__ big) {
-    __shared__ uint32_t s_cur[128];
+                                                          const uint32_t* __restrict__ bigslot, uint32_t* __restrict__ big, sort_hi hi) {
+    __shared__ uint32_t s_cur[FINE_BINS_MAX];
+    __shared__ uint32_t s_wtot[FINE_BINS_MAX / 64];
+    __shared__ uint32_t s_bnd[SUPER_MAX];
     constexpr uint32_t CAP = (uint32_t)FINE_BLOCK * FINE_PER_THREAD;
     __shared__ uint32_t s_out[CAP];
+    const uint32_t nfine = 1u << fine_bits;
     if (blockIdx.x >= ncoarse) {  // worker block: count the batches of oversized regions into their global fine histograms
-        const uint32_t nitems = min(big[0], BIG_MAX_ITEMS), fmask = (1u << fine_bits) - 1u;
-        for (uint32_t it = (blockIdx.x - ncoarse) + BIG_WORKERS_X * blockIdx.y; it < nitems; it += BIG_WORKERS_X * gridDim.y) {
+        const uint32_t nitems = min(big[0], BIG_MAX_ITEMS), fmask = nfine - 1u;
+        const uint32_t wx = gridDim.x - ncoarse;  // worker blocks per window row
+        for (uint32_t it = (blockIdx.x - ncoarse) + wx * blockIdx.y; it < nitems; it += wx * gridDim.y) {
             const uint32_t rr = big[BIG_ITEMS_OFF + 2 * it], z = big[BIG_ITEMS_OFF + 2 * it + 1];
             if (rr == BIG_NONE) continue;  // uniform
             const uint32_t b0 = region_start[rr] + z * CAP, b1 = min(region_start[rr + 1], b0 + CAP);
             __syncthreads();
-            if (threadIdx.x < 128) s_cur[threadIdx.x] = 0;
+            for (uint32_t f = threadIdx.x; f < nfine; f += FINE_BLOCK) s_cur[f] = 0;
             __syncthreads();
             uint32_t eb[FINE_PER_THREAD];
 #pragma unroll
@@ -780,18 +889,19 @@ __global__ void __launch_bounds__(FINE_BLOCK) k_fine_sort(const uint32_t* __rest
             for (int k = 0; k < FINE_PER_THREAD; k++)
                 if (eb[k] != DIGIT_SKIP) lds_inc(s_cur, (eb[k] >> idx_bits) & fmask);
             __syncthreads();
-            if (threadIdx.x < 128 && s_cur[threadIdx.x]) atomicAdd(&big[BIG_TAB_OFF + (size_t)bigslot[rr] * 256 + threadIdx.x], s_cur[threadIdx.x]);
+            for (uint32_t f = threadIdx.x; f < nfine; f += FINE_BLOCK)
+                if (s_cur[f]) atomicAdd(&big[BIG_TAB_OFF + (size_t)bigslot[rr] * BIG_SLOT_WORDS + f], s_cur[f]);
         }
         return;
     }
     const uint32_t cb = blockIdx.x, w = blockIdx.y;
-    const uint32_t nfine = 1u << fine_bits;
     const uint32_t r = w * ncoarse + cb;
     if (bigslot[r] != BIG_NONE) return;  // oversized region: its batches are shared out to the worker blocks (uniform per workgroup)
     const uint32_t rs = region_start[r], re = region_start[r + 1], S = re - rs;
     const uint32_t fine_mask = nfine - 1u, idx_mask = (1u << idx_bits) - 1u;
     const bool staged = S <= CAP;
-    if (threadIdx.x < 128) s_cur[threadIdx.x] = 0;
+    for (uint32_t f = threadIdx.x; f < nfine; f += FINE_BLOCK) s_cur[f] = 0;
+    sort_hi_load(hi, w, cb, ncoarse, s_bnd);
     __syncthreads();
     uint32_t e[FINE_PER_THREAD];
     if (staged) {  // the whole region in registers: FINE_PER_THREAD independent loads per thread
@@ -816,23 +926,9 @@ __global__ void __launch_bounds__(FINE_BLOCK) k_fine_sort(const uint32_t* __rest
         }
     }
     __syncthreads();
-    // exclusive prefix of the <= 128 fine counts: the first two wavefronts scan 64 counts each with shuffles, one barrier
-    // joins them (a Hillis-Steele scan in LDS cost this kernel 14 workgroup barriers of 1024 threads)
-    __shared__ uint32_t s_half;
-    uint32_t ex = 0;
-    if (threadIdx.x < 128) {
-        const uint32_t lane = threadIdx.x & 63u, cnt = s_cur[threadIdx.x];
-        uint32_t x = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t y = __shfl_up(x, d, 64);
-            if (lane >= (uint32_t)d) x += y;
-        }
-        if (threadIdx.x == 63) s_half = x;  // total of the first 64 counts
-        ex = x - cnt;
-    }
-    __syncthreads();
-    if (threadIdx.x >= 64 && threadIdx.x < 128) ex += s_half;
+    // exclusive prefix of the <= 512 fine counts: every wavefront scans its 64 counts with shuffles, the wavefront totals are joined
+    // through LDS (a Hillis-Steele scan in LDS cost this kernel 14 workgroup barriers of 1024 threads)
+    const uint32_t ex = fine_scan(threadIdx.x < nfine ? s_cur[threadIdx.x] : 0u, s_wtot);
     if (threadIdx.x < nfine) {
         s_cur[threadIdx.x] = ex;                                                       // local cursor
         offsets[(size_t)w * nb + ((size_t)cb << fine_bits) + threadIdx.x] = rs + ex;  // the bucket's CSC column pointer
@@ -843,7 +939,7 @@ __global__ void __launch_bounds__(FINE_BLOCK) k_fine_sort(const uint32_t* __rest
         for (int k = 0; k < FINE_PER_THREAD; k++) {
             if (e[k] == DIGIT_SKIP) continue;
             uint32_t pos = lds_inc(s_cur, (e[k] >> idx_bits) & fine_mask);
-            s_out[pos] = (e[k] & idx_mask) | (e[k] & SIGN_BIT);
+            s_out[pos] = ((e[k] & idx_mask) + sort_hi_of(hi, s_bnd, threadIdx.x + k * FINE_BLOCK, idx_bits)) | (e[k] & SIGN_BIT);
         }
         __syncthreads();
         for (uint32_t k = threadIdx.x; k < S; k += FINE_BLOCK) sorted[rs + k] = s_out[k];
@@ -859,7 +955,7 @@ __global__ void __launch_bounds__(FINE_BLOCK) k_fine_sort(const uint32_t* __rest
             for (int k = 0; k < FINE_PER_THREAD; k++) {
                 if (e[k] == DIGIT_SKIP) continue;
                 uint32_t pos = lds_inc(s_cur, (e[k] >> idx_bits) & fine_mask);
-                sorted[rs + pos] = (e[k] & idx_mask) | (e[k] & SIGN_BIT);
+                sorted[rs + pos] = ((e[k] & idx_mask) + sort_hi_of(hi, s_bnd, base - rs + threadIdx.x + k * FINE_BLOCK, idx_bits)) | (e[k] & SIGN_BIT);
             }
         }
     }
@@ -871,31 +967,24 @@ template <int FINE_BLOCK>
 __global__ void __launch_bounds__(FINE_BLOCK) k_big_place(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ region_start,
                                                           uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted, uint32_t nb,
                                                           uint32_t fine_bits, uint32_t idx_bits, uint32_t ncoarse,
-                                                          const uint32_t* __restrict__ bigslot, uint32_t* __restrict__ big) {
+                                                          const uint32_t* __restrict__ bigslot, uint32_t* __restrict__ big, sort_hi hi) {
     constexpr uint32_t CAP = (uint32_t)FINE_BLOCK * FINE_PER_THREAD;
-    __shared__ uint32_t s_ex[128], s_cnt[128], s_base[128], s_half;
+    __shared__ uint32_t s_ex[FINE_BINS_MAX], s_cnt[FINE_BINS_MAX], s_base[FINE_BINS_MAX], s_wtot[FINE_BINS_MAX / 64], s_bnd[SUPER_MAX];
     const uint32_t nitems = min(big[0], BIG_MAX_ITEMS);
     const uint32_t nfine = 1u << fine_bits, fmask = nfine - 1u, idx_mask = (1u << idx_bits) - 1u;
-    for (uint32_t it = blockIdx.x + BIG_WORKERS_X * blockIdx.y; it < nitems; it += BIG_WORKERS_X * gridDim.y) {
+    for (uint32_t it = blockIdx.x + gridDim.x * blockIdx.y; it < nitems; it += gridDim.x * gridDim.y) {
         const uint32_t rr = big[BIG_ITEMS_OFF + 2 * it], z = big[BIG_ITEMS_OFF + 2 * it + 1];
         if (rr == BIG_NONE) continue;  // uniform
-        uint32_t* tab = big + BIG_TAB_OFF + (size_t)bigslot[rr] * 256;
+        uint32_t* tab = big + BIG_TAB_OFF + (size_t)bigslot[rr] * BIG_SLOT_WORDS;
         const uint32_t r0 = region_start[rr], b0 = r0 + z * CAP, b1 = min(region_start[rr + 1], b0 + CAP);
         __syncthreads();
-        if (threadIdx.x < 128) {  // exclusive prefix of the region's 128 bucket counts (two wavefronts, shuffle scans)
-            const uint32_t lane = threadIdx.x & 63u, cnt = tab[threadIdx.x];
-            uint32_t x = cnt;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                uint32_t y = __shfl_up(x, d, 64);
-                if (lane >= (uint32_t)d) x += y;
-            }
-            if (threadIdx.x == 63) s_half = x;
-            s_ex[threadIdx.x] = x - cnt;
+        sort_hi_load(hi, rr / ncoarse, rr % ncoarse, ncoarse, s_bnd);
+        // exclusive prefix of the region's bucket counts
+        const uint32_t ex = fine_scan(threadIdx.x < nfine ? tab[threadIdx.x] : 0u, s_wtot);
+        if (threadIdx.x < nfine) {
+            s_ex[threadIdx.x] = ex;
             s_cnt[threadIdx.x] = 0;
         }
-        __syncthreads();
-        if (threadIdx.x >= 64 && threadIdx.x < 128) s_ex[threadIdx.x] += s_half;
         __syncthreads();
         if (z == 0 && threadIdx.x < nfine)  // the first batch publishes the buckets' CSC column pointers
             offsets[(size_t)(rr / ncoarse) * nb + ((size_t)(rr % ncoarse) << fine_bits) + threadIdx.x] = r0 + s_ex[threadIdx.x];
@@ -909,10 +998,10 @@ __global__ void __launch_bounds__(FINE_BLOCK) k_big_place(const uint32_t* __rest
         for (int k = 0; k < FINE_PER_THREAD; k++)
             if (eb[k] != DIGIT_SKIP) lds_inc(s_cnt, (eb[k] >> idx_bits) & fmask);
         __syncthreads();
-        if (threadIdx.x < 128) {
+        if (threadIdx.x < nfine) {
             const uint32_t cn = s_cnt[threadIdx.x];
-            s_base[threadIdx.x] = cn ? atomicAdd(&tab[128 + threadIdx.x], cn) : 0u;  // this batch's slice of every bucket
-            s_cnt[threadIdx.x] = 0;                                                   // becomes the local cursor
+            s_base[threadIdx.x] = cn ? atomicAdd(&tab[FINE_BINS_MAX + threadIdx.x], cn) : 0u;  // this batch's slice of every bucket
+            s_cnt[threadIdx.x] = 0;                                                             // becomes the local cursor
         }
         __syncthreads();
 #pragma unroll
@@ -920,7 +1009,7 @@ __global__ void __launch_bounds__(FINE_BLOCK) k_big_place(const uint32_t* __rest
             if (eb[k] == DIGIT_SKIP) continue;
             const uint32_t f = (eb[k] >> idx_bits) & fmask;
             const uint32_t pos = r0 + s_ex[f] + s_base[f] + lds_inc(s_cnt, f);
-            sorted[pos] = (eb[k] & idx_mask) | (eb[k] & SIGN_BIT);
+            sorted[pos] = ((eb[k] & idx_mask) + sort_hi_of(hi, s_bnd, b0 - r0 + threadIdx.x + k * FINE_BLOCK, idx_bits)) | (eb[k] & SIGN_BIT);
         }
     }
 }
@@ -1026,10 +1115,23 @@ __global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__
     bool is_head = offsets[k] < j0;  // the first bucket of this chunk began in an earlier chunk
     xyzz acc = xyzz_identity();
     if (INTO && !is_head) acc = load_xyzz(buckets + (size_t)k * XW);
-    // software pipeline: the 64-byte record of entry j+1 (and the index of entry j+2) are in flight while entry j
-    // is folded.  Only ONE raw record is kept: it is unpacked to 29-bit limbs before the next gather is issued.
+    // Software pipeline: the 64-byte record of entry j+1, the index of entry j+2 and a bucket end two buckets ahead are in flight
+    // while entry j is folded.  Only ONE raw record is kept: it is unpacked to 29-bit limbs before the next gather is issued.
+    // Round 3: every one of these loads is UNCONDITIONAL and is issued at the top of the iteration, IN FRONT of the bucket switch and
+    // its stores (the last entry of a chunk fetches its own record once more, indices are clamped).  gfx950 counts loads and stores
+    // with ONE in-order counter (vmcnt): a wait on any load also waits for every memory instruction issued before it.  The compiler
+    // used to close the conditional prefetch with register copies of the freshly loaded words (s_waitcnt vmcnt(1) a few instructions
+    // after the gather was issued, in every iteration), and the bucket switch waited for offsets[k + 1] -- and with it for the gather
+    // issued just before, then for its own nine 16-byte stores.  That put the whole memory latency on the critical path of the
+    // wavefront in ~9 of 10 iterations (some lane switches buckets); with a window table (832 MB of records instead of 64 MB that live
+    // in the Infinity Cache) that latency is HBM's.  Now a switch reads registers only -- seg_end and end1 = offsets[k + 2] are kept
+    // one bucket ahead, refilled from the load `ahead` = offsets[k + 3] of the iteration before -- and the only waits sit at the top
+    // of an iteration, one whole mixed addition after everything was issued.
     uint32_t e_cur = sorted[j0];
-    uint32_t e_nxt = j0 + 1 < j1 ? sorted[j0 + 1] : 0u;
+    uint32_t e_nxt = sorted[min(j0 + 1, j1 - 1)];
+    uint32_t end1 = offsets[min(k + 2, total_buckets)];  // seg_end of the bucket after this one
+    uint32_t ahead = 0;                                     // offsets[k + 3] as of the previous iteration: the next end1 after a switch
+    bool switched = false;
     uint4 g[4];
     {
         const uint4* bp = reinterpret_cast<const uint4*>(bases + (size_t)(e_cur & ~SIGN_BIT) * 16);
@@ -1045,17 +1147,20 @@ __global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__
             q.y = fp_unpack(wy);
         }
         if (e_cur & SIGN_BIT) q.y = fp_neg_raw<2>(q.y);  // raw: only ever a multiplier in xyzz_madd
-        uint32_t e_nn = 0;
-        if (j + 1 < j1) {
+        if (switched) end1 = ahead;                      // the previous iteration moved to bucket k: its offsets[k_old + 3] is offsets[k + 2]
+        {
             const uint4* bp = reinterpret_cast<const uint4*>(bases + (size_t)(e_nxt & ~SIGN_BIT) * 16);
 #pragma unroll
             for (int i = 0; i < 4; i++) g[i] = bp[i];
-            if (j + 2 < j1) e_nn = sorted[j + 2];
         }
+        const uint32_t e_nn = sorted[min(j + 2, j1 - 1)];
+        ahead = offsets[min(k + 3, total_buckets)];
+        switched = false;
         if (j == seg_end) {  // bucket k is finished: flush and move to the bucket that owns entry j
             store_xyzz((is_head ? heads + (size_t)t * XW : buckets + (size_t)k * XW), acc);
             k++;
-            seg_end = offsets[k + 1];
+            seg_end = end1;  // == offsets[k + 1]
+            switched = true;
             if (seg_end <= j) {  // empty buckets follow: binary-search the bucket that owns entry j (skewed scalars
                                  // leave thousands of empty buckets between two occupied ones)
                 uint32_t lo = k + 1, hi = total_buckets - 1;
@@ -1066,6 +1171,11 @@ __global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__
                 }
                 k = lo;
                 seg_end = offsets[k + 1];
+                end1 = offsets[min(k + 2, total_buckets)];
+                switched = false;  // `ahead` belongs to the bucket we left
+                // the rare path waits for its own loads HERE: left pending, they make the compiler wait at the join below -- on the
+                // common path too, where that wait covers the gather and the stores just issued
+                asm volatile("" ::"v"(seg_end), "v"(end1));
             }
             is_head = false;
             if (INTO) acc = load_xyzz(buckets + (size_t)k * XW);

@@ -59,7 +59,7 @@ inline size_t glv_max_from_env() {
     return GLV_MAX_POINTS;
 }
 inline int32_t make_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_plan_t* out, size_t glv_max = GLV_MAX_POINTS) {
-    if (flags & ~(MSM_FLAG_UNSIGNED_DIGITS | MSM_FLAG_NO_GLV)) return MSM_ERR_BAD_ARG;
+    if (flags & ~(MSM_FLAG_UNSIGNED_DIGITS | MSM_FLAG_NO_GLV | MSM_FLAG_WINDOW_TABLE)) return MSM_ERR_BAD_ARG;
     bool is_signed = !(flags & MSM_FLAG_UNSIGNED_DIGITS);
     bool use_glv = !(flags & MSM_FLAG_NO_GLV) && n <= glv_max;
     uint32_t c = window_bits ? window_bits : (use_glv ? plan_window_bits_glv(n, is_signed) : plan_window_bits(n, is_signed));
@@ -78,6 +78,46 @@ inline int32_t make_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_pla
     size_t pairs = (size_t)out->num_windows * nv;
     size_t tb = (size_t)out->num_windows * out->num_buckets;
     out->workspace_bytes = nv * 64 + n * (32 + 1) + pairs * 12 + tb * (8 + 144) + tb * 144 * 3 / 2;
+    out->table_factor = 1;
+    out->bucket_arrays = out->num_windows;
+    out->table_bytes = 0;
+    return MSM_OK;
+}
+
+// ---- the window table of a RESIDENT base set (MSM_FLAG_WINDOW_TABLE): T_j[i] = 2^(c*j) P_i, j < f.
+// The f windows of a group add into ONE bucket array; with f = W (the default here) every window shares the same array, so the
+// 2^(c-1) buckets are reduced once per MSM instead of once per window -- the reference's cost model (window_size_optimizer.rs:38-51:
+// (n + 2^(s+1)) * ceil(lambda/s)) loses its per-window bucket term and the optimum moves to wider windows: c = 20 at 2^20 points
+// (13 windows instead of 16: 19 % fewer additions).  Widths whose top window is only 1-2 bits wide (254 mod c: c = 18, 21) are skipped
+// as in plan_window_bits; above 20 bits the LDS sort no longer covers a window.  Memory: f * (n or 2n) * 64 bytes.
+struct table_knobs {
+    uint32_t c = 0, f = 0;                // MSM_HIP_TABLE_C / MSM_HIP_TABLE_F: force the width / the factor (0 = planner)
+    size_t max_bytes = (size_t)64 << 30;  // MSM_HIP_TABLE_MAX_GB: no table beyond this
+};
+inline uint32_t plan_table_bits(size_t nv, bool glv) {
+    // nv = sorted points per window (2n with the GLV split).  Provisional thresholds, re-measured on the GPU (profiles/r3_f4_*.txt)
+    if (glv) return nv <= ((size_t)1 << 15) ? 10u : 16u;
+    return nv <= ((size_t)1 << 17) ? 16u : nv <= ((size_t)1 << 18) ? 17u : nv <= ((size_t)1 << 19) ? 19u : 20u;
+}
+// plan of a resident call on all n points of a set uploaded under `flags` (window_bits: the context's forced width or 0).  Without
+// MSM_FLAG_WINDOW_TABLE, with plain digits, or when the table would not fit: the ordinary plan, table_factor 1.
+inline int32_t make_table_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_plan_t* out, size_t glv_max, const table_knobs& tk) {
+    int32_t rc = make_plan(n, window_bits, flags, out, glv_max);
+    if (rc != MSM_OK || !(flags & MSM_FLAG_WINDOW_TABLE) || (flags & MSM_FLAG_UNSIGNED_DIGITS)) return rc;
+    const bool glv0 = out->glv != 0;
+    uint32_t c = tk.c ? tk.c : window_bits ? window_bits : plan_table_bits((size_t)out->virtual_points, glv0);
+    msm_plan_t t;
+    if (make_plan(n, c, flags, &t, glv_max) != MSM_OK) return rc;  // (a forced width out of range: keep the ordinary plan)
+    uint32_t f = tk.f ? tk.f : t.num_windows;
+    if (f < 2 || t.num_windows % f) return rc;
+    const uint64_t bytes = (uint64_t)f * t.virtual_points * 64;
+    if (bytes > tk.max_bytes) return rc;
+    t.table_factor = f;
+    t.bucket_arrays = t.num_windows / f;
+    t.table_bytes = bytes;
+    const size_t tb = (size_t)t.bucket_arrays * t.num_buckets, pairs = (size_t)t.num_windows * (size_t)t.virtual_points;
+    t.workspace_bytes = bytes + n * (32 + 1) + pairs * 12 + tb * (8 + 144) + tb * 144 * 3 / 2;
+    *out = t;
     return MSM_OK;
 }
 

@@ -22,6 +22,7 @@ LIB_PATH = os.environ.get("MSM_HIP_LIB") or os.path.join(os.path.dirname(_HERE),
 FORM_STD, FORM_MONT = 0, 1
 FLAG_UNSIGNED_DIGITS = 1
 FLAG_NO_GLV = 2
+FLAG_WINDOW_TABLE = 4  # resident sets carry their window table
 OK, ERR_EMPTY, ERR_BAD_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_STATE, ERR_INVALID_DATA = 0, -1, -2, -3, -4, -5, -6, -7
 
 # every symbol include/msm_hip.h declares (checked by tests/test_abi.py)
@@ -55,7 +56,8 @@ class Config(C.Structure):
 class Plan(C.Structure):
     _fields_ = [("window_bits", C.c_uint32), ("num_windows", C.c_uint32), ("num_buckets", C.c_uint32),
                 ("signed_digits", C.c_uint32), ("workspace_bytes", C.c_uint64), ("virtual_points", C.c_uint64),
-                ("glv", C.c_uint32), ("scalar_bits", C.c_uint32)]
+                ("glv", C.c_uint32), ("scalar_bits", C.c_uint32), ("table_factor", C.c_uint32), ("bucket_arrays", C.c_uint32),
+                ("table_bytes", C.c_uint64)]
 
 
 class Timings(C.Structure):

@@ -102,11 +102,15 @@ class HooksContext(MsmContext):
         kb = nb.bit_length() - 1
         d = StageDump()
         d.plan, d.W, d.nb, d.nv, d.kb = p, W, nb, nv, kb
+        # bucket arrays (= windows without a window table), table factor, pseudo-windows of the reduction (arrays above 2^17 buckets)
+        d.V, d.tf = int(p.bucket_arrays), int(p.table_factor)
+        d.pw_bits = kb - 16 if kb > 17 else 0
+        d.rkb = kb - d.pw_bits
         d.digits = np.zeros((W, nv), np.uint32)
-        d.offsets = np.zeros(W * nb + 1, np.uint32)
+        d.offsets = np.zeros(d.V * nb + 1, np.uint32)
         d.sorted = np.zeros(W * nv, np.uint32)
-        d.buckets = np.zeros((W * nb, 24), np.uint32) if want_buckets else None
-        d.bit_sums = np.zeros((W, kb + 1, 24), np.uint32)
+        d.buckets = np.zeros((d.V * nb, 24), np.uint32) if want_buckets else None
+        d.bit_sums = np.zeros((d.V << d.pw_bits, d.rkb + 1, 24), np.uint32)
         d.jacobian = np.zeros(24, np.uint32)
         sp, bi = C.c_uint32(0), C.c_uint32(0)
         infp = None

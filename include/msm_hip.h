@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MSM_HIP_ABI_VERSION 2u
+#define MSM_HIP_ABI_VERSION 3u
 
 /* status codes */
 #define MSM_OK 0
@@ -55,6 +55,16 @@ extern "C" {
 #define MSM_FLAG_UNSIGNED_DIGITS 1u /* plain radix-2^c digits, 2^c-1 buckets/window (BASELINE config "fixed 16-bit window") */
 #define MSM_FLAG_NO_GLV 2u          /* do not split scalars with the curve endomorphism (csrc/glv_bn254.hpp); the default splits
                                        k = k1 + lambda*k2, |k_j| < 2^127: 2N points phi-extended, half the windows        */
+
+#define MSM_FLAG_WINDOW_TABLE 4u     /* msm_bn254_g1_upload_bases / _upload_compressed also precompute the
+                                       WINDOW TABLE of the resident set, T_j[i] = 2^(c*j) P_i for every window j (c doublings and one
+                                       inversion per record, once per upload), and msm_bn254_g1_resident / _resident_batch on the whole
+                                       set add a digit of window j as +-T_j[i] into ONE bucket array shared by all windows: the buckets are
+                                       reduced once per MSM instead of once per window, which moves the optimum to wider windows (c = 20
+                                       at 2^20 points: 13 windows instead of 16, 19 % fewer additions, a 19-position host chain instead of
+                                       254).  Memory: W x 64 bytes per (virtual) point -- 832 MB at 2^20 -- see msm_plan_t.table_bytes.
+                                       Every other entry point, and a resident call on fewer scalars than bases, is unaffected.
+                                       Results are the same group element either way (bit-exact affine coordinates).            */
 
 typedef struct msm_ctx msm_ctx;
 
@@ -81,6 +91,9 @@ typedef struct {
     uint64_t virtual_points; /* points each window sorts and accumulates: n, or 2n with the GLV split       */
     uint32_t glv;            /* 1 = scalars are split with the endomorphism                                  */
     uint32_t scalar_bits;    /* bits the windows cover: 254, or 127 with GLV                                 */
+    uint32_t table_factor;   /* f: window-table levels per base (MSM_FLAG_WINDOW_TABLE); 1 = no table        */
+    uint32_t bucket_arrays;  /* num_windows / table_factor bucket arrays of num_buckets buckets each         */
+    uint64_t table_bytes;    /* HBM the window table of the resident set takes (0 without one)               */
 } msm_plan_t;
 
 /* per-stage device times of the last call on this context, milliseconds (hipEvent) */
@@ -217,6 +230,8 @@ int32_t msm_multi_get_timings(const msm_multi *m, int32_t g, msm_timings_t *out)
 int32_t msm_multi_get_exchange_stats(const msm_multi *m, float *exchange_ms, float *shard_ms, int32_t nshard);
 
 /* ---- introspection --------------------------------------------------------------------------- */
+/* the plan of a call on n points under (window_bits, flags); with MSM_FLAG_WINDOW_TABLE in flags: the plan of a RESIDENT call on a
+ * set of n bases uploaded under those flags (window width, table factor, table memory) */
 int32_t msm_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_plan_t *out);
 int32_t msm_get_timings(const msm_ctx *ctx, msm_timings_t *out);
 /* per-stage hipEvents are OFF by default (every record costs ~6 us of stream time); when off, the stage fields of

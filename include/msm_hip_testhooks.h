@@ -56,6 +56,11 @@ int32_t msm_calibrate(msm_ctx *ctx, double *mad_per_s, double *fp_mul_per_s);
  *        sorted      W x nv     first offsets[W*nb] entries valid: virtual point index | negate << 31, grouped by bucket
  *        buckets     W*nb x 24  bucket sums, Jacobian Montgomery words (bucket b of window w holds the digit magnitude b + 1)
  *        bit_sums    W x (kb+1) x 24   Q_{w,u} (u < kb: buckets whose index has bit u set) and Q_{w,kb} = all buckets
+ *      With MSM_FLAG_WINDOW_TABLE in the context's flags the RESIDENT path runs (upload + window table, then the resident
+ *      pipeline): V = msm_plan_t.bucket_arrays arrays instead of W windows -- offsets V*nb + 1, buckets V*nb x 24, sorted entries are
+ *      TABLE indices j*nv + i (window j of the group, virtual point i).  Arrays of more than 2^17 buckets are reduced as
+ *      P = 2^(kb-16) pseudo-windows of 2^16 buckets: bit_sums then is (V*P) x 17 x 24 (Q_u over the index INSIDE the slice, u < 16,
+ *      and the slice's plain sum).
  *      sort_path (nullable) receives 2 = two-level LDS sort, 1 = tiled LDS histogram, 0 = global-atomic fallback;
  *      big_items (nullable) the number of (region, batch) items of oversized sort regions handed to k_big_place. */
 int32_t msm_test_stage_dump(msm_ctx *ctx, const uint32_t *bases_xy, uint32_t base_form, const uint8_t *inf_mask,

@@ -312,6 +312,12 @@ void oracle_fq_inv_mont(const uint32_t a[8], uint32_t out[8]) { fq x; fq_load(&x
 
 /* ------------------------------------------------------------- C API: G1 --- */
 void oracle_g1_dbl(const uint32_t a[24], uint32_t out[24]) { jac p; jac_load(&p, a); jac_dbl(&p, &p); jac_store(out, &p); }
+/* 2^k * a: k doublings (the window-table levels T_j = 2^(c*j) P of the engine's resident path, row f4; checker only) */
+void oracle_g1_dbl_n(const uint32_t a[24], uint32_t k, uint32_t out[24]) {
+    jac p; jac_load(&p, a);
+    for (uint32_t i = 0; i < k; i++) jac_dbl(&p, &p);
+    jac_store(out, &p);
+}
 void oracle_g1_add(const uint32_t a[24], const uint32_t b[24], uint32_t out[24]) {
     jac p, q, r; jac_load(&p, a); jac_load(&q, b); jac_add(&r, &p, &q); jac_store(out, &r);
 }

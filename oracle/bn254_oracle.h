@@ -59,6 +59,7 @@ void oracle_fq_inv_mont(const uint32_t a[8], uint32_t out[8]); /* a, out Montgom
 
 /* ---- G1 Jacobian, Montgomery words, identity has Z = 0 -------------------- */
 void oracle_g1_dbl(const uint32_t a[24], uint32_t out[24]);
+void oracle_g1_dbl_n(const uint32_t a[24], uint32_t k, uint32_t out[24]); /* 2^k * a */
 void oracle_g1_add(const uint32_t a[24], const uint32_t b[24], uint32_t out[24]);
 void oracle_g1_madd(const uint32_t a[24], const uint32_t b_xy_mont[16], uint32_t out[24]);
 /* Jacobian (Montgomery) -> canonical affine standard-form words; returns 1 for infinity */

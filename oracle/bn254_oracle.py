@@ -50,6 +50,7 @@ def lib():
         L.oracle_gen_scalars.argtypes = [C.c_uint64, C.c_size_t, C.c_int, _u32p]
         L.oracle_gen_bases_from_logs.argtypes = [_u32p, C.c_size_t, C.c_uint32, _u32p]
         L.oracle_g1_to_affine_std.restype = C.c_int
+        L.oracle_g1_dbl_n.argtypes = [_u32p, C.c_uint32, _u32p]
         L.oracle_g1_decompress.argtypes = [_u8p, C.c_size_t, C.c_uint32, _u32p, _u8p]
         L.oracle_g1_decompress.restype = C.c_size_t
         L.oracle_g1_compress.argtypes = [_u32p, C.c_uint32, _u8p, C.c_size_t, _u8p]
@@ -113,6 +114,11 @@ def fq_sub(a, b): return _bin(lib().oracle_fq_sub, a, b)
 # ---- group ---------------------------------------------------------------------
 def g1_dbl(a):
     a = _w(a); o = np.zeros(24, np.uint32); lib().oracle_g1_dbl(_p32(a), _p32(o)); return o
+
+
+def g1_dbl_n(a, k):
+    """2^k * a"""
+    a = _w(a); o = np.zeros(24, np.uint32); lib().oracle_g1_dbl_n(_p32(a), int(k), _p32(o)); return o
 
 
 def g1_add(a, b):

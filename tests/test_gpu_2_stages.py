@@ -8,7 +8,9 @@ Counterparts of the reference's per-kernel tests:
                                                of the non-zero digits grouped by bucket, signs preserved
   accumulate tests/cuzk/smvp.rs:119-303        bucket sums == oracle_bucket_sums (SMVP sign folding, smvp.metal:46-105)
   reduce     tests/cuzk/pbpr.rs:26-247         bit sums == oracle_bit_sums; Horner over them == the MSM
-on the two-level LDS sort, the tiled-histogram fallback, the global-atomic fallback and an oversized region (k_big_place)."""
+on the two-level LDS sort, the tiled-histogram fallback, the global-atomic fallback and an oversized region (k_big_place); and on
+the resident path's WINDOW TABLE (row f4: bucket arrays shared by the windows of a group, table indices in `sorted`, 2^19-bucket
+arrays sorted with super-tiles and reduced as 2^16-bucket slices)."""
 import numpy as np
 import pytest
 
@@ -121,14 +123,150 @@ def test_stages_tiled_fallback(monkeypatch):
     check_buckets_and_bits(d, g["bases"], orc.FORM_STD, ds, g["inf"], g["expected"])
 
 
-def test_stages_global_atomic_fallback():
-    """c = 19: 2^18 buckets per window do not fit an LDS histogram -> device-scope atomics in k_decompose + k_scatter.
+def test_stages_wide_windows_two_level():
+    """c = 19: 2^18 buckets per window.  Round 3: the two-level sort covers them (10 coarse + 8 fine bits; 9 fine bits at c = 20) and
+    the reduction takes each array as 2^16-bucket slices (pseudo-windows) whose offsets the host adds back.
     (offsets and sorted only: 14 x 2^18 bucket records would be 340 MB of Jacobian words)"""
     g = load_golden("rand_n1024")
-    with th.HooksContext(window_bits=19, flags=mh.FLAG_NO_GLV) as c:
+    for c_bits in (19, 20):
+        with th.HooksContext(window_bits=c_bits, flags=mh.FLAG_NO_GLV) as c:
+            d = c.stage_dump(g["bases"], g["scalars"], mh.FORM_STD, g["inf"], want_buckets=False)
+        assert d.sort_path == 2 and d.pw_bits == c_bits - 17 and d.bit_sums.shape == (d.W << d.pw_bits, 17, 24)
+        check_sort(d, signed_digits(g["scalars"], c_bits, d.W), g["inf"])
+        aff, _ = orc.g1_to_affine_std(d.jacobian)
+        assert (aff == g["expected"]).all()
+
+
+def test_stages_global_atomic_fallback():
+    """unsigned 20-bit windows: 2^20 buckets per window are beyond the LDS sort (10 coarse + 10 fine bits) -> device-scope atomics in
+    k_decompose + k_scan_* + k_scatter.  (offsets and sorted only)"""
+    g = load_golden("rand_n1024")
+    fl = mh.FLAG_NO_GLV | mh.FLAG_UNSIGNED_DIGITS
+    with th.HooksContext(window_bits=20, flags=fl) as c:
         d = c.stage_dump(g["bases"], g["scalars"], mh.FORM_STD, g["inf"], want_buckets=False)
     assert d.sort_path == 0
-    check_sort(d, signed_digits(g["scalars"], 19, d.W), g["inf"])
+    check_sort(d, signed_digits(g["scalars"], 20, d.W, signed=False), g["inf"])
+    aff, _ = orc.g1_to_affine_std(d.jacobian)
+    assert (aff == g["expected"]).all()
+
+
+# ---- row f4: the window table of a resident base set, shared bucket arrays ---------------------------------------------------------
+def check_sort_table(d, digits_signed, inf=None):
+    """as check_sort, for V = W / f bucket arrays: array v sorts the f*nv digits of windows v*f .. v*f+f-1 and an entry is the TABLE
+    index j*nv + i (window j of the group, point i)"""
+    V, f, nb, nv = d.V, d.tf, d.nb, d.nv
+    assert d.offsets[0] == 0 and V * f == d.W
+    total = 0
+    for v in range(V):
+        rows = digits_signed[v * f:(v + 1) * f].copy()
+        if inf is not None:
+            rows[:, inf != 0] = 0
+        row = rows.reshape(-1)
+        mag = np.abs(row)
+        hist = np.bincount(mag[mag > 0] - 1, minlength=nb)
+        off = d.offsets[v * nb: (v + 1) * nb + 1].astype(np.int64)
+        assert (np.diff(off) == hist).all(), ("offsets != exclusive prefix of the group's digit histogram", v)
+        code = np.where(mag > 0, (mag - 1).astype(np.uint32) | np.where(row < 0, SIGN, 0).astype(np.uint32), SKIP).astype(np.uint32)
+        assert (d.digits[v * f:(v + 1) * f].reshape(-1) == code).all(), ("digit codes", v)
+        seg = d.sorted[off[0]: off[-1]]
+        idx = (seg & ~np.uint32(SIGN)).astype(np.int64)
+        assert np.array_equal(np.sort(idx), np.flatnonzero(mag > 0)), ("sorted is not a permutation of the group's non-zero digits", v)
+        assert (mag[idx] - 1 == np.repeat(np.arange(nb), hist)).all(), ("entry in the wrong bucket", v)
+        assert (((seg & SIGN) != 0) == (row[idx] < 0)).all(), ("sign lost", v)
+        total += int((mag > 0).sum())
+    assert int(d.offsets[V * nb]) == total
+
+
+def top_shift(d, c_bits, scalar_bits=254):
+    """ONE shared array (table factor == windows): the short top window's digit d enters as d * 2^s and its table level is
+    2^(c*(W-1) - s) P (csrc/msm_hip.hip table_top_shift): s = (c - 1) - top bits"""
+    if d.tf != d.W or d.tf <= 1:
+        return 0
+    top_bits = scalar_bits - c_bits * (d.W - 1)
+    return max(0, c_bits - 1 - top_bits)
+
+
+def table_digits(d, scalars, c_bits):
+    ds = signed_digits(scalars, c_bits, d.W)
+    ds[d.W - 1] <<= top_shift(d, c_bits)
+    return ds
+
+
+def table_bucket_sums(bases, form, digits_signed, inf, d, c_bits, buckets=None):
+    """expected shared buckets: B[v][b] = sum_j 2^(c*j) * (bucket b of window v*f + j)  -- Horner over the group's windows
+    (the top level of a full table is 2^(c*(W-1) - s) P: its first Horner step doubles s times fewer)"""
+    per_window = orc.bucket_sums(bases, digits_signed, d.nb, form, inf).reshape(d.W, d.nb, 24)
+    out = np.zeros((d.V * d.nb, 24), np.uint32)
+    sh = top_shift(d, c_bits)
+    for v in range(d.V):
+        for b in (range(d.nb) if buckets is None else buckets):
+            acc = per_window[v * d.tf + d.tf - 1, b]
+            for j in range(d.tf - 2, -1, -1):
+                acc = orc.g1_add(orc.g1_dbl_n(acc, c_bits - (sh if j == d.tf - 2 else 0)), per_window[v * d.tf + j, b])
+            out[v * d.nb + b] = acc
+    return out
+
+
+TABLE_CASES = [  # (window_bits, table factor (0 = all windows), golden case)
+    (8, 0, "rand_n1024"),            # ONE array shared by all 32 windows
+    (8, 4, "rand_n1024"),            # 8 arrays of 4 windows each
+    (6, 0, "edge_inf_bases"),
+    (7, 0, "edge_same_base_same_scalar"),
+    (10, 0, "edge_p_minus_p"),
+    (13, 5, "rand_n4096"),
+]
+
+
+@pytest.mark.parametrize("wb,tf,name", TABLE_CASES)
+def test_stages_window_table_shared_buckets(monkeypatch, wb, tf, name):
+    """MSM_FLAG_WINDOW_TABLE, stage by stage: digits as without a table; offsets/sorted per bucket ARRAY with table indices; the
+    shared buckets hold sum_j 2^(c*j) x (that bucket of window j); bit sums and the final point follow"""
+    if tf:
+        monkeypatch.setenv("MSM_HIP_TABLE_F", str(tf))
+    g = load_golden(name)
+    fl = mh.FLAG_NO_GLV | mh.FLAG_WINDOW_TABLE
+    with th.HooksContext(window_bits=wb, flags=fl) as c:
+        d = c.stage_dump(g["bases"], g["scalars"], mh.FORM_STD, g["inf"])
+    assert d.tf == (tf or d.W) and d.V == d.W // d.tf and d.sort_path == 2
+    ds = table_digits(d, g["scalars"], wb)
+    check_sort_table(d, ds, g["inf"])
+    exp_b = table_bucket_sums(g["bases"], orc.FORM_STD, ds, g["inf"], d, wb)
+    for k in range(d.V * d.nb):
+        assert same_point(d.buckets[k], exp_b[k]), ("shared bucket", k // d.nb, k % d.nb)
+    exp_q = orc.bit_sums(exp_b, d.V, d.nb)
+    for v in range(d.V):
+        for u in range(d.kb + 1):
+            assert same_point(d.bit_sums[v, u], exp_q[v, u]), ("bit sum", v, u)
+    aff, _ = orc.g1_to_affine_std(d.jacobian)
+    assert (aff == g["expected"]).all()
+
+
+def test_stages_window_table_c20_super_tiles_and_pseudo_windows():
+    """the shape the table exists for: c = 20, ONE array of 2^19 buckets shared by 13 windows.  The sort runs with 9 fine bits, so a
+    staged element keeps 22 bits of its position and the rest is recovered from where it sits in its region (sort_hi; 4096 points x 13
+    windows stay inside one super-tile, the 2^19-point test of tests/test_gpu_1_parity.py crosses them); the reduction sees 8 slices
+    of 2^16 buckets.  Buckets are compared where the oracle has entries, the rest must be the identity."""
+    g = load_golden("rand_n4096")
+    fl = mh.FLAG_NO_GLV | mh.FLAG_WINDOW_TABLE
+    with th.HooksContext(window_bits=20, flags=fl) as c:
+        d = c.stage_dump(g["bases"], g["scalars"], mh.FORM_STD, g["inf"])
+    assert (d.tf, d.V, d.W, d.kb, d.pw_bits, d.rkb) == (13, 1, 13, 19, 3, 16) and d.sort_path == 2
+    assert top_shift(d, 20) == 5  # the 14-bit top window enters as d * 32
+    ds = table_digits(d, g["scalars"], 20)
+    check_sort_table(d, ds, g["inf"])
+    mags = np.abs(ds)
+    mags[:, g["inf"] != 0] = 0
+    used = np.unique(mags[mags > 0] - 1)
+    exp_b = table_bucket_sums(g["bases"], orc.FORM_STD, ds, g["inf"], d, 20, buckets=used)
+    for b in used:
+        assert same_point(d.buckets[b], exp_b[b]), ("shared bucket", int(b))
+    empty = np.setdiff1d(np.arange(d.nb), used)
+    assert (d.buckets[empty, 16:24] == 0).all()  # Z == 0: identity
+    exp_b[empty] = d.buckets[empty]              # ... in the words the device wrote
+    exp_q = orc.bit_sums(exp_b, d.V << d.pw_bits, 1 << d.rkb)
+    for q in range(d.V << d.pw_bits):
+        for u in range(d.rkb + 1):
+            assert same_point(d.bit_sums[q, u], exp_q[q, u]), ("bit sum of slice", q, u)
     aff, _ = orc.g1_to_affine_std(d.jacobian)
     assert (aff == g["expected"]).all()
 
