@@ -297,7 +297,6 @@ struct PipeState {
     uint32_t tf = 1, sW = 0;
     size_t sn = 0;
     uint32_t top_shift = 0;  // full table (tf == W): the short top window's digits enter as d * 2^top_shift (table_top_shift)
-    size_t digit_off = 0;  // first entry of this sort in the digits array (window ranges of a table MSM)
     // REDUCTION view: arrays of more than 2^17 buckets are reduced as 2^pw_bits PSEUDO-windows of 2^rkb buckets each (bucket index
     // b = q * 2^rkb + b'); the host adds q * 2^rkb * (plain sum of pseudo-window q) back in (host_finish).  rW = sW << pw_bits.
     uint32_t rW = 0, rkb = 0, pw_bits = 0, kb_lo = 0, kb_hi = 0, n_lo = 0, n_hi = 0;
@@ -325,7 +324,6 @@ int32_t pipe_prepare(msm_ctx* c, size_t n_real, size_t plan_n, uint32_t extra_fl
     ps->sW = W / ps->tf;
     ps->sn = (size_t)ps->tf * n;
     ps->top_shift = table_top_shift(pl, ps->tf);
-    ps->digit_off = 0;
     const size_t pairs = ps->pairs = (size_t)W * n, tb = ps->tb = (size_t)ps->sW * nb;
     if (pairs > 0xFFFFFFFFull) return fail(c, MSM_ERR_BAD_ARG, "n*W = %zu does not fit 32-bit offsets", pairs);
     ps->kb = ilog2(nb);
@@ -446,7 +444,7 @@ int32_t enqueue_decompose(msm_ctx* c, const PipeState& ps, const uint8_t* d_inf,
     return MSM_OK;
 }
 
-// K2 + chunk map on stream st: the digits of ps.sW sort windows x ps.sn entries (from digits + ps.digit_off) -> offsets / sorted /
+// K2 + chunk map on stream st: the digits of ps.sW sort windows x ps.sn entries -> offsets / sorted /
 // chunk owners.  into = true: the bucket array keeps what earlier chunks / window ranges of the same MSM left in it.
 int32_t enqueue_sort(msm_ctx* c, const PipeState& ps, hipStream_t st, bool into) {
     Range r_("msm:sort");
@@ -457,7 +455,7 @@ int32_t enqueue_sort(msm_ctx* c, const PipeState& ps, hipStream_t st, bool into)
     uint32_t* hist = (uint32_t*)c->hist.p;
     uint32_t* offsets = (uint32_t*)c->offsets.p;
     uint32_t* flags = (uint32_t*)c->flags.p;
-    const uint32_t* digits = (const uint32_t*)c->digits.p + ps.digit_off;
+    const uint32_t* digits = (const uint32_t*)c->digits.p;
     const SortGeom sg = sort_geometry(c, ps);
     const uint32_t coarse_bits = sg.coarse_bits, fine_bits = sg.fine_bits, idx_bits = sg.idx_bits, ncoarse = sg.ncoarse, NS = sg.NS;
     uint32_t T = 1, tile_len = (uint32_t)sn;
@@ -480,7 +478,10 @@ int32_t enqueue_sort(msm_ctx* c, const PipeState& ps, hipStream_t st, bool into)
         const uint32_t fine_cap = fine_block * 16u;
         uint32_t* bigslot = (uint32_t*)c->bigslot.p;
         uint32_t* big = (uint32_t*)c->big.p;
-        msmk::k_coarse_starts<<<1, msmk::SCAN_BLOCK, 0, st>>>(rtotal, rstart, nregions, flags + msmk::FLAG_PAIRS, offsets + tb, bigslot, big, fine_cap);
+        // (a region up to four staging areas long is still sorted by its owner, batch after batch, placing directly: the worker-block
+        // path pays a global cursor add per bucket and batch and is meant for the few huge regions of skewed scalars -- with every
+        // region ~3 x oversized (2^22 points x 13 windows in one array) it took 5 ms where the owners take 0.6)
+        msmk::k_coarse_starts<<<1, msmk::SCAN_BLOCK, 0, st>>>(rtotal, rstart, nregions, flags + msmk::FLAG_PAIRS, offsets + tb, bigslot, big, 4 * fine_cap, fine_cap);
         msmk::k_coarse_scatter<<<dim3(NS, sW), msmk::TILE_BLOCK, 0, st>>>(digits, counts, rstart, tmp, (uint32_t)sn, fine_bits, idx_bits, ncoarse, NS);
         // workgroup size by mean region size (a workgroup stages up to 16 elements per thread); grid.x = the window's regions +
         // BIG_WORKERS_X worker blocks for the batches of oversized regions, which k_big_place then places
@@ -726,29 +727,13 @@ int32_t finish_sync(msm_ctx* c, const PipeState& ps, size_t n_total, hipStream_t
 }
 
 // K1b + K2 + K3 of a whole MSM whose inputs are in HBM, on stream st.  d_bases: INTERNAL-domain records (with a window table: the
-// table, record j * n + i = 2^(c*j) P_i).
-// A table MSM whose ONE shared bucket array would see more than ~2^24 entries in a single sort -- the regions of the fine sort hold
-// sn / 1024 entries and stage 16384 -- is cut into WINDOW RANGES: the digits are made once, then windows [j0, j1) are sorted and
-// accumulated INTO the shared array range after range (the entries of a window range are contiguous in the digits array and their
-// table records start at j0 * n: no kernel knows about it).
-constexpr size_t TABLE_SORT_MAX = (size_t)15 << 20;
+// table, record j * n + i = 2^(c*j) P_i; the planner only makes tables whose shared array is sorted in ONE piece --
+// msmplan::TABLE_MAX_ENTRIES: cutting the windows into ranges that accumulate INTO the array was built, found bit-exact and 17 % slower
+// than no table at 2^22 points, profiles/r3_f4_shared_buckets.txt).
 int32_t enqueue_body(msm_ctx* c, const PipeState& ps, const uint32_t* d_bases, const uint8_t* d_inf, const uint32_t* d_scalars,
                      uint32_t scalars_mont, hipStream_t st, hipEvent_t bases_ready) {
     int32_t rc;
     if ((rc = enqueue_decompose(c, ps, d_inf, d_scalars, scalars_mont, st, true))) return rc;
-    if (ps.tf > 1 && ps.sW == 1 && ps.sn > TABLE_SORT_MAX && ps.n <= TABLE_SORT_MAX) {
-        const uint32_t per = (uint32_t)std::max<size_t>(1, TABLE_SORT_MAX / ps.n);  // windows per range
-        for (uint32_t j0 = 0; j0 < ps.tf; j0 += per) {
-            PipeState r = ps;
-            const uint32_t cnt = std::min(per, ps.tf - j0);
-            r.sn = (size_t)cnt * ps.n;
-            r.digit_off = (size_t)j0 * ps.n;
-            r.nchunks_max = (r.sn + r.chunk_len - 1) / r.chunk_len;
-            if ((rc = enqueue_sort(c, r, st, j0 > 0))) return rc;
-            if ((rc = enqueue_accumulate(c, r, d_bases + (size_t)j0 * ps.n * 16, st, j0 == 0 ? bases_ready : nullptr, j0 > 0, true))) return rc;
-        }
-        return MSM_OK;
-    }
     if ((rc = enqueue_sort(c, ps, st, false))) return rc;
     return enqueue_accumulate(c, ps, d_bases, st, bases_ready, false);
 }

@@ -620,8 +620,8 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_coarse_hist(const uint32_t* __re
                                                             uint32_t* __restrict__ flags) {
     __shared__ uint32_t s_h[COARSE_BINS_MAX];
     const uint32_t st = blockIdx.x, w = blockIdx.y;
-    // list counters of THIS sort call (k_chunk_map fills them later in the stream): k_decompose zeroes them too, but a window-table MSM
-    // cut into window ranges decomposes once and sorts several times
+    // list counters of THIS sort call (k_chunk_map fills them later in the stream; k_decompose zeroes them too -- kept here so that a
+    // sort never depends on which kernel ran before it)
     if (st == 0 && w == 0 && threadIdx.x == 0) flags[FLAG_LONG] = 0, flags[FLAG_MID] = 0, flags[FLAG_ONCE] = 0;
     if (threadIdx.x < COARSE_BINS_MAX) s_h[threadIdx.x] = 0;
     __syncthreads();
@@ -693,7 +693,7 @@ constexpr size_t BIG_WORDS = (size_t)BIG_TAB_OFF + (size_t)BIG_MAX_ITEMS * BIG_S
 
 __global__ void k_coarse_starts(const uint32_t* __restrict__ region_total, uint32_t* __restrict__ region_start, uint32_t nregions,
                                 uint32_t* __restrict__ total_out, uint32_t* __restrict__ offsets_end, uint32_t* __restrict__ bigslot,
-                                uint32_t* __restrict__ big, uint32_t big_threshold) {
+                                uint32_t* __restrict__ big, uint32_t big_threshold, uint32_t batch_cap) {
     if (threadIdx.x < 2) big[threadIdx.x] = 0;
     for (uint32_t k = threadIdx.x; k < 2 * BIG_MAX_ITEMS; k += blockDim.x) big[BIG_ITEMS_OFF + k] = BIG_NONE;
     __syncthreads();
@@ -714,7 +714,7 @@ __global__ void k_coarse_starts(const uint32_t* __restrict__ region_total, uint3
                 region_start[base + k] = ex;
                 uint32_t slot = BIG_NONE;
                 if (v[k] > big_threshold) {  // rare: list the region's batches for the worker blocks
-                    const uint32_t nit = (v[k] + big_threshold - 1) / big_threshold, ib = atomicAdd(&big[0], nit);
+                    const uint32_t nit = (v[k] + batch_cap - 1) / batch_cap, ib = atomicAdd(&big[0], nit);  // batches of one staging area
                     if (ib + nit <= BIG_MAX_ITEMS) {
                         slot = atomicAdd(&big[1], 1u);
                         for (uint32_t z = 0; z < nit; z++) {

@@ -94,24 +94,33 @@ struct table_knobs {
     uint32_t c = 0, f = 0;                // MSM_HIP_TABLE_C / MSM_HIP_TABLE_F: force the width / the factor (0 = planner)
     size_t max_bytes = (size_t)64 << 30;  // MSM_HIP_TABLE_MAX_GB: no table beyond this
 };
+// one sort of the shared array covers this many entries (regions of the fine sort: entries / 1024, sorted by their owner workgroup up
+// to four LDS staging areas of 16384); beyond it the pipeline would cut the windows into ranges that accumulate INTO the array
+// (k_accumulate<true, true>: a dependent bucket load per switch) and loses what the table gains -- such sets get no table
+constexpr size_t TABLE_MAX_ENTRIES = (size_t)60 << 20;
+// Measured (tools/table_sweep.py, profiles/r3_f4_shared_buckets.txt; resident batch, ms per MSM, table vs plain):
+//   2^14 GLV c = 16 0.172 vs 0.214;  2^16 0.233 vs 0.280;  2^17 0.321 vs 0.374;  2^18 0.494 vs 0.547 (unsplit c = 20: 0.545)
+//   2^19 unsplit c = 20 0.855 vs 0.934 (GLV c = 16: 0.899);  2^20 c = 20 1.395 vs 1.521 (c = 17: 1.487);  2^21 2.83 vs 2.95;  2^22 5.35 vs 5.48
+// => up to 2^18 points the GLV split with c = 16 (eight windows, ONE array of 2^15 buckets), from 2^19 unsplit c = 20.
+constexpr size_t TABLE_GLV_MAX_POINTS = (size_t)1 << 18;
 inline uint32_t plan_table_bits(size_t nv, bool glv) {
-    // nv = sorted points per window (2n with the GLV split).  Provisional thresholds, re-measured on the GPU (profiles/r3_f4_*.txt)
-    if (glv) return nv <= ((size_t)1 << 15) ? 10u : 16u;
-    return nv <= ((size_t)1 << 17) ? 16u : nv <= ((size_t)1 << 18) ? 17u : nv <= ((size_t)1 << 19) ? 19u : 20u;
+    if (glv) return nv <= ((size_t)1 << 13) ? 10u : 16u;
+    return nv <= ((size_t)1 << 17) ? 16u : nv <= ((size_t)1 << 18) ? 17u : 20u;
 }
 // plan of a resident call on all n points of a set uploaded under `flags` (window_bits: the context's forced width or 0).  Without
 // MSM_FLAG_WINDOW_TABLE, with plain digits, or when the table would not fit: the ordinary plan, table_factor 1.
 inline int32_t make_table_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_plan_t* out, size_t glv_max, const table_knobs& tk) {
     int32_t rc = make_plan(n, window_bits, flags, out, glv_max);
     if (rc != MSM_OK || !(flags & MSM_FLAG_WINDOW_TABLE) || (flags & MSM_FLAG_UNSIGNED_DIGITS)) return rc;
-    const bool glv0 = out->glv != 0;
-    uint32_t c = tk.c ? tk.c : window_bits ? window_bits : plan_table_bits((size_t)out->virtual_points, glv0);
+    const uint32_t tflags = n > TABLE_GLV_MAX_POINTS ? (flags | MSM_FLAG_NO_GLV) : flags;  // (the split pays up to 2^18 points here)
+    const bool glv0 = !(tflags & MSM_FLAG_NO_GLV) && n <= glv_max;
+    uint32_t c = tk.c ? tk.c : window_bits ? window_bits : plan_table_bits(glv0 ? 2 * n : n, glv0);
     msm_plan_t t;
-    if (make_plan(n, c, flags, &t, glv_max) != MSM_OK) return rc;  // (a forced width out of range: keep the ordinary plan)
+    if (make_plan(n, c, tflags, &t, glv_max) != MSM_OK) return rc;  // (a forced width out of range: keep the ordinary plan)
     uint32_t f = tk.f ? tk.f : t.num_windows;
     if (f < 2 || t.num_windows % f) return rc;
     const uint64_t bytes = (uint64_t)f * t.virtual_points * 64;
-    if (bytes > tk.max_bytes) return rc;
+    if (bytes > tk.max_bytes || (uint64_t)f * t.virtual_points > TABLE_MAX_ENTRIES) return rc;
     t.table_factor = f;
     t.bucket_arrays = t.num_windows / f;
     t.table_bytes = bytes;

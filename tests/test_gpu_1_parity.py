@@ -468,6 +468,123 @@ def test_glv_split_full_size_matches_unsplit_and_closed_form(monkeypatch, hk, lo
         assert (cg.msm_resident(s[:m]).affine_std == e2).all()
 
 
+# ---- row f4: the window table of a resident base set (MSM_FLAG_WINDOW_TABLE) --------------------------------------------------------
+TABLE = mh.FLAG_WINDOW_TABLE
+
+
+@pytest.mark.parametrize("wb,flags", [(0, TABLE), (0, TABLE | mh.FLAG_NO_GLV), (8, TABLE | mh.FLAG_NO_GLV), (13, TABLE), (16, TABLE),
+                                      (20, TABLE | mh.FLAG_NO_GLV), (5, TABLE | mh.FLAG_NO_GLV)])
+def test_window_table_golden_cases(wb, flags):
+    """every golden case through upload_bases (+ table build) and msm_resident: one bucket array shared by all windows, digits of
+    window j add +-T_j[i] = +-2^(c*j) P_i.  Planner plans (GLV split, c = 10 / 16) and forced widths incl. c = 20 (2^19 buckets, super-
+    tile sort, pseudo-window reduction) and c = 5 (51 windows: long buckets in the shared array).  Edge cases of the goldens: bases at
+    infinity, P and -P, equal bases, zero scalars, r - 1."""
+    with mh.MsmContext(window_bits=wb, flags=flags) as c:
+        for name in golden_cases():
+            g = load_golden(name)
+            n = g["bases"].shape[0]
+            pl = mh.plan(n, wb, flags)
+            assert pl.table_factor == pl.num_windows >= 2 and pl.bucket_arrays == 1 and pl.table_bytes == pl.table_factor * pl.virtual_points * 64
+            c.upload_bases(g["bases"], mh.FORM_STD, g["inf"])
+            r = c.msm_resident(g["scalars"])
+            assert r.is_infinity == bool(g["expected_inf"]) and (r.affine_std == g["expected"]).all(), (name, wb, flags)
+            if n > 2:  # fewer scalars than bases: the plain pipeline on the first records of level 0
+                m = n - 1
+                exp, einf, _ = orc.msm_pippenger(g["bases"][:m], g["scalars"][:m], orc.FORM_STD, g["inf"][:m])
+                r = c.msm_resident(g["scalars"][:m])
+                assert r.is_infinity == bool(einf) and (r.affine_std == exp).all(), (name, "truncated")
+            # and the host-pointer entry of the same context is unaffected by the flag
+            r = c.msm(g["bases"], g["scalars"], mh.FORM_STD, g["inf"])
+            assert r.is_infinity == bool(g["expected_inf"]) and (r.affine_std == g["expected"]).all(), (name, "host call")
+
+
+def test_window_table_collisions_across_windows():
+    """what a shared bucket array adds to the complete group law's job: table records of DIFFERENT windows can be equal or opposite
+    points.  Bases k*G and (2^c k)*G: T_1 of the first is T_0 of the second; with equal (opposite) digits in the two windows they meet
+    in one bucket as P + P (P + (-P)).  Against the closed form."""
+    c_bits, n = 8, 512
+    k = orc.gen_scalars(0xB2540401, n, nonzero=True)
+    ki = [orc.words_to_int(w) for w in k]
+    for i in range(0, n, 2):  # odd points: 2^c times the point before
+        ki[i + 1] = (ki[i] << c_bits) % R
+    k = np.array([orc.int_to_words(v) for v in ki], dtype=np.uint32)
+    bases = orc.gen_bases_from_logs(k, orc.FORM_MONT)
+    s = orc.gen_scalars(0xB2540402, n)
+    si = [orc.words_to_int(w) for w in s]
+    for i in range(0, n, 2):
+        d = (si[i] >> c_bits) & 0x7F  # window 1 of the even point (small enough to stay a positive digit; no carry from window 0) ...
+        si[i] = (si[i] & ~(0xFF << c_bits) & ~0x80) | (d << c_bits)
+        si[i + 1] = (si[i + 1] & ~0xFF) | ((d if i % 4 == 0 else (256 - d) & 0xFF))  # ... equals / negates window 0 of the odd one
+    s = np.array([orc.int_to_words(v % R) for v in si], dtype=np.uint32)
+    exp, einf = orc.closed_form_expected(k, s)
+    with mh.MsmContext(window_bits=c_bits, flags=TABLE | mh.FLAG_NO_GLV) as c:
+        c.upload_bases(bases, mh.FORM_MONT)
+        r = c.msm_resident(s)
+    assert r.is_infinity == bool(einf) and (r.affine_std == exp).all()
+
+
+@pytest.mark.parametrize("logn,extra", [(16, 0), (19, 12345), (20, 0)])
+def test_window_table_full_size_closed_form_batch_and_skew(hk, logn, extra):
+    """the planner's table plans at full size against the closed form: 2^16 (GLV, c = 16, 8 windows in one array), 2^19 + 12345
+    (unsplit c = 20: 13 windows x n entries cross the sort's super-tiles of 2^22 positions; infinity mask) and 2^20 (the BASELINE
+    size).  Single resident calls, the batch entry (two MSMs in flight), a truncated call, all-equal scalars (13 buckets hold everything:
+    oversized regions with 512 fine bins), and the same set without the table as the reference bits."""
+    import torch
+    n = (1 << logn) + extra
+    seed = 0xB2540410 + logn
+    d_b = torch.empty(n * 16, dtype=torch.int32, device="cuda:0")
+    d_s = torch.empty(n * 8, dtype=torch.int32, device="cuda:0")
+    hk.generate_device(seed, seed + 1, n, d_b.data_ptr(), d_s.data_ptr())
+    torch.cuda.synchronize()
+    hb = d_b.cpu().numpy().view(np.uint32).reshape(n, 16)
+    k = th.generate_scalars_host(seed, n, nonzero=True)
+    vecs = [th.generate_scalars_host(seed + 1 + j, n) for j in range(3)]
+    inf = (np.arange(n) % 1013 == 7).astype(np.uint8) if extra else None
+    keep = slice(None) if inf is None else inf == 0
+    exp = [orc.closed_form_expected(k[keep], v[keep])[0] for v in vecs]
+    pl = mh.plan(n, 0, TABLE)
+    assert pl.table_factor == pl.num_windows and pl.bucket_arrays == 1
+    assert (pl.window_bits, pl.glv) == ((16, 1) if logn <= 18 else (20, 0))
+    with mh.MsmContext(flags=TABLE) as c, mh.MsmContext() as plain:
+        c.upload_bases(hb, mh.FORM_MONT, inf)
+        plain.upload_bases(hb, mh.FORM_MONT, inf)
+        for v, e in zip(vecs, exp):
+            r = c.msm_resident(v)
+            assert not r.is_infinity and (r.affine_std == e).all()
+        res = c.msm_resident_batch(vecs + vecs)
+        for j, r in enumerate(res):
+            assert (r.affine_std == exp[j % 3]).all(), ("batch", j)
+        m = n - 4321
+        assert (c.msm_resident(vecs[0][:m]).affine_std == plain.msm_resident(vecs[0][:m]).affine_std).all()
+        eq = np.tile(vecs[1][5], (n, 1))  # every scalar equal: W buckets of the one array hold all n*W entries
+        assert (c.msm_resident(eq).affine_std == plain.msm_resident(eq).affine_std).all()
+        small = vecs[2].copy()
+        small[:, 1:] = 0                   # 32-bit scalars: only the two lowest windows are populated
+        assert (c.msm_resident(small).affine_std == plain.msm_resident(small).affine_std).all()
+        bad = vecs[0].copy()
+        bad[n // 3, 7] = 0x40000000
+        with pytest.raises(mh.MsmError) as e:
+            c.msm_resident(bad)
+        assert e.value.code == mh.ERR_BAD_ARG
+        assert (c.msm_resident(vecs[0]).affine_std == exp[0]).all()  # the context and its table survive an error
+
+
+def test_window_table_compressed_upload_and_memory_cap(monkeypatch):
+    """msm_bn254_g1_upload_compressed builds the table behind the decoded points; MSM_HIP_TABLE_MAX_GB=0 (read when the context is
+    created) leaves a set without table and the calls on the ordinary path"""
+    g = load_golden("rand_n4096")
+    images = mh.compress_points(g["bases"], mh.FORM_STD, g["inf"])
+    with mh.MsmContext(flags=TABLE) as c:
+        c.upload_compressed(images)
+        r = c.msm_resident(g["scalars"])
+        assert (r.affine_std == g["expected"]).all()
+    monkeypatch.setenv("MSM_HIP_TABLE_MAX_GB", "0")
+    assert mh.plan(4096, 0, TABLE).table_factor == 1
+    with mh.MsmContext(flags=TABLE) as c:
+        c.upload_bases(g["bases"], mh.FORM_STD, g["inf"])
+        assert (c.msm_resident(g["scalars"]).affine_std == g["expected"]).all()
+
+
 # ---- BASELINE config 5: streamed host->HBM chunks overlapped with the pipeline ---------------------
 def test_streamed_chunks_match_oracle(hk):
     """msm_bn254_g1 cuts n >= 2*chunk points into chunks (double-buffered H2D on a copy stream; every chunk accumulates INTO the

@@ -289,6 +289,25 @@ def test_stages_oversized_region_big_place():
     check_buckets_and_bits(d, bases, orc.FORM_MONT, ds, None, exp)
 
 
+def test_stages_moderately_oversized_region_sorted_by_its_owner():
+    """a region between one and four staging areas long (here ~10000 entries against 4096) stays with its owner workgroup, which
+    counts and places it batch after batch straight into `sorted` (k_fine_sort, staged == false) -- the path every region of a
+    2^22-point window-table MSM takes; none is handed to the worker blocks"""
+    n = 1 << 15
+    k = orc.gen_scalars(41, n, nonzero=True)
+    bases = orc.gen_bases_from_logs(k, orc.FORM_MONT)
+    s = orc.gen_scalars(42, n)
+    s[: n // 4] = s[0]  # a quarter of the points share one scalar: every window has one region of ~8192 + 96 entries
+    # (c = 13: the 7-bit top window spreads over 8 regions of ~3000-11000 entries; at c = 12 it would be one region of 24576)
+    with th.HooksContext(window_bits=13, flags=mh.FLAG_NO_GLV) as c:
+        d = c.stage_dump(bases, s, mh.FORM_MONT, None)
+    assert d.sort_path == 2 and d.big_items == 0
+    ds = signed_digits(s, 13, d.W)
+    check_sort(d, ds)
+    exp, einf = orc.closed_form_expected(k, s)
+    check_buckets_and_bits(d, bases, orc.FORM_MONT, ds, None, exp)
+
+
 def test_stages_glv_plan_sort_invariants_and_result():
     """default plan at n = 4096 (GLV split: 2n virtual points, digits of the two 127-bit halves): the sort invariants hold on the
     dumped digit codes, the bit sums are the bit sums of the dumped buckets, Horner over them is the golden MSM"""
