@@ -178,16 +178,24 @@ def main():
         hbn = hb_pin.numpy().view(np.uint32).reshape(-1, 16)
         hsn = hs_pin.numpy().view(np.uint32).reshape(-1, 8)
 
+    shard_ms_acc = [0.0, 0]  # this rank's local MSM: summed wall clock, calls (reset before the timed loop)
+
+    def local_msm():
+        t_l = time.perf_counter()
+        r = ctx.msm(hbn, hsn, mh.FORM_MONT) if args.streamed else ctx.msm_device(d_bases[rank].data_ptr(), d_scalars[rank].data_ptr(), n_local)
+        shard_ms_acc[0] += (time.perf_counter() - t_l) * 1e3
+        shard_ms_acc[1] += 1
+        return r
+
     def step():
         # HIP pipeline on this rank's shard, then (N > 1) the exchange step: EC addition is not an RCCL
-        # reduction op, so the "all-reduce" of partial group elements is an all-gather of 96 bytes per rank
-        # over RCCL + a local fold in rank order (identical on all ranks)
+        # reduction op, so the "all-reduce" of partial group elements is an all-gather of 96 bytes (+ a status word) per rank
+        # over RCCL + a local fold in rank order (identical on all ranks).  A rank whose local MSM fails still joins the
+        # all-gather (md.guarded): every rank raises the first failing rank's code, nobody hangs.
         if in_proc:
             return multi.msm_device([d_bases[g].data_ptr() for g in my_shards], [d_scalars[g].data_ptr() for g in my_shards],
                                     [shard(g)[1] - shard(g)[0] for g in my_shards])
-        if args.streamed:
-            return md.all_reduce_msm(ctx.msm(hbn, hsn, mh.FORM_MONT), xdev)
-        return md.distributed_msm_device(ctx, d_bases[rank].data_ptr(), d_scalars[rank].data_ptr(), n_local, device=xdev)
+        return md.guarded(local_msm, xdev)
 
     def fence():
         if world > 1:
@@ -210,10 +218,14 @@ def main():
         res = step()
     if ctx is not None:
         ctx.reset_kernel_stats()
+    shard_ms_acc[0], shard_ms_acc[1] = 0.0, 0
+    exch_ms_sum = 0.0
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
+        if world > 1:
+            exch_ms_sum += md.last_exchange_ms(xdev)
     fence()
     elapsed = time.perf_counter() - t0
     if ctx is not None:
@@ -253,10 +265,29 @@ def main():
         tm = ctx.timings()
     else:
         tm = multi.timings(0)
+    # what makes the first multi-GPU run self-explaining (no 8-GPU node was available to the builder): the world size the exchange
+    # really saw, what the exchange cost, and every rank's own shard time
+    exchange = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=xdev if xdev is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {"rank": rank, "device": torch.cuda.current_device(), "shard_points": n_local,
+                                          "shard_ms": shard_ms_acc[0] / max(1, shard_ms_acc[1]), "exchange_ms": exch_ms_sum / max(1, args.steps)})
+        sh = [p["shard_ms"] for p in per_rank]
+        exchange = {"backend": "gloo (debug: every rank on cuda:0)" if args.debug_same_device else "rccl (torch.distributed nccl backend)",
+                    "world_seen": dist.get_world_size(), "devices_seen": sorted({p["device"] for p in per_rank}),
+                    "payload_bytes_per_rank": 4 * md.WORDS, "ms_per_step": round(max(p["exchange_ms"] for p in per_rank), 4),
+                    "ms_per_step_min_rank": round(min(p["exchange_ms"] for p in per_rank), 4),
+                    "shard_ms_max": round(max(sh), 4), "shard_ms_min": round(min(sh), 4),
+                    "note": "exchange ms = host wall clock of the 100-byte all-gather incl. its two copies and the wait for the slowest rank"}
+    elif in_proc:
+        ex_ms, sh = multi.exchange_stats()
+        exchange = {"backend": {1: "rccl (in-library, ncclCommInitAll)", 2: "host fold"}.get(multi.exchange, "?"),
+                    "world_seen": multi.num_devices, "devices_seen": sorted({devs[g].index for g in my_shards}),
+                    "payload_bytes_per_rank": 96, "ms_per_step": round(ex_ms, 4), "shard_ms_max": round(max(sh), 4),
+                    "shard_ms_min": round(min(sh), 4), "note": "last step; shard ms = wall clock of each rank's local MSM on its host thread"}
     ms_per_step = elapsed * 1e3 / args.steps
 
     # ---- correctness gate (outside the timed region): closed form (sum s_i k_i mod r) * G ----------
@@ -291,18 +322,21 @@ def main():
         # (with the GLV split a window sorts and accumulates 2n virtual points in half as many windows: same point term)
         alg_bytes = W * (int(pl.virtual_points) * 68 + H * 96)
         achieved = alg_bytes / (acc_avg_ms * 1e-3) / 1e9 if acc_avg_ms > 0 and not args.streamed else 0.0
-        traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "accumulate_pmc.json")
-        if os.path.exists(pmc):
+        # HBM traffic of one k_accumulate launch: PMC counters cannot be read from inside this process, so the figure comes from the
+        # committed offline passes (tools/pmc_accumulate.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, corrected as the
+        # microarchitecture guide prescribes) of the SAME shape -- profiles/accumulate_pmc*.json, one file per shard size -- and says so
+        traffic, traffic_src = None, {"source": "none", "detail": "no committed PMC pass for n_local %d, c %d" % (n_local, pl.window_bits)}
+        import glob
+        for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "accumulate_pmc*.json"))):
             try:
                 j = json.load(open(pmc))
-                if j.get("n_local") == n_local and j.get("window_bits") == pl.window_bits:
-                    traffic = j.get("hbm_bytes_per_launch")
-                    traffic_src = "profiles/accumulate_pmc.json (offline rocprofv3 --pmc passes on the same box class, tools/pmc_accumulate.sh; not measured in this run)"
-                else:
-                    traffic_src = "null: profiles/accumulate_pmc.json holds another shape (n_local %s, c %s)" % (j.get("n_local"), j.get("window_bits"))
             except Exception:
-                traffic = None
+                continue
+            if j.get("n_local") == n_local and j.get("window_bits") == pl.window_bits:
+                traffic = j.get("hbm_bytes_per_launch")
+                traffic_src = {"source": "file", "file": os.path.relpath(pmc, ROOT), "build": j.get("build", "round 2"),
+                               "detail": "offline rocprofv3 --pmc passes on the same box class (tools/pmc_accumulate.sh); not measured in this run"}
+                break
         sort_ms = float(tm.get("sort_ms", 0.0) or 0.0)
         sort_bytes = 8 * int(pl.virtual_points) * W  # per window N*(2 read + 2 read + 4 write)
         out = {
@@ -325,6 +359,7 @@ def main():
             "bit_exact": bit_exact,
             "roofline": {"bound": "hbm", "kernel": "k_accumulate", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_over_algorithmic": round(traffic / alg_bytes, 3) if traffic else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_ms": round(acc_avg_ms, 4), "launches_per_step": launches_per_step,
                          "launches_timed": int(acc_launches),
                          "note": "integer-multiply (VALU) bound kernel; HBM fraction reported because BASELINE.json asks for it; "
@@ -340,6 +375,26 @@ def main():
             "roofline_valu": valu_roofline(int(tm.get("num_adds", 0)), acc_avg_ms, mad_peak, fpmul_peak) if not args.streamed else None,
             "stage_ms_untimed_diagnostic_step": {k: round(v, 4) for k, v in tm.items() if k.endswith("_ms")},
         }
+        if exchange is not None:
+            out["exchange"] = exchange
+        # projected strong scaling of THIS instance size from the per-shard single-GPU times committed under profiles/ (measured on
+        # one device: what each rank would take alone) + the measured exchange of this run (or the committed estimate at N = 1)
+        st_file = os.path.join(ROOT, "profiles", "shard_times.json")
+        if os.path.exists(st_file):
+            try:
+                stj = json.load(open(st_file))
+                tms = {int(k): float(v) for k, v in stj["device_call_ms_by_log2_points"].items()}
+                ex_est = exchange["ms_per_step"] if exchange and world > 1 else float(stj.get("exchange_ms_estimate", 0.04))
+                if args.log_n in tms:
+                    proj = {}
+                    for g in (2, 4, 8):
+                        lg = args.log_n - g.bit_length() + 1
+                        if lg in tms:
+                            proj["x%d" % g] = {"ms": round(tms[lg] + ex_est, 4), "speedup": round(tms[args.log_n] / (tms[lg] + ex_est), 2)}
+                    out["projected_strong_scaling"] = {"from": "profiles/shard_times.json (single-GPU device calls, %s)" % stj.get("build", "?"),
+                                                       "exchange_ms_used": round(ex_est, 4), "one_gpu_ms": tms[args.log_n], **proj}
+            except Exception:
+                pass
 
         # ---- host-pointer legs (the reference's own measurement shape: benches/e2e.rs:46-60 times the call from HOST slices);
         #      same instance, copied to the host once outside every timed region; never `value`
@@ -377,6 +432,21 @@ def main():
             r, avg, _ = timed_calls(lambda: ctx.msm_resident_batch([hspn] * K), 3)
             legs["resident_batch_ms_per_msm"] = round(avg / K, 4)
             ok = ok and all(bool((x.affine_std == exp).all()) for x in r)
+            # row f4: the same resident set with its WINDOW TABLE (MSM_FLAG_WINDOW_TABLE: one bucket array shared by all windows)
+            with mh.MsmContext(device=local_rank, flags=ctx_flags | mh.FLAG_WINDOW_TABLE) as tctx:
+                tpl = mh.plan(n_local, args.window_bits, ctx_flags | mh.FLAG_WINDOW_TABLE)
+                t_u = time.perf_counter()
+                tctx.upload_bases(hbpn, mh.FORM_MONT)
+                up_ms = (time.perf_counter() - t_u) * 1e3
+                r, avg, _ = timed_calls(lambda: [tctx.msm_resident(hspn) for _ in range(K)], 3)
+                legs["resident_table_single_calls_ms_per_msm"] = round(avg / K, 4)
+                ok = ok and all(bool((x.affine_std == exp).all()) for x in r)
+                r, avg, _ = timed_calls(lambda: tctx.msm_resident_batch([hspn] * K), 3)
+                legs["resident_table_batch_ms_per_msm"] = round(avg / K, 4)
+                ok = ok and all(bool((x.affine_std == exp).all()) for x in r)
+                legs["resident_table_plan"] = {"window_bits": tpl.window_bits, "num_windows": tpl.num_windows, "table_factor": tpl.table_factor,
+                                               "bucket_arrays": tpl.bucket_arrays, "buckets_per_array": tpl.num_buckets, "glv_split": bool(tpl.glv),
+                                               "table_MB": round(tpl.table_bytes / 1e6, 1), "upload_and_build_ms": round(up_ms, 1)}
             legs["bit_exact"] = ok
             legs["note"] = ("host-pointer calls on the same instance (PCIe-inclusive, 96-104 B per point); pageable = numpy arrays, "
                             "pinned = torch pin_memory; median and min of %d calls" % reps)
