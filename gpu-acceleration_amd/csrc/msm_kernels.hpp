@@ -1364,6 +1364,54 @@ __global__ void __launch_bounds__(256) k_pair_level8(const uint32_t* __restrict_
     store_xyzz(out, acc);
 }
 
+// ALL pairwise levels behind k_pair_level8 in ONE launch.  After the first three levels a row sum R[w][hi] is still spread over
+// m_r = n_lo / 8 consecutive partials and a column sum C[w][lo] over m_c = n_hi / 8 partials n_lo records apart: 16 and 32 at 2^15
+// buckets per window -- five more levels that round 2 ran as five launches of 65536 .. 4096 additions, each paying its dispatch and
+// a memory round trip (54 us at 2^20 points, 48 at 2^17: they do not shrink with the instance).  Here ONE WAVEFRONT owns an output:
+// its eight 8-lane groups each fold every eighth partial in series (running sum in an LDS slot: 1 resp. 3 additions), then three
+// tree levels over the eight slots -- 4 resp. 6 dependent eight-lane additions, 6144 wavefronts at once.  (Round 2 tried one GROUP
+// per output -- seven additions in series cost what three launches did; the wavefront-wide tree halves the depth.)
+// grid: blocks of PAIR_TAIL_WAVES wavefronts; the first ceil(n_r / PAIR_TAIL_WAVES) blocks take rows, the rest columns.
+constexpr uint32_t PAIR_TAIL_WAVES = 4;
+__global__ void __launch_bounds__(64 * PAIR_TAIL_WAVES) k_pair_tail(const uint32_t* __restrict__ in_r, const uint32_t* __restrict__ in_c,
+                                                                    uint32_t* __restrict__ out_r, uint32_t* __restrict__ out_c, uint32_t n_r,
+                                                                    uint32_t n_c, uint32_t m_r, uint32_t m_c, uint32_t n_lo) {
+    __shared__ uint32_t s_slot[PAIR_TAIL_WAVES][WIDE_LANES][XW];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u, g = lane / WIDE_LANES, role = lane % WIDE_LANES;
+    const uint32_t rblocks = (n_r + PAIR_TAIL_WAVES - 1) / PAIR_TAIL_WAVES;
+    const bool rows = blockIdx.x < rblocks;  // uniform per workgroup: both kinds keep their barriers in step
+    const uint32_t o = (rows ? blockIdx.x : blockIdx.x - rblocks) * PAIR_TAIL_WAVES + wv;
+    const bool live = o < (rows ? n_r : n_c);
+    const uint32_t m = rows ? m_r : m_c;
+    // input t of output o: rows  in_r[o * m_r + t];  columns  in_c[((o / n_lo) * m_c + t) * n_lo + o % n_lo]
+    const uint32_t* src = rows ? in_r + (size_t)o * m_r * XW : in_c + ((size_t)(o / n_lo) * m_c * n_lo + o % n_lo) * XW;
+    const size_t stride = rows ? (size_t)XW : (size_t)n_lo * XW;
+    uint32_t* slot = s_slot[wv][g];
+    // 1. every group folds inputs g, g + 8, ... into its slot
+    if (live) {
+        if (g >= m) {
+            if (role == 0) store_xyzz(slot, xyzz_identity());
+        } else if (g + WIDE_LANES >= m) {  // a single input: copy (4 lanes, one coordinate each)
+            if (role < 4) store_coord(slot, role, load_coord(src + g * stride, role));
+        } else {
+            wide_add_records(src + g * stride, src + (g + WIDE_LANES) * stride, slot);
+        }
+    }
+    for (uint32_t t = g + 2 * WIDE_LANES; t < m; t += WIDE_LANES) {  // (m and g: same trip count for the lanes of a group; barrier-free)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (live) wide_add_records(slot, src + t * stride, slot);
+    }
+    // 2. tree over the eight slots of the wavefront
+    for (uint32_t h = WIDE_LANES / 2; h >= 1; h >>= 1) {
+        __syncthreads();
+        if (live && g < h) wide_add_records(s_slot[wv][g], s_slot[wv][g + h], s_slot[wv][g]);
+    }
+    __syncthreads();
+    // 3. slot 0 -> the output record
+    if (live && lane < 4) store_coord((rows ? out_r : out_c) + (size_t)o * XW, lane, load_coord(s_slot[wv][0], lane));
+}
+
 // k_reduce_bits with wide additions: one 512-thread workgroup per (window, bit); the selected elements are staged in LDS
 // and folded by a pairwise tree (log2(nsel) levels of 4 multiplications each).  Needs nsel <= WIDE_TREE_MAX.
 __global__ void __launch_bounds__(512) k_reduce_bits_wide(const uint32_t* __restrict__ R, const uint32_t* __restrict__ C,
