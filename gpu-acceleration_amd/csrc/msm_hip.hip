@@ -108,7 +108,6 @@ struct Knobs {
     int host_threads = -1;                     // MSM_HIP_HOST_THREADS: CPU finish threads incl. the caller; -1 = default (2)
     size_t wide_max = 40960;                   // MSM_HIP_WIDE_MAX: pairwise levels up to this many additions use 8 lanes per addition; 0 = never
     bool reduce_v1 = false;                    // MSM_HIP_REDUCE_V1: one launch per pairwise level (round 1)
-    bool no_pair_tail = false;                 // MSM_HIP_NO_PAIR_TAIL: the levels behind k_pair_level8 as one launch each (round 2; A/B)
     int batch_copy_own = 0;                    // MSM_HIP_BATCH_COPY=0: each batch pipeline uploads on its own copy stream
     int lane_priority = 1;                     // MSM_HIP_LANE_PRIORITY: low (1, default) | high (2) | normal (0)
     int batch_mode = -1;                       // MSM_HIP_BATCH_MODE: shared (1) | lanes (0); -1 = by size
@@ -137,7 +136,6 @@ struct Knobs {
         if (std::getenv("MSM_HIP_HOST_THREADS")) k.host_threads = (int)num("MSM_HIP_HOST_THREADS", 0, 64, 2);
         k.wide_max = (size_t)num("MSM_HIP_WIDE_MAX", 0, 1 << 30, 40960);
         k.reduce_v1 = on("MSM_HIP_REDUCE_V1");
-        k.no_pair_tail = on("MSM_HIP_NO_PAIR_TAIL");
         if (const char* e = std::getenv("MSM_HIP_BATCH_COPY")) k.batch_copy_own = e[0] == '0';
         if (const char* e = std::getenv("MSM_HIP_LANE_PRIORITY")) k.lane_priority = !strcmp(e, "high") ? 2 : !strcmp(e, "normal") ? 0 : 1;
         if (const char* e = std::getenv("MSM_HIP_BATCH_MODE")) k.batch_mode = !strcmp(e, "shared") ? 1 : 0;
@@ -590,22 +588,13 @@ int32_t enqueue_reduce(msm_ctx* c, const PipeState& ps, hipStream_t st, uint32_t
     // replaced (2^20: 52 vs 37 us: a tree's upper levels leave most lanes of its wavefront idle): profiles/NOTES_r2.md.
     // MSM_HIP_REDUCE_V1=1 at context creation = one launch per level throughout (round 1; A/B knob).
     uint32_t l = 0;
-    bool tail_done = false;
     if (!c->knobs.reduce_v1 && levels >= 3 && kb_lo >= 3 && tb * XB <= ((size_t)100 << 20)) {
         rn = tb / 8, cn = tb / 8;
         msmk::k_pair_level8<<<grid1(rn + cn, 256), 256, 0, st>>>(bk, rbuf[0], cbuf[0], (uint32_t)rn, n_lo);
         rin = rbuf[0], cin = cbuf[0];  // where level 2 would have left them
         l = 3;
-        if (c->knobs.wide_max && !c->knobs.no_pair_tail) {
-            // Round 3: every remaining level in ONE launch (k_pair_tail: a wavefront per row / column sum) instead of one launch per
-            // level -- 54 -> 2x us at 2^20 points, the same saving at every size (profiles/r3_reduce_tail.txt)
-            const uint32_t n_r = W * n_hi, n_c = W * n_lo, tw = msmk::PAIR_TAIL_WAVES;
-            msmk::k_pair_tail<<<(n_r + tw - 1) / tw + (n_c + tw - 1) / tw, 64 * tw, 0, st>>>(rin, cin, rbuf[1], cbuf[1], n_r, n_c, n_lo / 8, n_hi / 8, n_lo);
-            rin = rbuf[1], cin = cbuf[1];
-            tail_done = true;
-        }
     }
-    for (; l < levels && !tail_done; l++) {
+    for (; l < levels; l++) {
         msmk::pair_job ja{nullptr, nullptr, 0, 1}, jb{nullptr, nullptr, 0, 1};
         if (l < kb_lo) {
             rn /= 2;

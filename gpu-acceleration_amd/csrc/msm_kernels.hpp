@@ -108,6 +108,12 @@ __device__ __forceinline__ void store_coord(uint32_t* rec, uint32_t coord, const
 // out = a + b by the EIGHT lanes of a group (ec_wide.hpp: 4 multiplications in series instead of 14).  Records in HBM or
 // LDS; out may alias a.  Must be reached by whole 8-lane groups.  Special pairs (identity operand, equal or opposite
 // points) fall back to the scalar complete addition on the group's first lane.
+// the rare pairs (an identity operand, equal or opposite points): the scalar complete addition.  ~40 KB of code wherever it is inlined:
+// a kernel keeps ONE eight-lane call site (the instruction cache is 64 KB for two CUs).  Out of line it would cost nothing in code, but
+// a callee's register needs become the kernel's: 248 VGPRs, two wavefronts per SIMD for every reduction kernel.
+__device__ __forceinline__ void add_records_complete(const uint32_t* a_rec, const uint32_t* b_rec, uint32_t* out_rec) {
+    store_xyzz(out_rec, xyzz_add(load_xyzz(a_rec), load_xyzz(b_rec)));
+}
 __device__ __forceinline__ void wide_add_records(const uint32_t* a_rec, const uint32_t* b_rec, uint32_t* out_rec) {
     const uint32_t role = threadIdx.x & (WIDE_LANES - 1);
     const fp opa = load_coord(wide_opa_rec(role) ? b_rec : a_rec, wide_opa_coord(role));
@@ -115,7 +121,7 @@ __device__ __forceinline__ void wide_add_records(const uint32_t* a_rec, const ui
     const bool ident = role == 4 && (fp_is_zero_exact(opa) || fp_is_zero_exact(opb));  // role 4 holds ZZ1 and ZZ2
     fp o0, o1;
     if (xyzz_add_wide(opa, opb, ident, o0, o1)) {
-        if (role == 0) store_xyzz(out_rec, xyzz_add(load_xyzz(a_rec), load_xyzz(b_rec)));
+        if (role == 0) add_records_complete(a_rec, b_rec, out_rec);
         return;
     }
     if (role == 1) {
@@ -1362,54 +1368,6 @@ __global__ void __launch_bounds__(256) k_pair_level8(const uint32_t* __restrict_
 #pragma unroll 1
     for (uint32_t j = 1; j < 8; j++) acc = xyzz_add(acc, load_xyzz(in + (i0 + j * stride) * XW));
     store_xyzz(out, acc);
-}
-
-// ALL pairwise levels behind k_pair_level8 in ONE launch.  After the first three levels a row sum R[w][hi] is still spread over
-// m_r = n_lo / 8 consecutive partials and a column sum C[w][lo] over m_c = n_hi / 8 partials n_lo records apart: 16 and 32 at 2^15
-// buckets per window -- five more levels that round 2 ran as five launches of 65536 .. 4096 additions, each paying its dispatch and
-// a memory round trip (54 us at 2^20 points, 48 at 2^17: they do not shrink with the instance).  Here ONE WAVEFRONT owns an output:
-// its eight 8-lane groups each fold every eighth partial in series (running sum in an LDS slot: 1 resp. 3 additions), then three
-// tree levels over the eight slots -- 4 resp. 6 dependent eight-lane additions, 6144 wavefronts at once.  (Round 2 tried one GROUP
-// per output -- seven additions in series cost what three launches did; the wavefront-wide tree halves the depth.)
-// grid: blocks of PAIR_TAIL_WAVES wavefronts; the first ceil(n_r / PAIR_TAIL_WAVES) blocks take rows, the rest columns.
-constexpr uint32_t PAIR_TAIL_WAVES = 4;
-__global__ void __launch_bounds__(64 * PAIR_TAIL_WAVES) k_pair_tail(const uint32_t* __restrict__ in_r, const uint32_t* __restrict__ in_c,
-                                                                    uint32_t* __restrict__ out_r, uint32_t* __restrict__ out_c, uint32_t n_r,
-                                                                    uint32_t n_c, uint32_t m_r, uint32_t m_c, uint32_t n_lo) {
-    __shared__ uint32_t s_slot[PAIR_TAIL_WAVES][WIDE_LANES][XW];
-    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u, g = lane / WIDE_LANES, role = lane % WIDE_LANES;
-    const uint32_t rblocks = (n_r + PAIR_TAIL_WAVES - 1) / PAIR_TAIL_WAVES;
-    const bool rows = blockIdx.x < rblocks;  // uniform per workgroup: both kinds keep their barriers in step
-    const uint32_t o = (rows ? blockIdx.x : blockIdx.x - rblocks) * PAIR_TAIL_WAVES + wv;
-    const bool live = o < (rows ? n_r : n_c);
-    const uint32_t m = rows ? m_r : m_c;
-    // input t of output o: rows  in_r[o * m_r + t];  columns  in_c[((o / n_lo) * m_c + t) * n_lo + o % n_lo]
-    const uint32_t* src = rows ? in_r + (size_t)o * m_r * XW : in_c + ((size_t)(o / n_lo) * m_c * n_lo + o % n_lo) * XW;
-    const size_t stride = rows ? (size_t)XW : (size_t)n_lo * XW;
-    uint32_t* slot = s_slot[wv][g];
-    // 1. every group folds inputs g, g + 8, ... into its slot
-    if (live) {
-        if (g >= m) {
-            if (role == 0) store_xyzz(slot, xyzz_identity());
-        } else if (g + WIDE_LANES >= m) {  // a single input: copy (4 lanes, one coordinate each)
-            if (role < 4) store_coord(slot, role, load_coord(src + g * stride, role));
-        } else {
-            wide_add_records(src + g * stride, src + (g + WIDE_LANES) * stride, slot);
-        }
-    }
-    for (uint32_t t = g + 2 * WIDE_LANES; t < m; t += WIDE_LANES) {  // (m and g: same trip count for the lanes of a group; barrier-free)
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (live) wide_add_records(slot, src + t * stride, slot);
-    }
-    // 2. tree over the eight slots of the wavefront
-    for (uint32_t h = WIDE_LANES / 2; h >= 1; h >>= 1) {
-        __syncthreads();
-        if (live && g < h) wide_add_records(s_slot[wv][g], s_slot[wv][g + h], s_slot[wv][g]);
-    }
-    __syncthreads();
-    // 3. slot 0 -> the output record
-    if (live && lane < 4) store_coord((rows ? out_r : out_c) + (size_t)o * XW, lane, load_coord(s_slot[wv][0], lane));
 }
 
 // k_reduce_bits with wide additions: one 512-thread workgroup per (window, bit); the selected elements are staged in LDS
