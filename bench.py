@@ -332,7 +332,7 @@ def main():
                 j = json.load(open(pmc))
             except Exception:
                 continue
-            if j.get("n_local") == n_local and j.get("window_bits") == pl.window_bits:
+            if j.get("n_local") == n_local and j.get("window_bits") == pl.window_bits and j.get("num_windows", W) == W:
                 traffic = j.get("hbm_bytes_per_launch")
                 traffic_src = {"source": "file", "file": os.path.relpath(pmc, ROOT), "build": j.get("build", "round 2"),
                                "detail": "offline rocprofv3 --pmc passes on the same box class (tools/pmc_accumulate.sh); not measured in this run"}

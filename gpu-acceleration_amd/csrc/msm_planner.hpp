@@ -38,8 +38,11 @@ inline uint32_t plan_window_bits(size_t n, bool is_signed) {
 // reduce, half the host's Horner chain.  Interleaved A/B against the unsplit pipeline (tools/ab_glv.py): 2^10 -12.8 %, 2^14 -11.9 %,
 // 2^16 -12.3 %, 2^17 -12.2 %, 2^18 -9.6 %, 2^19 +1.1 %, 2^20 -0.4 %, 2^21 +9.2 %, 2^22 +6.8 % (twice the base records to gather
 // from, k_accumulate unchanged, and the fixed costs it halves no longer matter).  With the chunk length following the bucket
-// occupancy: 2^18 -10.4 %, 2^19 -3.4 %, 2^20 -0.3 %, 2^21 +3.6 %, 2^22 +9.9 %  => on by default up to 2^19 points.
-constexpr size_t GLV_MAX_POINTS = (size_t)1 << 19;
+// occupancy: 2^18 -10.4 %, 2^19 -3.4 %, 2^20 -0.3 %, 2^21 +3.6 %, 2^22 +9.9 %  => on by default up to 2^19 points (round 2).
+// Round 3, after k_accumulate stopped waiting for its own gathers (the 2n base records of the split no longer cost latency): 2^19 -2.3 %,
+// 2^20 -2.2 / -2.5 % on one box and -5.0 % on another, 2^21 -1.3 % (inside the noise), 2^22 +5.2 % (profiles/r3_glv_ab.txt)
+// => on by default up to 2^20 points.
+constexpr size_t GLV_MAX_POINTS = (size_t)1 << 20;
 inline uint32_t plan_window_bits_glv(size_t n, bool is_signed) {
     // measured (tools/sweep_c.py, split on): 2^10 c = 9/10 0.247/0.249 ms; 2^12 10/11 0.286/0.281; 2^13 10 0.308 (16: 0.364);
     // 2^14 10 0.330 (16: 0.440); 2^15 12 0.365 (16: 0.435); 2^16 16 0.420 (13: 0.439); 2^17 16 0.504 (13: 0.541); 2^18 16 0.671

@@ -43,18 +43,22 @@ def test_hooks_live_in_their_own_library():
 
 
 def test_planner_matches_design():
-    # up to 2^19 points: GLV split -- 2n virtual points, 127-bit halves, half the windows
+    # up to 2^20 points: GLV split -- 2n virtual points, 127-bit halves, half the windows
     p = mh.plan(1 << 17)
     assert p.signed_digits == 1 and p.num_buckets == 1 << (p.window_bits - 1)
     assert p.glv == 1 and p.scalar_bits == 127 and p.virtual_points == 2 << 17
     assert p.num_windows == 127 // p.window_bits + 1
     assert 13 <= p.window_bits <= 17
-    # without the split, and above 2^19 points (where it no longer pays): the reference's shape
+    # without the split, and above 2^20 points (where it no longer pays): the reference's shape
     p = mh.plan(1 << 17, 0, mh.FLAG_NO_GLV)
     assert p.glv == 0 and p.scalar_bits == 254 and p.virtual_points == 1 << 17 and p.num_windows == 254 // p.window_bits + 1
-    p = mh.plan(1 << 20)
+    p = mh.plan(1 << 20)  # the BASELINE size: still split (round 3) -- eight 16-bit windows over 2^21 virtual points
+    assert p.glv == 1 and p.window_bits == 16 and p.num_windows == 8 and p.virtual_points == 2 << 20
+    p = mh.plan(1 << 20, 0, mh.FLAG_NO_GLV)
     assert p.glv == 0 and p.window_bits == 16 and p.num_windows == 16 and p.virtual_points == 1 << 20
-    assert mh.plan(1 << 19).glv == 1 and mh.plan((1 << 19) + 1).glv == 0
+    p = mh.plan(1 << 21)
+    assert p.glv == 0 and p.window_bits == 17 and p.num_windows == 15
+    assert mh.plan(1 << 20).glv == 1 and mh.plan((1 << 20) + 1).glv == 0
     # BASELINE config 2: fixed 16-bit window, plain digits
     p = mh.plan(1 << 16, 16, mh.FLAG_UNSIGNED_DIGITS | mh.FLAG_NO_GLV)
     assert (p.window_bits, p.num_windows, p.num_buckets, p.signed_digits) == (16, 16, 65536, 0)

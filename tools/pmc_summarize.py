@@ -30,8 +30,12 @@ try:  # the bench line printed under the profiler names the workload the counter
     line = [l for l in open(f"{d}/bench_FETCH_SIZE.log") if l.startswith("{")][-1]
     cfg = json.loads(line)["config"]
     res["n_local"], res["window_bits"] = cfg["n_per_gpu"], cfg["window_bits"]
+    res["num_windows"], res["glv_split"] = cfg.get("num_windows"), cfg.get("glv_split")
+    res["algorithmic_bytes_per_launch"] = json.loads(line)["roofline"]["algorithmic_bytes_per_launch"]
+    res["traffic_over_algorithmic"] = round(res["hbm_bytes_per_launch"] / res["algorithmic_bytes_per_launch"], 3)
 except Exception as e:
     res["n_local"], res["window_bits"] = None, None
+res["build"] = sys.argv[2] if len(sys.argv) > 2 else "?"
 res["how"] = ("tools/pmc_accumulate.sh on an MI355X gpurun box: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes "
               "(with --kernel-trace only) around `python3 bench.py --steps 3 --warmup 1`; counters corrected with the factors measured "
               "by tools/calib_gather on the same box (64-B record gathers count exactly, 16 B/lane streams count 1/2, 144-B record "
