@@ -142,6 +142,7 @@ struct Knobs {
         k.table.c = (uint32_t)num("MSM_HIP_TABLE_C", 0, 20, 0);
         k.table.f = (uint32_t)num("MSM_HIP_TABLE_F", 0, 128, 0);
         k.table.max_bytes = (size_t)num("MSM_HIP_TABLE_MAX_GB", 0, 1024, 64) << 30;
+        if (std::getenv("MSM_HIP_TABLE_GLV_MAX_LOG2")) k.table.glv_max = (size_t)1 << num("MSM_HIP_TABLE_GLV_MAX_LOG2", 0, 23, 18);
         return k;
     }
 };
@@ -311,7 +312,10 @@ int32_t pipe_prepare(msm_ctx* c, size_t n_real, size_t plan_n, uint32_t extra_fl
                      uint32_t table_f = 1) {
     if (trace_enabled() && c->flags_clean) c->t_prepare = std::chrono::steady_clock::now();  // (flags_clean: first prepare of a call)
     if (n_real > 0x3FFFFFFFull) return fail(c, MSM_ERR_BAD_ARG, "n = %zu exceeds 2^30-1 points per context call", n_real);
-    int32_t rc = table_c ? make_plan(plan_n ? plan_n : n_real, table_c, c->cfg.flags | extra_flags, &ps->pl, c->knobs.glv_max)
+    // (a table call re-derives the plan its upload made: same width, and the split wherever make_table_plan allowed it -- the caller
+    // passes MSM_FLAG_NO_GLV when the uploaded set has no phi records)
+    const size_t table_glv = std::max(c->knobs.glv_max, c->knobs.table.glv_max ? c->knobs.table.glv_max : msmplan::TABLE_GLV_MAX_POINTS);
+    int32_t rc = table_c ? make_plan(plan_n ? plan_n : n_real, table_c, c->cfg.flags | extra_flags, &ps->pl, table_glv)
                          : ctx_plan(c, plan_n ? plan_n : n_real, extra_flags, &ps->pl);
     if (rc) return fail(c, rc, "bad window_bits/flags (%u, 0x%x)", table_c ? table_c : c->cfg.window_bits, c->cfg.flags);
     const msm_plan_t& pl = ps->pl;

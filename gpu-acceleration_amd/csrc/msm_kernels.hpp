@@ -821,7 +821,10 @@ constexpr uint32_t FINE_BINS_MAX = 512;  // fine part of the bucket index: up to
 constexpr uint32_t SUPER_MAX = 16;       // super-tiles of 2^idx_bits elements a sort window may span
 static_assert(BIG_SLOT_WORDS == 2 * FINE_BINS_MAX, "oversized-region tables hold counts + cursors of every fine bin");
 // An element travels through the staging array as  (position in its sort window) mod 2^idx_bits | fine << idx_bits | sign << 31 with
-// idx_bits = 31 - fine_bits.  A sort window longer than 2^idx_bits elements (the shared bucket array of a window table: 13 x 2^20
+// idx_bits = 31 - fine_bits.  EVERY 32-bit pattern is a valid element -- 0xFFFFFFFF is the last position of a super-tile with all fine
+// bits set and a negative digit, which the top window of a full table produces on purpose (digit * 2^top_shift - 1 ends in ones):
+// whether a register slot holds an element is decided by its index, never by a sentinel value (round 3; a c = 17 split table at 2^21
+// points lost exactly that one entry).  A sort window longer than 2^idx_bits elements (the shared bucket array of a window table: 13 x 2^20
 // entries with 9 fine bits) is cut into SUPER-TILES of 2^idx_bits elements; the dropped high bits of the position are recovered from
 // where the element sits in its region: k_coarse_scatter lays a region out sub-tile after sub-tile, so the region's elements of
 // super-tile h are exactly the positions [bnd[h-1], bnd[h]) with bnd[h] = counts[w][(h+1) * sub_per_super][bin] -- the exclusive prefix
@@ -889,11 +892,11 @@ __global__ void __launch_bounds__(FINE_BLOCK) k_fine_sort(const uint32_t* __rest
 #pragma unroll
             for (int k = 0; k < FINE_PER_THREAD; k++) {
                 uint32_t j = b0 + threadIdx.x + k * FINE_BLOCK;
-                eb[k] = j < b1 ? tmp[j] : DIGIT_SKIP;
+                eb[k] = j < b1 ? tmp[j] : 0u;
             }
 #pragma unroll
             for (int k = 0; k < FINE_PER_THREAD; k++)
-                if (eb[k] != DIGIT_SKIP) lds_inc(s_cur, (eb[k] >> idx_bits) & fmask);
+                if (b0 + threadIdx.x + k * FINE_BLOCK < b1) lds_inc(s_cur, (eb[k] >> idx_bits) & fmask);
             __syncthreads();
             for (uint32_t f = threadIdx.x; f < nfine; f += FINE_BLOCK)
                 if (s_cur[f]) atomicAdd(&big[BIG_TAB_OFF + (size_t)bigslot[rr] * BIG_SLOT_WORDS + f], s_cur[f]);
@@ -914,21 +917,21 @@ __global__ void __launch_bounds__(FINE_BLOCK) k_fine_sort(const uint32_t* __rest
 #pragma unroll
         for (int k = 0; k < FINE_PER_THREAD; k++) {
             uint32_t j = rs + threadIdx.x + k * FINE_BLOCK;
-            e[k] = j < re ? tmp[j] : DIGIT_SKIP;
+            e[k] = j < re ? tmp[j] : 0u;
         }
 #pragma unroll
         for (int k = 0; k < FINE_PER_THREAD; k++)
-            if (e[k] != DIGIT_SKIP) lds_inc(s_cur, (e[k] >> idx_bits) & fine_mask);
+            if (rs + threadIdx.x + k * FINE_BLOCK < re) lds_inc(s_cur, (e[k] >> idx_bits) & fine_mask);
     } else {  // oversized region (one bucket holds a large share of the window): FINE_PER_THREAD loads in flight per thread
         for (uint32_t base = rs; base < re; base += CAP) {
 #pragma unroll
             for (int k = 0; k < FINE_PER_THREAD; k++) {
                 uint32_t j = base + threadIdx.x + k * FINE_BLOCK;
-                e[k] = j < re ? tmp[j] : DIGIT_SKIP;
+                e[k] = j < re ? tmp[j] : 0u;
             }
 #pragma unroll
             for (int k = 0; k < FINE_PER_THREAD; k++)
-                if (e[k] != DIGIT_SKIP) lds_inc(s_cur, (e[k] >> idx_bits) & fine_mask);
+                if (base + threadIdx.x + k * FINE_BLOCK < re) lds_inc(s_cur, (e[k] >> idx_bits) & fine_mask);
         }
     }
     __syncthreads();
@@ -943,7 +946,7 @@ __global__ void __launch_bounds__(FINE_BLOCK) k_fine_sort(const uint32_t* __rest
     if (staged) {
 #pragma unroll
         for (int k = 0; k < FINE_PER_THREAD; k++) {
-            if (e[k] == DIGIT_SKIP) continue;
+            if (rs + threadIdx.x + k * FINE_BLOCK >= re) continue;
             uint32_t pos = lds_inc(s_cur, (e[k] >> idx_bits) & fine_mask);
             s_out[pos] = ((e[k] & idx_mask) + sort_hi_of(hi, s_bnd, threadIdx.x + k * FINE_BLOCK, idx_bits)) | (e[k] & SIGN_BIT);
         }
@@ -955,11 +958,11 @@ __global__ void __launch_bounds__(FINE_BLOCK) k_fine_sort(const uint32_t* __rest
 #pragma unroll
             for (int k = 0; k < FINE_PER_THREAD; k++) {
                 uint32_t j = base + threadIdx.x + k * FINE_BLOCK;
-                e[k] = j < re ? tmp[j] : DIGIT_SKIP;
+                e[k] = j < re ? tmp[j] : 0u;
             }
 #pragma unroll
             for (int k = 0; k < FINE_PER_THREAD; k++) {
-                if (e[k] == DIGIT_SKIP) continue;
+                if (base + threadIdx.x + k * FINE_BLOCK >= re) continue;
                 uint32_t pos = lds_inc(s_cur, (e[k] >> idx_bits) & fine_mask);
                 sorted[rs + pos] = ((e[k] & idx_mask) + sort_hi_of(hi, s_bnd, base - rs + threadIdx.x + k * FINE_BLOCK, idx_bits)) | (e[k] & SIGN_BIT);
             }
@@ -998,11 +1001,11 @@ __global__ void __launch_bounds__(FINE_BLOCK) k_big_place(const uint32_t* __rest
 #pragma unroll
         for (int k = 0; k < FINE_PER_THREAD; k++) {
             uint32_t j = b0 + threadIdx.x + k * FINE_BLOCK;
-            eb[k] = j < b1 ? tmp[j] : DIGIT_SKIP;
+            eb[k] = j < b1 ? tmp[j] : 0u;
         }
 #pragma unroll
         for (int k = 0; k < FINE_PER_THREAD; k++)
-            if (eb[k] != DIGIT_SKIP) lds_inc(s_cnt, (eb[k] >> idx_bits) & fmask);
+            if (b0 + threadIdx.x + k * FINE_BLOCK < b1) lds_inc(s_cnt, (eb[k] >> idx_bits) & fmask);
         __syncthreads();
         if (threadIdx.x < nfine) {
             const uint32_t cn = s_cnt[threadIdx.x];
@@ -1012,7 +1015,7 @@ __global__ void __launch_bounds__(FINE_BLOCK) k_big_place(const uint32_t* __rest
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < FINE_PER_THREAD; k++) {
-            if (eb[k] == DIGIT_SKIP) continue;
+            if (b0 + threadIdx.x + k * FINE_BLOCK >= b1) continue;
             const uint32_t f = (eb[k] >> idx_bits) & fmask;
             const uint32_t pos = r0 + s_ex[f] + s_base[f] + lds_inc(s_cnt, f);
             sorted[pos] = ((eb[k] & idx_mask) + sort_hi_of(hi, s_bnd, b0 - r0 + threadIdx.x + k * FINE_BLOCK, idx_bits)) | (eb[k] & SIGN_BIT);

@@ -96,6 +96,7 @@ inline int32_t make_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_pla
 struct table_knobs {
     uint32_t c = 0, f = 0;                // MSM_HIP_TABLE_C / MSM_HIP_TABLE_F: force the width / the factor (0 = planner)
     size_t max_bytes = (size_t)64 << 30;  // MSM_HIP_TABLE_MAX_GB: no table beyond this
+    size_t glv_max = 0;                   // MSM_HIP_TABLE_GLV_MAX_LOG2: table plans split up to this many points (0 = TABLE_GLV_MAX_POINTS)
 };
 // one sort of the shared array covers this many entries (regions of the fine sort: entries / 1024, sorted by their owner workgroup up
 // to four LDS staging areas of 16384); beyond it the pipeline would cut the windows into ranges that accumulate INTO the array
@@ -115,7 +116,9 @@ inline uint32_t plan_table_bits(size_t nv, bool glv) {
 inline int32_t make_table_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_plan_t* out, size_t glv_max, const table_knobs& tk) {
     int32_t rc = make_plan(n, window_bits, flags, out, glv_max);
     if (rc != MSM_OK || !(flags & MSM_FLAG_WINDOW_TABLE) || (flags & MSM_FLAG_UNSIGNED_DIGITS)) return rc;
-    const uint32_t tflags = n > TABLE_GLV_MAX_POINTS ? (flags | MSM_FLAG_NO_GLV) : flags;  // (the split pays up to 2^18 points here)
+    const size_t tglv = tk.glv_max ? tk.glv_max : TABLE_GLV_MAX_POINTS;
+    const uint32_t tflags = n > tglv ? (flags | MSM_FLAG_NO_GLV) : flags;  // (the split pays up to 2^18 points here)
+    if (tglv > glv_max) glv_max = tglv;
     const bool glv0 = !(tflags & MSM_FLAG_NO_GLV) && n <= glv_max;
     uint32_t c = tk.c ? tk.c : window_bits ? window_bits : plan_table_bits(glv0 ? 2 * n : n, glv0);
     msm_plan_t t;

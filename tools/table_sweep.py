@@ -49,12 +49,17 @@ def main():
         exp = [orc.closed_form_expected(k, v)[0] for v in vecs]
         ref = None
         for cfg in args.configs.split(","):
-            for v in ("MSM_HIP_TABLE_C", "MSM_HIP_TABLE_F"):
+            for v in ("MSM_HIP_TABLE_C", "MSM_HIP_TABLE_F", "MSM_HIP_TABLE_GLV_MAX_LOG2"):
                 os.environ.pop(v, None)
             flags = mh.FLAG_NO_GLV if args.no_glv else 0
             if cfg != "plain":
                 flags |= mh.FLAG_WINDOW_TABLE
-                c, _, f = cfg.partition("x")
+                if cfg.endswith("g"):  # `16g`: with the GLV split whatever the size
+                    cfg_c = cfg[:-1]
+                    os.environ["MSM_HIP_TABLE_GLV_MAX_LOG2"] = "23"
+                else:
+                    cfg_c = cfg
+                c, _, f = cfg_c.partition("x")
                 os.environ["MSM_HIP_TABLE_C"] = c
                 if f:
                     os.environ["MSM_HIP_TABLE_F"] = f
