@@ -34,17 +34,31 @@ for it in range(cases):
     inf = None
     if rng.random() < 0.4:
         inf = (rng.random(n) < rng.choice([0.001, 0.05, 0.9])).astype(np.uint8)
-    wb = int(rng.choice([0, 0, 0, 2, 3, 5, 8, 11, 12, 13, 14, 15, 16, 17, 18]))
-    flags = mh.FLAG_UNSIGNED_DIGITS if (rng.random() < 0.25 and wb not in (17, 18)) else 0
+    wb = int(rng.choice([0, 0, 0, 2, 3, 5, 8, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20]))
+    flags = mh.FLAG_UNSIGNED_DIGITS if (rng.random() < 0.25 and wb not in (17, 18, 19, 20)) else 0
     if rng.random() < 0.35:
         flags |= mh.FLAG_NO_GLV
+    table = rng.random() < 0.4  # row f4: the resident path with its window table (shared bucket arrays), random factor
+    for kk in ("MSM_HIP_TABLE_F",):
+        os.environ.pop(kk, None)
+    if table:
+        flags |= mh.FLAG_WINDOW_TABLE
+        pl = mh.plan(n, wb, flags)
+        divs = [f for f in range(2, pl.num_windows + 1) if pl.num_windows % f == 0]
+        if divs and rng.random() < 0.5:
+            os.environ["MSM_HIP_TABLE_F"] = str(int(rng.choice(divs)))
     with mh.MsmContext(window_bits=wb, flags=flags) as ctx:
-        r = ctx.msm(bases, s, mh.FORM_MONT, inf)
-        r2 = ctx.msm(bases, s, mh.FORM_MONT, inf)
+        if table:
+            ctx.upload_bases(bases, mh.FORM_MONT, inf)
+            r = ctx.msm_resident(s)
+            r2 = ctx.msm_resident_batch([s, s])[1]
+        else:
+            r = ctx.msm(bases, s, mh.FORM_MONT, inf)
+            r2 = ctx.msm(bases, s, mh.FORM_MONT, inf)
     exp, einf, _ = orc.msm_pippenger(bases, s, orc.FORM_MONT, inf)
     ok = r.is_infinity == bool(einf) and (r.affine_std == exp).all() and (r2.affine_std == r.affine_std).all()
     if not ok:
         bad += 1
-        print("MISMATCH case", it, dict(n=n, off=off, mode=mode, wb=wb, flags=flags, inf=None if inf is None else int(inf.sum())), flush=True)
+        print("MISMATCH case", it, dict(n=n, off=off, mode=mode, wb=wb, flags=flags, table_f=os.environ.get('MSM_HIP_TABLE_F'), inf=None if inf is None else int(inf.sum())), flush=True)
 print(f"fuzz_parity: {cases} cases, {bad} mismatches, {time.time() - t0:.1f} s")
 sys.exit(1 if bad else 0)
