@@ -69,7 +69,7 @@ def valu_roofline(num_adds, acc_ms, mad_peak, fpmul_peak):
     if os.path.exists(vb):  # hardware VALU-busy counters of the same kernel, collected offline (tools/pmc_valu.sh)
         try:
             j = json.load(open(vb))
-            out["valu_busy_counters"] = {k: j[k] for k in ("valu_busy_frac", "valu_util_frac", "source") if k in j}
+            out["valu_busy_counters"] = {k: j[k] for k in ("valu_busy_frac", "valu_util_frac", "valu_insts_per_mixed_addition", "build", "source") if k in j}
         except Exception:
             pass
     return out

@@ -37,5 +37,14 @@ res = {"kernels": out, "source": "tools/pmc_valu.sh: rocprofv3 --pmc (SQ_* / GRB
 a = out.get("k_accumulate", {})
 for k in ("valu_busy_frac", "valu_util_frac"):
     if k in a: res[k] = a[k]
+res["build"] = sys.argv[2] if len(sys.argv) > 2 else "?"
+try:  # vector instructions per mixed addition and lane: wave instructions x 64 lanes / additions of the launch (from the bench line)
+    line = [l for l in open(f"{d}/sq.log") if l.startswith("{")][-1]
+    adds = json.loads(line)["roofline_valu"]["mixed_additions_per_launch"]
+    res["mixed_additions_per_launch"] = adds
+    res["valu_insts_per_mixed_addition"] = round(a["counters_per_launch"]["SQ_INSTS_VALU"] * 64 / adds, 1)
+    res["effective_clock_ghz"] = a.get("effective_clock_ghz")
+except Exception:
+    pass
 json.dump(res, open(f"{d}/summary.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
