@@ -98,10 +98,11 @@ struct table_knobs {
     size_t max_bytes = (size_t)64 << 30;  // MSM_HIP_TABLE_MAX_GB: no table beyond this
     size_t glv_max = 0;                   // MSM_HIP_TABLE_GLV_MAX_LOG2: table plans split up to this many points (0 = TABLE_GLV_MAX_POINTS)
 };
-// one sort of the shared array covers this many entries (regions of the fine sort: entries / 1024, sorted by their owner workgroup up
-// to four LDS staging areas of 16384); beyond it the pipeline would cut the windows into ranges that accumulate INTO the array
-// (k_accumulate<true, true>: a dependent bucket load per switch) and loses what the table gains -- such sets get no table
-constexpr size_t TABLE_MAX_ENTRIES = (size_t)60 << 20;
+// A table is made while ONE sort covers the shared array and the table pays: up to 2^21 points (13 x 2^21 = 27 M entries; the regions of
+// the fine sort hold entries / 1024 and are sorted by their owner workgroup up to four LDS staging areas of 16384).  At 2^22 points
+// (54 M entries, 3.5 GB of records) the gathers cost what the 13 % fewer additions save: -2.3 % on one box, +0.8 % on another; beyond, the
+// pipeline would have to cut the windows into ranges that accumulate INTO the array (built, bit-exact, 17 % slower than no table).
+constexpr size_t TABLE_MAX_ENTRIES = (size_t)32 << 20;
 // Measured (tools/table_sweep.py, profiles/r3_f4_shared_buckets.txt; resident batch, ms per MSM, table vs plain):
 //   2^14 GLV c = 16 0.172 vs 0.214;  2^16 0.233 vs 0.280;  2^17 0.321 vs 0.374;  2^18 0.494 vs 0.547 (unsplit c = 20: 0.545)
 //   2^19 unsplit c = 20 0.855 vs 0.934 (GLV c = 16: 0.899);  2^20 c = 20 1.395 vs 1.521 (c = 17: 1.487);  2^21 2.83 vs 2.95;  2^22 5.35 vs 5.48
