@@ -154,7 +154,7 @@ struct msm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;     // host->HBM uploads and base conversion beside the sort
-    hipEvent_t ev_copied[2]{}, ev_free[2]{};
+    hipEvent_t ev_copied[2]{}, ev_free[2]{}, ev_scal[2]{};  // streamed host call: slot's bases+scalars there / slot free again / its scalars there
     hipEvent_t ev_fork = nullptr, ev_bases = nullptr;  // base conversion runs on copy_stream beside the sort kernels
     DevBuf sbases[2], sscalars[2], sinf[2];  // double-buffered raw inputs of the streamed path
     DevBuf sibases[2];                        // ... and of the converted bases (the conversion of chunk j+1 runs beside the accumulation of chunk j)
@@ -934,13 +934,17 @@ int32_t run_streamed(msm_ctx* c, const HostInput& in, size_t n, const std::vecto
             Range r_("msm:h2d chunk");
             if (j >= 2) HIPCHK(c, hipStreamWaitEvent(cs, c->ev_free[s], 0));  // the pipeline that read this slot is done
             if ((rc = feed_scalars(c, in, lo, cnt, c->sscalars[s].p, d_inf, cs))) return rc;
+            HIPCHK(c, hipEventRecord(c->ev_scal[s], cs));
             if ((rc = feed_bases(c, in, lo, cnt, c->sbases[s].p, (uint32_t*)c->sibases[s].p, d_inf, glv, cs))) return rc;
             HIPCHK(c, hipEventRecord(c->ev_copied[s], cs));
         }
-        HIPCHK(c, hipStreamWaitEvent(st, c->ev_copied[s], 0));
+        // the sort only needs the scalars (a third of the chunk's bytes): it starts while the bases still travel.  (The struct form
+        // carries the infinity flags inside the base records, which k_decompose reads: there the sort waits for the whole chunk.)
+        const bool early_sort = in.kind != KIND_ARK;
+        HIPCHK(c, hipStreamWaitEvent(st, early_sort ? c->ev_scal[s] : c->ev_copied[s], 0));
         if ((rc = pipe_prepare(c, cnt, n, 0, st, &ps))) return rc;
         if ((rc = enqueue_digits_sort(c, ps, d_inf, (const uint32_t*)c->sscalars[s].p, in.scalars_mont, st, j == 0))) return rc;
-        if ((rc = enqueue_accumulate(c, ps, (const uint32_t*)c->sibases[s].p, st, nullptr, j > 0, true))) return rc;
+        if ((rc = enqueue_accumulate(c, ps, (const uint32_t*)c->sibases[s].p, st, early_sort ? c->ev_copied[s] : nullptr, j > 0, true))) return rc;
         HIPCHK(c, hipEventRecord(c->ev_free[s], st));
         lo += cnt;
     }
@@ -1092,6 +1096,7 @@ static int32_t ctx_create_impl(const msm_config_t* cfg, msm_ctx** out, int main_
     for (int i = 0; i < 2 && e == hipSuccess; i++) {
         e = hipEventCreateWithFlags(&c->ev_copied[i], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_free[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_scal[i], hipEventDisableTiming);
     }
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_qsums, MAX_QSUM_POINTS * 96, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_flags, 64, hipHostMallocDefault);
@@ -1163,6 +1168,7 @@ void msm_ctx_destroy(msm_ctx* c) {
             release(c->sibases[i]);
             if (c->ev_copied[i]) (void)hipEventDestroy(c->ev_copied[i]);
             if (c->ev_free[i]) (void)hipEventDestroy(c->ev_free[i]);
+            if (c->ev_scal[i]) (void)hipEventDestroy(c->ev_scal[i]);
         }
         if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
         if (c->ev_bases) (void)hipEventDestroy(c->ev_bases);
