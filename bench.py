@@ -460,9 +460,12 @@ def main():
             n_cpu = min(n_local, (1 << 20) if threads >= 8 else (1 << 18))
             hbc = d_bases[0][: n_cpu * 16].cpu().numpy().view(np.uint32).reshape(n_cpu, 16)
             hsc = d_scalars[0][: n_cpu * 8].cpu().numpy().view(np.uint32).reshape(n_cpu, 8)
-            t0 = time.perf_counter()
-            cpu_aff, cpu_inf, _ = orc.msm_pippenger(hbc, hsc, orc.FORM_MONT, None, threads)
-            cpu_ms = (time.perf_counter() - t0) * 1e3
+            cpu_runs = []
+            for _ in range(3):  # best of three: one run moved by 35 % between two driver runs of round 2 (a shared host)
+                t0 = time.perf_counter()
+                cpu_aff, cpu_inf, _ = orc.msm_pippenger(hbc, hsc, orc.FORM_MONT, None, threads)
+                cpu_runs.append((time.perf_counter() - t0) * 1e3)
+            cpu_ms = min(cpu_runs)
             if n_cpu == n_local:
                 cpu_ok = bool((cpu_aff == res.affine_std).all())
             else:
@@ -472,8 +475,8 @@ def main():
             lg = int(np.log2(n_cpu))
             c_ark = 3 if n_cpu < 32 else (lg * 69) // 100 + 2
             busy = min(threads, -(-254 // c_ark))
-            out["cpu_baseline"] = {"value": round(cpu_ms, 2), "unit": "ms", "cores": busy, "kind": "port",
-                                   "sample": "first 2^%d points of the same instance, one MSM; arkworks-0.4 algorithm restated in C "
+            out["cpu_baseline"] = {"value": round(cpu_ms, 2), "all_runs_ms": [round(x, 1) for x in cpu_runs], "unit": "ms", "cores": busy, "kind": "port",
+                                   "sample": "first 2^%d points of the same instance, one MSM, best of three runs; arkworks-0.4 algorithm restated in C "
                                              "(not arkworks itself): one thread per window, %d windows of %d bits, %d host threads available"
                                              % (lg, -(-254 // c_ark), c_ark, threads),
                                    "agrees_with_gpu": cpu_ok}

@@ -39,6 +39,7 @@ const MSM_FORM_MONT: u32 = 1;
 
 extern "C" {
     fn msm_ctx_create(cfg: *const MsmConfig, out: *mut *mut MsmCtx) -> i32;
+    fn msm_ctx_destroy(ctx: *mut MsmCtx);
     fn msm_last_error(ctx: *const MsmCtx) -> *const c_char;
     fn msm_bn254_g1(
         ctx: *mut MsmCtx, bases_xy: *const u32, base_form: u32, inf_mask: *const u8, scalars: *const u32, n: usize,
@@ -328,6 +329,95 @@ pub fn hip_variable_base_msm_batch(bases: &[G1Affine], scalar_sets: &[&[BigInt<4
         return Err(last_error(ctx.0).into());
     }
     Ok(jac.iter().map(to_projective).collect())
+}
+
+/// `msm_config_t.flags` bit: resident sets carry their window table (include/msm_hip.h MSM_FLAG_WINDOW_TABLE).
+pub const MSM_FLAG_WINDOW_TABLE: u32 = 4;
+
+/// A base set that stays in HBM for the lifetime of the value -- a prover's proving key.  The reference has no counterpart (it re-packs
+/// and re-uploads the bases on every `metal_variable_base_msm` call, metal_msm.rs:94, 274-344); `hip_variable_base_msm_batch` above uploads
+/// per call.  With `window_table = true` the upload also builds T_j[i] = 2^(c j) P_i for every window (39 ms and 872 MB at 2^20 points) and
+/// every MSM on the whole set adds all windows into ONE bucket array: -7..-11 % per MSM at 2^20, -10..-20 % from 2^14 to 2^18 points.  The
+/// build pays for itself after a few hundred MSMs at 2^20 (tens at 2^16): use it for keys that live as long as the process.
+/// Owns a context of its own, so the process-global one behind `metal_variable_base_msm` is not disturbed.
+pub struct HipResidentBases {
+    ctx: *mut MsmCtx,
+    n: usize,
+}
+unsafe impl Send for HipResidentBases {}
+
+impl HipResidentBases {
+    pub fn new(bases: &[G1Affine], window_table: bool) -> Result<Self, Box<dyn Error>> {
+        if bases.is_empty() {
+            return Err("Empty input".into());
+        }
+        let cfg = MsmConfig {
+            device: -1, window_bits: 0, flags: if window_table { MSM_FLAG_WINDOW_TABLE } else { 0 }, stream_chunk_log2: 0, max_points: 0,
+        };
+        let mut p: *mut MsmCtx = std::ptr::null_mut();
+        if unsafe { msm_ctx_create(&cfg, &mut p) } != 0 {
+            return Err(last_error(std::ptr::null()).into());
+        }
+        let n = bases.len();
+        let mut xy = vec![0u64; n * 8];
+        let mut inf = vec![0u8; n];
+        for (i, b) in bases.iter().enumerate() {
+            if b.infinity {
+                inf[i] = 1;
+            } else {
+                xy[i * 8..i * 8 + 4].copy_from_slice(&b.x.0 .0);
+                xy[i * 8 + 4..i * 8 + 8].copy_from_slice(&b.y.0 .0);
+            }
+        }
+        let me = HipResidentBases { ctx: p, n };
+        if unsafe { msm_bn254_g1_upload_bases(p, xy.as_ptr() as *const u32, MSM_FORM_MONT, inf.as_ptr(), n) } != 0 {
+            return Err(last_error(p).into()); // `me` is dropped: the context is destroyed
+        }
+        Ok(me)
+    }
+
+    /// one MSM; fewer scalars than bases truncate to the shorter (metal_msm.rs:652-656)
+    pub fn msm(&self, scalars: &[BigInt<4>]) -> Result<G1Projective, Box<dyn Error>> {
+        if scalars.is_empty() {
+            return Err("Empty input".into());
+        }
+        let mut jac = [0u64; 12];
+        let mut is_inf = 0u8;
+        let rc = unsafe {
+            msm_bn254_g1_resident(
+                self.ctx, scalars.as_ptr() as *const u32, scalars.len().min(self.n), jac.as_mut_ptr() as *mut u32, std::ptr::null_mut(), &mut is_inf,
+            )
+        };
+        if rc != 0 {
+            return Err(last_error(self.ctx).into());
+        }
+        Ok(to_projective(&jac))
+    }
+
+    /// several scalar vectors, two MSMs in flight (`msm_bn254_g1_resident_batch`)
+    pub fn msm_batch(&self, scalar_sets: &[&[BigInt<4>]]) -> Result<Vec<G1Projective>, Box<dyn Error>> {
+        if scalar_sets.is_empty() || scalar_sets.iter().any(|s| s.is_empty()) {
+            return Err("Empty input".into());
+        }
+        let n = scalar_sets.iter().map(|s| s.len()).min().unwrap().min(self.n);
+        let ptrs: Vec<*const u32> = scalar_sets.iter().map(|s| s.as_ptr() as *const u32).collect();
+        let mut jac = vec![[0u64; 12]; ptrs.len()];
+        let rc = unsafe {
+            msm_bn254_g1_resident_batch(
+                self.ctx, ptrs.as_ptr(), n, ptrs.len(), jac.as_mut_ptr() as *mut u32, std::ptr::null_mut(), std::ptr::null_mut(),
+            )
+        };
+        if rc != 0 {
+            return Err(last_error(self.ctx).into());
+        }
+        Ok(jac.iter().map(to_projective).collect())
+    }
+}
+
+impl Drop for HipResidentBases {
+    fn drop(&mut self) {
+        unsafe { msm_ctx_destroy(self.ctx) };
+    }
 }
 
 /// Alias under the engine's own name.
