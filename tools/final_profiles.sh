@@ -12,7 +12,7 @@ cd "$R"
 export BUILD="${BUILD:-round 3 final}"
 python3 bench.py > $O/bench_line.json 2> $O/bench.err; echo "bench rc $?"
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o p -- python3 $R/bench.py > $O/bench_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o p -- python3 $R/bench.py --no-host-legs > $O/bench_under_rocprof.json 2>/dev/null  # (no host legs: k_accumulate<false,false> then only has the timed shape)
 cp $O/stats/p_kernel_stats.csv $O/kernel_stats.csv
 cd "$R"
 python3 tools/shard_times.py --build "$BUILD" > $O/shard_times.txt 2>&1
