@@ -561,11 +561,10 @@ int32_t enqueue_accumulate(msm_ctx* c, const PipeState& ps, const uint32_t* d_ba
     else msmk::k_accumulate<false, false><<<ga, 256, 0, st>>>(d_bases, srt, offsets, cm, bk, hd, tl, tp, ps.chunk_len, (uint32_t)tb);
     HIPCHK(c, hipEventRecord(c->ev[EV_ACC1], st));
     const size_t once_max = std::min(ps.nchunks_max, tb);  // a once-cut bucket owns one chunk border
-    msmk::k_combine<<<dim3(msmk::MID_BLOCKS + (unsigned)((once_max + 255) / 256)), 256, 0, st>>>(
+    msmk::k_combine<<<dim3(msmk::LONG_BLOCKS + msmk::MID_BLOCKS + (unsigned)((once_max + 511) / 512)), 512, 0, st>>>(
         offsets, (uint32_t*)c->heads.p, (uint32_t*)c->tails.p, (uint32_t*)c->buckets.p, ps.chunk_len, flags + msmk::FLAG_MID,
-        (uint32_t*)c->midlist.p, flags + msmk::FLAG_ONCE, (uint32_t*)c->oncelist.p);
-    msmk::k_combine_long<<<1024, 512, 0, st>>>(offsets, (uint32_t*)c->heads.p, (uint32_t*)c->tails.p, (uint32_t*)c->buckets.p,
-                                               flags + msmk::FLAG_LONG, (uint32_t*)c->longlist.p, (uint32_t*)c->longdone.p, ps.chunk_len);
+        (uint32_t*)c->midlist.p, flags + msmk::FLAG_ONCE, (uint32_t*)c->oncelist.p, flags + msmk::FLAG_LONG, (uint32_t*)c->longlist.p,
+        (uint32_t*)c->longdone.p);
     return MSM_OK;
 }
 

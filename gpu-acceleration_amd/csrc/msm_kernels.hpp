@@ -7,7 +7,7 @@
 //        k_coarse_starts, k_coarse_scatter, k_fine_sort (fallbacks: k_tile_* for n > 2^24, device-scope atomics in
 //        k_decompose + k_scan_* + k_scatter for windows of more than 2^17 buckets)
 //   K3 smvp (full 16-mul Jacobian add, one thread per bucket pair) -> k_chunk_map, k_accumulate (XYZZ mixed add over
-//        fixed-length chunks), k_combine / k_combine_long (buckets cut by chunk borders)
+//        fixed-length chunks), k_combine (buckets cut by chunk borders: once / 3+ times / long, one launch)
 //   K4/K5 bpr_stage_1/2 -> k_pair_level / k_pair_level_wide (row/column plain sums, dense pairwise levels) +
 //        k_reduce_bits_wide (per-bit sums, LDS trees of eight-lane additions; k_reduce_bits = the one-lane fallback)
 //   final_reduction (CPU) -> stays on the CPU: host_g1.hpp
@@ -1048,11 +1048,11 @@ __global__ void k_scatter(const uint32_t* __restrict__ digits, const uint32_t* _
 // Each point is gathered as one 64-byte affine record and folded into an XYZZ accumulator in registers.
 
 // chunk_bucket[t] = bucket that owns sorted entry t*L  (one thread per bucket writes the chunks it starts)
-// Buckets cut into LONG_SPAN or more chunks (tiny top windows, adversarial scalars) are listed for k_combine_long,
+// Buckets cut into LONG_SPAN or more chunks (tiny top windows, adversarial scalars) are listed for k_combine's long workgroups,
 // buckets cut into 3..LONG_SPAN-1 chunks for k_combine_mid; k_combine itself only meets buckets cut once, so that
 // every one of its wavefronts runs exactly one XYZZ add (a few 3-chunk buckets per wavefront used to double its time).
 constexpr uint32_t LONG_SPAN = 8;
-constexpr uint32_t LONG_SEG = 2048;  // pieces of a long bucket folded by one k_combine_long workgroup
+constexpr uint32_t LONG_SEG = 2048;  // pieces of a long bucket folded by one long workgroup of k_combine
 __global__ void __launch_bounds__(1024) k_chunk_map(const uint32_t* __restrict__ offsets, uint32_t* __restrict__ chunk_bucket,
                                                    uint32_t total_buckets, uint32_t L, uint32_t* __restrict__ flags,
                                                    uint32_t* __restrict__ long_list, uint32_t* __restrict__ mid_list,
@@ -1198,35 +1198,6 @@ __global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__
     store_xyzz(dst, acc);
 }
 
-// ONE launch, two kinds of workgroups (the listed buckets take 2..6 dependent adds, so their workgroups come FIRST in
-// the grid and run beside the single-add bulk instead of after it):
-//   blockIdx <  MID_BLOCKS : one thread per LISTED bucket (cut into 3..LONG_SPAN-1 chunks), grid-stride over the list
-//   blockIdx >= MID_BLOCKS : one thread per bucket of the ONCE-CUT list: tails[t0] + heads[t1].  The list (k_chunk_map) makes
-//                            these wavefronts dense -- with one thread per bucket ~40 % of the lanes idled through the addition
-//                            (buckets lying inside one chunk, empty ones): 74 -> 5x us at 2^20.
-constexpr uint32_t MID_BLOCKS = 256;
-__global__ void __launch_bounds__(256) k_combine(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ heads,
-                                                 const uint32_t* __restrict__ tails, uint32_t* __restrict__ buckets, uint32_t L,
-                                                 const uint32_t* __restrict__ mid_count, const uint32_t* __restrict__ mid_list,
-                                                 const uint32_t* __restrict__ once_count, const uint32_t* __restrict__ once_list) {
-    if (blockIdx.x < MID_BLOCKS) {
-        const uint32_t nmid = *mid_count;
-        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nmid; i += MID_BLOCKS * blockDim.x) {
-            const uint32_t k = mid_list[i];
-            const uint32_t t0 = offsets[k] / L, t1 = (offsets[k + 1] - 1) / L;
-            xyzz acc = load_xyzz(tails + (size_t)t0 * XW);
-            for (uint32_t t = t0 + 1; t <= t1; t++) acc = xyzz_add(acc, load_xyzz(heads + (size_t)t * XW));
-            store_xyzz(buckets + (size_t)k * XW, acc);
-        }
-        return;
-    }
-    const uint32_t i = (blockIdx.x - MID_BLOCKS) * blockDim.x + threadIdx.x;
-    if (i >= *once_count) return;
-    const uint32_t k = once_list[i];
-    const uint32_t t0 = offsets[k] / L;
-    store_xyzz(buckets + (size_t)k * XW, xyzz_add(load_xyzz(tails + (size_t)t0 * XW), load_xyzz(heads + (size_t)(t0 + 1) * XW)));
-}
-
 // Long buckets (cut into LONG_SPAN or more pieces: tiny top windows, skewed scalars).  Pieces e(0) = tails[t0],
 // e(i) = heads[t0+i].  One 512-thread workgroup per SEGMENT of LONG_SEG pieces: staged in LDS (more than 256: threads
 // 0..255 first fold strided, scalar) and folded by a pairwise tree of WIDE additions.  A bucket of several segments
@@ -1253,14 +1224,43 @@ __device__ __forceinline__ void long_fold(uint32_t* e, const uint32_t* heads, co
     }
     lds_tree_wide(e, count < CAP ? count : CAP);
 }
-__global__ void __launch_bounds__(512) k_combine_long(const uint32_t* __restrict__ offsets, uint32_t* __restrict__ heads,
-                                                      uint32_t* __restrict__ tails, uint32_t* __restrict__ buckets,
-                                                      const uint32_t* __restrict__ long_count, const uint32_t* __restrict__ long_list,
-                                                      uint32_t* __restrict__ long_done, uint32_t L) {
+// ONE launch for every bucket cut by chunk borders, three kinds of 512-thread workgroups -- the ones with the longest dependent chains
+// come FIRST in the grid and run beside the single-add bulk instead of after it:
+//   blockIdx <  LONG_BLOCKS              : long buckets (LONG_SPAN or more pieces), one workgroup per (bucket, segment) item, grid-stride
+//   next MID_BLOCKS workgroups           : one thread per LISTED bucket (cut into 3..LONG_SPAN-1 chunks), grid-stride over the list
+//   the rest                             : one thread per bucket of the ONCE-CUT list: tails[t0] + heads[t1].  The list (k_chunk_map) makes
+//                                          these wavefronts dense -- with one thread per bucket ~40 % of the lanes idled through the addition
+// (Round 3: the long buckets had a launch of their own, k_combine_long -- 5 us per MSM for a list that is empty on uniform scalars.)
+constexpr uint32_t LONG_BLOCKS = 512, MID_BLOCKS = 128;
+__global__ void __launch_bounds__(512) k_combine(const uint32_t* __restrict__ offsets, uint32_t* __restrict__ heads, uint32_t* __restrict__ tails,
+                                                 uint32_t* __restrict__ buckets, uint32_t L, const uint32_t* __restrict__ mid_count,
+                                                 const uint32_t* __restrict__ mid_list, const uint32_t* __restrict__ once_count,
+                                                 const uint32_t* __restrict__ once_list, const uint32_t* __restrict__ long_count,
+                                                 const uint32_t* __restrict__ long_list, uint32_t* __restrict__ long_done) {
+    if (blockIdx.x >= LONG_BLOCKS) {
+        const uint32_t b = blockIdx.x - LONG_BLOCKS;
+        if (b < MID_BLOCKS) {
+            const uint32_t nmid = *mid_count;
+            for (uint32_t i = b * blockDim.x + threadIdx.x; i < nmid; i += MID_BLOCKS * blockDim.x) {
+                const uint32_t k = mid_list[i];
+                const uint32_t t0 = offsets[k] / L, t1 = (offsets[k + 1] - 1) / L;
+                xyzz acc = load_xyzz(tails + (size_t)t0 * XW);
+                for (uint32_t t = t0 + 1; t <= t1; t++) acc = xyzz_add(acc, load_xyzz(heads + (size_t)t * XW));
+                store_xyzz(buckets + (size_t)k * XW, acc);
+            }
+            return;
+        }
+        const uint32_t i = (b - MID_BLOCKS) * blockDim.x + threadIdx.x;
+        if (i >= *once_count) return;
+        const uint32_t k = once_list[i];
+        const uint32_t t0 = offsets[k] / L;
+        store_xyzz(buckets + (size_t)k * XW, xyzz_add(load_xyzz(tails + (size_t)t0 * XW), load_xyzz(heads + (size_t)(t0 + 1) * XW)));
+        return;
+    }
     __shared__ uint32_t e[WIDE_TREE_MAX * XW];
     __shared__ uint32_t s_last;
     const uint32_t nlong = *long_count;
-    for (uint32_t item = blockIdx.x; item < nlong; item += gridDim.x) {
+    for (uint32_t item = blockIdx.x; item < nlong; item += LONG_BLOCKS) {
         const uint32_t k = long_list[2 * (size_t)item], seg = long_list[2 * (size_t)item + 1];
         const uint32_t beg = offsets[k], end = offsets[k + 1];
         const uint32_t t0 = beg / L, t1 = (end - 1) / L;
