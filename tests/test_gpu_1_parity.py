@@ -523,11 +523,12 @@ def test_window_table_collisions_across_windows():
     assert r.is_infinity == bool(einf) and (r.affine_std == exp).all()
 
 
-@pytest.mark.parametrize("logn,extra", [(16, 0), (19, 12345), (20, 0)])
+@pytest.mark.parametrize("logn,extra", [(16, 0), (19, 12345), (20, 0), (21, 0)])
 def test_window_table_full_size_closed_form_batch_and_skew(hk, logn, extra):
     """the planner's table plans at full size against the closed form: 2^16 (GLV, c = 16, 8 windows in one array), 2^19 + 12345
-    (unsplit c = 20: 13 windows x n entries cross the sort's super-tiles of 2^22 positions; infinity mask) and 2^20 (the BASELINE
-    size).  Single resident calls, the batch entry (two MSMs in flight), a truncated call, all-equal scalars (13 buckets hold everything:
+    (unsplit c = 20: 13 windows x n entries cross the sort's super-tiles of 2^22 positions; infinity mask), 2^20 (the BASELINE
+    size) and 2^21 (the largest size that gets a table: 27 M entries in one sort, every region of the fine sort 1.6 staging areas long and
+    placed directly by its owner, with the super-tile recovery).  Single resident calls, the batch entry (two MSMs in flight), a truncated call, all-equal scalars (13 buckets hold everything:
     oversized regions with 512 fine bins), and the same set without the table as the reference bits."""
     import torch
     n = (1 << logn) + extra
