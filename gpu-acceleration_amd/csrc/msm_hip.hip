@@ -968,7 +968,8 @@ std::vector<size_t> stream_schedule(const msm_ctx* c, size_t n) {
     // ~0.2 ms do not shrink with the chunk: sort launches, k_combine over all buckets, bucket read-modify-write), whichever is
     // longer.  Uniform chunks of 2^18 points (2^19 / 2^20 for large instances): shorter chunks at the end, meant to leave less work
     // after the last byte, cost more in fixed per-chunk work than they hide (measured: 2^20 in 4 chunks 2.89 ms, 3 x 2^18 +
-    // 2^17 + 2 x 2^16: 3.48 ms -- profiles/NOTES_r2.md).  A remainder below half a chunk joins the last chunk.
+    // 2^17 + 2 x 2^16: 3.48 ms -- profiles/NOTES_r2.md; round 3, with the sort already overlapped: the last chunk halved once / twice /
+    // three times costs +0.12 / +0.24 / +0.41 ms at 2^20, profiles/r3_stream_tail_split.txt).  A remainder below half a chunk joins the last chunk.
     const uint32_t min_log2 = c->knobs.stream_min_log2;
     uint32_t lg = n < ((size_t)1 << 21) ? 18u : n < ((size_t)1 << 23) ? 19u : 20u;
     if (c->knobs.stream_chunk_log2) lg = c->knobs.stream_chunk_log2;
