@@ -108,6 +108,7 @@ struct Knobs {
     int host_threads = -1;                     // MSM_HIP_HOST_THREADS: CPU finish threads incl. the caller; -1 = default (2)
     size_t wide_max = 40960;                   // MSM_HIP_WIDE_MAX: pairwise levels up to this many additions use 8 lanes per addition; 0 = never
     bool reduce_v1 = false;                    // MSM_HIP_REDUCE_V1: one launch per pairwise level (round 1)
+    uint32_t pair8_lanes = 0;                  // MSM_HIP_PAIR8_LANES: lanes per output of k_pair_level8 (1, 2, 4; 0 = by size)
     int batch_copy_own = 0;                    // MSM_HIP_BATCH_COPY=0: each batch pipeline uploads on its own copy stream
     int lane_priority = 1;                     // MSM_HIP_LANE_PRIORITY: low (1, default) | high (2) | normal (0)
     int batch_mode = -1;                       // MSM_HIP_BATCH_MODE: shared (1) | lanes (0); -1 = by size
@@ -136,6 +137,10 @@ struct Knobs {
         if (std::getenv("MSM_HIP_HOST_THREADS")) k.host_threads = (int)num("MSM_HIP_HOST_THREADS", 0, 64, 2);
         k.wide_max = (size_t)num("MSM_HIP_WIDE_MAX", 0, 1 << 30, 40960);
         k.reduce_v1 = on("MSM_HIP_REDUCE_V1");
+        {
+            const long v = num("MSM_HIP_PAIR8_LANES", 0, 4, 0);
+            k.pair8_lanes = v == 1 || v == 2 || v == 4 ? (uint32_t)v : 0u;
+        }
         if (const char* e = std::getenv("MSM_HIP_BATCH_COPY")) k.batch_copy_own = e[0] == '0';
         if (const char* e = std::getenv("MSM_HIP_LANE_PRIORITY")) k.lane_priority = !strcmp(e, "high") ? 2 : !strcmp(e, "normal") ? 0 : 1;
         if (const char* e = std::getenv("MSM_HIP_BATCH_MODE")) k.batch_mode = !strcmp(e, "shared") ? 1 : 0;
@@ -593,7 +598,15 @@ int32_t enqueue_reduce(msm_ctx* c, const PipeState& ps, hipStream_t st, uint32_t
     uint32_t l = 0;
     if (!c->knobs.reduce_v1 && levels >= 3 && kb_lo >= 3 && tb * XB <= ((size_t)100 << 20)) {
         rn = tb / 8, cn = tb / 8;
-        msmk::k_pair_level8<<<grid1(rn + cn, 256), 256, 0, st>>>(bk, rbuf[0], cbuf[0], (uint32_t)rn, n_lo);
+        // lanes per output: one lane while every SIMD has a wavefront of outputs (the kernel is multiplier bound then: 8 x 32768 buckets,
+        // 2^14 .. 2^20 points: 1 / 2 / 4 lanes 0.471 / 0.470 / 0.487 ms at 2^17); below that the seven dependent additions of an output are
+        // what the kernel waits for and 2 or 4 lanes cut the chain to 4 or 3 (2^12: 0.307 / 0.283 / 0.275 ms; one shared array of 2^15 buckets
+        // of a window table: profiles/r3_pair8_lanes_ab.txt)
+        const size_t outs = rn + cn;
+        const uint32_t lanes = c->knobs.pair8_lanes ? c->knobs.pair8_lanes : outs >= 65536 ? 1u : outs * 2 >= 65536 ? 2u : 4u;
+        if (lanes == 1) msmk::k_pair_level8<1><<<grid1(outs, 256), 256, 0, st>>>(bk, rbuf[0], cbuf[0], (uint32_t)rn, n_lo);
+        else if (lanes == 2) msmk::k_pair_level8<2><<<grid1(outs * 2, 256), 256, 0, st>>>(bk, rbuf[0], cbuf[0], (uint32_t)rn, n_lo);
+        else msmk::k_pair_level8<4><<<grid1(outs * 4, 256), 256, 0, st>>>(bk, rbuf[0], cbuf[0], (uint32_t)rn, n_lo);
         rin = rbuf[0], cin = cbuf[0];  // where level 2 would have left them
         l = 3;
     }

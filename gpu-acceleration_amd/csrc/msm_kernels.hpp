@@ -1351,9 +1351,15 @@ __global__ void __launch_bounds__(256) k_pair_level_wide(pair_job ja, pair_job j
 // out_c[w][a][b] = in[w][8a][b] + ... + in[w][8a+7][b] (cols: the hi dimension shrinks by 8).  One thread per output, seven dependent
 // additions; every bucket is read twice (once per family) and the two intermediate levels are never written: three launches and
 // ~2.5x the bucket array of traffic less than k_pair_level x 3 (measured 2^20: 119 -> 103 us, 2^17: 74 -> 60 us).
+// G lanes per output (round 3): the seven additions of an output are a dependent CHAIN, and with 2 * tb / 8 threads -- 65 536 at 8 x 32768
+// buckets: one wavefront per SIMD -- the kernel is priced by that chain (7 x 6.4 us), not by its work.  G adjacent lanes fold 8 / G buckets
+// each and join with log2 G shuffle levels: chains of 4 (G = 2) or 3 (G = 4) additions, the same 7 additions per output.
+template <int G>
 __global__ void __launch_bounds__(256) k_pair_level8(const uint32_t* __restrict__ in, uint32_t* __restrict__ out_r, uint32_t* __restrict__ out_c,
                                                      uint32_t n_out, uint32_t n_lo) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t t = gt / G;
+    const uint32_t sub = gt % G;
     size_t i0, stride;
     uint32_t* out;
     if (t < n_out) {  // rows
@@ -1362,15 +1368,28 @@ __global__ void __launch_bounds__(256) k_pair_level8(const uint32_t* __restrict_
         out = out_r + (size_t)t * XW;
     } else {
         t -= n_out;
-        if (t >= n_out) return;
+        if (t >= n_out) return;  // (the G lanes of an output leave together)
         i0 = (size_t)8 * (t / n_lo) * n_lo + (t % n_lo);
         stride = n_lo;
         out = out_c + (size_t)t * XW;
     }
-    xyzz acc = load_xyzz(in + i0 * XW);
+    constexpr uint32_t PER = 8 / G, SERIAL = PER - 1, LEVELS = G == 1 ? 0 : G == 2 ? 1 : 2;
+    const size_t first = i0 + (size_t)sub * PER * stride;
+    xyzz acc = load_xyzz(in + first * XW);
+    // ONE call site for the serial folds and the shuffle levels (an inlined complete addition is ~40 KB of code)
 #pragma unroll 1
-    for (uint32_t j = 1; j < 8; j++) acc = xyzz_add(acc, load_xyzz(in + (i0 + j * stride) * XW));
-    store_xyzz(out, acc);
+    for (uint32_t step = 0; step < SERIAL + LEVELS; step++) {
+        xyzz other;
+        if (step < SERIAL) {
+            other = load_xyzz(in + (first + (size_t)(step + 1) * stride) * XW);
+        } else {
+            const uint32_t d = (G / 2) >> (step - SERIAL);
+            other = shfl_down_xyzz(acc, (int)d, G);
+            if (sub >= d) other = xyzz_identity();  // spectator lanes: adding their own value would take the doubling branch
+        }
+        acc = xyzz_add(acc, other);
+    }
+    if (sub == 0) store_xyzz(out, acc);
 }
 
 // k_reduce_bits with wide additions: one 512-thread workgroup per (window, bit); the selected elements are staged in LDS
