@@ -359,6 +359,10 @@ int32_t pipe_prepare(msm_ctx* c, size_t n_real, size_t plan_n, uint32_t extra_fl
     // ... and from there the chunk follows the mean bucket occupancy n/nb (32 at 2^20 unsplit, 64 with the GLV split: measured
     // 1.728 ms at L = 32 against 1.698 at 64), as long as ~2^17 chunks remain to fill the chip
     while (chunk_len < 1024 && chunk_len < occ && pairs / (chunk_len * 2) >= 131072) chunk_len *= 2;
+    // (round 3, one shared array of a split window table at 2^17 points: 64 entries per bucket in 2^21 sorted entries -- at L = 16 every
+    // bucket is cut three times and k_combine's listed-bucket path costs more than the half-filled SIMDs of L = 32: single resident calls
+    // 0.493-0.508 -> 0.462-0.476 ms; at 2^16 (32 per bucket) and 2^18 (L = 32 already) nothing changes: profiles/r3_table_chunk_len.txt)
+    if (pairs <= ((size_t)1 << 21) && chunk_len * 4 <= occ && pairs / (chunk_len * 2) >= 65536) chunk_len *= 2;
     if (c->knobs.chunk_len) chunk_len = c->knobs.chunk_len;  // MSM_HIP_CHUNK_LEN at context creation (any value >= 1 is correct)
     ps->chunk_len = chunk_len;
     const size_t nchunks_max = ps->nchunks_max = (pairs + chunk_len - 1) / chunk_len;
