@@ -241,15 +241,7 @@ struct DevTmp {
 
 static_assert(msmplan::GLV_SPLIT_BITS == (uint32_t)glv::SPLIT_BITS, "planner and GLV split disagree");
 using msmplan::make_plan;
-// Window table with ONE shared bucket array (table factor == number of windows): the top window only holds
-// scalar_bits - c*(W-1) bits (14 of 20 at c = 20), so its digits would all land in the lowest buckets -- a few regions of the sort and
-// a few hundred chunks of k_accumulate would carry a whole window.  Its table level is built as 2^(c*(W-1) - s) P and the digit d enters
-// as d * 2^s instead (same group element, every 2^s-th bucket): s = (c - 1) - top bits, so that d * 2^s <= 2^(c-1) still holds.
-inline uint32_t table_top_shift(const msm_plan_t& pl, uint32_t tf) {
-    if (tf <= 1 || tf != pl.num_windows || !pl.signed_digits) return 0;
-    const uint32_t top_bits = pl.scalar_bits - pl.window_bits * (pl.num_windows - 1);  // max top digit 2^top_bits (carry included)
-    return top_bits < pl.window_bits - 1 ? pl.window_bits - 1 - top_bits : 0u;
-}
+using msmplan::table_top_shift;
 // the plan of a call on n points under this context's configuration and knobs (+ per-call extra flags)
 inline int32_t ctx_plan(const msm_ctx* c, size_t n, uint32_t extra_flags, msm_plan_t* pl) {
     return make_plan(n, c->cfg.window_bits, c->cfg.flags | extra_flags, pl, c->knobs.glv_max);

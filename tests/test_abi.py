@@ -64,6 +64,18 @@ def test_planner_matches_design():
     assert (p.window_bits, p.num_windows, p.num_buckets, p.signed_digits) == (16, 16, 65536, 0)
     p = mh.plan(1 << 16, 16, mh.FLAG_UNSIGNED_DIGITS)
     assert (p.window_bits, p.num_windows, p.num_buckets, p.signed_digits, p.glv) == (16, 8, 65536, 0, 1)
+    # row f4: MSM_FLAG_WINDOW_TABLE -- the plan of a resident call on a set uploaded under that flag (host-only: no GPU needed)
+    T = mh.FLAG_WINDOW_TABLE
+    p = mh.plan(1 << 20, 0, T)
+    assert (p.window_bits, p.num_windows, p.table_factor, p.bucket_arrays, p.glv) == (20, 13, 13, 1, 0)
+    assert p.num_buckets == 1 << 19 and p.table_bytes == 13 * (1 << 20) * 64 and p.workspace_bytes > p.table_bytes
+    p = mh.plan(1 << 17, 0, T)  # up to 2^18 points: split, eight 16-bit windows in ONE array of 2^15 buckets
+    assert (p.window_bits, p.num_windows, p.table_factor, p.bucket_arrays, p.glv, p.virtual_points) == (16, 8, 8, 1, 1, 2 << 17)
+    assert mh.plan((1 << 18) + 1, 0, T).glv == 0 and mh.plan(1 << 21, 0, T).table_factor == 13
+    assert mh.plan(1 << 22, 0, T).table_factor == 1                            # 13 x 2^22 entries: beyond TABLE_MAX_ENTRIES, no table
+    assert mh.plan(1 << 16, 0, T | mh.FLAG_UNSIGNED_DIGITS).table_factor == 1   # plain digits: no table
+    p, q = mh.plan(1 << 16, 0, 0), mh.plan(1 << 16, 0, T)
+    assert p.table_factor == 1 and p.bucket_arrays == p.num_windows and p.table_bytes == 0 and q.num_windows == p.num_windows
     # reference table values are accepted as overrides (metal_msm.rs:661-673)
     for w, W in ((8, 32), (13, 20), (15, 17), (16, 16)):
         p = mh.plan(1 << 16, w, mh.FLAG_NO_GLV)

@@ -22,6 +22,52 @@
         }                                                                       \
     } while (0)
 
+// row f4: the window-table planner (make_table_plan) and the top-window shift
+static int check_table_planner() {
+    const msmplan::table_knobs tk{};
+    for (uint32_t base : {0u, (uint32_t)MSM_FLAG_NO_GLV})
+        for (uint32_t c = 0; c <= 20; c++) {
+            if (c == 1) continue;
+            for (size_t n : {(size_t)1, (size_t)255, (size_t)1 << 10, (size_t)1 << 16, (size_t)1 << 18, ((size_t)1 << 18) + 1, (size_t)1 << 20, (size_t)1 << 21,
+                             ((size_t)1 << 21) + 1, (size_t)1 << 24}) {
+                msm_plan_t p, q;
+                REQUIRE(msmplan::make_table_plan(n, c, base | MSM_FLAG_WINDOW_TABLE, &p, msmplan::GLV_MAX_POINTS, tk) == MSM_OK);
+                REQUIRE(msmplan::make_plan(n, c, base, &q) == MSM_OK);
+                if (p.table_factor > 1) {
+                    REQUIRE(p.table_factor == p.num_windows && p.bucket_arrays == 1);  // the planner only makes FULL tables
+                    REQUIRE(p.table_bytes == (uint64_t)p.table_factor * p.virtual_points * 64);
+                    REQUIRE((uint64_t)p.table_factor * p.virtual_points <= msmplan::TABLE_MAX_ENTRIES);
+                    REQUIRE((uint64_t)p.num_windows * p.window_bits >= p.scalar_bits);
+                    const uint32_t s = msmplan::table_top_shift(p, p.table_factor);
+                    const uint32_t top_bits = p.scalar_bits - p.window_bits * (p.num_windows - 1);
+                    REQUIRE(((uint64_t)1 << (top_bits + s)) <= ((uint64_t)1 << (p.window_bits - 1)));  // shifted top digit <= H
+                    REQUIRE(s == 0 || top_bits + s == p.window_bits - 1);
+                    if (c) REQUIRE(p.window_bits == c);
+                    if (n > msmplan::TABLE_GLV_MAX_POINTS) REQUIRE(!p.glv);
+                } else {  // no table: exactly the ordinary plan
+                    REQUIRE(p.window_bits == q.window_bits && p.num_windows == q.num_windows && p.glv == q.glv && p.table_bytes == 0);
+                }
+            }
+        }
+    msm_plan_t p;
+    REQUIRE(msmplan::make_table_plan((size_t)1 << 20, 0, MSM_FLAG_WINDOW_TABLE, &p, msmplan::GLV_MAX_POINTS, tk) == MSM_OK);
+    REQUIRE(p.window_bits == 20 && p.num_windows == 13 && p.table_factor == 13 && !p.glv && msmplan::table_top_shift(p, 13) == 5);
+    REQUIRE(msmplan::make_table_plan((size_t)1 << 17, 0, MSM_FLAG_WINDOW_TABLE, &p, msmplan::GLV_MAX_POINTS, tk) == MSM_OK);
+    REQUIRE(p.window_bits == 16 && p.num_windows == 8 && p.table_factor == 8 && p.glv && msmplan::table_top_shift(p, 8) == 0);
+    REQUIRE(msmplan::make_table_plan((size_t)1 << 22, 0, MSM_FLAG_WINDOW_TABLE, &p, msmplan::GLV_MAX_POINTS, tk) == MSM_OK && p.table_factor == 1);
+    REQUIRE(msmplan::make_table_plan((size_t)1 << 16, 0, MSM_FLAG_WINDOW_TABLE | MSM_FLAG_UNSIGNED_DIGITS, &p, msmplan::GLV_MAX_POINTS, tk) == MSM_OK && p.table_factor == 1);
+    msmplan::table_knobs small = tk;
+    small.max_bytes = (size_t)1 << 20;  // 1 MiB cap: a 2^16 table (67 MB) is not made
+    REQUIRE(msmplan::make_table_plan((size_t)1 << 16, 0, MSM_FLAG_WINDOW_TABLE, &p, msmplan::GLV_MAX_POINTS, small) == MSM_OK && p.table_factor == 1);
+    msmplan::table_knobs part = tk;
+    part.c = 16, part.f = 4;  // a forced partial table: 2 arrays of 4 windows, no top shift
+    REQUIRE(msmplan::make_table_plan((size_t)1 << 16, 0, MSM_FLAG_WINDOW_TABLE, &p, msmplan::GLV_MAX_POINTS, part) == MSM_OK);
+    REQUIRE(p.table_factor == 4 && p.bucket_arrays == 2 && msmplan::table_top_shift(p, 4) == 0);
+    part.f = 3;  // does not divide 8 windows: the ordinary plan
+    REQUIRE(msmplan::make_table_plan((size_t)1 << 16, 0, MSM_FLAG_WINDOW_TABLE, &p, msmplan::GLV_MAX_POINTS, part) == MSM_OK && p.table_factor == 1);
+    return 0;
+}
+
 static int check_planner() {
     for (uint32_t flags = 0; flags < 4; flags++)
         for (uint32_t c = 0; c <= 20; c++) {
@@ -141,7 +187,7 @@ static int check_partitions() {
 }
 
 int main() {
-    if (check_planner() || check_pool() || check_g1() || check_glv() || check_partitions()) return 1;
-    std::puts("host runtime: planner, pool, host_g1, glv split, partitions clean under ASan/UBSan");
+    if (check_planner() || check_table_planner() || check_pool() || check_g1() || check_glv() || check_partitions()) return 1;
+    std::puts("host runtime: planner, window-table planner, pool, host_g1, glv split, partitions clean under ASan/UBSan");
     return 0;
 }
