@@ -110,6 +110,7 @@ struct Knobs {
     bool reduce_v1 = false;                    // MSM_HIP_REDUCE_V1: one launch per pairwise level (round 1)
     uint32_t pair8_lanes = 0;                  // MSM_HIP_PAIR8_LANES: lanes per output of k_pair_level8 (1, 2, 4; 0 = by size)
     int batch_copy_own = 0;                    // MSM_HIP_BATCH_COPY=0: each batch pipeline uploads on its own copy stream
+    int batch_reduce_stream = 1;               // MSM_HIP_BATCH_REDUCE_STREAM=0: the bucket reduction of a batch MSM stays on the shared stream
     int lane_priority = 1;                     // MSM_HIP_LANE_PRIORITY: low (1, default) | high (2) | normal (0)
     int batch_mode = -1;                       // MSM_HIP_BATCH_MODE: shared (1) | lanes (0); -1 = by size
     msmplan::table_knobs table;                // MSM_HIP_TABLE_C / MSM_HIP_TABLE_F / MSM_HIP_TABLE_MAX_GB (window table of a resident set)
@@ -142,6 +143,7 @@ struct Knobs {
             k.pair8_lanes = v == 1 || v == 2 || v == 4 ? (uint32_t)v : 0u;
         }
         if (const char* e = std::getenv("MSM_HIP_BATCH_COPY")) k.batch_copy_own = e[0] == '0';
+        if (const char* e = std::getenv("MSM_HIP_BATCH_REDUCE_STREAM")) k.batch_reduce_stream = e[0] != '0';
         if (const char* e = std::getenv("MSM_HIP_LANE_PRIORITY")) k.lane_priority = !strcmp(e, "high") ? 2 : !strcmp(e, "normal") ? 0 : 1;
         if (const char* e = std::getenv("MSM_HIP_BATCH_MODE")) k.batch_mode = !strcmp(e, "shared") ? 1 : 0;
         k.table.c = (uint32_t)num("MSM_HIP_TABLE_C", 0, 20, 0);
@@ -159,6 +161,7 @@ struct msm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;     // host->HBM uploads and base conversion beside the sort
+    hipEvent_t ev_body = nullptr;          // batch: behind k_combine on the shared stream; the bucket reduction waits for it on another
     hipEvent_t ev_copied[2]{}, ev_free[2]{}, ev_scal[2]{};  // streamed host call: slot's bases+scalars there / slot free again / its scalars there
     hipEvent_t ev_fork = nullptr, ev_bases = nullptr;  // base conversion runs on copy_stream beside the sort kernels
     DevBuf sbases[2], sscalars[2], sinf[2];  // double-buffered raw inputs of the streamed path
@@ -1182,6 +1185,7 @@ void msm_ctx_destroy(msm_ctx* c) {
         if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
         if (c->ev_bases) (void)hipEventDestroy(c->ev_bases);
         if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+        if (c->ev_body) (void)hipEventDestroy(c->ev_body);
         for (int i = 0; i < EV_COUNT; i++)
             if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
         if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1381,7 +1385,8 @@ static int32_t resident_on_lane(msm_ctx* w, const msm_ctx* owner, const uint32_t
         // slowed the kernels running beside them 1.4-4.6x -- k_coarse_scatter 33 -> 47 us, k_fine_sort 42 -> 85, k_chunk_map 18 -> 84 --
         // while the owner's did not: 1.61-1.62 -> 1.51-1.58 ms per MSM at 2^20, NOTES_r2.md section 7)
         // (MSM_HIP_BATCH_COPY=0 at context creation, A/B: each pipeline's own copy stream)
-        hipStream_t cs = shared ? (o->knobs.batch_copy_own ? w->copy_stream : o->copy_stream) : w->stream, st = shared ? o->stream : w->stream;
+        hipStream_t cs = shared ? (o->knobs.batch_copy_own ? w->copy_stream : o->copy_stream) : w->stream;
+        hipStream_t st = shared ? o->stream : w->stream;
         {
             std::lock_guard<std::mutex> cp(o->copy_mu);
             if (o->last_copy && o->last_copy != w->ev_fork) HIPCHK(w, hipStreamWaitEvent(cs, o->last_copy, 0));
@@ -1396,8 +1401,20 @@ static int32_t resident_on_lane(msm_ctx* w, const msm_ctx* owner, const uint32_t
             if (shared) HIPCHK(w, hipStreamWaitEvent(st, w->ev_fork, 0));
             if ((rc = pipe_prepare(w, n, 0, extra, st, &ps, tab_c, tab_f))) return rc;
             if ((rc = enqueue_body(w, ps, rb, ri, (const uint32_t*)w->scalars.p, 0, st, nullptr))) return rc;
-            if ((rc = enqueue_reduce(w, ps, st, w->h_qsums, w->h_flags))) return rc;
-            if (shared) HIPCHK(w, hipEventRecord(w->ev_bases, st));
+            // The bucket reduction -- launch-bound pairwise levels that leave most of the GPU idle -- leaves the shared stream: it runs on
+            // the second pipeline's copy stream (idle in this mode, HIGH-priority pool) beside the decomposition and sort of the next MSM:
+            // per MSM 2^19 0.929 -> 0.875-0.895 ms, 2^20 1.55-1.56 -> 1.49-1.51, with the window table 1.46-1.475 -> 1.40-1.425, 2^21
+            // 2.85 -> 2.75 (profiles/r3_batch_reduce_stream.txt).  The priority is what makes it work: on a plain stream -- also one with
+            // a hardware queue of its own (full CU mask) -- the levels queue behind the next accumulation's workgroups and the batch
+            // LOSES 10-18 %; leaving 8-32 CUs out of the shared stream's CU mask for them loses 5-10 %; k_combine moved along: no gain.
+            hipStream_t rs = st;
+            if (shared && o->knobs.batch_reduce_stream && o->lane1 && w->ev_body) {
+                rs = o->lane1->copy_stream;
+                HIPCHK(w, hipEventRecord(w->ev_body, st));
+                HIPCHK(w, hipStreamWaitEvent(rs, w->ev_body, 0));
+            }
+            if ((rc = enqueue_reduce(w, ps, rs, w->h_qsums, w->h_flags))) return rc;
+            if (shared) HIPCHK(w, hipEventRecord(w->ev_bases, rs));
         }
         if ((rc = finish_sync(w, ps, n, st, out_jac, out_aff, out_inf, shared ? w->ev_bases : nullptr))) return rc;
     }
@@ -1461,6 +1478,9 @@ int32_t msm_bn254_g1_resident_batch(msm_ctx* c, const uint32_t* const* scalars, 
         // (MSM_HIP_BATCH_MODE at context creation, experiment: shared | lanes)
         c->batch_shared_stream = c->knobs.batch_mode >= 0 ? c->knobs.batch_mode == 1 : n >= ((size_t)1 << 19);
     }
+    if (count > 1 && c->batch_shared_stream && c->knobs.batch_reduce_stream && c->knobs.copy_priority && !c->knobs.batch_copy_own)
+        for (msm_ctx* w : {c, c->lane1})
+            if (!w->ev_body) HIPCHK(c, hipEventCreateWithFlags(&w->ev_body, hipEventDisableTiming));
     if (count > 1) c->batch_pool->run(2, lane);
     else lane(0);
     if (rcs[0] == MSM_OK && rcs[1] != MSM_OK) c->err = c->lane1->err;
