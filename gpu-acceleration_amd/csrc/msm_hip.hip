@@ -100,6 +100,7 @@ bool trace_enabled() {
 struct Knobs {
     size_t glv_max = msmplan::GLV_MAX_POINTS;  // MSM_HIP_GLV_MAX_LOG2
     uint32_t chunk_len = 0;                    // MSM_HIP_CHUNK_LEN: entries per k_accumulate thread; 0 = by size
+    int chunk_rounds = 1;                      // MSM_HIP_CHUNK_ROUNDS=0: keep the power-of-two chunk length (no fitting to whole rounds of workgroups)
     bool direct_scatter = false;               // MSM_HIP_DIRECT_SCATTER: skip the two-level LDS sort
     uint32_t device_chunk_log2 = 22;           // MSM_HIP_DEVICE_CHUNK_LOG2: point ranges of device-resident instances; 0 = never cut
     uint32_t stream_min_log2 = 19;             // MSM_HIP_STREAM_MIN_LOG2: host calls are streamed from this size on
@@ -144,6 +145,7 @@ struct Knobs {
         }
         if (const char* e = std::getenv("MSM_HIP_BATCH_COPY")) k.batch_copy_own = e[0] == '0';
         if (const char* e = std::getenv("MSM_HIP_BATCH_REDUCE_STREAM")) k.batch_reduce_stream = e[0] != '0';
+        if (const char* e = std::getenv("MSM_HIP_CHUNK_ROUNDS")) k.chunk_rounds = e[0] != '0';
         if (const char* e = std::getenv("MSM_HIP_LANE_PRIORITY")) k.lane_priority = !strcmp(e, "high") ? 2 : !strcmp(e, "normal") ? 0 : 1;
         if (const char* e = std::getenv("MSM_HIP_BATCH_MODE")) k.batch_mode = !strcmp(e, "shared") ? 1 : 0;
         k.table.c = (uint32_t)num("MSM_HIP_TABLE_C", 0, 20, 0);
@@ -161,6 +163,7 @@ struct msm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;     // host->HBM uploads and base conversion beside the sort
+    uint32_t num_cus = 0;                  // compute units of the device (rounds of k_accumulate workgroups)
     hipEvent_t ev_body = nullptr;          // batch: behind k_combine on the shared stream; the bucket reduction waits for it on another
     hipEvent_t ev_copied[2]{}, ev_free[2]{}, ev_scal[2]{};  // streamed host call: slot's bases+scalars there / slot free again / its scalars there
     hipEvent_t ev_fork = nullptr, ev_bases = nullptr;  // base conversion runs on copy_stream beside the sort kernels
@@ -306,6 +309,7 @@ struct PipeState {
     size_t nchunks_max = 0;
 };
 
+
 // plan + workspace.  May reallocate buffers (hipFree synchronises the device), so with chunks in flight it must not grow
 // anything: the first chunk of a streamed MSM is the largest.
 int32_t pipe_prepare(msm_ctx* c, size_t n_real, size_t plan_n, uint32_t extra_flags, hipStream_t st, PipeState* ps, uint32_t table_c = 0,
@@ -358,6 +362,7 @@ int32_t pipe_prepare(msm_ctx* c, size_t n_real, size_t plan_n, uint32_t extra_fl
     // bucket is cut three times and k_combine's listed-bucket path costs more than the half-filled SIMDs of L = 32: single resident calls
     // 0.493-0.508 -> 0.462-0.476 ms; at 2^16 (32 per bucket) and 2^18 (L = 32 already) nothing changes: profiles/r3_table_chunk_len.txt)
     if (pairs <= ((size_t)1 << 21) && chunk_len * 4 <= occ && pairs / (chunk_len * 2) >= 65536) chunk_len *= 2;
+    if (c->knobs.chunk_rounds) chunk_len = msmplan::fit_chunk_to_rounds(pairs, chunk_len, c->num_cus);
     if (c->knobs.chunk_len) chunk_len = c->knobs.chunk_len;  // MSM_HIP_CHUNK_LEN at context creation (any value >= 1 is correct)
     ps->chunk_len = chunk_len;
     const size_t nchunks_max = ps->nchunks_max = (pairs + chunk_len - 1) / chunk_len;
@@ -1087,8 +1092,9 @@ static int32_t ctx_create_impl(const msm_config_t* cfg, msm_ctx** out, int main_
     c->knobs = knobs;
     c->stage_timing = trace_enabled();
     DeviceGuard g(dev);
-    int least = 0, greatest = 0;
+    int least = 0, greatest = 0, cus = 0;
     if (g.ok && hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
+    if (g.ok && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) c->num_cus = (uint32_t)cus;
     hipError_t e = !g.ok ? hipErrorInvalidDevice
                    : (main_priority && least != greatest) ? hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, main_priority == 1 ? least : greatest)
                                                               : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);

@@ -147,4 +147,33 @@ inline uint32_t table_top_shift(const msm_plan_t& pl, uint32_t tf) {
     return top_bits < pl.window_bits - 1 ? pl.window_bits - 1 - top_bits : 0u;
 }
 
+// k_accumulate keeps 3 wavefronts per SIMD (141 VGPRs), i.e. 3 workgroups of 256 threads per CU, and every thread folds the same number L of
+// sorted entries, so the workgroups run in ROUNDS of 3 x CUs; the last, partial round keeps ceil(r / CUs) wavefronts per SIMD busy for a
+// whole chunk (a lone wavefront already fills its SIMD's multiplier).  Wall time in units of one addition of a lone wavefront:
+//     T(L) = L * (3 * full_rounds + ceil(r / CUs))
+// 8 x 2^21 entries at L = 64 are 1024 workgroups = one round + 256: every SIMD busy to the end, T = 256 = entries / lanes, nothing lost --
+// but the 13 x 2^20 entries of a window table at L = 32 are 1664 = two rounds + 128: half the CUs idle through the last chunk (T = 224 against
+// 208), and 2^19 + 12345 points (1049 workgroups) pay a whole extra chunk for 25 workgroups.  The length moves by up to a quarter to the
+// value with the smallest T (ties: closest to L0) -- while the rounds are still rounds (at most three full ones: behind that the workgroups
+// have drifted apart and a shorter chunk only costs k_combine more) and the model promises 2 % or more.  Measured (profiles/
+// r3_chunk_rounds.txt): k_accumulate with the table 2^20 0.883 -> 0.81-0.84 ms, 2^21 1.98-2.00 -> 1.87; device calls on 536 633 points
+// 1.073 -> 0.959 ms, 600 000 1.214 -> 1.039, 3 000 000 3.92 -> 3.75; powers of two without a table were whole rounds already.
+inline uint64_t chunk_rounds_cost(size_t pairs, uint32_t L, uint32_t cus) {
+    const size_t wgs = ((pairs + L - 1) / L + 255) / 256, slots = (size_t)3 * cus;
+    return (uint64_t)L * (3 * (wgs / slots) + (wgs % slots + cus - 1) / cus);
+}
+inline uint32_t fit_chunk_to_rounds(size_t pairs, uint32_t L0, uint32_t cus) {
+    if (cus == 0 || L0 < 8 || pairs == 0) return L0;
+    if (((pairs + L0 - 1) / L0 + 255) / 256 / ((size_t)3 * cus) > 3) return L0;
+    uint32_t best = L0;
+    uint64_t best_t = chunk_rounds_cost(pairs, L0, cus);
+    const uint64_t t0 = best_t;
+    for (uint32_t d = 1; d <= L0 / 4; d++)
+        for (uint32_t L : {L0 - d, L0 + d}) {
+            const uint64_t t = chunk_rounds_cost(pairs, L, cus);
+            if (t < best_t) best = L, best_t = t;
+        }
+    return best_t * 100 <= t0 * 98 ? best : L0;
+}
+
 }  // namespace msmplan

@@ -468,6 +468,37 @@ def test_glv_split_full_size_matches_unsplit_and_closed_form(monkeypatch, hk, lo
         assert (cg.msm_resident(s[:m]).affine_std == e2).all()
 
 
+@pytest.mark.parametrize("chunk_len", ["1", "7", "26", "35", "rounds-off"])
+def test_chunk_lengths_that_are_not_powers_of_two(monkeypatch, hk, chunk_len):
+    """k_accumulate's fixed-length chunks: the length is fitted to whole rounds of workgroups (13 x 2^k entries of a window table take
+    26 or 35 instead of 32), so every kernel that divides by it (k_chunk_map, k_accumulate, k_combine) sees odd values.  Forced lengths
+    incl. 1 (every bucket with two entries is a cut bucket) and 7, plain + GLV + window table + batch, against the closed form."""
+    import torch
+    if chunk_len == "rounds-off":
+        monkeypatch.setenv("MSM_HIP_CHUNK_ROUNDS", "0")
+    else:
+        monkeypatch.setenv("MSM_HIP_CHUNK_LEN", chunk_len)
+    n = (1 << 16) + 4321
+    dev = torch.device("cuda:0")
+    d_bases = torch.empty(n * 16, dtype=torch.int32, device=dev)
+    d_s = torch.empty(n * 8, dtype=torch.int32, device=dev)
+    k = th.generate_scalars_host(0xB2540061, n, nonzero=True)
+    s = th.generate_scalars_host(0xB2540062, n)
+    s[: n // 5] = s[0]          # a long bucket in every window
+    exp, einf = orc.closed_form_expected(k, s)
+    hk.generate_device(0xB2540061, 0xB2540062, n, d_bases.data_ptr(), d_s.data_ptr())
+    d_s.copy_(torch.from_numpy(s.view(np.int32).reshape(-1)))
+    torch.cuda.synchronize()
+    hb = d_bases.cpu().numpy().view(np.uint32).reshape(n, 16)
+    for flags in (0, mh.FLAG_NO_GLV, TABLE, TABLE | mh.FLAG_NO_GLV):
+        with mh.MsmContext(flags=flags) as c:
+            r = c.msm_device(d_bases.data_ptr(), d_s.data_ptr(), n)
+            assert (r.affine_std == exp).all() and r.is_infinity == bool(einf), (chunk_len, flags)
+            c.upload_bases(hb, mh.FORM_MONT)
+            for r in c.msm_resident_batch([s, s, s], want_affine=True):
+                assert (r.affine_std == exp).all(), (chunk_len, flags, "batch")
+
+
 # ---- row f4: the window table of a resident base set (MSM_FLAG_WINDOW_TABLE) --------------------------------------------------------
 TABLE = mh.FLAG_WINDOW_TABLE
 

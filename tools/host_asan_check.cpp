@@ -186,8 +186,30 @@ static int check_partitions() {
     return 0;
 }
 
+static int check_chunk_fit() {
+    // whole rounds already: nothing moves
+    REQUIRE(msmplan::fit_chunk_to_rounds((size_t)8 << 21, 64, 256) == 64);
+    REQUIRE(msmplan::fit_chunk_to_rounds((size_t)15 << 21, 32, 256) == 32);
+    // 13 x 2^20 entries of a window table: 1664 workgroups at 32 -> 2048 at 26 (T 224 -> 208 = entries / lanes)
+    REQUIRE(msmplan::fit_chunk_to_rounds((size_t)13 << 20, 32, 256) == 26);
+    REQUIRE(msmplan::chunk_rounds_cost((size_t)13 << 20, 32, 256) == 224 && msmplan::chunk_rounds_cost((size_t)13 << 20, 26, 256) == 208);
+    REQUIRE(msmplan::fit_chunk_to_rounds((size_t)13 << 21, 64, 256) == 52);
+    // more than three full rounds, tiny lengths, unknown device: untouched
+    REQUIRE(msmplan::fit_chunk_to_rounds((size_t)15 * (((size_t)1 << 20) + 1), 16, 256) == 16);
+    REQUIRE(msmplan::fit_chunk_to_rounds((size_t)1 << 16, 4, 256) == 4 && msmplan::fit_chunk_to_rounds((size_t)13 << 20, 32, 0) == 32);
+    // never worse than L0 by its own model, always within a quarter of L0, for a spread of sizes and CU counts
+    for (uint32_t cus : {64u, 104u, 256u, 304u})
+        for (size_t pairs = 1000; pairs < ((size_t)1 << 27); pairs = pairs * 5 / 3 + 17)
+            for (uint32_t L0 : {8u, 16u, 32u, 64u, 128u}) {
+                const uint32_t L = msmplan::fit_chunk_to_rounds(pairs, L0, cus);
+                REQUIRE(L >= L0 - L0 / 4 && L <= L0 + L0 / 4);
+                REQUIRE(msmplan::chunk_rounds_cost(pairs, L, cus) <= msmplan::chunk_rounds_cost(pairs, L0, cus));
+            }
+    return 0;
+}
+
 int main() {
-    if (check_planner() || check_table_planner() || check_pool() || check_g1() || check_glv() || check_partitions()) return 1;
-    std::puts("host runtime: planner, window-table planner, pool, host_g1, glv split, partitions clean under ASan/UBSan");
+    if (check_planner() || check_table_planner() || check_chunk_fit() || check_pool() || check_g1() || check_glv() || check_partitions()) return 1;
+    std::puts("host runtime: planner, window-table planner, chunk fit, pool, host_g1, glv split, partitions clean under ASan/UBSan");
     return 0;
 }
