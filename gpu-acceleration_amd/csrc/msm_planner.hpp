@@ -29,8 +29,10 @@ inline uint32_t plan_window_bits(size_t n, bool is_signed) {
     // Round 2 (tools/c17_sweep.py, interleaved): c = 17 (15 windows of 65536 buckets; the two-level sort covers them) against 16:
     // 2^20 +4.5 % (1.735 vs 1.661 ms: the doubled bucket reduction outweighs the 6 % fewer additions), 2^21 -2.3 %, 2^22 -4.1 %,
     // 2^23 -6.0 %, 2^24 -5.9 % (22.39 vs 23.79 ms)  => 17 above 2^20 points.
+    // Round 3, between the powers of two (tools/odd_size_ab.py, profiles/r3_glv_between_pow2.txt): 2^20 + 1 points c = 16 1.686 ms against
+    // 17 1.779 (-5 %), 1 500 000 2.199 / 2.274 (-3 %), 2^21 2.852 / 2.878 (inside the noise)  => 17 from 2^21 points on.
     uint32_t c = n <= ((size_t)1 << 13) ? 8u : n <= ((size_t)1 << 15) ? 10u : n <= ((size_t)1 << 16) ? 13u : n <= ((size_t)1 << 18) ? 15u
-               : n <= ((size_t)1 << 20) ? 16u : 17u;
+               : n < ((size_t)1 << 21) ? 16u : 17u;
     if (!is_signed && c > 15u) c = 15u;
     return c;
 }

@@ -59,6 +59,8 @@ def test_planner_matches_design():
     p = mh.plan(1 << 21)
     assert p.glv == 0 and p.window_bits == 17 and p.num_windows == 15
     assert mh.plan(1 << 20).glv == 1 and mh.plan((1 << 20) + 1).glv == 0
+    # between 2^20 and 2^21 points: unsplit, still 16-bit windows (17 from 2^21 on)
+    assert [mh.plan(n).window_bits for n in ((1 << 20) + 1, 1500000, (1 << 21) - 1, 1 << 21)] == [16, 16, 16, 17]
     # BASELINE config 2: fixed 16-bit window, plain digits
     p = mh.plan(1 << 16, 16, mh.FLAG_UNSIGNED_DIGITS | mh.FLAG_NO_GLV)
     assert (p.window_bits, p.num_windows, p.num_buckets, p.signed_digits) == (16, 16, 65536, 0)
