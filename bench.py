@@ -432,6 +432,11 @@ def main():
             r, avg, _ = timed_calls(lambda: ctx.msm_resident_batch([hspn] * K), 3)
             legs["resident_batch_ms_per_msm"] = round(avg / K, 4)
             ok = ok and all(bool((x.affine_std == exp).all()) for x in r)
+            # ... and with the scalars in HBM as well (a prover whose witness lives on the GPU): msm_bn254_g1_resident_device
+            dsp = d_scalars[0].data_ptr()
+            r, avg, _ = timed_calls(lambda: [ctx.msm_resident_device(dsp, n_local) for _ in range(K)], 3)
+            legs["resident_device_scalars_ms_per_msm"] = round(avg / K, 4)
+            ok = ok and all(bool((x.affine_std == exp).all()) for x in r)
             # row f4: the same resident set with its WINDOW TABLE (MSM_FLAG_WINDOW_TABLE: one bucket array shared by all windows)
             with mh.MsmContext(device=local_rank, flags=ctx_flags | mh.FLAG_WINDOW_TABLE) as tctx:
                 tpl = mh.plan(n_local, args.window_bits, ctx_flags | mh.FLAG_WINDOW_TABLE)
@@ -443,6 +448,9 @@ def main():
                 ok = ok and all(bool((x.affine_std == exp).all()) for x in r)
                 r, avg, _ = timed_calls(lambda: tctx.msm_resident_batch([hspn] * K), 3)
                 legs["resident_table_batch_ms_per_msm"] = round(avg / K, 4)
+                ok = ok and all(bool((x.affine_std == exp).all()) for x in r)
+                r, avg, _ = timed_calls(lambda: [tctx.msm_resident_device(dsp, n_local) for _ in range(K)], 3)
+                legs["resident_table_device_scalars_ms_per_msm"] = round(avg / K, 4)
                 ok = ok and all(bool((x.affine_std == exp).all()) for x in r)
                 legs["resident_table_plan"] = {"window_bits": tpl.window_bits, "num_windows": tpl.num_windows, "table_factor": tpl.table_factor,
                                                "bucket_arrays": tpl.bucket_arrays, "buckets_per_array": tpl.num_buckets, "glv_split": bool(tpl.glv),

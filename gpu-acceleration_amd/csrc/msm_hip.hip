@@ -1354,13 +1354,15 @@ int32_t msm_bn254_g1_compress(const uint32_t* bases_xy, uint32_t base_form, cons
 // one MSM of `scalars` (host) against the resident set of `owner`, on the pipeline (streams, workspace, pinned results) of `w`
 // (w == owner, or owner's second lane)
 static int32_t resident_on_lane(msm_ctx* w, const msm_ctx* owner, const uint32_t* scalars, size_t n, uint32_t* out_jac, uint32_t* out_aff,
-                                uint8_t* out_inf, bool batch = false) {
+                                uint8_t* out_inf, bool batch = false, const uint32_t* d_scalars = nullptr /* already in HBM: no upload */,
+                                hipStream_t caller_stream = nullptr) {
     int32_t rc;
     if (n > owner->resident_n) n = owner->resident_n;  // unequal lengths truncate to the shorter (metal_msm.rs:652-656)
     Range r_("msm_bn254_g1_resident");
     auto t0 = std::chrono::steady_clock::now();
-    if (w->stage_timing) HIPCHK(w, hipEventRecord(w->ev[EV_START], w->stream));
-    if ((rc = ensure(w, w->scalars, n * 32))) return rc;
+    const hipStream_t st0 = caller_stream ? caller_stream : w->stream;
+    if (w->stage_timing) HIPCHK(w, hipEventRecord(w->ev[EV_START], st0));
+    if (!d_scalars && (rc = ensure(w, w->scalars, n * 32))) return rc;
     // the phi records sit at index resident_n + i: a call on fewer scalars (truncation) or a set uploaded without them runs unsplit
     const uint32_t extra = (owner->resident_glv && n == owner->resident_n) ? 0u : MSM_FLAG_NO_GLV;
     // the window table (MSM_FLAG_WINDOW_TABLE) serves calls on the WHOLE resident set; a call on fewer scalars runs the plain pipeline
@@ -1371,9 +1373,10 @@ static int32_t resident_on_lane(msm_ctx* w, const msm_ctx* owner, const uint32_t
     const uint8_t* ri = owner->resident_has_inf ? (const uint8_t*)owner->rinf.p : nullptr;
     PipeState ps;
     if (!batch) {
-        HIPCHK(w, hipMemcpyAsync(w->scalars.p, scalars, n * 32, hipMemcpyHostToDevice, w->stream));
-        if (w->stage_timing) HIPCHK(w, hipEventRecord(w->ev[EV_H2D], w->stream));
-        rc = run_pipeline(w, rb, ri, (const uint32_t*)w->scalars.p, n, w->stream, out_jac, out_aff, out_inf, 0, nullptr, extra, &ps, tab_c, tab_f);
+        if (!d_scalars) HIPCHK(w, hipMemcpyAsync(w->scalars.p, scalars, n * 32, hipMemcpyHostToDevice, st0));
+        if (w->stage_timing) HIPCHK(w, hipEventRecord(w->ev[EV_H2D], st0));
+        rc = run_pipeline(w, rb, ri, d_scalars ? d_scalars : (const uint32_t*)w->scalars.p, n, st0, out_jac, out_aff, out_inf, 0, nullptr, extra, &ps,
+                          tab_c, tab_f);
         if (rc) return rc;
     } else {
         // Two MSMs in flight.  The pipelines must run in ANTI-phase: one uploads its scalars (DMA, 0.6 ms at 2^20) and finishes on
@@ -1427,7 +1430,7 @@ static int32_t resident_on_lane(msm_ctx* w, const msm_ctx* owner, const uint32_t
     w->tm.h2d_ms = stage_ms(w, EV_START, EV_H2D);
     w->tm.convert_ms = 0;
     w->tm.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    trace_line(w, "resident", ps);
+    trace_line(w, d_scalars ? "resident device" : "resident", ps);
     return MSM_OK;
 }
 
@@ -1439,6 +1442,17 @@ int32_t msm_bn254_g1_resident(msm_ctx* c, const uint32_t* scalars, size_t n, uin
     if (c->resident_n == 0) return fail(c, MSM_ERR_STATE, "no resident bases: call msm_bn254_g1_upload_bases first");
     DeviceGuard g(c->device);
     return resident_on_lane(c, c, scalars, n, out_jac, out_aff, out_inf);
+}
+
+// scalars already in HBM (a prover whose witness lives on the GPU) against the resident set -- and its window table, when it has one
+int32_t msm_bn254_g1_resident_device(msm_ctx* c, const void* d_scalars, size_t n, void* hip_stream, uint32_t out_jac[24],
+                                     uint32_t out_aff[16], uint8_t* out_inf) {
+    int32_t rc = check_common(c, d_scalars, d_scalars, n);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->resident_n == 0) return fail(c, MSM_ERR_STATE, "no resident bases: call msm_bn254_g1_upload_bases first");
+    DeviceGuard g(c->device);
+    return resident_on_lane(c, c, nullptr, n, out_jac, out_aff, out_inf, false, (const uint32_t*)d_scalars, (hipStream_t)hip_stream);
 }
 
 // `count` MSMs against the resident bases with TWO of them in flight: a second pipeline inside the context (a context of its

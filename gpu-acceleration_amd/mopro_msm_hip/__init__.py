@@ -28,7 +28,7 @@ OK, ERR_EMPTY, ERR_BAD_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_STATE, ERR_INVA
 # every symbol include/msm_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "msm_abi_version", "msm_ctx_create", "msm_ctx_destroy", "msm_last_error", "msm_bn254_g1",
-    "msm_bn254_g1_arkworks", "msm_bn254_g1_upload_bases", "msm_bn254_g1_resident", "msm_bn254_g1_resident_batch", "msm_bn254_g1_device",
+    "msm_bn254_g1_arkworks", "msm_bn254_g1_upload_bases", "msm_bn254_g1_resident", "msm_bn254_g1_resident_batch", "msm_bn254_g1_resident_device", "msm_bn254_g1_device",
     "msm_bn254_g1_combine",
     "msm_plan", "msm_get_timings", "msm_set_stage_timing", "msm_get_accumulate_kernel_stats", "msm_reset_kernel_stats",
     "msm_bn254_g1_decompress", "msm_bn254_g1_upload_compressed", "msm_bn254_g1_compress",
@@ -101,6 +101,7 @@ def bind_product_abi(L):
     L.msm_bn254_g1_resident.argtypes = [vp, _u32p, C.c_size_t, _u32p, _u32p, _u8p]
     L.msm_bn254_g1_resident_batch.argtypes = [vp, C.POINTER(_u32p), C.c_size_t, C.c_size_t, _u32p, _u32p, _u8p]
     L.msm_bn254_g1_device.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, _u32p, _u32p, _u8p]
+    L.msm_bn254_g1_resident_device.argtypes = [vp, vp, C.c_size_t, vp, _u32p, _u32p, _u8p]
     L.msm_bn254_g1_combine.argtypes = [_u32p, C.c_size_t, _u32p, _u32p, _u8p]
     L.msm_plan.argtypes = [C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(Plan)]
     L.msm_get_timings.argtypes = [vp, C.POINTER(Timings)]
@@ -331,6 +332,14 @@ class MsmContext:
         self._check(self._lib.msm_bn254_g1_resident(self._h, _p32(scalars), scalars.shape[0], _p32(jac), _p32(aff),
                                                     C.byref(oi)))
         return MsmResult(jac, aff, oi.value)
+
+    def msm_resident_device(self, d_scalars_ptr, n, stream=None):
+        """scalars already in HBM (raw device pointer) against the resident bases and, if the context has one, their window table"""
+        if n == 0:
+            raise MsmError(ERR_EMPTY, "Empty input")
+        jac, _, oi = self._outs()
+        self._check(self._lib.msm_bn254_g1_resident_device(self._h, d_scalars_ptr, n, stream, _p32(jac), None, C.byref(oi)))
+        return MsmResult(jac, None, oi.value)
 
     def msm_resident_batch(self, scalar_vectors, want_affine=True):
         """several scalar vectors against the resident bases, two MSMs in flight (how provers call MSM): list of MsmResult"""

@@ -66,6 +66,10 @@ extern "C" {
         ctx: *mut MsmCtx, scalars: *const *const u32, n: usize, count: usize, out_jacobian_mont: *mut u32, out_affine_std: *mut u32,
         out_is_inf: *mut u8,
     ) -> i32;
+    fn msm_bn254_g1_resident_device(
+        ctx: *mut MsmCtx, d_scalars: *const core::ffi::c_void, n: usize, hip_stream: *mut core::ffi::c_void, out_jacobian_mont: *mut u32,
+        out_affine_std: *mut u32, out_is_inf: *mut u8,
+    ) -> i32;
 }
 
 struct Ctx(*mut MsmCtx);
@@ -388,6 +392,26 @@ impl HipResidentBases {
                 self.ctx, scalars.as_ptr() as *const u32, scalars.len().min(self.n), jac.as_mut_ptr() as *mut u32, std::ptr::null_mut(), &mut is_inf,
             )
         };
+        if rc != 0 {
+            return Err(last_error(self.ctx).into());
+        }
+        Ok(to_projective(&jac))
+    }
+
+    /// scalars that already live in HBM (`n` x `BigInt<4>` at the device address `d_scalars`, produced on `hip_stream` or NULL):
+    /// a prover whose witness is computed on the GPU.  Nothing but the result crosses PCIe (`msm_bn254_g1_resident_device`).
+    ///
+    /// # Safety
+    /// `d_scalars` must be a device pointer to at least `n` scalars on this handle's device, valid until the call returns.
+    pub unsafe fn msm_device_scalars(&self, d_scalars: *const core::ffi::c_void, n: usize, hip_stream: *mut core::ffi::c_void) -> Result<G1Projective, Box<dyn Error>> {
+        if n == 0 || d_scalars.is_null() {
+            return Err("Empty input".into());
+        }
+        let mut jac = [0u64; 12];
+        let mut is_inf = 0u8;
+        let rc = msm_bn254_g1_resident_device(
+            self.ctx, d_scalars, n.min(self.n), hip_stream, jac.as_mut_ptr() as *mut u32, std::ptr::null_mut(), &mut is_inf,
+        );
         if rc != 0 {
             return Err(last_error(self.ctx).into());
         }

@@ -468,6 +468,48 @@ def test_glv_split_full_size_matches_unsplit_and_closed_form(monkeypatch, hk, lo
         assert (cg.msm_resident(s[:m]).affine_std == e2).all()
 
 
+@pytest.mark.parametrize("flags", [0, mh.FLAG_WINDOW_TABLE, mh.FLAG_NO_GLV | mh.FLAG_WINDOW_TABLE])
+def test_resident_bases_with_scalars_in_hbm(hk, flags):
+    """msm_bn254_g1_resident_device (ABI 4): the scalars of a prover whose witness lives on the GPU -- resident bases (and their window
+    table), device scalars, the caller's stream.  Same bits as the host-scalar call and the closed form; fewer scalars than bases run on
+    the first n; no resident set -> MSM_ERR_STATE; NULL / empty -> the reference's errors (metal_msm.rs:647-656)."""
+    import torch
+    n = (1 << 17) + 77
+    dev = torch.device("cuda:0")
+    d_bases = torch.empty(n * 16, dtype=torch.int32, device=dev)
+    d_s = torch.empty(n * 8, dtype=torch.int32, device=dev)
+    k = th.generate_scalars_host(0xB2540071, n, nonzero=True)
+    s = th.generate_scalars_host(0xB2540072, n)
+    exp, einf = orc.closed_form_expected(k, s)
+    hk.generate_device(0xB2540071, 0xB2540072, n, d_bases.data_ptr(), d_s.data_ptr())
+    torch.cuda.synchronize()
+    hb = d_bases.cpu().numpy().view(np.uint32).reshape(n, 16)
+    with mh.MsmContext(flags=flags) as c:
+        with pytest.raises(mh.MsmError) as e:
+            c.msm_resident_device(d_s.data_ptr(), n)
+        assert e.value.code == mh.ERR_STATE
+        c.upload_bases(hb, mh.FORM_MONT)
+        r = c.msm_resident_device(d_s.data_ptr(), n)
+        assert (r.affine_std == exp).all() and r.is_infinity == bool(einf)
+        assert (c.msm_resident(s).affine_std == exp).all()  # (Jacobian words are not compared: the order inside a bucket is the sort's atomics')
+        # the caller's stream produced the scalars: they are written on a side stream right before the call
+        side = torch.cuda.Stream(device=dev)
+        d_t = torch.empty_like(d_s)
+        with torch.cuda.stream(side):
+            d_t.copy_(d_s, non_blocking=True)
+            r2 = c.msm_resident_device(d_t.data_ptr(), n, stream=side.cuda_stream)
+        assert (r2.affine_std == exp).all()
+        m = n // 3
+        e3, _ = orc.closed_form_expected(k[:m], s[:m])
+        assert (c.msm_resident_device(d_s.data_ptr(), m).affine_std == e3).all()
+        with pytest.raises(mh.MsmError) as e:
+            c.msm_resident_device(d_s.data_ptr(), 0)
+        assert e.value.code == mh.ERR_EMPTY
+        with pytest.raises(mh.MsmError) as e:
+            c.msm_resident_device(None, n)
+        assert e.value.code == mh.ERR_BAD_ARG
+
+
 @pytest.mark.parametrize("chunk_len", ["1", "7", "26", "35", "rounds-off"])
 def test_chunk_lengths_that_are_not_powers_of_two(monkeypatch, hk, chunk_len):
     """k_accumulate's fixed-length chunks: the length is fitted to whole rounds of workgroups (13 x 2^k entries of a window table take
