@@ -8,11 +8,11 @@ import numpy as np, torch
 import mopro_msm_hip as mh
 from mopro_msm_hip import testhooks as th
 name, vals = sys.argv[1], sys.argv[2].split(",")
-sizes = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "12,14,16,17,18,20").split(",")]
+sizes = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "12,14,16,17,18,20").split(",")]  # log2(n), or n itself when > 64
 gen = th.HooksContext()
 FLAGS = mh.FLAG_WINDOW_TABLE if os.environ.get("AB_TABLE", "1") == "1" else 0
 for lg in sizes:
-    n = 1 << lg
+    n = 1 << lg if lg <= 64 else lg
     d_b = torch.empty(n * 16, dtype=torch.int32, device="cuda:0"); d_s = torch.empty(n * 8, dtype=torch.int32, device="cuda:0")
     gen.generate_device(31, 32, n, d_b.data_ptr(), d_s.data_ptr()); torch.cuda.synchronize()
     hb = d_b.cpu().numpy().view(np.uint32).reshape(n, 16)
@@ -39,6 +39,6 @@ for lg in sizes:
             if rnd == 0:
                 rb = c.msm_resident_batch([hs] * 5, want_affine=True)
                 rows[v].append((rows[v][-1][0], all(bool((x.affine_std == ref).all()) for x in rb)))
-    print(f"2^{lg} {'table' if FLAGS else 'plain'}: " + "  ".join(f"{name}={v}: single {statistics.median(y[0] for y in rows[v]):.4f} batch {min(brows[v]):.4f} ms" for v in vals)
+    print(f"{'2^%d' % lg if lg <= 64 else lg} {'table' if FLAGS else 'plain'}: " + "  ".join(f"{name}={v}: single {statistics.median(y[0] for y in rows[v]):.4f} batch {min(brows[v]):.4f} ms" for v in vals)
           + f"  same={all(y[1] for v in vals for y in rows[v])}", flush=True)
     for c in ctxs.values(): c.close()
