@@ -165,6 +165,8 @@ struct msm_ctx {
     hipStream_t copy_stream = nullptr;     // host->HBM uploads and base conversion beside the sort
     uint32_t num_cus = 0;                  // compute units of the device (rounds of k_accumulate workgroups)
     hipEvent_t ev_body = nullptr;          // batch: behind k_combine on the shared stream; the bucket reduction waits for it on another
+    int red_state = 0;                     // the batch's reduce stream: 0 = not yet measured in this context, 1 = kept, 2 = found slower here
+    bool red_active = false;               // ... in use by the batch call that is running
     hipEvent_t ev_copied[2]{}, ev_free[2]{}, ev_scal[2]{};  // streamed host call: slot's bases+scalars there / slot free again / its scalars there
     hipEvent_t ev_fork = nullptr, ev_bases = nullptr;  // base conversion runs on copy_stream beside the sort kernels
     DevBuf sbases[2], sscalars[2], sinf[2];  // double-buffered raw inputs of the streamed path
@@ -1416,8 +1418,9 @@ static int32_t resident_on_lane(msm_ctx* w, const msm_ctx* owner, const uint32_t
             // 2.85 -> 2.75 (profiles/r3_batch_reduce_stream.txt).  The priority is what makes it work: on a plain stream -- also one with
             // a hardware queue of its own (full CU mask) -- the levels queue behind the next accumulation's workgroups and the batch
             // LOSES 10-18 %; leaving 8-32 CUs out of the shared stream's CU mask for them loses 5-10 %; k_combine moved along: no gain.
+            // (o->red_active: msm_bn254_g1_resident_batch measures the mechanism once per context and drops it where it is slower.)
             hipStream_t rs = st;
-            if (shared && o->knobs.batch_reduce_stream && o->lane1 && w->ev_body) {
+            if (shared && o->red_active && o->lane1 && w->ev_body) {
                 rs = o->lane1->copy_stream;
                 HIPCHK(w, hipEventRecord(w->ev_body, st));
                 HIPCHK(w, hipStreamWaitEvent(rs, w->ev_body, 0));
@@ -1480,13 +1483,14 @@ int32_t msm_bn254_g1_resident_batch(msm_ctx* c, const uint32_t* const* scalars, 
         if (!c->batch_pool) return fail(c, MSM_ERR_OOM, "host allocation failed");
     }
     std::atomic<size_t> next{0};
+    size_t upto = count;  // the lanes share the MSMs [next, upto)
     std::atomic<int32_t> rcs[2] = {{MSM_OK}, {MSM_OK}};
     auto lane = [&](int k) {
         msm_ctx* w = k == 0 ? c : c->lane1;
         DeviceGuard gl(c->device);  // per host thread
         for (;;) {
             const size_t i = next.fetch_add(1);
-            if (i >= count || rcs[0] != MSM_OK || rcs[1] != MSM_OK) break;
+            if (i >= upto || rcs[0] != MSM_OK || rcs[1] != MSM_OK) break;
             const int32_t rc = resident_on_lane(w, c, scalars[i], n, out_jac + i * 24, out_aff ? out_aff + i * 16 : nullptr,
                                                 out_inf ? out_inf + i : nullptr, count > 1);
             if (rc) rcs[k] = rc;
@@ -1498,11 +1502,31 @@ int32_t msm_bn254_g1_resident_batch(msm_ctx* c, const uint32_t* const* scalars, 
         // (MSM_HIP_BATCH_MODE at context creation, experiment: shared | lanes)
         c->batch_shared_stream = c->knobs.batch_mode >= 0 ? c->knobs.batch_mode == 1 : n >= ((size_t)1 << 19);
     }
-    if (count > 1 && c->batch_shared_stream && c->knobs.batch_reduce_stream && c->knobs.copy_priority && !c->knobs.batch_copy_own)
+    const bool red_possible = count > 1 && c->batch_shared_stream && c->knobs.batch_reduce_stream && c->knobs.copy_priority && !c->knobs.batch_copy_own;
+    if (red_possible)
         for (msm_ctx* w : {c, c->lane1})
             if (!w->ev_body) HIPCHK(c, hipEventCreateWithFlags(&w->ev_body, hipEventDisableTiming));
-    if (count > 1) c->batch_pool->run(2, lane);
+    // The reduce stream (resident_on_lane) needs three of this context's streams to sit on three hardware queues, and which queues
+    // streams get depends on every stream the PROCESS has created: with three or four other contexts alive the same batch took 1.9-2.3 ms
+    // per MSM instead of 1.5 at 2^20 (profiles/r3_batch_many_contexts.txt).  So a context MEASURES it once -- the first batch of four or
+    // more MSMs runs its first half without and its second half with the reduce stream -- and keeps it unless it is clearly slower here.
+    c->red_active = red_possible && c->red_state != 2;
+    if (red_possible && c->red_state == 0 && count >= 4) {
+        const size_t half = count / 2;
+        double ms[2];
+        for (int part = 0; part < 2; part++) {
+            c->red_active = part == 1;
+            upto = part == 0 ? half : count;
+            const auto t0 = std::chrono::steady_clock::now();
+            c->batch_pool->run(2, lane);
+            ms[part] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / (double)(part == 0 ? half : count - half);
+            next = upto;  // (the lanes may have overshot the counter by one each)
+            if (rcs[0] != MSM_OK || rcs[1] != MSM_OK) break;
+        }
+        if (rcs[0] == MSM_OK && rcs[1] == MSM_OK) c->red_state = ms[1] <= 1.10 * ms[0] ? 1 : 2;
+    } else if (count > 1) c->batch_pool->run(2, lane);
     else lane(0);
+    c->red_active = false;
     if (rcs[0] == MSM_OK && rcs[1] != MSM_OK) c->err = c->lane1->err;
     return rcs[0] != MSM_OK ? rcs[0] : rcs[1];
 }

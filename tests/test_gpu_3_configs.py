@@ -285,6 +285,39 @@ def test_resident_batch_two_in_flight(ctx, inst20):
     c2.close()
 
 
+@pytest.mark.parametrize("flags", [0, mh.FLAG_WINDOW_TABLE])
+def test_resident_batch_first_call_measures_the_reduce_stream(hk, flags):
+    """From 2^19 points the batch runs each MSM's bucket reduction on a second, high-priority stream -- unless the context found it slower:
+    the FIRST batch of four or more MSMs runs its first half without and its second half with it (whether streams share hardware queues
+    depends on everything the process has created).  A fresh context, a first batch of 5 (halves of 2 and 3) and a later batch of 6, distinct
+    scalar vectors, every result against the closed form -- with three more contexts alive, the constellation that made it slower."""
+    import torch
+    n = (1 << 19) + 4097
+    dev = torch.device("cuda:0")
+    d_bases = torch.empty(n * 16, dtype=torch.int32, device=dev)
+    d_s = torch.empty(n * 8, dtype=torch.int32, device=dev)
+    k = th.generate_scalars_host(0xB25400C1, n, nonzero=True)
+    hk.generate_device(0xB25400C1, 0xB25400C2, n, d_bases.data_ptr(), d_s.data_ptr())
+    torch.cuda.synchronize()
+    hb = d_bases.cpu().numpy().view(np.uint32).reshape(n, 16)
+    vecs = [th.generate_scalars_host(0xB25400D0 + j, n) for j in range(6)]
+    exp = [orc.closed_form_expected(k, v)[0] for v in vecs]
+    others = [mh.MsmContext() for _ in range(3)]
+    try:
+        for o in others:  # each with its second pipeline
+            o.upload_bases(hb[:2048], mh.FORM_MONT)
+            o.msm_resident_batch([vecs[0][:2048], vecs[1][:2048]])
+        with mh.MsmContext(flags=flags) as c:
+            c.upload_bases(hb, mh.FORM_MONT)
+            for batch in (vecs[:5], vecs, vecs[3:5]):
+                off = 0 if len(batch) != 2 else 3
+                for j, r in enumerate(c.msm_resident_batch(batch)):
+                    assert (r.affine_std == exp[off + j]).all(), (flags, len(batch), j)
+    finally:
+        for o in others:
+            o.close()
+
+
 # ---- N > 1 -------------------------------------------------------------------------------------------------------------------
 def test_multi_in_process_on_one_gpu(hk, inst20):
     """msm_multi (include/msm_hip.h "multi-GPU"): one context + host thread per listed device.  On a 1-GPU box the list names
