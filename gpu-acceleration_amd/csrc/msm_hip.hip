@@ -165,8 +165,11 @@ struct msm_ctx {
     hipStream_t copy_stream = nullptr;     // host->HBM uploads and base conversion beside the sort
     uint32_t num_cus = 0;                  // compute units of the device (rounds of k_accumulate workgroups)
     hipEvent_t ev_body = nullptr;          // batch: behind k_combine on the shared stream; the bucket reduction waits for it on another
-    int red_state = 0;                     // the batch's reduce stream: 0 = not yet measured in this context, 1 = kept, 2 = found slower here
-    bool red_active = false;               // ... in use by the batch call that is running
+    int batch_choice = 0, batch_choice_class = 0;  // the batch's stream layout for this size class: 0 = not yet measured here, 1 = the default, 2 = the alternative
+    int batch_phase = 0;                   // ... measuring: calls 0 / 1 warm the alternative / the default up, calls 2 / 3 time them
+    double batch_alt_ms = 0;
+    size_t batch_alt_count = 0;
+    bool red_active = false;               // the reduce stream is in use by the batch call that is running
     hipEvent_t ev_copied[2]{}, ev_free[2]{}, ev_scal[2]{};  // streamed host call: slot's bases+scalars there / slot free again / its scalars there
     hipEvent_t ev_fork = nullptr, ev_bases = nullptr;  // base conversion runs on copy_stream beside the sort kernels
     DevBuf sbases[2], sscalars[2], sinf[2];  // double-buffered raw inputs of the streamed path
@@ -1483,7 +1486,7 @@ int32_t msm_bn254_g1_resident_batch(msm_ctx* c, const uint32_t* const* scalars, 
         if (!c->batch_pool) return fail(c, MSM_ERR_OOM, "host allocation failed");
     }
     std::atomic<size_t> next{0};
-    size_t upto = count;  // the lanes share the MSMs [next, upto)
+    const size_t upto = count;
     std::atomic<int32_t> rcs[2] = {{MSM_OK}, {MSM_OK}};
     auto lane = [&](int k) {
         msm_ctx* w = k == 0 ? c : c->lane1;
@@ -1497,35 +1500,51 @@ int32_t msm_bn254_g1_resident_batch(msm_ctx* c, const uint32_t* const* scalars, 
         }
     };
     c->last_copy = nullptr;
-    {
-        // from 2^19 points the kernels fill the GPU: one compute stream; below, two (measured crossover 2^18..2^19)
-        // (MSM_HIP_BATCH_MODE at context creation, experiment: shared | lanes)
-        c->batch_shared_stream = c->knobs.batch_mode >= 0 ? c->knobs.batch_mode == 1 : n >= ((size_t)1 << 19);
-    }
-    const bool red_possible = count > 1 && c->batch_shared_stream && c->knobs.batch_reduce_stream && c->knobs.copy_priority && !c->knobs.batch_copy_own;
-    if (red_possible)
+    // How the two pipelines share the GPU.  From 2^19 points the kernels fill it: ONE compute stream, MSM after MSM, each MSM's bucket
+    // reduction on a second, high-priority stream beside the next MSM's sort (resident_on_lane); below, two compute streams whose
+    // kernels overlap (measured crossover 2^18..2^19; MSM_HIP_BATCH_MODE at context creation forces one: shared | lanes).
+    // Both defaults need this context's streams to sit on different hardware queues, and which queues streams get depends on every
+    // stream the PROCESS has created: with three or four other contexts alive the same batch took 1.9-2.3 ms per MSM instead of 1.5 at
+    // 2^20, 0.70 instead of 0.55 at 2^18 (profiles/r3_batch_many_contexts.txt) -- and nothing in HIP lets a library ask.  So a context
+    // MEASURES: its first batch calls (per size class) alternate between the alternative mode -- one stream without the reduce stream from
+    // 2^19 points, one stream + reduce stream below -- and the default, and the default is kept unless the alternative is more than 10 %
+    // faster per MSM here.
+    struct BatchMode { bool shared, red; };
+    const bool forced = c->knobs.batch_mode >= 0, big = n >= ((size_t)1 << 19);
+    const bool red_ok = count > 1 && c->knobs.batch_reduce_stream && c->knobs.copy_priority && !c->knobs.batch_copy_own;
+    const BatchMode def = forced ? BatchMode{c->knobs.batch_mode == 1, red_ok && c->knobs.batch_mode == 1} : big ? BatchMode{true, red_ok} : BatchMode{false, false};
+    BatchMode alt = def;
+    bool have_alt = false;
+    if (def.shared && def.red) alt = BatchMode{true, false}, have_alt = true;
+    else if (!def.shared && !forced && red_ok) alt = BatchMode{true, true}, have_alt = true;
+    if (count > 1)
         for (msm_ctx* w : {c, c->lane1})
             if (!w->ev_body) HIPCHK(c, hipEventCreateWithFlags(&w->ev_body, hipEventDisableTiming));
-    // The reduce stream (resident_on_lane) needs three of this context's streams to sit on three hardware queues, and which queues
-    // streams get depends on every stream the PROCESS has created: with three or four other contexts alive the same batch took 1.9-2.3 ms
-    // per MSM instead of 1.5 at 2^20 (profiles/r3_batch_many_contexts.txt).  So a context MEASURES it once -- the first batch of four or
-    // more MSMs runs its first half without and its second half with the reduce stream -- and keeps it unless it is clearly slower here.
-    c->red_active = red_possible && c->red_state != 2;
-    if (red_possible && c->red_state == 0 && count >= 4) {
-        const size_t half = count / 2;
-        double ms[2];
-        for (int part = 0; part < 2; part++) {
-            c->red_active = part == 1;
-            upto = part == 0 ? half : count;
-            const auto t0 = std::chrono::steady_clock::now();
-            c->batch_pool->run(2, lane);
-            ms[part] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / (double)(part == 0 ? half : count - half);
-            next = upto;  // (the lanes may have overshot the counter by one each)
-            if (rcs[0] != MSM_OK || rcs[1] != MSM_OK) break;
-        }
-        if (rcs[0] == MSM_OK && rcs[1] == MSM_OK) c->red_state = ms[1] <= 1.10 * ms[0] ? 1 : 2;
-    } else if (count > 1) c->batch_pool->run(2, lane);
+    // (four batch calls of a size class decide: the alternative and the default once each as a warm-up -- a stream's first kernel creates its
+    // hardware queue, a pipeline's first MSM allocates its workspace: milliseconds -- then once each on the clock)
+    const int size_class = big ? 2 : 1;
+    if (c->batch_choice_class != size_class) c->batch_choice = 0, c->batch_phase = 0, c->batch_choice_class = size_class;
+    auto set_mode = [&](const BatchMode& m) { c->batch_shared_stream = m.shared, c->red_active = m.red, c->last_copy = nullptr; };
+    const bool measuring = count > 1 && have_alt && c->batch_choice == 0;
+    if (measuring && c->batch_phase == 3 && count != c->batch_alt_count) c->batch_phase = 2;  // compare batches of one length
+    const bool use_alt = measuring ? (c->batch_phase & 1) == 0 : (have_alt && c->batch_choice == 2);
+    set_mode(use_alt ? alt : def);
+    const auto t_batch = std::chrono::steady_clock::now();
+    if (count > 1) c->batch_pool->run(2, lane);
     else lane(0);
+    if (measuring && rcs[0] == MSM_OK && rcs[1] == MSM_OK) {
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_batch).count() / (double)count;
+        if (c->batch_phase == 2) c->batch_alt_ms = ms, c->batch_alt_count = count;
+        if (c->batch_phase == 3) {
+            c->batch_choice = c->batch_alt_ms * 1.10 < ms ? 2 : 1;
+            if (trace_enabled() || std::getenv("MSM_HIP_BATCH_TRACE"))
+                std::fprintf(stderr, "[msm_hip] batch layout measured at n %zu: %s %.4f ms per MSM, default (%s) %.4f -> %s\n", n,
+                             alt.shared ? (alt.red ? "one stream + reduce stream" : "one stream") : "two streams", c->batch_alt_ms,
+                             def.shared ? (def.red ? "one stream + reduce stream" : "one stream") : "two streams", ms,
+                             c->batch_choice == 2 ? "the alternative" : "the default");
+        }
+        c->batch_phase++;
+    }
     c->red_active = false;
     if (rcs[0] == MSM_OK && rcs[1] != MSM_OK) c->err = c->lane1->err;
     return rcs[0] != MSM_OK ? rcs[0] : rcs[1];

@@ -159,9 +159,10 @@ int32_t msm_bn254_g1_resident_device(msm_ctx *ctx, const void *d_scalars, size_t
  * out_affine_std[i*16..] (nullable), out_is_inf[i] (nullable).  This is how provers call MSM: several scalar vectors per proof against
  * fixed bases.  A second pipeline inside the context (second host thread, own workspace) uploads the next
  * scalar vector and finishes the previous MSM on the CPU while the GPU computes: from 2^19 points both pipelines feed ONE compute
- * stream, MSM after MSM without a gap (each MSM's bucket reduction on a second, high-priority stream beside the next MSM's sort: the
- * first batch of >= 4 MSMs of a context measures whether that pays in this process and keeps or drops it); below, where no kernel
- * fills the GPU, each keeps its own stream and the kernels overlap.
+ * stream, MSM after MSM without a gap (each MSM's bucket reduction on a second, high-priority stream beside the next MSM's sort);
+ * below, where no kernel fills the GPU, each keeps its own stream and the kernels overlap.  Whether a context's streams get
+ * hardware queues of their own depends on every stream the process has created, so a context measures its layout: its first
+ * four batch calls alternate between the default and the alternative, then the faster one stays (MSM_HIP_BATCH_TRACE=1 prints it).
  * Per MSM, single calls -> batch: 2^14 0.40 -> 0.24 ms, 2^17 0.56 -> 0.40, 2^20 2.28 -> 1.63, 2^22 8.54 -> 5.80.
  * Results are identical to `count` msm_bn254_g1_resident calls; on an error the first failing code is returned. */
 int32_t msm_bn254_g1_resident_batch(msm_ctx *ctx, const uint32_t *const *scalars, size_t n, size_t count,
