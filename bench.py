@@ -34,6 +34,7 @@ STREAM_MUL = 0xD1342543DE82EF95  # element i of a stream = SplitMix64 seeded wit
 HBM_PEAK_GBPS = 8000.0           # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 R_ORDER = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
 MASK64 = (1 << 64) - 1
+LAYOUT_NAMES = {1: "one stream", 2: "one stream + reduce stream", 3: "two streams"}  # MSM_BATCH_LAYOUT_*
 
 
 def words_to_ints(a):
@@ -112,7 +113,24 @@ def main():
                     help="N GPUs driven by ONE process through msm_multi (context + host thread per device, in-library RCCL exchange)")
     ap.add_argument("--debug-same-device", action="store_true",
                     help="functional check of the N>1 path on a 1-GPU box: every rank uses cuda:0 and the exchange runs over gloo / the host fold")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launched torchrun (0 = a free one)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` started plainly (no torchrun around it): start the N ranks ourselves -- as a CHILD process, before
+    # anything here has touched the GPU (never a re-exec) -- relay rank 0's JSON line and exit with the child's code.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.in_process:
+        import socket
+        import subprocess
+        port = args.master_port
+        if not port:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.call(cmd, env=env))
 
     import torch
     import torch.distributed as dist
@@ -123,8 +141,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and not (world == 1 and args.in_process):
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N (or with --in-process)")
+        raise SystemExit("WORLD_SIZE %d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MSM engine has no CPU fallback")
     if args.debug_same_device:
@@ -220,15 +237,19 @@ def main():
         ctx.reset_kernel_stats()
     shard_ms_acc[0], shard_ms_acc[1] = 0.0, 0
     exch_ms_sum = 0.0
+    step_jac = []  # the Jacobian words every timed step returned (96 bytes each): all checked after the loop
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
+        step_jac.append(res.jacobian_mont)
         if world > 1:
             exch_ms_sum += md.last_exchange_ms(xdev)
     fence()
     elapsed = time.perf_counter() - t0
+    clk_loop = clk_single = None
     if ctx is not None:
+        clk_loop = ctx.clock_stats()  # k_accumulate's own cycle / constant-rate counters over the timed launches
         acc_avg_ms, acc_launches = ctx.accumulate_kernel_stats()
         # instances cut into point ranges (device inputs from 2^23 points, streamed host inputs) launch k_accumulate once per range:
         # the roofline prices the MSM's accumulation = all of a step's launches together, against the whole instance's bytes
@@ -258,8 +279,10 @@ def main():
     tm = {}
     if ctx is not None and not args.streamed:
         ctx.set_stage_timing(True)
+        ctx.reset_kernel_stats()
         step()
         tm = ctx.timings()
+        clk_single = ctx.clock_stats()
         ctx.set_stage_timing(False)
     elif ctx is not None:
         tm = ctx.timings()
@@ -306,6 +329,9 @@ def main():
 
     bit_exact = True
     if rank == 0:
+        # the CPU leg's OpenMP threads stay on their cores (libgomp reads these when the oracle library is loaded)
+        os.environ.setdefault("OMP_PROC_BIND", "close")
+        os.environ.setdefault("OMP_PLACES", "cores")
         from oracle import bn254_oracle as orc  # checker + cpu_baseline leg only
         gpt = np.zeros(16, np.uint32)
         gpt[0], gpt[8] = 1, 2
@@ -315,6 +341,15 @@ def main():
 
         exp, exp_inf = expect(dot)
         bit_exact = bool((res.affine_std == exp).all() and res.is_infinity == bool(exp_inf))
+        # EVERY timed step is checked: its Jacobian words are normalised (the one field inversion, outside the timed region) and the
+        # affine words compared with the closed form.  The words themselves may differ from step to step -- the sort places the entries of a
+        # bucket with LDS atomics, so the order of a bucket's additions, and with it the projective representation, is not fixed -- the
+        # group element is.
+        steps_ok = 0
+        for jw in step_jac:
+            a = mh.combine_partials(jw.reshape(1, 24))
+            steps_ok += int(bool((a.affine_std == exp).all()) and a.is_infinity == bool(exp_inf))
+        bit_exact = bit_exact and steps_ok == len(step_jac)
 
         pl = mh.plan(n_local, args.window_bits, ctx_flags)
         W, H = pl.num_windows, pl.num_buckets
@@ -355,8 +390,21 @@ def main():
                        "buckets_per_window": H, "glv_split": bool(pl.glv), "points_per_window": int(pl.virtual_points),
                        "parallelism": "point-range x%d%s" % (nshards, " (one process, msm_multi, exchange=%s)" %
                                                              {1: "rccl", 2: "host-fold"}.get(multi.exchange, "?") if in_proc else ""),
-                       "timed_call": "msm_multi_device" if in_proc else "msm_bn254_g1 (host pointers, pinned)" if args.streamed else "msm_bn254_g1_device"},
+                       "timed_call": "msm_multi_device" if in_proc else "msm_bn254_g1 (host pointers, pinned)" if args.streamed else "msm_bn254_g1_device",
+                       "timed_call_returns": "Jacobian Montgomery words (the reference's own result type, metal_msm.rs:228-241); the one field "
+                                             "inversion that gives the compared affine words (~10 us on the host) is outside the timed region"},
             "bit_exact": bit_exact,
+            "bit_exact_steps": {"checked": len(step_jac), "equal_to_closed_form": steps_ok,
+                                "distinct_jacobian_representations": len({bytes(jw.tobytes()) for jw in step_jac})},
+            # Is a slower line a slower kernel or a slower box?  k_accumulate's first workgroup reads the shader-cycle counter and the
+            # constant-rate counter around its chunk in EVERY launch: the GHz the kernel really sustained, and shader cycles per mixed
+            # addition of one wavefront -- equal on two boxes that run the same instruction stream, whatever their clocks.
+            "clock": ({"sclk_ghz_timed_loop": round(clk_loop["sclk_ghz"], 4), "sclk_ghz_single_step": round(clk_single["sclk_ghz"], 4) if clk_single else None,
+                       "cycles_per_addition_timed_loop": round(clk_loop["cycles_per_addition"], 1),
+                       "cycles_per_addition_single_step": round(clk_single["cycles_per_addition"], 1) if clk_single else None,
+                       "k_accumulate_mcycles": round(acc_avg_ms * 1e-3 * clk_loop["sclk_ghz"] * 1e3, 3), "launches_sampled": int(clk_loop["samples"]),
+                       "note": "k_accumulate_mcycles = avg_kernel_ms x sclk_ghz_timed_loop (10^6 shader cycles per launch); cycles per addition are those of "
+                               "the launch's first wavefront, which shares its SIMD with two others"} if clk_loop and clk_loop["samples"] else None),
             "roofline": {"bound": "hbm", "kernel": "k_accumulate", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_over_algorithmic": round(traffic / alg_bytes, 3) if traffic else None,
@@ -431,6 +479,14 @@ def main():
             ok = ok and all(bool((x.affine_std == exp).all()) for x in r)
             r, avg, _ = timed_calls(lambda: ctx.msm_resident_batch([hspn] * K), 3)
             legs["resident_batch_ms_per_msm"] = round(avg / K, 4)
+            legs["resident_batch_layout"] = LAYOUT_NAMES.get(ctx.timings()["batch_layout"])  # AUTO: deterministic, by size
+            ok = ok and all(bool((x.affine_std == exp).all()) for x in r)
+            # ... and after the explicit, opt-in measurement of the three stream layouts on this context (msm_tune_batch)
+            chosen, tune_ms = ctx.tune_batch([hspn] * 4, reps=2)
+            r, avg, _ = timed_calls(lambda: ctx.msm_resident_batch([hspn] * K), 3)
+            legs["resident_batch_tuned_ms_per_msm"] = round(avg / K, 4)
+            legs["resident_batch_tuned_layout"] = LAYOUT_NAMES.get(chosen)
+            legs["resident_batch_tune_ms_per_msm"] = {LAYOUT_NAMES.get(k): round(v, 4) for k, v in tune_ms.items()}
             ok = ok and all(bool((x.affine_std == exp).all()) for x in r)
             # ... and with the scalars in HBM as well (a prover whose witness lives on the GPU): msm_bn254_g1_resident_device
             dsp = d_scalars[0].data_ptr()
@@ -448,6 +504,11 @@ def main():
                 ok = ok and all(bool((x.affine_std == exp).all()) for x in r)
                 r, avg, _ = timed_calls(lambda: tctx.msm_resident_batch([hspn] * K), 3)
                 legs["resident_table_batch_ms_per_msm"] = round(avg / K, 4)
+                ok = ok and all(bool((x.affine_std == exp).all()) for x in r)
+                chosen, _tm = tctx.tune_batch([hspn] * 4, reps=2)
+                r, avg, _ = timed_calls(lambda: tctx.msm_resident_batch([hspn] * K), 3)
+                legs["resident_table_batch_tuned_ms_per_msm"] = round(avg / K, 4)
+                legs["resident_table_batch_tuned_layout"] = LAYOUT_NAMES.get(chosen)
                 ok = ok and all(bool((x.affine_std == exp).all()) for x in r)
                 r, avg, _ = timed_calls(lambda: [tctx.msm_resident_device(dsp, n_local) for _ in range(K)], 3)
                 legs["resident_table_device_scalars_ms_per_msm"] = round(avg / K, 4)
@@ -469,11 +530,11 @@ def main():
             hbc = d_bases[0][: n_cpu * 16].cpu().numpy().view(np.uint32).reshape(n_cpu, 16)
             hsc = d_scalars[0][: n_cpu * 8].cpu().numpy().view(np.uint32).reshape(n_cpu, 8)
             cpu_runs = []
-            for _ in range(3):  # best of three: one run moved by 35 % between two driver runs of round 2 (a shared host)
+            for _ in range(5):  # MEDIAN of five, spread in the line (a shared host: single runs moved by 35-43 % in rounds 2 and 3)
                 t0 = time.perf_counter()
                 cpu_aff, cpu_inf, _ = orc.msm_pippenger(hbc, hsc, orc.FORM_MONT, None, threads)
                 cpu_runs.append((time.perf_counter() - t0) * 1e3)
-            cpu_ms = min(cpu_runs)
+            cpu_ms = sorted(cpu_runs)[len(cpu_runs) // 2]
             if n_cpu == n_local:
                 cpu_ok = bool((cpu_aff == res.affine_std).all())
             else:
@@ -483,10 +544,12 @@ def main():
             lg = int(np.log2(n_cpu))
             c_ark = 3 if n_cpu < 32 else (lg * 69) // 100 + 2
             busy = min(threads, -(-254 // c_ark))
-            out["cpu_baseline"] = {"value": round(cpu_ms, 2), "all_runs_ms": [round(x, 1) for x in cpu_runs], "unit": "ms", "cores": busy, "kind": "port",
-                                   "sample": "first 2^%d points of the same instance, one MSM, best of three runs; arkworks-0.4 algorithm restated in C "
+            out["cpu_baseline"] = {"value": round(cpu_ms, 2), "all_runs_ms": [round(x, 1) for x in cpu_runs],
+                                   "spread": round((max(cpu_runs) - min(cpu_runs)) / cpu_ms, 3), "unit": "ms", "cores": busy, "kind": "port",
+                                   "sample": "first 2^%d points of the same instance, one MSM, MEDIAN of five runs (spread = (max - min) / median), threads "
+                                             "pinned (OMP_PROC_BIND=%s OMP_PLACES=%s); arkworks-0.4 algorithm restated in C "
                                              "(not arkworks itself): one thread per window, %d windows of %d bits, %d host threads available"
-                                             % (lg, -(-254 // c_ark), c_ark, threads),
+                                             % (lg, os.environ.get("OMP_PROC_BIND"), os.environ.get("OMP_PLACES"), -(-254 // c_ark), c_ark, threads),
                                    "agrees_with_gpu": cpu_ok}
             bit_exact = bit_exact and cpu_ok
         out["bit_exact"] = bit_exact

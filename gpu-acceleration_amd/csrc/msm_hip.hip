@@ -111,9 +111,7 @@ struct Knobs {
     bool reduce_v1 = false;                    // MSM_HIP_REDUCE_V1: one launch per pairwise level (round 1)
     uint32_t pair8_lanes = 0;                  // MSM_HIP_PAIR8_LANES: lanes per output of k_pair_level8 (1, 2, 4; 0 = by size)
     int batch_copy_own = 0;                    // MSM_HIP_BATCH_COPY=0: each batch pipeline uploads on its own copy stream
-    int batch_reduce_stream = 1;               // MSM_HIP_BATCH_REDUCE_STREAM=0: the bucket reduction of a batch MSM stays on the shared stream
     int lane_priority = 1;                     // MSM_HIP_LANE_PRIORITY: low (1, default) | high (2) | normal (0)
-    int batch_mode = -1;                       // MSM_HIP_BATCH_MODE: shared (1) | lanes (0); -1 = by size
     msmplan::table_knobs table;                // MSM_HIP_TABLE_C / MSM_HIP_TABLE_F / MSM_HIP_TABLE_MAX_GB (window table of a resident set)
     static Knobs from_env() {
         Knobs k;
@@ -144,10 +142,8 @@ struct Knobs {
             k.pair8_lanes = v == 1 || v == 2 || v == 4 ? (uint32_t)v : 0u;
         }
         if (const char* e = std::getenv("MSM_HIP_BATCH_COPY")) k.batch_copy_own = e[0] == '0';
-        if (const char* e = std::getenv("MSM_HIP_BATCH_REDUCE_STREAM")) k.batch_reduce_stream = e[0] != '0';
         if (const char* e = std::getenv("MSM_HIP_CHUNK_ROUNDS")) k.chunk_rounds = e[0] != '0';
         if (const char* e = std::getenv("MSM_HIP_LANE_PRIORITY")) k.lane_priority = !strcmp(e, "high") ? 2 : !strcmp(e, "normal") ? 0 : 1;
-        if (const char* e = std::getenv("MSM_HIP_BATCH_MODE")) k.batch_mode = !strcmp(e, "shared") ? 1 : 0;
         k.table.c = (uint32_t)num("MSM_HIP_TABLE_C", 0, 20, 0);
         k.table.f = (uint32_t)num("MSM_HIP_TABLE_F", 0, 128, 0);
         k.table.max_bytes = (size_t)num("MSM_HIP_TABLE_MAX_GB", 0, 1024, 64) << 30;
@@ -164,11 +160,10 @@ struct msm_ctx {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;     // host->HBM uploads and base conversion beside the sort
     uint32_t num_cus = 0;                  // compute units of the device (rounds of k_accumulate workgroups)
+    uint32_t acc_wgs_per_cu = 3;           // resident k_accumulate workgroups per CU (hipOccupancyMaxActiveBlocksPerMultiprocessor at creation)
     hipEvent_t ev_body = nullptr;          // batch: behind k_combine on the shared stream; the bucket reduction waits for it on another
-    int batch_choice = 0, batch_choice_class = 0;  // the batch's stream layout for this size class: 0 = not yet measured here, 1 = the default, 2 = the alternative
-    int batch_phase = 0;                   // ... measuring: calls 0 / 1 warm the alternative / the default up, calls 2 / 3 time them
-    double batch_alt_ms = 0;
-    size_t batch_alt_count = 0;
+    uint32_t tuned_layout[2] = {0, 0};     // msm_tune_batch: the measured MSM_BATCH_LAYOUT_* per size class (below / from 2^19 points); 0 = not tuned
+    uint32_t last_batch_layout = 0;        // what the last batch call ran under (msm_timings_t.batch_layout)
     bool red_active = false;               // the reduce stream is in use by the batch call that is running
     hipEvent_t ev_copied[2]{}, ev_free[2]{}, ev_scal[2]{};  // streamed host call: slot's bases+scalars there / slot free again / its scalars there
     hipEvent_t ev_fork = nullptr, ev_bases = nullptr;  // base conversion runs on copy_stream beside the sort kernels
@@ -186,6 +181,8 @@ struct msm_ctx {
     hipEvent_t last_copy = nullptr;  // ... the other pipeline's latest upload, recorded under copy_mu
     msm_ctx* lane1 = nullptr;      // second pipeline of msm_bn254_g1_resident_batch: a context of its own (streams, workspace, pinned results)
     HostPool* batch_pool = nullptr;  // ... and the host thread that drives it
+    DevBuf clk;           // 4 x u64: shader cycles, constant-rate ticks, samples, additions of k_accumulate's first workgroup (clock probe)
+    uint32_t wall_clock_khz = 0;  // rate of the constant counter (hipDeviceAttributeWallClockRate)
     DevBuf rbases, rinf;  // the RESIDENT base set (msm_bn254_g1_upload_bases / _upload_compressed): never used as scratch
     bool pow2_ready = false;
     uint32_t* h_qsums = nullptr;  // pinned: W x (kb+1) Jacobian bit sums
@@ -317,8 +314,12 @@ struct PipeState {
 
 // plan + workspace.  May reallocate buffers (hipFree synchronises the device), so with chunks in flight it must not grow
 // anything: the first chunk of a streamed MSM is the largest.
+// fixed_chunk_len != 0: a later chunk / point range of an instance whose FIRST (largest) piece was prepared with that k_accumulate chunk
+// length -- the length is fixed once per instance, so that a smaller piece can never need more chunks (heads, tails, chunk map, lists)
+// than the workspace sized for the first one holds (a shorter fitted length on a smaller last piece could outgrow the 12.5 %
+// slack of ensure() and make it reallocate -- a device synchronisation -- with chunks in flight).
 int32_t pipe_prepare(msm_ctx* c, size_t n_real, size_t plan_n, uint32_t extra_flags, hipStream_t st, PipeState* ps, uint32_t table_c = 0,
-                     uint32_t table_f = 1) {
+                     uint32_t table_f = 1, uint32_t fixed_chunk_len = 0) {
     if (trace_enabled() && c->flags_clean) c->t_prepare = std::chrono::steady_clock::now();  // (flags_clean: first prepare of a call)
     if (n_real > 0x3FFFFFFFull) return fail(c, MSM_ERR_BAD_ARG, "n = %zu exceeds 2^30-1 points per context call", n_real);
     // (a table call re-derives the plan its upload made: same width, and the split wherever make_table_plan allowed it -- the caller
@@ -367,7 +368,8 @@ int32_t pipe_prepare(msm_ctx* c, size_t n_real, size_t plan_n, uint32_t extra_fl
     // bucket is cut three times and k_combine's listed-bucket path costs more than the half-filled SIMDs of L = 32: single resident calls
     // 0.493-0.508 -> 0.462-0.476 ms; at 2^16 (32 per bucket) and 2^18 (L = 32 already) nothing changes: profiles/r3_table_chunk_len.txt)
     if (pairs <= ((size_t)1 << 21) && chunk_len * 4 <= occ && pairs / (chunk_len * 2) >= 65536) chunk_len *= 2;
-    if (c->knobs.chunk_rounds) chunk_len = msmplan::fit_chunk_to_rounds(pairs, chunk_len, c->num_cus);
+    if (c->knobs.chunk_rounds) chunk_len = msmplan::fit_chunk_to_rounds(pairs, chunk_len, c->num_cus, c->acc_wgs_per_cu);
+    if (fixed_chunk_len) chunk_len = fixed_chunk_len;
     if (c->knobs.chunk_len) chunk_len = c->knobs.chunk_len;  // MSM_HIP_CHUNK_LEN at context creation (any value >= 1 is correct)
     ps->chunk_len = chunk_len;
     const size_t nchunks_max = ps->nchunks_max = (pairs + chunk_len - 1) / chunk_len;
@@ -570,9 +572,10 @@ int32_t enqueue_accumulate(msm_ctx* c, const PipeState& ps, const uint32_t* d_ba
     const dim3 ga = grid1(ps.nchunks_max, 256);  // (64- and 128-thread workgroups: no difference at any size, tools/env_sweep.py)
     const uint32_t *srt = (const uint32_t*)c->sorted.p, *cm = (const uint32_t*)c->chunkmap.p, *tp = flags + msmk::FLAG_PAIRS;
     uint32_t *bk = (uint32_t*)c->buckets.p, *hd = (uint32_t*)c->heads.p, *tl = (uint32_t*)c->tails.p;
-    if (into) msmk::k_accumulate<true, true><<<ga, 256, 0, st>>>(d_bases, srt, offsets, cm, bk, hd, tl, tp, ps.chunk_len, (uint32_t)tb);
-    else if (chunked) msmk::k_accumulate<false, true><<<ga, 256, 0, st>>>(d_bases, srt, offsets, cm, bk, hd, tl, tp, ps.chunk_len, (uint32_t)tb);
-    else msmk::k_accumulate<false, false><<<ga, 256, 0, st>>>(d_bases, srt, offsets, cm, bk, hd, tl, tp, ps.chunk_len, (uint32_t)tb);
+    unsigned long long* clk = (unsigned long long*)c->clk.p;  // clock probe of the launch's first workgroup (msm_get_clock_stats)
+    if (into) msmk::k_accumulate<true, true><<<ga, 256, 0, st>>>(d_bases, srt, offsets, cm, bk, hd, tl, tp, ps.chunk_len, (uint32_t)tb, clk);
+    else if (chunked) msmk::k_accumulate<false, true><<<ga, 256, 0, st>>>(d_bases, srt, offsets, cm, bk, hd, tl, tp, ps.chunk_len, (uint32_t)tb, clk);
+    else msmk::k_accumulate<false, false><<<ga, 256, 0, st>>>(d_bases, srt, offsets, cm, bk, hd, tl, tp, ps.chunk_len, (uint32_t)tb, clk);
     HIPCHK(c, hipEventRecord(c->ev[EV_ACC1], st));
     const size_t once_max = std::min(ps.nchunks_max, tb);  // a once-cut bucket owns one chunk border
     msmk::k_combine<<<dim3(msmk::LONG_BLOCKS + msmk::MID_BLOCKS + (unsigned)((once_max + 511) / 512)), 512, 0, st>>>(
@@ -780,10 +783,11 @@ int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, 
     const size_t dchunk = dev_chunk_log2 ? (size_t)1 << dev_chunk_log2 : 0;
     if (table_f <= 1 && dchunk && n >= 2 * dchunk && !plan_glv(c, n, extra_flags)) {
         if ((rc = pipe_prepare(c, dchunk, n, extra_flags, st, &ps))) return rc;
+        const uint32_t range_chunk_len = ps.chunk_len;  // fixed by the first, largest range
         uint32_t nch = 0;
         for (size_t lo = 0; lo < n; lo += dchunk, nch++) {
             const size_t cnt = std::min(dchunk, n - lo);
-            if ((rc = pipe_prepare(c, cnt, n, extra_flags, st, &ps))) return rc;
+            if ((rc = pipe_prepare(c, cnt, n, extra_flags, st, &ps, 0, 1, range_chunk_len))) return rc;
             if ((rc = enqueue_digits_sort(c, ps, d_inf ? d_inf + lo : nullptr, d_scalars + lo * 8, scalars_mont, st, lo == 0))) return rc;
             if ((rc = enqueue_accumulate(c, ps, d_bases + lo * 16, st, lo == 0 ? bases_ready : nullptr, lo > 0, true))) return rc;
         }
@@ -946,6 +950,7 @@ int32_t run_streamed(msm_ctx* c, const HostInput& in, size_t n, const std::vecto
     hipStream_t st = c->stream, cs = c->copy_stream;
     PipeState ps;
     if ((rc = pipe_prepare(c, chunk, n, 0, st, &ps))) return rc;  // workspace for the largest chunk before anything is in flight
+    const uint32_t stream_chunk_len = ps.chunk_len;                // k_accumulate's chunk length: fixed by the largest chunk
     size_t lo = 0;
     for (size_t j = 0; j < sizes.size(); j++) {
         const int s = (int)(j & 1);
@@ -963,7 +968,7 @@ int32_t run_streamed(msm_ctx* c, const HostInput& in, size_t n, const std::vecto
         // carries the infinity flags inside the base records, which k_decompose reads: there the sort waits for the whole chunk.)
         const bool early_sort = in.kind != KIND_ARK;
         HIPCHK(c, hipStreamWaitEvent(st, early_sort ? c->ev_scal[s] : c->ev_copied[s], 0));
-        if ((rc = pipe_prepare(c, cnt, n, 0, st, &ps))) return rc;
+        if ((rc = pipe_prepare(c, cnt, n, 0, st, &ps, 0, 1, stream_chunk_len))) return rc;
         if ((rc = enqueue_digits_sort(c, ps, d_inf, (const uint32_t*)c->sscalars[s].p, in.scalars_mont, st, j == 0))) return rc;
         if ((rc = enqueue_accumulate(c, ps, (const uint32_t*)c->sibases[s].p, st, early_sort ? c->ev_copied[s] : nullptr, j > 0, true))) return rc;
         HIPCHK(c, hipEventRecord(c->ev_free[s], st));
@@ -1087,6 +1092,7 @@ static int32_t ctx_create_impl(const msm_config_t* cfg, msm_ctx** out, int main_
         return fail(nullptr, MSM_ERR_BAD_ARG, "bad window_bits/flags (%u, 0x%x)", c0.window_bits, c0.flags);
     if (c0.stream_chunk_log2 && (c0.stream_chunk_log2 < 8 || c0.stream_chunk_log2 > 28))
         return fail(nullptr, MSM_ERR_BAD_ARG, "stream_chunk_log2 = %u out of range [8, 28]", c0.stream_chunk_log2);
+    if (c0.batch_layout > MSM_BATCH_LAYOUT_TWO_STREAMS) return fail(nullptr, MSM_ERR_BAD_ARG, "unknown batch_layout %u", c0.batch_layout);
     int dev = c0.device;
     if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return fail(nullptr, MSM_ERR_NO_DEVICE, "hipGetDevice failed");
     if (dev >= ndev) return fail(nullptr, MSM_ERR_NO_DEVICE, "device %d out of range (%d visible)", dev, ndev);
@@ -1114,6 +1120,12 @@ static int32_t ctx_create_impl(const msm_config_t* cfg, msm_ctx** out, int main_
         e = least != greatest ? hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, greatest)
                               : hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
     }
+    if (e == hipSuccess) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)msmk::k_accumulate<false, false>, 256, 0) == hipSuccess && per_cu > 0)
+            c->acc_wgs_per_cu = (uint32_t)per_cu;
+        (void)hipGetLastError();
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_bases, hipEventDisableTiming);
     for (int i = 0; i < 2 && e == hipSuccess; i++) {
@@ -1123,6 +1135,15 @@ static int32_t ctx_create_impl(const msm_config_t* cfg, msm_ctx** out, int main_
     }
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_qsums, MAX_QSUM_POINTS * 96, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_flags, 64, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc(&c->clk.p, 32);
+    if (e == hipSuccess) {
+        c->clk.cap = 32;
+        e = hipMemset(c->clk.p, 0, 32);
+    }
+    if (e == hipSuccess) {
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess && khz > 0) c->wall_clock_khz = (uint32_t)khz;
+    }
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)msmk::k_tile_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_HIST_BYTES);
     if (e == hipSuccess)
@@ -1180,7 +1201,7 @@ void msm_ctx_destroy(msm_ctx* c) {
         DevBuf* bufs[] = {&c->bases,   &c->inf,       &c->scalars, &c->digits,  &c->ranks,  &c->sorted, &c->hist,
                           &c->offsets, &c->blocksums, &c->buckets, &c->rc,      &c->flags,  &c->pow2,
                           &c->heads,   &c->tails,     &c->chunkmap, &c->tilecounts, &c->ibases, &c->longlist, &c->longdone, &c->midlist, &c->oncelist, &c->ccounts, &c->cregion, &c->bigslot, &c->big,
-                          &c->rbases,  &c->rinf};
+                          &c->rbases,  &c->rinf,      &c->clk};
         for (DevBuf* b : bufs) release(*b);
         if (c->h_qsums) (void)hipHostFree(c->h_qsums);
         if (c->h_flags) (void)hipHostFree(c->h_flags);
@@ -1250,6 +1271,7 @@ int32_t msm_bn254_g1_upload_bases(msm_ctx* c, const uint32_t* bases_xy, uint32_t
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
     c->resident_n = 0;
+    c->tuned_layout[0] = c->tuned_layout[1] = 0;  // a measured batch layout belongs to the base set it was measured on
     if ((rc = upload_resident_locked(c, bases_xy, base_form, inf_mask, n))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
@@ -1305,6 +1327,7 @@ int32_t msm_bn254_g1_upload_compressed(msm_ctx* c, const uint8_t* compressed, si
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
     c->resident_n = 0;
+    c->tuned_layout[0] = c->tuned_layout[1] = 0;
     msm_plan_t pl;
     if ((rc = resident_plan(c, n, &pl))) return fail(c, rc, "bad window_bits/flags (%u, 0x%x)", c->cfg.window_bits, c->cfg.flags);
     const bool glv = pl.glv != 0;
@@ -1466,16 +1489,17 @@ int32_t msm_bn254_g1_resident_device(msm_ctx* c, const void* d_scalars, size_t n
 // (several scalar vectors per proof against fixed bases; SURVEY.md section 8 row f2 "multiple MSMs in flight").  Measured per MSM,
 // single calls -> batch (tools/two_ctx_throughput.py, pinned host scalars): 2^14 0.40 -> 0.24 ms, 2^16 0.45 -> 0.30, 2^17 0.56 -> 0.40,
 // 2^18 0.81 -> 0.63, 2^20 2.28 -> 1.63, 2^22 8.54 -> 5.80 (= the kernel time of one MSM: upload and host finish fully hidden).
-int32_t msm_bn254_g1_resident_batch(msm_ctx* c, const uint32_t* const* scalars, size_t n, size_t count, uint32_t* out_jac,
-                                    uint32_t* out_aff, uint8_t* out_inf) {
-    if (!c) return MSM_ERR_BAD_ARG;
-    if (n == 0 || count == 0) return fail(c, MSM_ERR_EMPTY, "Empty input");
-    if (!scalars || !out_jac) return fail(c, MSM_ERR_BAD_ARG, "NULL scalars / result pointer");
-    for (size_t i = 0; i < count; i++)
-        if (!scalars[i]) return fail(c, MSM_ERR_BAD_ARG, "NULL scalar vector %zu", i);
-    std::lock_guard<std::mutex> lk(c->mu);
-    if (c->resident_n == 0) return fail(c, MSM_ERR_STATE, "no resident bases: call msm_bn254_g1_upload_bases first");
-    DeviceGuard g(c->device);
+// the layout of a batch call on n (already clamped) points: configured, else tuned (msm_tune_batch), else by size
+static uint32_t batch_layout_for(const msm_ctx* c, size_t n) {
+    if (c->cfg.batch_layout) return c->cfg.batch_layout;
+    const int cls = n >= ((size_t)1 << 19) ? 1 : 0;
+    if (c->tuned_layout[cls]) return c->tuned_layout[cls];
+    return cls ? MSM_BATCH_LAYOUT_ONE_STREAM : MSM_BATCH_LAYOUT_TWO_STREAMS;
+}
+
+// msm_bn254_g1_resident_batch under the context's mutex; forced_layout != 0: msm_tune_batch measuring that layout
+static int32_t resident_batch_locked(msm_ctx* c, const uint32_t* const* scalars, size_t n, size_t count, uint32_t* out_jac, uint32_t* out_aff,
+                                     uint8_t* out_inf, uint32_t forced_layout) {
     if (count > 1 && !c->lane1) {
         msm_config_t cfg = c->cfg;
         cfg.device = c->device;
@@ -1500,54 +1524,75 @@ int32_t msm_bn254_g1_resident_batch(msm_ctx* c, const uint32_t* const* scalars, 
         }
     };
     c->last_copy = nullptr;
-    // How the two pipelines share the GPU.  From 2^19 points the kernels fill it: ONE compute stream, MSM after MSM, each MSM's bucket
-    // reduction on a second, high-priority stream beside the next MSM's sort (resident_on_lane); below, two compute streams whose
-    // kernels overlap (measured crossover 2^18..2^19; MSM_HIP_BATCH_MODE at context creation forces one: shared | lanes).
-    // Both defaults need this context's streams to sit on different hardware queues, and which queues streams get depends on every
-    // stream the PROCESS has created: with three or four other contexts alive the same batch took 1.9-2.3 ms per MSM instead of 1.5 at
-    // 2^20, 0.70 instead of 0.55 at 2^18 (profiles/r3_batch_many_contexts.txt) -- and nothing in HIP lets a library ask.  So a context
-    // MEASURES: its first batch calls (per size class) alternate between the alternative mode -- one stream without the reduce stream from
-    // 2^19 points, one stream + reduce stream below -- and the default, and the default is kept unless the alternative is more than 10 %
-    // faster per MSM here.
-    struct BatchMode { bool shared, red; };
-    const bool forced = c->knobs.batch_mode >= 0, big = n >= ((size_t)1 << 19);
-    const bool red_ok = count > 1 && c->knobs.batch_reduce_stream && c->knobs.copy_priority && !c->knobs.batch_copy_own;
-    const BatchMode def = forced ? BatchMode{c->knobs.batch_mode == 1, red_ok && c->knobs.batch_mode == 1} : big ? BatchMode{true, red_ok} : BatchMode{false, false};
-    BatchMode alt = def;
-    bool have_alt = false;
-    if (def.shared && def.red) alt = BatchMode{true, false}, have_alt = true;
-    else if (!def.shared && !forced && red_ok) alt = BatchMode{true, true}, have_alt = true;
+    // How the two pipelines share the GPU: msm_config_t.batch_layout, else what msm_tune_batch measured for this size class, else by size
+    // (include/msm_hip.h MSM_BATCH_LAYOUT_*).  A pure function of the configuration, the tuned choice and the CLAMPED n: round 3 timed the
+    // first four batch calls of a context to choose, and one noisy call decided for the context's life.
+    const uint32_t layout = forced_layout ? forced_layout : batch_layout_for(c, std::min(n, c->resident_n));
+    const bool red_ok = count > 1 && c->knobs.copy_priority && !c->knobs.batch_copy_own;  // the reduce stream is the second pipeline's copy stream
+    c->batch_shared_stream = layout != MSM_BATCH_LAYOUT_TWO_STREAMS;
+    c->red_active = layout == MSM_BATCH_LAYOUT_ONE_STREAM_REDUCE && red_ok;
+    c->last_batch_layout = layout;
     if (count > 1)
         for (msm_ctx* w : {c, c->lane1})
             if (!w->ev_body) HIPCHK(c, hipEventCreateWithFlags(&w->ev_body, hipEventDisableTiming));
-    // (four batch calls of a size class decide: the alternative and the default once each as a warm-up -- a stream's first kernel creates its
-    // hardware queue, a pipeline's first MSM allocates its workspace: milliseconds -- then once each on the clock)
-    const int size_class = big ? 2 : 1;
-    if (c->batch_choice_class != size_class) c->batch_choice = 0, c->batch_phase = 0, c->batch_choice_class = size_class;
-    auto set_mode = [&](const BatchMode& m) { c->batch_shared_stream = m.shared, c->red_active = m.red, c->last_copy = nullptr; };
-    const bool measuring = count > 1 && have_alt && c->batch_choice == 0;
-    if (measuring && c->batch_phase == 3 && count != c->batch_alt_count) c->batch_phase = 2;  // compare batches of one length
-    const bool use_alt = measuring ? (c->batch_phase & 1) == 0 : (have_alt && c->batch_choice == 2);
-    set_mode(use_alt ? alt : def);
-    const auto t_batch = std::chrono::steady_clock::now();
     if (count > 1) c->batch_pool->run(2, lane);
     else lane(0);
-    if (measuring && rcs[0] == MSM_OK && rcs[1] == MSM_OK) {
-        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_batch).count() / (double)count;
-        if (c->batch_phase == 2) c->batch_alt_ms = ms, c->batch_alt_count = count;
-        if (c->batch_phase == 3) {
-            c->batch_choice = c->batch_alt_ms * 1.10 < ms ? 2 : 1;
-            if (trace_enabled() || std::getenv("MSM_HIP_BATCH_TRACE"))
-                std::fprintf(stderr, "[msm_hip] batch layout measured at n %zu: %s %.4f ms per MSM, default (%s) %.4f -> %s\n", n,
-                             alt.shared ? (alt.red ? "one stream + reduce stream" : "one stream") : "two streams", c->batch_alt_ms,
-                             def.shared ? (def.red ? "one stream + reduce stream" : "one stream") : "two streams", ms,
-                             c->batch_choice == 2 ? "the alternative" : "the default");
-        }
-        c->batch_phase++;
-    }
     c->red_active = false;
+    c->tm.batch_layout = c->last_batch_layout;
     if (rcs[0] == MSM_OK && rcs[1] != MSM_OK) c->err = c->lane1->err;
     return rcs[0] != MSM_OK ? rcs[0] : rcs[1];
+}
+
+int32_t msm_bn254_g1_resident_batch(msm_ctx* c, const uint32_t* const* scalars, size_t n, size_t count, uint32_t* out_jac,
+                                    uint32_t* out_aff, uint8_t* out_inf) {
+    if (!c) return MSM_ERR_BAD_ARG;
+    if (n == 0 || count == 0) return fail(c, MSM_ERR_EMPTY, "Empty input");
+    if (!scalars || !out_jac) return fail(c, MSM_ERR_BAD_ARG, "NULL scalars / result pointer");
+    for (size_t i = 0; i < count; i++)
+        if (!scalars[i]) return fail(c, MSM_ERR_BAD_ARG, "NULL scalar vector %zu", i);
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->resident_n == 0) return fail(c, MSM_ERR_STATE, "no resident bases: call msm_bn254_g1_upload_bases first");
+    DeviceGuard g(c->device);
+    return resident_batch_locked(c, scalars, n, count, out_jac, out_aff, out_inf, 0);
+}
+
+// The explicit measurement of the batch layout (include/msm_hip.h).  Every layout: one untimed batch (hardware queues, the second
+// pipeline's workspace), then `reps` timed ones, the minimum counts.
+int32_t msm_tune_batch(msm_ctx* c, const uint32_t* const* scalars, size_t n, size_t count, uint32_t reps, uint32_t* chosen, double* ms_per_msm) {
+    if (!c) return MSM_ERR_BAD_ARG;
+    if (n == 0 || count == 0) return fail(c, MSM_ERR_EMPTY, "Empty input");
+    if (!scalars) return fail(c, MSM_ERR_BAD_ARG, "NULL scalars pointer");
+    if (count < 2) return fail(c, MSM_ERR_BAD_ARG, "msm_tune_batch needs at least two scalar vectors (two MSMs in flight)");
+    for (size_t i = 0; i < count; i++)
+        if (!scalars[i]) return fail(c, MSM_ERR_BAD_ARG, "NULL scalar vector %zu", i);
+    if (reps == 0) reps = 3;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->resident_n == 0) return fail(c, MSM_ERR_STATE, "no resident bases: call msm_bn254_g1_upload_bases first");
+    DeviceGuard g(c->device);
+    std::vector<uint32_t> jac(count * 24);
+    const uint32_t layouts[3] = {MSM_BATCH_LAYOUT_ONE_STREAM, MSM_BATCH_LAYOUT_ONE_STREAM_REDUCE, MSM_BATCH_LAYOUT_TWO_STREAMS};
+    double best[3] = {0, 0, 0};
+    for (int pass = 0; pass < 2; pass++)  // pass 0 warms every layout up, pass 1 times them (interleaved, so that a drifting clock hits all three)
+        for (uint32_t r = 0; r < (pass ? reps : 1u); r++)
+            for (int k = 0; k < 3; k++) {
+                const auto t0 = std::chrono::steady_clock::now();
+                const int32_t rc = resident_batch_locked(c, scalars, n, count, jac.data(), nullptr, nullptr, layouts[k]);
+                if (rc) return rc;
+                const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / (double)count;
+                if (pass && (best[k] == 0 || ms < best[k])) best[k] = ms;
+            }
+    int win = 0;
+    for (int k = 1; k < 3; k++)
+        if (best[k] < best[win]) win = k;
+    const size_t nc = std::min(n, c->resident_n);
+    c->tuned_layout[nc >= ((size_t)1 << 19) ? 1 : 0] = layouts[win];
+    if (chosen) *chosen = c->cfg.batch_layout ? c->cfg.batch_layout : layouts[win];
+    if (ms_per_msm)
+        for (int k = 0; k < 3; k++) ms_per_msm[k] = best[k];
+    if (trace_enabled())
+        std::fprintf(stderr, "[msm_hip] msm_tune_batch n %zu count %zu: one stream %.4f, one stream + reduce stream %.4f, two streams %.4f ms per MSM -> layout %u\n",
+                     nc, count, best[0], best[1], best[2], layouts[win]);
+    return MSM_OK;
 }
 
 int32_t msm_bn254_g1_device(msm_ctx* c, const void* d_bases_mont, const void* d_inf_mask, const void* d_scalars, size_t n,
@@ -1625,8 +1670,29 @@ int32_t msm_set_stage_timing(msm_ctx* c, int32_t enabled) {
 }
 void msm_reset_kernel_stats(msm_ctx* c) {
     if (!c) return;
+    std::lock_guard<std::mutex> lk(c->mu);
     c->acc_ms_sum = 0;
     c->acc_launches = 0;
+    if (c->clk.p) {
+        DeviceGuard g(c->device);
+        (void)hipMemsetAsync(c->clk.p, 0, 32, c->stream);
+        (void)hipStreamSynchronize(c->stream);
+    }
+}
+// Clock probe of k_accumulate since the last reset: the first workgroup of every launch reads the shader-cycle counter and the
+// constant-rate counter around its chunk.  sclk_ghz = cycles / ticks x the constant counter's rate: the shader clock the kernel really
+// sustained; cycles_per_addition = shader cycles one wavefront needed per mixed addition (with its two neighbours on the SIMD).
+int32_t msm_get_clock_stats(msm_ctx* c, double* sclk_ghz, double* cycles_per_addition, uint64_t* samples) {
+    if (!c) return MSM_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    unsigned long long v[4] = {0, 0, 0, 0};
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(v, c->clk.p, 32, hipMemcpyDeviceToHost));
+    if (sclk_ghz) *sclk_ghz = v[1] ? (double)v[0] / (double)v[1] * (double)c->wall_clock_khz * 1e-6 : 0.0;
+    if (cycles_per_addition) *cycles_per_addition = v[3] ? (double)v[0] / (double)v[3] : 0.0;
+    if (samples) *samples = v[2];
+    return MSM_OK;
 }
 
 }  // extern "C"

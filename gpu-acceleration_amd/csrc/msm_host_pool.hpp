@@ -7,7 +7,17 @@
 #include <mutex>
 #include <thread>
 #include <vector>
-#include <immintrin.h>
+
+// spin-wait hint of the host architecture (x86: pause; AArch64: yield; elsewhere: a compiler barrier)
+static inline void msm_cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__) || defined(__arm__)
+    __asm__ __volatile__("yield" ::: "memory");
+#else
+    __asm__ __volatile__("" ::: "memory");
+#endif
+}
 
 // Small persistent host thread pool for the CPU finish (per-window Horner chains are independent).  The
 // reference runs its CPU finish under rayon (metal_msm.rs:214-247); std::thread + a condition variable here.
@@ -87,7 +97,7 @@ private:
                 const auto t0 = std::chrono::steady_clock::now();
                 for (uint32_t spins = 1; (uint32_t)(ticket_.load(std::memory_order_acquire) >> 32) == (uint32_t)seen; spins++) {
                     if ((spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
-                    __builtin_ia32_pause();
+                    msm_cpu_relax();
                 }
                 continue;  // re-read generation and job under the lock (cv wait returns at once if run() has published)
             }

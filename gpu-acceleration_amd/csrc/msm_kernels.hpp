@@ -1113,8 +1113,15 @@ __global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__
                                                     const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ chunk_bucket,
                                                     uint32_t* __restrict__ buckets, uint32_t* __restrict__ heads,
                                                     uint32_t* __restrict__ tails, const uint32_t* __restrict__ total_pairs_ptr,
-                                                    uint32_t L, uint32_t total_buckets) {
+                                                    uint32_t L, uint32_t total_buckets, unsigned long long* __restrict__ clk) {
     const uint32_t total_pairs = *total_pairs_ptr;  // non-zero digits, known only on the device (k_scan_block_sums)
+    // Clock probe (msm_get_clock_stats): the first workgroup of every launch brackets its own chunk with the shader-cycle counter
+    // (s_memtime: counts at whatever frequency the device sustains) and the constant-rate counter (s_memrealtime); the ratio of the two
+    // deltas is the shader clock the kernel really ran at, and the cycle delta says whether two boxes execute the same instruction
+    // stream in the same number of cycles.  Both values live in scalar registers; the cost is two atomics per launch.
+    const bool probe = blockIdx.x == 0;
+    long long clk_c0 = 0, clk_w0 = 0;
+    if (probe) clk_c0 = clock64(), clk_w0 = wall_clock64();
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t j0 = t * L;
     if (j0 >= total_pairs) return;
@@ -1196,6 +1203,12 @@ __global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__
     }
     uint32_t* dst = is_head ? heads + (size_t)t * XW : (seg_end == j1 ? buckets + (size_t)k * XW : tails + (size_t)t * XW);
     store_xyzz(dst, acc);
+    if (probe && threadIdx.x == 0) {  // [0] shader cycles, [1] constant-rate ticks, [2] samples, [3] mixed additions of the sampled thread
+        atomicAdd(clk + 0, (unsigned long long)(clock64() - clk_c0));
+        atomicAdd(clk + 1, (unsigned long long)(wall_clock64() - clk_w0));
+        atomicAdd(clk + 2, 1ull);
+        atomicAdd(clk + 3, (unsigned long long)(j1 - j0));
+    }
 }
 
 // Long buckets (cut into LONG_SPAN or more pieces: tiny top windows, skewed scalars).  Pieces e(0) = tails[t0],

@@ -160,19 +160,20 @@ inline uint32_t table_top_shift(const msm_plan_t& pl, uint32_t tf) {
 // have drifted apart and a shorter chunk only costs k_combine more) and the model promises 2 % or more.  Measured (profiles/
 // r3_chunk_rounds.txt): k_accumulate with the table 2^20 0.883 -> 0.81-0.84 ms, 2^21 1.98-2.00 -> 1.87; device calls on 536 633 points
 // 1.073 -> 0.959 ms, 600 000 1.214 -> 1.039, 3 000 000 3.92 -> 3.75; powers of two without a table were whole rounds already.
-inline uint64_t chunk_rounds_cost(size_t pairs, uint32_t L, uint32_t cus) {
-    const size_t wgs = ((pairs + L - 1) / L + 255) / 256, slots = (size_t)3 * cus;
-    return (uint64_t)L * (3 * (wgs / slots) + (wgs % slots + cus - 1) / cus);
+// (per_cu: resident k_accumulate workgroups per CU -- 3 for the 143-VGPR build; the context asks hipOccupancyMaxActiveBlocksPerMultiprocessor)
+inline uint64_t chunk_rounds_cost(size_t pairs, uint32_t L, uint32_t cus, uint32_t per_cu = 3) {
+    const size_t wgs = ((pairs + L - 1) / L + 255) / 256, slots = (size_t)per_cu * cus;
+    return (uint64_t)L * (per_cu * (wgs / slots) + (wgs % slots + cus - 1) / cus);
 }
-inline uint32_t fit_chunk_to_rounds(size_t pairs, uint32_t L0, uint32_t cus) {
-    if (cus == 0 || L0 < 8 || pairs == 0) return L0;
-    if (((pairs + L0 - 1) / L0 + 255) / 256 / ((size_t)3 * cus) > 3) return L0;
+inline uint32_t fit_chunk_to_rounds(size_t pairs, uint32_t L0, uint32_t cus, uint32_t per_cu = 3) {
+    if (cus == 0 || per_cu == 0 || L0 < 8 || pairs == 0) return L0;
+    if (((pairs + L0 - 1) / L0 + 255) / 256 / ((size_t)per_cu * cus) > 3) return L0;
     uint32_t best = L0;
-    uint64_t best_t = chunk_rounds_cost(pairs, L0, cus);
+    uint64_t best_t = chunk_rounds_cost(pairs, L0, cus, per_cu);
     const uint64_t t0 = best_t;
     for (uint32_t d = 1; d <= L0 / 4; d++)
         for (uint32_t L : {L0 - d, L0 + d}) {
-            const uint64_t t = chunk_rounds_cost(pairs, L, cus);
+            const uint64_t t = chunk_rounds_cost(pairs, L, cus, per_cu);
             if (t < best_t) best = L, best_t = t;
         }
     return best_t * 100 <= t0 * 98 ? best : L0;

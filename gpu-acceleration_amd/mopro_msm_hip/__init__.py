@@ -28,9 +28,9 @@ OK, ERR_EMPTY, ERR_BAD_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_STATE, ERR_INVA
 # every symbol include/msm_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "msm_abi_version", "msm_ctx_create", "msm_ctx_destroy", "msm_last_error", "msm_bn254_g1",
-    "msm_bn254_g1_arkworks", "msm_bn254_g1_upload_bases", "msm_bn254_g1_resident", "msm_bn254_g1_resident_batch", "msm_bn254_g1_resident_device", "msm_bn254_g1_device",
+    "msm_bn254_g1_arkworks", "msm_bn254_g1_upload_bases", "msm_bn254_g1_resident", "msm_bn254_g1_resident_batch", "msm_tune_batch", "msm_bn254_g1_resident_device", "msm_bn254_g1_device",
     "msm_bn254_g1_combine",
-    "msm_plan", "msm_get_timings", "msm_set_stage_timing", "msm_get_accumulate_kernel_stats", "msm_reset_kernel_stats",
+    "msm_plan", "msm_get_timings", "msm_set_stage_timing", "msm_get_accumulate_kernel_stats", "msm_reset_kernel_stats", "msm_get_clock_stats",
     "msm_bn254_g1_decompress", "msm_bn254_g1_upload_compressed", "msm_bn254_g1_compress",
     "msm_multi_create", "msm_multi_destroy", "msm_multi_last_error", "msm_multi_num_devices", "msm_multi_exchange",
     "msm_bn254_g1_multi", "msm_bn254_g1_multi_arkworks", "msm_bn254_g1_multi_device", "msm_multi_get_timings",
@@ -38,6 +38,8 @@ ABI_SYMBOLS = [
 ]
 ERR_RCCL = -8
 EXCHANGE_AUTO, EXCHANGE_RCCL, EXCHANGE_HOST = 0, 1, 2
+# msm_config_t.batch_layout (include/msm_hip.h MSM_BATCH_LAYOUT_*)
+BATCH_LAYOUT_AUTO, BATCH_LAYOUT_ONE_STREAM, BATCH_LAYOUT_ONE_STREAM_REDUCE, BATCH_LAYOUT_TWO_STREAMS = 0, 1, 2, 3
 
 
 class MsmError(RuntimeError):
@@ -50,7 +52,7 @@ class MsmError(RuntimeError):
 
 class Config(C.Structure):
     _fields_ = [("device", C.c_int32), ("window_bits", C.c_uint32), ("flags", C.c_uint32),
-                ("stream_chunk_log2", C.c_uint32), ("max_points", C.c_uint64)]
+                ("stream_chunk_log2", C.c_uint32), ("max_points", C.c_uint64), ("batch_layout", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class Plan(C.Structure):
@@ -64,7 +66,7 @@ class Timings(C.Structure):
     _fields_ = [("h2d_ms", C.c_float), ("convert_ms", C.c_float), ("decompose_ms", C.c_float),
                 ("sort_ms", C.c_float), ("accumulate_ms", C.c_float), ("reduce_ms", C.c_float),
                 ("finish_ms", C.c_float), ("total_ms", C.c_float), ("num_points", C.c_uint64),
-                ("num_adds", C.c_uint64), ("stream_chunks", C.c_uint32), ("reserved", C.c_uint32)]
+                ("num_adds", C.c_uint64), ("stream_chunks", C.c_uint32), ("batch_layout", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -100,6 +102,7 @@ def bind_product_abi(L):
     L.msm_bn254_g1_upload_bases.argtypes = [vp, _u32p, C.c_uint32, _u8p, C.c_size_t]
     L.msm_bn254_g1_resident.argtypes = [vp, _u32p, C.c_size_t, _u32p, _u32p, _u8p]
     L.msm_bn254_g1_resident_batch.argtypes = [vp, C.POINTER(_u32p), C.c_size_t, C.c_size_t, _u32p, _u32p, _u8p]
+    L.msm_tune_batch.argtypes = [vp, C.POINTER(_u32p), C.c_size_t, C.c_size_t, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
     L.msm_bn254_g1_device.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, _u32p, _u32p, _u8p]
     L.msm_bn254_g1_resident_device.argtypes = [vp, vp, C.c_size_t, vp, _u32p, _u32p, _u8p]
     L.msm_bn254_g1_combine.argtypes = [_u32p, C.c_size_t, _u32p, _u32p, _u8p]
@@ -109,6 +112,7 @@ def bind_product_abi(L):
     L.msm_get_accumulate_kernel_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.msm_reset_kernel_stats.argtypes = [vp]
     L.msm_reset_kernel_stats.restype = None
+    L.msm_get_clock_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.msm_bn254_g1_decompress.argtypes = [vp, _u8p, C.c_size_t, _u32p, _u8p, C.POINTER(C.c_int64)]
     L.msm_bn254_g1_upload_compressed.argtypes = [vp, _u8p, C.c_size_t, C.POINTER(C.c_int64)]
     L.msm_bn254_g1_compress.argtypes = [_u32p, C.c_uint32, _u8p, C.c_size_t, _u8p]
@@ -218,9 +222,9 @@ class MsmContext:
 
     _loader = staticmethod(lambda: load_library())  # testhooks.HooksContext runs the same class on the hooks build
 
-    def __init__(self, device=-1, window_bits=0, flags=0, max_points=0, stream_chunk_log2=0):
+    def __init__(self, device=-1, window_bits=0, flags=0, max_points=0, stream_chunk_log2=0, batch_layout=BATCH_LAYOUT_AUTO):
         self._lib = self._loader()
-        cfg = Config(device, window_bits, flags, stream_chunk_log2, max_points)
+        cfg = Config(device, window_bits, flags, stream_chunk_log2, max_points, batch_layout, 0)
         h = C.c_void_p()
         rc = self._lib.msm_ctx_create(C.byref(cfg), C.byref(h))
         if rc != OK:
@@ -355,6 +359,19 @@ class MsmContext:
         self._check(self._lib.msm_bn254_g1_resident_batch(self._h, ptrs, n, k, _p32(jac), _p32(aff), inf.ctypes.data_as(_u8p)))
         return [MsmResult(jac[i], aff[i] if want_affine else None, inf[i]) for i in range(k)]
 
+    def tune_batch(self, scalar_vectors, reps=0):
+        """explicit, opt-in measurement of the batch layout on this context as the process is now (msm_tune_batch): returns
+        (chosen MSM_BATCH_LAYOUT_*, {layout: ms per MSM}); AUTO contexts use the choice until the next upload"""
+        vecs = [_words(s, 8) for s in scalar_vectors]
+        if len(vecs) < 2 or any(v.shape[0] == 0 for v in vecs):
+            raise MsmError(ERR_BAD_ARG, "tune_batch needs at least two non-empty scalar vectors")
+        n = min(v.shape[0] for v in vecs)
+        k = len(vecs)
+        ptrs = (_u32p * k)(*[_p32(v) for v in vecs])
+        chosen, ms = C.c_uint32(0), (C.c_double * 3)()
+        self._check(self._lib.msm_tune_batch(self._h, ptrs, n, k, reps, C.byref(chosen), ms))
+        return int(chosen.value), {BATCH_LAYOUT_ONE_STREAM: ms[0], BATCH_LAYOUT_ONE_STREAM_REDUCE: ms[1], BATCH_LAYOUT_TWO_STREAMS: ms[2]}
+
     def msm_device(self, d_bases_ptr, d_scalars_ptr, n, d_inf_ptr=None, stream=None):
         """All operands already in HBM (raw device pointers, e.g. torch.Tensor.data_ptr())."""
         if n == 0:
@@ -380,6 +397,13 @@ class MsmContext:
     def reset_kernel_stats(self):
         self._lib.msm_reset_kernel_stats(self._h)
 
+    def clock_stats(self):
+        """clock probe of k_accumulate since the last reset_kernel_stats: {"sclk_ghz": shader clock the kernel sustained,
+        "cycles_per_addition": shader cycles of one wavefront per mixed addition, "samples": launches sampled}"""
+        ghz, cpa, cnt = C.c_double(0), C.c_double(0), C.c_uint64(0)
+        self._check(self._lib.msm_get_clock_stats(self._h, C.byref(ghz), C.byref(cpa), C.byref(cnt)))
+        return {"sclk_ghz": ghz.value, "cycles_per_addition": cpa.value, "samples": cnt.value}
+
 
 class MsmMulti:
     """One MSM over several GPUs of ONE process (include/msm_hip.h "multi-GPU"): contiguous point-range shards, one context
@@ -388,7 +412,7 @@ class MsmMulti:
 
     def __init__(self, devices=None, window_bits=0, flags=0, stream_chunk_log2=0, exchange=EXCHANGE_AUTO, _lib=None):
         self._lib = _lib or load_library()
-        cfg = Config(-1, window_bits, flags, stream_chunk_log2, 0)
+        cfg = Config(-1, window_bits, flags, stream_chunk_log2, 0, 0, 0)
         h = C.c_void_p()
         if devices is None:
             rc = self._lib.msm_multi_create(None, 0, C.byref(cfg), exchange, C.byref(h))

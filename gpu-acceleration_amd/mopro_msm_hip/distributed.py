@@ -7,7 +7,7 @@ in rank order -- identical bits on every rank.  The reference has no multi-devic
 """
 import numpy as np
 
-from . import OK, MsmError, MsmResult, combine_partials
+from . import ERR_HIP, OK, MsmError, MsmResult, combine_partials
 
 WORDS = 25  # what a rank sends: 24 words of its partial (Jacobian, Montgomery) + 1 status word (C-ABI code, 0 = ok)
 
@@ -110,12 +110,22 @@ def all_reduce_msm(local_result, device=None, group=None) -> MsmResult:
 
 def guarded(local_call, device=None, group=None) -> MsmResult:
     """run this rank's local MSM (`local_call()` -> MsmResult) and all-reduce it; an MsmError raised by the local call travels
-    through the exchange instead of keeping this rank out of the collective"""
+    through the exchange instead of keeping this rank out of the collective -- and so does ANY other exception (status ERR_HIP on
+    the peers; this rank re-raises the original exception after the exchange)"""
+    pending = None
     try:
         local = local_call()
     except MsmError as e:
         local = e
-    return all_reduce_msm(local, device, group)
+    except Exception as e:  # argument packing (ValueError), torch / HIP RuntimeError (out of memory) ...: the peers are already on
+        pending = e         # their way into the all-gather, so this rank joins it too, with a generic status, and re-raises afterwards
+        local = MsmError(ERR_HIP, "%s: %s" % (type(e).__name__, e))
+    try:
+        return all_reduce_msm(local, device, group)
+    except MsmError:
+        if pending is not None:
+            raise pending
+        raise
 
 
 def distributed_msm_device(ctx, d_bases_ptr, d_scalars_ptr, n_local, device=None, group=None, d_inf_ptr=None) -> MsmResult:

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MSM_HIP_ABI_VERSION 4u
+#define MSM_HIP_ABI_VERSION 5u
 
 /* status codes */
 #define MSM_OK 0
@@ -81,7 +81,25 @@ typedef struct {
                                    Copies run on a stream with a hardware queue of its own: from pinned caller memory at the link
                                    rate, from pageable memory as fast as the runtime stages it (both overlap the kernels) */
     uint64_t max_points;  /* pre-size the HBM workspace for this many points; 0 = grow on demand        */
+    uint32_t batch_layout; /* MSM_BATCH_LAYOUT_*: how msm_bn254_g1_resident_batch shares the GPU between its two pipelines (ABI 5) */
+    uint32_t reserved;     /* 0 */
 } msm_config_t;
+
+/* msm_config_t.batch_layout.  The layout of a batch call is a pure function of (this field, the context's tuned choice, n): nothing
+ * is timed behind the caller's back (the reference's whole configuration surface is one struct, metal_msm.rs:16-28).
+ *   ONE_STREAM         both pipelines queue whole MSMs on ONE compute stream, MSM after MSM without a gap; uploads and host finishes
+ *                      happen beside it.  Needs nothing from HIP's stream -> hardware-queue mapping: the layout that stays within ~12 %
+ *                      of its best whatever other contexts and streams the process has created.
+ *   ONE_STREAM_REDUCE  the same, and each MSM's bucket reduction runs on a second, high-priority stream beside the next MSM's sort:
+ *                      3-6 % faster per MSM from 2^19 points when the three streams get hardware queues of their own -- and 25-50 % SLOWER
+ *                      when they do not (three or four other contexts alive: profiles/r3_batch_many_contexts.txt).
+ *   TWO_STREAMS        each pipeline keeps its own compute stream and the kernels overlap: best below 2^19 points, where no kernel fills
+ *                      the GPU.
+ *   AUTO (0)           ONE_STREAM from 2^19 points, TWO_STREAMS below -- unless msm_tune_batch() has measured this context. */
+#define MSM_BATCH_LAYOUT_AUTO 0u
+#define MSM_BATCH_LAYOUT_ONE_STREAM 1u
+#define MSM_BATCH_LAYOUT_ONE_STREAM_REDUCE 2u
+#define MSM_BATCH_LAYOUT_TWO_STREAMS 3u
 
 typedef struct {
     uint32_t window_bits;  /* c                                         */
@@ -110,7 +128,7 @@ typedef struct {
     uint64_t num_points;
     uint64_t num_adds;   /* mixed additions executed by accumulate (non-zero digits) */
     uint32_t stream_chunks; /* host->HBM chunks the call was cut into (0 = single shot / device-resident)      */
-    uint32_t reserved;
+    uint32_t batch_layout;  /* MSM_BATCH_LAYOUT_* the last msm_bn254_g1_resident_batch call of this context ran under (0 before one) */
 } msm_timings_t;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
@@ -160,13 +178,21 @@ int32_t msm_bn254_g1_resident_device(msm_ctx *ctx, const void *d_scalars, size_t
  * fixed bases.  A second pipeline inside the context (second host thread, own workspace) uploads the next
  * scalar vector and finishes the previous MSM on the CPU while the GPU computes: from 2^19 points both pipelines feed ONE compute
  * stream, MSM after MSM without a gap (each MSM's bucket reduction on a second, high-priority stream beside the next MSM's sort);
- * below, where no kernel fills the GPU, each keeps its own stream and the kernels overlap.  Whether a context's streams get
- * hardware queues of their own depends on every stream the process has created, so a context measures its layout: its first
- * four batch calls alternate between the default and the alternative, then the faster one stays (MSM_HIP_BATCH_TRACE=1 prints it).
+ * below, where no kernel fills the GPU, each keeps its own stream and the kernels overlap.  Which of the three layouts a call runs
+ * under is decided by msm_config_t.batch_layout (see MSM_BATCH_LAYOUT_*), deterministically; msm_get_timings().batch_layout reports it.
+ * n is clamped to the resident set; a window table (MSM_FLAG_WINDOW_TABLE) serves calls on the WHOLE set only.
  * Per MSM, single calls -> batch: 2^14 0.40 -> 0.24 ms, 2^17 0.56 -> 0.40, 2^20 2.28 -> 1.63, 2^22 8.54 -> 5.80.
  * Results are identical to `count` msm_bn254_g1_resident calls; on an error the first failing code is returned. */
 int32_t msm_bn254_g1_resident_batch(msm_ctx *ctx, const uint32_t *const *scalars, size_t n, size_t count,
                                     uint32_t *out_jacobian_mont, uint32_t *out_affine_std, uint8_t *out_is_inf);
+/* Explicit, opt-in measurement of the batch layout (ABI 5): runs the batch `scalars[0..count)` (count >= 2; results discarded) under each
+ * of the three layouts on THIS context as the process is now -- once untimed (a layout's first use creates hardware queues and the
+ * second pipeline's workspace), then `reps` (0 = 3) timed batches, the minimum counts -- and keeps the fastest for this size class
+ * (below / from 2^19 points) until the next msm_bn254_g1_upload_bases / _upload_compressed; AUTO then uses it.  *chosen (nullable)
+ * receives the layout, ms_per_msm[3] (nullable) the three measurements in the order ONE_STREAM, ONE_STREAM_REDUCE, TWO_STREAMS.
+ * A context whose msm_config_t.batch_layout is not AUTO keeps its configured layout (the measurements are still returned). */
+int32_t msm_tune_batch(msm_ctx *ctx, const uint32_t *const *scalars, size_t n, size_t count, uint32_t reps, uint32_t *chosen,
+                       double *ms_per_msm);
 
 /* ---- arkworks `serialize_compressed` point images ---------------
  * The reference's benchmark harness keeps its instances on disk as `Vec<G1Affine>::serialize_compressed`
@@ -252,6 +278,12 @@ int32_t msm_set_stage_timing(msm_ctx *ctx, int32_t enabled);
  * hipEvents on the stream the kernel runs on; *launches receives the count */
 int32_t msm_get_accumulate_kernel_stats(const msm_ctx *ctx, double *avg_ms, uint64_t *launches);
 void msm_reset_kernel_stats(msm_ctx *ctx);
+/* Clock probe of the accumulate kernel since the last reset (ABI 5): the first workgroup of every launch brackets its chunk with the
+ * shader-cycle counter and the constant-rate counter.  *sclk_ghz = the shader clock the kernel really sustained (cycles / ticks x
+ * hipDeviceAttributeWallClockRate); *cycles_per_addition = shader cycles that wavefront needed per mixed addition (three wavefronts
+ * share a SIMD): equal on two boxes that execute the same instruction stream, whatever their clocks; *samples = launches sampled.
+ * Any pointer may be NULL.  Synchronises the context's stream. */
+int32_t msm_get_clock_stats(msm_ctx *ctx, double *sclk_ghz, double *cycles_per_addition, uint64_t *samples);
 
 #ifdef __cplusplus
 }

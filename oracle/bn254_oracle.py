@@ -258,6 +258,25 @@ def g1_compress(bases, form=FORM_MONT, inf=None):
     return out.tobytes()
 
 
+def dot_words(k_words, s_words):
+    """sum_i k_i * s_i as a Python integer for two (n, 8) arrays of little-endian u32 words, vectorised: the words are cut into 16-bit
+    halves and the 16 x 16 sums of half-products are taken by numpy in uint64 (each < 2^32 * n: exact up to 2^31 rows per call, done in
+    slices of 2^20) -- 2^24 points in seconds instead of minutes of Python big-integer loops."""
+    k = _w(k_words).reshape(-1, 8)
+    s = _w(s_words).reshape(-1, 8)
+    n = min(len(k), len(s))
+    tot = 0
+    for lo in range(0, n, 1 << 20):
+        k16 = np.ascontiguousarray(k[lo:lo + (1 << 20)]).view(np.uint16).reshape(-1, 16).astype(np.float64)
+        s16 = np.ascontiguousarray(s[lo:lo + (1 << 20)]).view(np.uint16).reshape(-1, 16).astype(np.float64)
+        # float64 BLAS is exact here: every partial sum stays below 2^32 * 2^20 = 2^52 < 2^53
+        m = k16.T @ s16
+        for a in range(16):
+            for b in range(16):
+                tot += int(m[a, b]) << (16 * (a + b))
+    return tot
+
+
 def closed_form_expected(k_words, s_words):
     """(sum s_i*k_i mod r) * G as canonical affine standard words -- O(n) integer work."""
     k = _w(k_words).reshape(-1, 8).astype(object)

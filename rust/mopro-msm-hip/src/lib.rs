@@ -26,6 +26,8 @@ struct MsmConfig {
     flags: u32,
     stream_chunk_log2: u32,
     max_points: u64,
+    batch_layout: u32,
+    reserved: u32,
 }
 #[repr(C)]
 struct MsmCtx {
@@ -78,7 +80,7 @@ unsafe impl Send for Ctx {}
 /// Process-global context: the reference rebuilds its whole Metal pipeline on every call
 /// (metal_msm.rs:693); here device, stream and HBM workspace persist.
 static CTX: Lazy<Mutex<Result<Ctx, String>>> = Lazy::new(|| {
-    let cfg = MsmConfig { device: -1, window_bits: 0, flags: 0, stream_chunk_log2: 0, max_points: 0 };
+    let cfg = MsmConfig { device: -1, window_bits: 0, flags: 0, stream_chunk_log2: 0, max_points: 0, batch_layout: 0, reserved: 0 };
     let mut p: *mut MsmCtx = std::ptr::null_mut();
     let rc = unsafe { msm_ctx_create(&cfg, &mut p) };
     Mutex::new(if rc == 0 { Ok(Ctx(p)) } else { Err(last_error(std::ptr::null())) })
@@ -142,7 +144,7 @@ static MULTI: Lazy<Mutex<Option<Multi>>> = Lazy::new(|| {
     if std::env::var_os("MSM_HIP_DEVICES").is_none() {
         return Mutex::new(None);
     }
-    let cfg = MsmConfig { device: -1, window_bits: 0, flags: 0, stream_chunk_log2: 0, max_points: 0 };
+    let cfg = MsmConfig { device: -1, window_bits: 0, flags: 0, stream_chunk_log2: 0, max_points: 0, batch_layout: 0, reserved: 0 };
     let mut p: *mut MsmMulti = std::ptr::null_mut();
     let rc = unsafe { msm_multi_create(std::ptr::null(), 0, &cfg, 0 /* MSM_MULTI_EXCHANGE_AUTO */, &mut p) };
     if rc == 0 && unsafe { msm_multi_num_devices(p) } > 1 {
@@ -305,7 +307,11 @@ pub fn hip_variable_base_msm_batch(bases: &[G1Affine], scalar_sets: &[&[BigInt<4
     if bases.is_empty() || scalar_sets.is_empty() || scalar_sets.iter().any(|s| s.is_empty()) {
         return Err("Empty input".into());
     }
-    let n = scalar_sets.iter().map(|s| s.len()).min().unwrap().min(bases.len());
+    let len0 = scalar_sets[0].len();
+    if scalar_sets.iter().any(|s| s.len() != len0) {
+        return Err("hip_variable_base_msm_batch: the scalar vectors of one batch must have the same length".into());
+    }
+    let n = len0.min(bases.len());
     let mut xy = vec![0u64; n * 8];
     let mut inf = vec![0u8; n];
     for i in 0..n {
@@ -356,7 +362,7 @@ impl HipResidentBases {
             return Err("Empty input".into());
         }
         let cfg = MsmConfig {
-            device: -1, window_bits: 0, flags: if window_table { MSM_FLAG_WINDOW_TABLE } else { 0 }, stream_chunk_log2: 0, max_points: 0,
+            device: -1, window_bits: 0, flags: if window_table { MSM_FLAG_WINDOW_TABLE } else { 0 }, stream_chunk_log2: 0, max_points: 0, batch_layout: 0, reserved: 0,
         };
         let mut p: *mut MsmCtx = std::ptr::null_mut();
         if unsafe { msm_ctx_create(&cfg, &mut p) } != 0 {
@@ -418,12 +424,20 @@ impl HipResidentBases {
         Ok(to_projective(&jac))
     }
 
-    /// several scalar vectors, two MSMs in flight (`msm_bn254_g1_resident_batch`)
+    /// several scalar vectors, two MSMs in flight (`msm_bn254_g1_resident_batch`).  Every vector must have the SAME length: the C call
+    /// takes one `n` for the whole batch, and truncating the longer vectors to the shortest would silently return results that differ
+    /// from per-call `msm()` (which truncates each call to `min(len, bases)` on its own, metal_msm.rs:652-656) -- so unequal lengths are
+    /// an error here.  The window table (and the GLV records) serve calls on the WHOLE resident set only: a batch of shorter vectors runs
+    /// the plain pipeline on the first `n` bases.
     pub fn msm_batch(&self, scalar_sets: &[&[BigInt<4>]]) -> Result<Vec<G1Projective>, Box<dyn Error>> {
         if scalar_sets.is_empty() || scalar_sets.iter().any(|s| s.is_empty()) {
             return Err("Empty input".into());
         }
-        let n = scalar_sets.iter().map(|s| s.len()).min().unwrap().min(self.n);
+        let len0 = scalar_sets[0].len();
+        if scalar_sets.iter().any(|s| s.len() != len0) {
+            return Err("msm_batch: the scalar vectors of one batch must have the same length (call msm() per vector, or batch by length)".into());
+        }
+        let n = len0.min(self.n);
         let ptrs: Vec<*const u32> = scalar_sets.iter().map(|s| s.as_ptr() as *const u32).collect();
         let mut jac = vec![[0u64; 12]; ptrs.len()];
         let rc = unsafe {

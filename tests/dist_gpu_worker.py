@@ -22,16 +22,24 @@ def main():
     from oracle import bn254_oracle as orc
 
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo")
-    torch.cuda.set_device(0)
-    n_total = 1 << 18
+    # MSM_TEST_BACKEND=nccl (tests/test_gpu_4_multi_device.py, boxes with >= 2 GPUs): one DEVICE per rank, exchange over RCCL/xGMI --
+    # what bench.py --gpus N runs; default: every rank on cuda:0, exchange over gloo (1-GPU boxes)
+    nccl = os.environ.get("MSM_TEST_BACKEND", "gloo") == "nccl"
+    dev_index = int(os.environ.get("LOCAL_RANK", "0")) if nccl else 0
+    torch.cuda.set_device(dev_index)
+    if nccl:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+    else:
+        dist.init_process_group("gloo")
+    xdev = torch.device("cuda", dev_index) if nccl else None  # device the 96-byte partials are exchanged on
+    n_total = 1 << int(os.environ.get("MSM_TEST_LOG_N", "18"))
     lo, hi = md.shard_range(n_total, rank, world)
     n = hi - lo
     mul, mask = 0xD1342543DE82EF95, (1 << 64) - 1
     bs, ss = (0xB2540091 + lo * mul) & mask, (0xB2540092 + lo * mul) & mask
-    d_b = torch.empty(n * 16, dtype=torch.int32, device="cuda:0")
-    d_s = torch.empty(n * 8, dtype=torch.int32, device="cuda:0")
-    with th.HooksContext(device=0) as gen:
+    d_b = torch.empty(n * 16, dtype=torch.int32, device=torch.device("cuda", dev_index))
+    d_s = torch.empty(n * 8, dtype=torch.int32, device=torch.device("cuda", dev_index))
+    with th.HooksContext(device=dev_index) as gen:
         gen.generate_device(bs, ss, n, d_b.data_ptr(), d_s.data_ptr())
     torch.cuda.synchronize()
     bad_rank = int(os.environ.get("MSM_TEST_BAD_SCALAR_RANK", "-1"))
@@ -41,10 +49,10 @@ def main():
             d_s[8 * (n // 3) + 7] = 0x40000000
             torch.cuda.synchronize()
         code, good, msg = None, False, ""
-        with mh.MsmContext(device=0) as ctx:
+        with mh.MsmContext(device=dev_index) as ctx:
             for _ in range(2):
                 try:
-                    md.distributed_msm_device(ctx, d_b.data_ptr(), d_s.data_ptr(), n, device=None)
+                    md.distributed_msm_device(ctx, d_b.data_ptr(), d_s.data_ptr(), n, device=xdev)
                 except mh.MsmError as e:
                     code = e.code
                     msg = str(e)
@@ -54,10 +62,10 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         sys.exit(0 if good else 1)
-    with mh.MsmContext(device=0) as ctx:
+    with mh.MsmContext(device=dev_index) as ctx:
         res = None
         for _ in range(3):
-            res = md.distributed_msm_device(ctx, d_b.data_ptr(), d_s.data_ptr(), n, device=None)
+            res = md.distributed_msm_device(ctx, d_b.data_ptr(), d_s.data_ptr(), n, device=xdev)
     k = th.generate_scalars_host(bs, n, nonzero=True)
     s = th.generate_scalars_host(ss, n)
     to_int = lambda a: [sum(int(w) << (32 * j) for j, w in enumerate(row)) for row in a.tolist()]
@@ -68,7 +76,8 @@ def main():
     g[0], g[8] = 1, 2
     exp, einf = orc.g1_to_affine_std(orc.g1_scalar_mul(g, orc.int_to_words(sum(dots) % orc.R_ORDER)))
     ok = bool((res.affine_std == exp).all()) and not res.is_infinity
-    sys.stdout.write(json.dumps({"rank": rank, "ok": ok, "affine": res.affine_std.tolist()}) + "\n")  # ONE write: the ranks share a pipe
+    sys.stdout.write(json.dumps({"rank": rank, "ok": ok, "affine": res.affine_std.tolist(), "device": dev_index,
+                                 "backend": "nccl" if nccl else "gloo"}) + "\n")  # ONE write: the ranks share a pipe
     sys.stdout.flush()
     dist.barrier()
     dist.destroy_process_group()

@@ -122,6 +122,55 @@ def test_gloo_failed_rank_fails_every_rank_and_nobody_hangs(world, bad_rank):
         assert ("this rank" in msg) == (rank == bad_rank)
 
 
+def _worker_other_exception(rank, world, port, bad_rank, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "gpu-acceleration_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    import mopro_msm_hip as mh
+    from mopro_msm_hip import distributed as md
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def local():
+        if rank == bad_rank:  # not an MsmError: argument packing, a torch / HIP RuntimeError (out of memory) ...
+            raise ValueError("cannot reshape array of size 7 into shape (8)")
+        return mh.MsmResult(np.zeros(24, np.uint32), None, True)
+
+    kind, code = None, None
+    try:
+        md.guarded(local)
+    except mh.MsmError as e:
+        kind, code = "MsmError", e.code
+    except ValueError:
+        kind = "ValueError"
+    q.put((rank, kind, code))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_any_exception_of_a_rank_travels_through_the_exchange():
+    """a rank whose local call raises something that is NOT an MsmError must still join the all-gather: its peers raise
+    MsmError(ERR_HIP) instead of blocking in the collective, and the rank itself re-raises its own exception afterwards"""
+    import torch.multiprocessing as mp
+
+    world, bad_rank = 2, 0
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_other_exception, args=(r, world, port, bad_rank, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict((r, (k, c)) for r, k, c in [q.get(timeout=120) for _ in range(world)])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    import mopro_msm_hip as mh
+    assert res[bad_rank] == ("ValueError", None)
+    assert res[1 - bad_rank] == ("MsmError", mh.ERR_HIP)
+
+
 def test_shard_ranges_partition_everything():
     from mopro_msm_hip import distributed as md
     for n in (1, 7, 1 << 20, (1 << 20) + 3):

@@ -26,10 +26,22 @@ with mh.MsmContext() as c:
             else: c.msm_device(d_b.data_ptr(), d_s.data_ptr(), n)
         wall = (time.perf_counter() - t0) * 1e3 / reps
         avg, cnt = c.accumulate_kernel_stats()
+        clk = c.clock_stats()
         c.set_stage_timing(False)
-        return wall, avg
+        return wall, avg, clk
     for _ in range(100): c.msm_device(d_b.data_ptr(), d_s.data_ptr(), n)
     for rnd in range(3):
         for kind in ("conversion beside the sort", "one stream", "resident"):
-            wall, acc = block(kind)
-            print(f"round {rnd} {kind:28s}: call {wall:.4f} ms, k_accumulate {acc:.4f} ms (200 calls back to back)", flush=True)
+            wall, acc, clk = block(kind)
+            print(f"round {rnd} {kind:28s}: call {wall:.4f} ms, k_accumulate {acc:.4f} ms (200 calls back to back); sclk {clk['sclk_ghz']:.3f} GHz, "
+                  f"{clk['cycles_per_addition']:.0f} shader cycles per addition (first wavefront), kernel {acc * clk['sclk_ghz']:.4f} Mcycles", flush=True)
+    # the same kernel in single calls separated by idle gaps: does the clock differ from the sustained loop's?
+    for gap_ms in (0, 1, 5, 20, 100):
+        c.reset_kernel_stats()
+        for _ in range(20):
+            c.msm_device(d_b.data_ptr(), d_s.data_ptr(), n)
+            time.sleep(gap_ms * 1e-3)
+        acc, _ = c.accumulate_kernel_stats()
+        clk = c.clock_stats()
+        print(f"20 calls with {gap_ms:3d} ms idle between them: k_accumulate {acc:.4f} ms, sclk {clk['sclk_ghz']:.3f} GHz, "
+              f"{clk['cycles_per_addition']:.0f} cycles per addition, kernel {acc * clk['sclk_ghz']:.4f} Mcycles", flush=True)
