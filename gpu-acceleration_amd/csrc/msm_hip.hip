@@ -99,7 +99,8 @@ bool trace_enabled() {
 // (MSM_HIP_TRACE / MSM_HIP_ROCTX are per process; MSM_HIP_DEVICES / MSM_HIP_MULTI_VERIFY belong to msm_multi_create.)
 struct Knobs {
     size_t glv_max = msmplan::GLV_MAX_POINTS;  // MSM_HIP_GLV_MAX_LOG2
-    uint32_t chunk_len = 0;                    // MSM_HIP_CHUNK_LEN: entries per k_accumulate thread; 0 = by size
+    uint32_t chunk_len = 0;                    // MSM_HIP_CHUNK_LEN: longest piece (pieces form) / entries per k_accumulate thread (chunk form); 0 = by size
+    bool acc_chunks = false;                   // MSM_HIP_ACC_CHUNKS=1: round 1-3's fixed-length chunks + k_combine instead of pieces sorted by length (A/B)
     int chunk_rounds = 1;                      // MSM_HIP_CHUNK_ROUNDS=0: keep the power-of-two chunk length (no fitting to whole rounds of workgroups)
     bool direct_scatter = false;               // MSM_HIP_DIRECT_SCATTER: skip the two-level LDS sort
     uint32_t device_chunk_log2 = 22;           // MSM_HIP_DEVICE_CHUNK_LOG2: point ranges of device-resident instances; 0 = never cut
@@ -130,6 +131,7 @@ struct Knobs {
             k.chunk_len = v >= 1 && v <= 4096 ? (uint32_t)v : 0u;
         }
         k.direct_scatter = std::getenv("MSM_HIP_DIRECT_SCATTER") != nullptr;
+        k.acc_chunks = on("MSM_HIP_ACC_CHUNKS");
         k.device_chunk_log2 = (uint32_t)num("MSM_HIP_DEVICE_CHUNK_LOG2", 0, 30, 22);
         k.stream_min_log2 = (uint32_t)num("MSM_HIP_STREAM_MIN_LOG2", 9, 31, 19);
         k.stream_chunk_log2 = std::getenv("MSM_HIP_STREAM_CHUNK_LOG2") ? (uint32_t)num("MSM_HIP_STREAM_CHUNK_LOG2", 8, 28, 0) : 0u;
@@ -174,7 +176,8 @@ struct msm_ctx {
     hipEvent_t ev[EV_COUNT]{};
     // HBM workspace
     DevBuf bases, ibases, inf, scalars, digits, ranks, sorted, hist, offsets, blocksums, buckets, heads, tails, chunkmap, rc, flags,
-        pow2, tilecounts, longlist, longdone, midlist, oncelist, ccounts, cregion, bigslot, big;
+        pow2, tilecounts, longlist, longdone, midlist, oncelist, ccounts, cregion, bigslot, big,
+        phist, pcursor, pbase, plist, partials;  // pieces form of the accumulation (k_piece_count / _scatter, k_accumulate_pieces, k_combine_pieces)
     std::mutex batch_mu;           // batch on one compute stream: a whole MSM is enqueued at a time
     bool batch_shared_stream = false;
     std::mutex copy_mu;            // batch: the two pipelines' scalar uploads take turns (see resident_on_lane)
@@ -309,6 +312,10 @@ struct PipeState {
     size_t pairs = 0, tb = 0;  // sorted entries at most (= W * n = sW * sn), buckets in all (= sW * nb)
     uint32_t chunk_len = 0;
     size_t nchunks_max = 0;
+    // pieces form: a piece is a whole bucket or at most pmax entries of a longer one
+    bool pieces = false;
+    uint32_t pmax = 0;
+    size_t maxpieces = 0, maxpartials = 0;
 };
 
 
@@ -371,17 +378,44 @@ int32_t pipe_prepare(msm_ctx* c, size_t n_real, size_t plan_n, uint32_t extra_fl
     if (c->knobs.chunk_rounds) chunk_len = msmplan::fit_chunk_to_rounds(pairs, chunk_len, c->num_cus, c->acc_wgs_per_cu);
     if (fixed_chunk_len) chunk_len = fixed_chunk_len;
     if (c->knobs.chunk_len) chunk_len = c->knobs.chunk_len;  // MSM_HIP_CHUNK_LEN at context creation (any value >= 1 is correct)
+    // PIECES (round 4, default): work items are whole buckets, or runs of at most pmax entries of the buckets that are longer than that --
+    // 4 x the mean occupancy, so uniform scalars never split one (the short top window of an unsplit plan holds ~2.7 x the mean) -- sorted by
+    // length.  pmax also stays small enough that an instance made of long buckets only (tiny windows, skewed scalars) still yields ~2^17 pieces.
+    ps->pieces = !c->knobs.acc_chunks;
+    if (ps->pieces) {
+        uint32_t pmax = (uint32_t)std::min<size_t>(msmk::PIECE_BINS, std::max<size_t>(32, 4 * occ));
+        while (pmax > 8 && pairs / pmax < 131072) pmax /= 2;
+        if (fixed_chunk_len) pmax = fixed_chunk_len;
+        if (c->knobs.chunk_len) pmax = std::min<uint32_t>(c->knobs.chunk_len, msmk::PIECE_BINS);  // MSM_HIP_CHUNK_LEN (tests force 1, 7, 26, 35)
+        ps->pmax = chunk_len = pmax;
+        ps->maxpieces = std::min(pairs, tb + pairs / pmax) + 1;
+        ps->maxpartials = std::min(pairs, 2 * (pairs / pmax) + 2) + 1;
+    }
     ps->chunk_len = chunk_len;
-    const size_t nchunks_max = ps->nchunks_max = (pairs + chunk_len - 1) / chunk_len;
+    const size_t nchunks_max = ps->nchunks_max = ps->pieces ? ps->maxpartials : (pairs + chunk_len - 1) / chunk_len;
     if ((rc = ensure(c, c->digits, pairs * 4))) return rc;
     if ((rc = ensure(c, c->sorted, pairs * 4))) return rc;
     if ((rc = ensure(c, c->hist, tb * 4))) return rc;
     if ((rc = ensure(c, c->offsets, (tb + 1) * 4))) return rc;
     if ((rc = ensure(c, c->blocksums, ((size_t)ntiles + 1) * 4))) return rc;
     if ((rc = ensure(c, c->buckets, tb * XB))) return rc;
-    if ((rc = ensure(c, c->heads, nchunks_max * XB > pairs * 4 ? nchunks_max * XB : pairs * 4))) return rc;  // also stages the 2-level sort
-    if ((rc = ensure(c, c->tails, nchunks_max * XB))) return rc;
-    if ((rc = ensure(c, c->chunkmap, nchunks_max * 4))) return rc;
+    if (ps->pieces) {
+        if ((rc = ensure(c, c->heads, pairs * 4))) return rc;  // stages the 2-level sort
+        if ((rc = ensure(c, c->partials, ps->maxpartials * XB))) return rc;
+        if ((rc = ensure(c, c->plist, ps->maxpieces * 16))) return rc;
+        if ((rc = ensure(c, c->pbase, tb * 4))) return rc;
+        const bool fresh = !c->phist.p || !c->pcursor.p;
+        if ((rc = ensure(c, c->phist, (msmk::PIECE_BINS + 1) * 4))) return rc;
+        if ((rc = ensure(c, c->pcursor, (msmk::PIECE_BINS + 1) * 4))) return rc;
+        if (fresh) {  // self-cleaning afterwards (k_accumulate_pieces zeroes them behind the plan kernels)
+            HIPCHK(c, hipMemsetAsync(c->phist.p, 0, c->phist.cap, st));
+            HIPCHK(c, hipMemsetAsync(c->pcursor.p, 0, c->pcursor.cap, st));
+        }
+    } else {
+        if ((rc = ensure(c, c->heads, nchunks_max * XB > pairs * 4 ? nchunks_max * XB : pairs * 4))) return rc;  // also stages the 2-level sort
+        if ((rc = ensure(c, c->tails, nchunks_max * XB))) return rc;
+        if ((rc = ensure(c, c->chunkmap, nchunks_max * 4))) return rc;
+    }
     {   // a long bucket owns >= LONG_SPAN chunks and gets one (bucket, segment) entry per LONG_SEG pieces
         const size_t entries = nchunks_max / msmk::LONG_SPAN + nchunks_max / msmk::LONG_SEG + 32;
         if ((rc = ensure(c, c->longlist, entries * 8))) return rc;
@@ -390,7 +424,7 @@ int32_t pipe_prepare(msm_ctx* c, size_t n_real, size_t plan_n, uint32_t extra_fl
         if (c->longdone.cap != had) HIPCHK(c, hipMemsetAsync(c->longdone.p, 0, c->longdone.cap, st));  // self-cleaning afterwards
     }
     if ((rc = ensure(c, c->midlist, (nchunks_max / 2 + 16) * 4))) return rc;                  // a listed bucket owns >= 2 chunk borders
-    if ((rc = ensure(c, c->oncelist, (std::min(nchunks_max, tb) + 16) * 4))) return rc;       // a once-cut bucket owns one chunk border
+    if (!ps->pieces && (rc = ensure(c, c->oncelist, (std::min(nchunks_max, tb) + 16) * 4))) return rc;  // a once-cut bucket owns one chunk border
     if ((rc = ensure(c, c->rc, (tb + tb / 2 + 4) * XB))) return rc;  // two families x (1/2 + 1/4) ping-pong levels
     if ((rc = ensure(c, c->flags, 64))) return rc;
     return MSM_OK;
@@ -543,6 +577,13 @@ int32_t enqueue_sort(msm_ctx* c, const PipeState& ps, hipStream_t st, bool into)
         }
     }
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_SORT], st));
+    if (ps.pieces) {  // the piece list, longest first (k_accumulate_pieces zeroes the histogram and the cursors again)
+        msmk::k_piece_count<<<grid1(tb, 1024), 1024, 0, st>>>(offsets, (uint32_t)tb, ps.pmax, (uint32_t*)c->phist.p, flags, (uint32_t*)c->longlist.p,
+                                                            (uint32_t*)c->midlist.p, (uint32_t*)c->pbase.p, (uint32_t*)c->buckets.p, into ? 1u : 0u);
+        msmk::k_piece_scatter<<<grid1(tb, 1024), 1024, 0, st>>>(offsets, (uint32_t)tb, ps.pmax, (const uint32_t*)c->phist.p, (uint32_t*)c->pcursor.p,
+                                                              (const uint32_t*)c->pbase.p, (uint4*)c->plist.p, flags);
+        return MSM_OK;
+    }
     msmk::k_chunk_map<<<grid1(tb, 1024), 1024, 0, st>>>(offsets, (uint32_t*)c->chunkmap.p, (uint32_t)tb, ps.chunk_len, flags,
                                                       (uint32_t*)c->longlist.p, (uint32_t*)c->midlist.p, (uint32_t*)c->oncelist.p,
                                                       (uint32_t*)c->buckets.p, into ? 1u : 0u);  // accumulating INTO the buckets
@@ -569,6 +610,21 @@ int32_t enqueue_accumulate(msm_ctx* c, const PipeState& ps, const uint32_t* d_ba
     const size_t tb = ps.tb;
     if (bases_ready) HIPCHK(c, hipStreamWaitEvent(st, bases_ready, 0));  // d_bases is being converted on another stream
     HIPCHK(c, hipEventRecord(c->ev[EV_ACC0], st));
+    if (ps.pieces) {
+        const dim3 gp = grid1(ps.maxpieces, 256);
+        const uint32_t *srt_ = (const uint32_t*)c->sorted.p, *np = flags + msmk::FLAG_ONCE;
+        const uint4* pl_ = (const uint4*)c->plist.p;
+        uint32_t *bk_ = (uint32_t*)c->buckets.p, *pt = (uint32_t*)c->partials.p, *hs = (uint32_t*)c->phist.p, *cu = (uint32_t*)c->pcursor.p;
+        unsigned long long* clk_ = (unsigned long long*)c->clk.p;
+        if (into) msmk::k_accumulate_pieces<true, true><<<gp, 256, 0, st>>>(d_bases, srt_, pl_, np, bk_, pt, hs, cu, ps.pmax, clk_);
+        else if (chunked) msmk::k_accumulate_pieces<false, true><<<gp, 256, 0, st>>>(d_bases, srt_, pl_, np, bk_, pt, hs, cu, ps.pmax, clk_);
+        else msmk::k_accumulate_pieces<false, false><<<gp, 256, 0, st>>>(d_bases, srt_, pl_, np, bk_, pt, hs, cu, ps.pmax, clk_);
+        HIPCHK(c, hipEventRecord(c->ev[EV_ACC1], st));
+        msmk::k_combine_pieces<<<dim3(msmk::LONG_BLOCKS + msmk::MID_BLOCKS), 512, 0, st>>>(
+            offsets, pt, bk_, ps.pmax, (const uint32_t*)c->pbase.p, flags + msmk::FLAG_MID, (const uint32_t*)c->midlist.p, flags + msmk::FLAG_LONG,
+            (const uint32_t*)c->longlist.p, (uint32_t*)c->longdone.p);
+        return MSM_OK;
+    }
     const dim3 ga = grid1(ps.nchunks_max, 256);  // (64- and 128-thread workgroups: no difference at any size, tools/env_sweep.py)
     const uint32_t *srt = (const uint32_t*)c->sorted.p, *cm = (const uint32_t*)c->chunkmap.p, *tp = flags + msmk::FLAG_PAIRS;
     uint32_t *bk = (uint32_t*)c->buckets.p, *hd = (uint32_t*)c->heads.p, *tl = (uint32_t*)c->tails.p;
@@ -1201,7 +1257,7 @@ void msm_ctx_destroy(msm_ctx* c) {
         DevBuf* bufs[] = {&c->bases,   &c->inf,       &c->scalars, &c->digits,  &c->ranks,  &c->sorted, &c->hist,
                           &c->offsets, &c->blocksums, &c->buckets, &c->rc,      &c->flags,  &c->pow2,
                           &c->heads,   &c->tails,     &c->chunkmap, &c->tilecounts, &c->ibases, &c->longlist, &c->longdone, &c->midlist, &c->oncelist, &c->ccounts, &c->cregion, &c->bigslot, &c->big,
-                          &c->rbases,  &c->rinf,      &c->clk};
+                          &c->rbases,  &c->rinf,      &c->clk,     &c->phist,   &c->pcursor, &c->pbase,  &c->plist,  &c->partials};
         for (DevBuf* b : bufs) release(*b);
         if (c->h_qsums) (void)hipHostFree(c->h_qsums);
         if (c->h_flags) (void)hipHostFree(c->h_flags);

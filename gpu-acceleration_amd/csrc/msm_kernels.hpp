@@ -37,7 +37,8 @@ constexpr int SCALAR_BITS = 254;
 constexpr int XW = 36;  // words per XYZZ record in HBM: 4 coordinates x 9 limbs
 // flags (u32 words, one set per context): [0] error bits  [4] sorted entries of this (chunk of an) MSM  [6,7] running 64-bit total of
 // sorted entries over the chunks of a streamed MSM  [8] long-list entries  [9] mid-list entries  [10] once-cut-list entries
-constexpr uint32_t FLAG_ERR = 0, FLAG_PAIRS = 4, FLAG_ADDS64 = 6, FLAG_LONG = 8, FLAG_MID = 9, FLAG_ONCE = 10;
+constexpr uint32_t FLAG_ERR = 0, FLAG_PAIRS = 4, FLAG_ADDS64 = 6, FLAG_LONG = 8, FLAG_MID = 9, FLAG_ONCE = 10, FLAG_PARTIALS = 11;
+// (pieces form of the accumulation: FLAG_ONCE holds the number of pieces, FLAG_PARTIALS the partial-sum slots reserved by split buckets)
 
 // packed 8-word field element (canonical value) -> 9 x 29-bit limbs
 __device__ __forceinline__ fp load_fp_packed(const uint32_t* p) {
@@ -91,6 +92,24 @@ __device__ __forceinline__ void store_xyzz(uint32_t* p, const xyzz& v) {
     uint4* q = reinterpret_cast<uint4*>(p);
 #pragma unroll
     for (int i = 0; i < XW / 4; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+// streaming variants (experiment ACC_NT): the record is written once and read once by a later kernel, the index stream is read once
+typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_xyzz_nt(uint32_t* p, const xyzz& v) {
+    uint32_t w[XW];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        w[i] = v.x.v[i];
+        w[9 + i] = v.y.v[i];
+        w[18 + i] = v.zz.v[i];
+        w[27 + i] = v.zzz.v[i];
+    }
+    v4u32* q = reinterpret_cast<v4u32*>(p);
+#pragma unroll
+    for (int i = 0; i < XW / 4; i++) {
+        v4u32 t = {w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]};
+        __builtin_nontemporal_store(t, q + i);
+    }
 }
 // one coordinate (0 = X, 1 = Y, 2 = ZZ, 3 = ZZZ) of an XYZZ record, HBM or LDS
 __device__ __forceinline__ fp load_coord(const uint32_t* rec, uint32_t coord) {
@@ -371,7 +390,7 @@ __global__ void k_decompose(const uint32_t* __restrict__ scalars, const uint8_t*
                             uint32_t* __restrict__ digits, uint32_t* __restrict__ ranks, uint32_t* __restrict__ err,
                             uint32_t scalars_mont, uint32_t top_shift) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) err[FLAG_LONG] = 0, err[FLAG_MID] = 0, err[FLAG_ONCE] = 0;  // list counters of this (chunk of an) MSM: k_chunk_map fills them later in the stream
+    if (i == 0) err[FLAG_LONG] = 0, err[FLAG_MID] = 0, err[FLAG_ONCE] = 0, err[FLAG_PARTIALS] = 0;  // list counters of this (chunk of an) MSM: k_chunk_map / k_piece_count fill them later in the stream
     if (i >= n) return;
     const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
     uint4 a = sp[0], b = sp[1];
@@ -425,7 +444,7 @@ __global__ void k_decompose_glv(const uint32_t* __restrict__ scalars, const uint
                                 uint32_t W, uint32_t* __restrict__ digits, uint32_t* __restrict__ err, uint32_t scalars_mont,
                                 uint32_t top_shift) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) err[FLAG_LONG] = 0, err[FLAG_MID] = 0, err[FLAG_ONCE] = 0;  // list counters of this (chunk of an) MSM: k_chunk_map fills them later in the stream
+    if (i == 0) err[FLAG_LONG] = 0, err[FLAG_MID] = 0, err[FLAG_ONCE] = 0, err[FLAG_PARTIALS] = 0;  // list counters of this (chunk of an) MSM: k_chunk_map / k_piece_count fill them later in the stream
     if (i >= n) return;
     const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
     uint4 a = sp[0], b = sp[1];
@@ -628,7 +647,7 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_coarse_hist(const uint32_t* __re
     const uint32_t st = blockIdx.x, w = blockIdx.y;
     // list counters of THIS sort call (k_chunk_map fills them later in the stream; k_decompose zeroes them too -- kept here so that a
     // sort never depends on which kernel ran before it)
-    if (st == 0 && w == 0 && threadIdx.x == 0) flags[FLAG_LONG] = 0, flags[FLAG_MID] = 0, flags[FLAG_ONCE] = 0;
+    if (st == 0 && w == 0 && threadIdx.x == 0) flags[FLAG_LONG] = 0, flags[FLAG_MID] = 0, flags[FLAG_ONCE] = 0, flags[FLAG_PARTIALS] = 0;
     if (threadIdx.x < COARSE_BINS_MAX) s_h[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t i0 = st * SUBTILE, i1 = min(n, i0 + SUBTILE);
@@ -1143,8 +1162,15 @@ __global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__
     // in the Infinity Cache) that latency is HBM's.  Now a switch reads registers only -- seg_end and end1 = offsets[k + 2] are kept
     // one bucket ahead, refilled from the load `ahead` = offsets[k + 3] of the iteration before -- and the only waits sit at the top
     // of an iteration, one whole mixed addition after everything was issued.
-    uint32_t e_cur = sorted[j0];
-    uint32_t e_nxt = sorted[min(j0 + 1, j1 - 1)];
+#ifdef ACC_NT
+#define ACC_LD_SORTED(i) __builtin_nontemporal_load(sorted + (i))
+#define ACC_STORE store_xyzz_nt
+#else
+#define ACC_LD_SORTED(i) sorted[i]
+#define ACC_STORE store_xyzz
+#endif
+    uint32_t e_cur = ACC_LD_SORTED(j0);
+    uint32_t e_nxt = ACC_LD_SORTED(min(j0 + 1, j1 - 1));
     uint32_t end1 = offsets[min(k + 2, total_buckets)];  // seg_end of the bucket after this one
     uint32_t ahead = 0;                                     // offsets[k + 3] as of the previous iteration: the next end1 after a switch
     bool switched = false;
@@ -1154,6 +1180,15 @@ __global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__
 #pragma unroll
         for (int i = 0; i < 4; i++) g[i] = bp[i];
     }
+#ifdef ACC_PF2  // experiment: the record of entry j+2 is in flight as well (16 more VGPRs)
+    uint4 g2[4];
+    uint32_t e_nn = ACC_LD_SORTED(min(j0 + 2, j1 - 1));
+    {
+        const uint4* bp = reinterpret_cast<const uint4*>(bases + (size_t)(e_nxt & ~SIGN_BIT) * 16);
+#pragma unroll
+        for (int i = 0; i < 4; i++) g2[i] = bp[i];
+    }
+#endif
     for (uint32_t j = j0; j < j1; j++) {
         affine q;
         {
@@ -1164,16 +1199,27 @@ __global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__
         }
         if (e_cur & SIGN_BIT) q.y = fp_neg_raw<2>(q.y);  // raw: only ever a multiplier in xyzz_madd
         if (switched) end1 = ahead;                      // the previous iteration moved to bucket k: its offsets[k_old + 3] is offsets[k + 2]
+#ifdef ACC_PF2
+#pragma unroll
+        for (int i = 0; i < 4; i++) g[i] = g2[i];        // record of entry j+1 (loaded one iteration ago)
+        {
+            const uint4* bp = reinterpret_cast<const uint4*>(bases + (size_t)(e_nn & ~SIGN_BIT) * 16);
+#pragma unroll
+            for (int i = 0; i < 4; i++) g2[i] = bp[i];   // record of entry j+2
+        }
+        const uint32_t e_n3 = ACC_LD_SORTED(min(j + 3, j1 - 1));
+#else
         {
             const uint4* bp = reinterpret_cast<const uint4*>(bases + (size_t)(e_nxt & ~SIGN_BIT) * 16);
 #pragma unroll
             for (int i = 0; i < 4; i++) g[i] = bp[i];
         }
-        const uint32_t e_nn = sorted[min(j + 2, j1 - 1)];
+        const uint32_t e_nn = ACC_LD_SORTED(min(j + 2, j1 - 1));
+#endif
         ahead = offsets[min(k + 3, total_buckets)];
         switched = false;
         if (j == seg_end) {  // bucket k is finished: flush and move to the bucket that owns entry j
-            store_xyzz((is_head ? heads + (size_t)t * XW : buckets + (size_t)k * XW), acc);
+            ACC_STORE((is_head ? heads + (size_t)t * XW : buckets + (size_t)k * XW), acc);
             k++;
             seg_end = end1;  // == offsets[k + 1]
             switched = true;
@@ -1200,9 +1246,14 @@ __global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__
         xyzz_madd(acc, q);
         e_cur = e_nxt;
         e_nxt = e_nn;
+#ifdef ACC_PF2
+        e_nn = e_n3;
+#endif
     }
     uint32_t* dst = is_head ? heads + (size_t)t * XW : (seg_end == j1 ? buckets + (size_t)k * XW : tails + (size_t)t * XW);
-    store_xyzz(dst, acc);
+    ACC_STORE(dst, acc);
+#undef ACC_LD_SORTED
+#undef ACC_STORE
     if (probe && threadIdx.x == 0) {  // [0] shader cycles, [1] constant-rate ticks, [2] samples, [3] mixed additions of the sampled thread
         atomicAdd(clk + 0, (unsigned long long)(clock64() - clk_c0));
         atomicAdd(clk + 1, (unsigned long long)(wall_clock64() - clk_w0));
@@ -1294,6 +1345,271 @@ __global__ void __launch_bounds__(512) k_combine(const uint32_t* __restrict__ of
         if (!s_last) continue;  // uniform
         __threadfence();        // see the other segments' sums
         long_fold(e, heads, tails, t0, 0, LONG_SEG, nseg);
+        if (threadIdx.x < 4) store_coord(buckets + (size_t)k * XW, threadIdx.x, load_coord(e, threadIdx.x));
+        if (threadIdx.x == 0) long_done[item - seg] = 0;  // ready for the next call
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3, second form (round 4): PIECES SORTED BY LENGTH instead of fixed-length chunks.
+//
+// The chunk form above gives every thread exactly L sorted entries, whatever buckets they belong to.  That balances any distribution,
+// but (i) almost every bucket is cut by a chunk border (mean bucket = L entries at 2^20 points), so k_combine has to add ~one pair of
+// partial sums per bucket (54 us at 2^20, 46 us at 2^17) after heads and tails travelled through HBM, and (ii) the launch is 1.33 rounds
+// of identical workgroups, whose last wavefront per SIMD runs alone for a whole chunk (measured round 4, tools/ab_libs.py chunk sweep:
+// 2.47 Mcycles at L = 64 against 2.28 at L = 22, where k_combine then costs 0.44 ms instead of 0.20).
+// Here a work item is a PIECE: a whole bucket, or -- only for buckets longer than `pmax` entries (4 x the mean occupancy: skewed scalars,
+// never uniform ones) -- a run of at most pmax entries of one.  The pieces are counting-sorted by length, longest first, so the 64 lanes
+// of a wavefront run the same trip count (the property the chunks were built for), the long items start first and the launch ends on its
+// shortest ones (LPT order), a bucket that is one piece is written straight to its slot, and nothing is left to combine on uniform
+// scalars.  Split buckets leave partial sums in `partials` and are listed for k_combine_pieces exactly like cut buckets were for k_combine
+// (2..7 pieces: one thread per bucket; 8 or more: LDS trees of eight-lane additions per 2048-piece segment).
+constexpr uint32_t PIECE_BINS = 1024;                 // pmax <= PIECE_BINS: one histogram bin per piece length
+constexpr uint32_t PF_WHOLE = 0x80000000u;            // piece.z: the bucket is this one piece -> the sum goes to buckets[k]
+constexpr uint32_t PF_FIRST = 0x40000000u;            // piece.z: first piece of a split bucket (INTO: starts from the bucket's old value)
+constexpr uint32_t PF_LEN_MASK = 0x00FFFFFFu;
+
+// exclusive scan over the 1024 threads of a workgroup (v -> sum of the values of lower threads); *total = sum of all
+__device__ __forceinline__ uint32_t block1024_exclusive_scan(uint32_t v, uint32_t* s_wsum /* 16 words of LDS */, uint32_t* total) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) s_wsum[wid] = x;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        if (k < wid) base += s_wsum[k];
+        tot += s_wsum[k];
+    }
+    __syncthreads();
+    *total = tot;
+    return base + x - v;
+}
+
+// pass 1: histogram of the piece lengths (LDS per workgroup, one global add per non-empty bin), the identity for empty buckets, a run of
+// partial-sum slots and a list entry for every split bucket.  One thread per bucket.
+__global__ void __launch_bounds__(1024) k_piece_count(const uint32_t* __restrict__ offsets, uint32_t total_buckets, uint32_t pmax,
+                                                     uint32_t* __restrict__ hist, uint32_t* __restrict__ flags, uint32_t* __restrict__ long_list,
+                                                     uint32_t* __restrict__ mid_list, uint32_t* __restrict__ pbase, uint32_t* __restrict__ buckets,
+                                                     uint32_t into) {
+    __shared__ uint32_t s_hist[PIECE_BINS + 1];
+    __shared__ uint32_t s_n[2], s_base[2];  // [0] mid list, [1] long list: slots are reserved once per workgroup
+    for (uint32_t i = threadIdx.x; i <= pmax; i += blockDim.x) s_hist[i] = 0;
+    if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0)  // mixed additions executed so far (msm_timings_t.num_adds), all chunks of a streamed MSM
+        *reinterpret_cast<unsigned long long*>(flags + FLAG_ADDS64) += (unsigned long long)flags[FLAG_PAIRS];
+    __syncthreads();
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t kindl = 2, slot = 0, nseg = 1, m = 0;  // 0 = mid list, 1 = long list, 2 = none
+    if (k < total_buckets) {
+        const uint32_t beg = offsets[k], sz = offsets[k + 1] - beg;
+        if (sz == 0) {
+            if (!into) store_xyzz(buckets + (size_t)k * XW, xyzz_identity());  // (into: the bucket keeps the earlier chunks' sum)
+        } else {
+            m = (sz + pmax - 1) / pmax;
+            if (m == 1) {
+                atomicAdd(&s_hist[sz], 1u);
+            } else {
+                atomicAdd(&s_hist[pmax], m - 1);
+                atomicAdd(&s_hist[sz - (m - 1) * pmax], 1u);
+                pbase[k] = atomicAdd(flags + FLAG_PARTIALS, m);  // device-scope, split buckets only
+                if (m >= LONG_SPAN) {
+                    kindl = 1;
+                    nseg = (m + LONG_SEG - 1) / LONG_SEG;
+                } else {
+                    kindl = 0;
+                }
+            }
+        }
+    }
+    if (kindl < 2) slot = atomicAdd(&s_n[kindl], nseg);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n[0]) s_base[0] = atomicAdd(flags + FLAG_MID, s_n[0]);
+    if (threadIdx.x == 1 && s_n[1]) s_base[1] = atomicAdd(flags + FLAG_LONG, s_n[1]);
+    for (uint32_t i = threadIdx.x; i <= pmax; i += blockDim.x)
+        if (s_hist[i]) atomicAdd(&hist[i], s_hist[i]);
+    __syncthreads();
+    if (kindl == 0) {
+        mid_list[s_base[0] + slot] = k;
+    } else if (kindl == 1) {  // one entry per LONG_SEG pieces: (bucket, segment)
+        for (uint32_t j = 0; j < nseg; j++) {
+            long_list[2 * (size_t)(s_base[1] + slot + j)] = k;
+            long_list[2 * (size_t)(s_base[1] + slot + j) + 1] = j;
+        }
+    }
+}
+
+// pass 2: the piece list, longest pieces first.  Every workgroup derives the bins' start positions from the global histogram (an
+// exclusive prefix in DESCENDING length order), reserves its share of every bin with one device-scope add per non-empty bin and places
+// its pieces with LDS cursors.  piece = (bucket, first sorted entry, length | flags, partial slot).
+__global__ void __launch_bounds__(1024) k_piece_scatter(const uint32_t* __restrict__ offsets, uint32_t total_buckets, uint32_t pmax,
+                                                       const uint32_t* __restrict__ hist, uint32_t* __restrict__ cursor,
+                                                       const uint32_t* __restrict__ pbase, uint4* __restrict__ plist, uint32_t* __restrict__ flags) {
+    __shared__ uint32_t s_start[PIECE_BINS + 1], s_cnt[PIECE_BINS + 1], s_cur[PIECE_BINS + 1];
+    __shared__ uint32_t s_wsum[16];
+    {   // thread r owns the bin of length pmax - r (r < pmax); lengths above pmax do not exist, length 0 is never a piece
+        const uint32_t len = threadIdx.x < pmax ? pmax - threadIdx.x : 0u;
+        const uint32_t h = len ? hist[len] : 0u;
+        uint32_t total;
+        const uint32_t ex = block1024_exclusive_scan(h, s_wsum, &total);
+        if (len) s_start[len] = ex;
+        if (blockIdx.x == 0 && threadIdx.x == 0) flags[FLAG_ONCE] = total;  // number of pieces: k_accumulate_pieces' trip count
+    }
+    for (uint32_t i = threadIdx.x; i <= pmax; i += blockDim.x) s_cnt[i] = 0, s_cur[i] = 0;
+    __syncthreads();
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t beg = 0, sz = 0, m = 0, rem = 0;
+    if (k < total_buckets) {
+        beg = offsets[k];
+        sz = offsets[k + 1] - beg;
+        if (sz) {
+            m = (sz + pmax - 1) / pmax;
+            rem = sz - (m - 1) * pmax;
+            if (m > 1) atomicAdd(&s_cnt[pmax], m - 1);
+            atomicAdd(&s_cnt[rem], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i <= pmax; i += blockDim.x)
+        if (s_cnt[i]) s_start[i] += atomicAdd(&cursor[i], s_cnt[i]);  // this workgroup's run inside bin i
+    __syncthreads();
+    if (m == 1) {
+        const uint32_t pos = s_start[sz] + atomicAdd(&s_cur[sz], 1u);
+        plist[pos] = make_uint4(k, beg, sz | PF_WHOLE, 0u);
+    } else if (m > 1) {
+        const uint32_t pb = pbase[k];
+        uint32_t pos = s_start[pmax] + atomicAdd(&s_cur[pmax], m - 1);  // the m - 1 full pieces: one reservation
+        for (uint32_t p = 0; p + 1 < m; p++) plist[pos + p] = make_uint4(k, beg + p * pmax, pmax | (p == 0 ? PF_FIRST : 0u), pb + p);
+        pos = s_start[rem] + atomicAdd(&s_cur[rem], 1u);
+        plist[pos] = make_uint4(k, beg + (m - 1) * pmax, rem, pb + m - 1);
+    }
+}
+
+// one thread per piece: the loop of k_accumulate without bucket switches.  INTO: a whole bucket, or the first piece of a split one, starts
+// from the value the bucket holds (earlier chunks of a streamed host call / point ranges of a device-resident instance).
+// Workgroup 0 also zeroes the histogram and the bin cursors for the next plan (they are only read by the two plan kernels, which
+// precede this launch in stream order).
+template <bool INTO, bool CHUNK>
+__global__ void __launch_bounds__(256) k_accumulate_pieces(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
+                                                           const uint4* __restrict__ plist, const uint32_t* __restrict__ npieces_ptr,
+                                                           uint32_t* __restrict__ buckets, uint32_t* __restrict__ partials,
+                                                           uint32_t* __restrict__ hist, uint32_t* __restrict__ cursor, uint32_t pmax,
+                                                           unsigned long long* __restrict__ clk) {
+    const bool probe = blockIdx.x == 0;  // clock probe: see k_accumulate
+    long long clk_c0 = 0, clk_w0 = 0;
+    if (probe) {
+        clk_c0 = clock64(), clk_w0 = wall_clock64();
+        for (uint32_t i = threadIdx.x; i <= pmax; i += blockDim.x) hist[i] = 0, cursor[i] = 0;
+    }
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= *npieces_ptr) return;
+    const uint4 pc = plist[t];
+    const uint32_t k = pc.x, j0 = pc.y, len = pc.z & PF_LEN_MASK, j1 = j0 + len;
+    const bool whole = (pc.z & PF_WHOLE) != 0;
+    xyzz acc = xyzz_identity();
+    if (INTO && (pc.z & (PF_WHOLE | PF_FIRST))) acc = load_xyzz(buckets + (size_t)k * XW);
+    // software pipeline as in k_accumulate: the record of entry j+1 and the index of entry j+2 are in flight while entry j is folded;
+    // every load is unconditional (the last entry fetches its own record once more) and issued at the top of the iteration
+    uint32_t e_cur = sorted[j0];
+    uint32_t e_nxt = sorted[min(j0 + 1, j1 - 1)];
+    uint4 g[4];
+    {
+        const uint4* bp = reinterpret_cast<const uint4*>(bases + (size_t)(e_cur & ~SIGN_BIT) * 16);
+#pragma unroll
+        for (int i = 0; i < 4; i++) g[i] = bp[i];
+    }
+    for (uint32_t j = j0; j < j1; j++) {
+        affine q;
+        {
+            uint32_t wx[8] = {g[0].x, g[0].y, g[0].z, g[0].w, g[1].x, g[1].y, g[1].z, g[1].w};
+            uint32_t wy[8] = {g[2].x, g[2].y, g[2].z, g[2].w, g[3].x, g[3].y, g[3].z, g[3].w};
+            q.x = fp_unpack(wx);
+            q.y = fp_unpack(wy);
+        }
+        if (e_cur & SIGN_BIT) q.y = fp_neg_raw<2>(q.y);  // raw: only ever a multiplier in xyzz_madd
+        {
+            const uint4* bp = reinterpret_cast<const uint4*>(bases + (size_t)(e_nxt & ~SIGN_BIT) * 16);
+#pragma unroll
+            for (int i = 0; i < 4; i++) g[i] = bp[i];
+        }
+        const uint32_t e_nn = sorted[min(j + 2, j1 - 1)];
+        xyzz_madd(acc, q);
+        e_cur = e_nxt;
+        e_nxt = e_nn;
+    }
+    store_xyzz(whole ? buckets + (size_t)k * XW : partials + (size_t)pc.w * XW, acc);
+    if (probe && threadIdx.x == 0) {  // [0] shader cycles, [1] constant-rate ticks, [2] samples, [3] mixed additions of the sampled thread
+        atomicAdd(clk + 0, (unsigned long long)(clock64() - clk_c0));
+        atomicAdd(clk + 1, (unsigned long long)(wall_clock64() - clk_w0));
+        atomicAdd(clk + 2, 1ull);
+        atomicAdd(clk + 3, (unsigned long long)len);
+    }
+}
+
+// Split buckets (longer than pmax entries: skewed scalars, tiny top windows): partial sums partials[pbase[k] .. + m).  ONE launch, the
+// two kinds of k_combine that remain: the leading LONG_BLOCKS workgroups take the long list -- (bucket, segment) items of buckets with
+// LONG_SPAN or more pieces: LDS trees of eight-lane additions per 2048-piece segment, the last-arriving workgroup of a bucket folds the
+// segment sums -- the others one bucket of 2..LONG_SPAN-1 pieces per thread.  On uniform scalars both lists are empty.
+__device__ __forceinline__ void fold_partials(uint32_t* e, const uint32_t* partials, uint32_t base, uint32_t first, uint32_t stride,
+                                              uint32_t count) {
+    constexpr uint32_t CAP = WIDE_TREE_MAX;
+    __syncthreads();  // e is reused
+    if (count <= CAP) {
+        for (uint32_t i = threadIdx.x >> 2; i < count; i += blockDim.x >> 2) {
+            const uint32_t co = threadIdx.x & 3u;
+            store_coord(e + (size_t)i * XW, co, load_coord(partials + (size_t)(base + first + i * stride) * XW, co));
+        }
+    } else if (threadIdx.x < CAP) {
+        xyzz acc = xyzz_identity();
+#pragma unroll 1
+        for (uint32_t i = threadIdx.x; i < count; i += CAP) acc = xyzz_add(acc, load_xyzz(partials + (size_t)(base + first + i * stride) * XW));
+        store_xyzz(e + (size_t)threadIdx.x * XW, acc);
+    }
+    lds_tree_wide(e, count < CAP ? count : CAP);
+}
+__global__ void __launch_bounds__(512) k_combine_pieces(const uint32_t* __restrict__ offsets, uint32_t* __restrict__ partials,
+                                                        uint32_t* __restrict__ buckets, uint32_t pmax, const uint32_t* __restrict__ pbase,
+                                                        const uint32_t* __restrict__ mid_count, const uint32_t* __restrict__ mid_list,
+                                                        const uint32_t* __restrict__ long_count, const uint32_t* __restrict__ long_list,
+                                                        uint32_t* __restrict__ long_done) {
+    if (blockIdx.x >= LONG_BLOCKS) {
+        const uint32_t nmid = *mid_count;
+        for (uint32_t i = (blockIdx.x - LONG_BLOCKS) * blockDim.x + threadIdx.x; i < nmid; i += MID_BLOCKS * blockDim.x) {
+            const uint32_t k = mid_list[i];
+            const uint32_t m = (offsets[k + 1] - offsets[k] + pmax - 1) / pmax, base = pbase[k];
+            xyzz acc = load_xyzz(partials + (size_t)base * XW);
+            for (uint32_t p = 1; p < m; p++) acc = xyzz_add(acc, load_xyzz(partials + (size_t)(base + p) * XW));
+            store_xyzz(buckets + (size_t)k * XW, acc);
+        }
+        return;
+    }
+    __shared__ uint32_t e[WIDE_TREE_MAX * XW];
+    __shared__ uint32_t s_last;
+    const uint32_t nlong = *long_count;
+    for (uint32_t item = blockIdx.x; item < nlong; item += LONG_BLOCKS) {
+        const uint32_t k = long_list[2 * (size_t)item], seg = long_list[2 * (size_t)item + 1];
+        const uint32_t cnt = (offsets[k + 1] - offsets[k] + pmax - 1) / pmax, nseg = (cnt + LONG_SEG - 1) / LONG_SEG, base = pbase[k];
+        const uint32_t first = seg * LONG_SEG, count = min(LONG_SEG, cnt - first);
+        fold_partials(e, partials, base, first, 1, count);
+        if (nseg == 1) {
+            if (threadIdx.x < 4) store_coord(buckets + (size_t)k * XW, threadIdx.x, load_coord(e, threadIdx.x));
+            continue;
+        }
+        // park the segment sum in the segment's first slot (only this workgroup ever read it), then count in
+        uint32_t* park = partials + (size_t)(base + first) * XW;
+        if (threadIdx.x < 4) store_coord(park, threadIdx.x, load_coord(e, threadIdx.x));
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) s_last = atomicAdd(&long_done[item - seg], 1u) == nseg - 1 ? 1u : 0u;
+        __syncthreads();
+        if (!s_last) continue;  // uniform
+        __threadfence();        // see the other segments' sums
+        fold_partials(e, partials, base, 0, LONG_SEG, nseg);
         if (threadIdx.x < 4) store_coord(buckets + (size_t)k * XW, threadIdx.x, load_coord(e, threadIdx.x));
         if (threadIdx.x == 0) long_done[item - seg] = 0;  // ready for the next call
     }
