@@ -99,9 +99,7 @@ bool trace_enabled() {
 // (MSM_HIP_TRACE / MSM_HIP_ROCTX are per process; MSM_HIP_DEVICES / MSM_HIP_MULTI_VERIFY belong to msm_multi_create.)
 struct Knobs {
     size_t glv_max = msmplan::GLV_MAX_POINTS;  // MSM_HIP_GLV_MAX_LOG2
-    uint32_t chunk_len = 0;                    // MSM_HIP_CHUNK_LEN: longest piece (pieces form) / entries per k_accumulate thread (chunk form); 0 = by size
-    bool acc_chunks = false;                   // MSM_HIP_ACC_CHUNKS=1: round 1-3's fixed-length chunks + k_combine instead of pieces sorted by length (A/B)
-    int chunk_rounds = 1;                      // MSM_HIP_CHUNK_ROUNDS=0: keep the power-of-two chunk length (no fitting to whole rounds of workgroups)
+    uint32_t piece_len = 0;                    // MSM_HIP_PIECE_LEN: longest whole bucket = split length of k_accumulate_pieces' work items; 0 = by size (tests force 1, 7, 26, 35)
     bool direct_scatter = false;               // MSM_HIP_DIRECT_SCATTER: skip the two-level LDS sort
     uint32_t device_chunk_log2 = 22;           // MSM_HIP_DEVICE_CHUNK_LOG2: point ranges of device-resident instances; 0 = never cut
     uint32_t stream_min_log2 = 19;             // MSM_HIP_STREAM_MIN_LOG2: host calls are streamed from this size on
@@ -126,12 +124,8 @@ struct Knobs {
             return e && *e && *e != '0';
         };
         k.glv_max = msmplan::glv_max_from_env();
-        {
-            const long v = num("MSM_HIP_CHUNK_LEN", 0, 1 << 30, 0);
-            k.chunk_len = v >= 1 && v <= 4096 ? (uint32_t)v : 0u;
-        }
+        k.piece_len = (uint32_t)num("MSM_HIP_PIECE_LEN", 0, msmk::PIECE_BINS, 0);
         k.direct_scatter = std::getenv("MSM_HIP_DIRECT_SCATTER") != nullptr;
-        k.acc_chunks = on("MSM_HIP_ACC_CHUNKS");
         k.device_chunk_log2 = (uint32_t)num("MSM_HIP_DEVICE_CHUNK_LOG2", 0, 30, 22);
         k.stream_min_log2 = (uint32_t)num("MSM_HIP_STREAM_MIN_LOG2", 9, 31, 19);
         k.stream_chunk_log2 = std::getenv("MSM_HIP_STREAM_CHUNK_LOG2") ? (uint32_t)num("MSM_HIP_STREAM_CHUNK_LOG2", 8, 28, 0) : 0u;
@@ -144,7 +138,6 @@ struct Knobs {
             k.pair8_lanes = v == 1 || v == 2 || v == 4 ? (uint32_t)v : 0u;
         }
         if (const char* e = std::getenv("MSM_HIP_BATCH_COPY")) k.batch_copy_own = e[0] == '0';
-        if (const char* e = std::getenv("MSM_HIP_CHUNK_ROUNDS")) k.chunk_rounds = e[0] != '0';
         if (const char* e = std::getenv("MSM_HIP_LANE_PRIORITY")) k.lane_priority = !strcmp(e, "high") ? 2 : !strcmp(e, "normal") ? 0 : 1;
         k.table.c = (uint32_t)num("MSM_HIP_TABLE_C", 0, 20, 0);
         k.table.f = (uint32_t)num("MSM_HIP_TABLE_F", 0, 128, 0);
@@ -162,7 +155,6 @@ struct msm_ctx {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;     // host->HBM uploads and base conversion beside the sort
     uint32_t num_cus = 0;                  // compute units of the device (rounds of k_accumulate workgroups)
-    uint32_t acc_wgs_per_cu = 3;           // resident k_accumulate workgroups per CU (hipOccupancyMaxActiveBlocksPerMultiprocessor at creation)
     hipEvent_t ev_body = nullptr;          // batch: behind k_combine on the shared stream; the bucket reduction waits for it on another
     uint32_t tuned_layout[2] = {0, 0};     // msm_tune_batch: the measured MSM_BATCH_LAYOUT_* per size class (below / from 2^19 points); 0 = not tuned
     uint32_t last_batch_layout = 0;        // what the last batch call ran under (msm_timings_t.batch_layout)
@@ -175,9 +167,9 @@ struct msm_ctx {
     std::string err;
     hipEvent_t ev[EV_COUNT]{};
     // HBM workspace
-    DevBuf bases, ibases, inf, scalars, digits, ranks, sorted, hist, offsets, blocksums, buckets, heads, tails, chunkmap, rc, flags,
-        pow2, tilecounts, longlist, longdone, midlist, oncelist, ccounts, cregion, bigslot, big,
-        phist, pcursor, pbase, plist, partials;  // pieces form of the accumulation (k_piece_count / _scatter, k_accumulate_pieces, k_combine_pieces)
+    DevBuf bases, ibases, inf, scalars, digits, ranks, sorted, hist, offsets, blocksums, buckets, sorttmp, rc, flags,
+        pow2, tilecounts, longlist, longdone, midlist, ccounts, cregion, bigslot, big,
+        phist, pcursor, pbase, plist, partials;  // the accumulation's work items (k_piece_count / _scatter, k_accumulate_pieces, k_combine_pieces)
     std::mutex batch_mu;           // batch on one compute stream: a whole MSM is enqueued at a time
     bool batch_shared_stream = false;
     std::mutex copy_mu;            // batch: the two pipelines' scalar uploads take turns (see resident_on_lane)
@@ -251,6 +243,7 @@ struct DevTmp {
 };
 
 static_assert(msmplan::GLV_SPLIT_BITS == (uint32_t)glv::SPLIT_BITS, "planner and GLV split disagree");
+static_assert(msmplan::PIECE_BINS_MAX == msmk::PIECE_BINS, "planner and piece sort disagree");
 using msmplan::make_plan;
 using msmplan::table_top_shift;
 // the plan of a call on n points under this context's configuration and knobs (+ per-call extra flags)
@@ -310,23 +303,20 @@ struct PipeState {
     // b = q * 2^rkb + b'); the host adds q * 2^rkb * (plain sum of pseudo-window q) back in (host_finish).  rW = sW << pw_bits.
     uint32_t rW = 0, rkb = 0, pw_bits = 0, kb_lo = 0, kb_hi = 0, n_lo = 0, n_hi = 0;
     size_t pairs = 0, tb = 0;  // sorted entries at most (= W * n = sW * sn), buckets in all (= sW * nb)
-    uint32_t chunk_len = 0;
-    size_t nchunks_max = 0;
-    // pieces form: a piece is a whole bucket or at most pmax entries of a longer one
-    bool pieces = false;
-    uint32_t pmax = 0;
+    // k_accumulate_pieces' work items: a whole bucket of at most pmax entries, or a run of psplit entries of a longer one
+    uint32_t pmax = 0, psplit = 0;
     size_t maxpieces = 0, maxpartials = 0;
 };
 
 
 // plan + workspace.  May reallocate buffers (hipFree synchronises the device), so with chunks in flight it must not grow
 // anything: the first chunk of a streamed MSM is the largest.
-// fixed_chunk_len != 0: a later chunk / point range of an instance whose FIRST (largest) piece was prepared with that k_accumulate chunk
-// length -- the length is fixed once per instance, so that a smaller piece can never need more chunks (heads, tails, chunk map, lists)
-// than the workspace sized for the first one holds (a shorter fitted length on a smaller last piece could outgrow the 12.5 %
-// slack of ensure() and make it reallocate -- a device synchronisation -- with chunks in flight).
+// first != nullptr: a later chunk / point range of an instance whose FIRST (largest) one was prepared as *first -- the piece lengths are
+// fixed once per instance, so that a smaller chunk can never need more pieces or partial-sum slots than the workspace sized for the first
+// one holds (lengths re-derived per chunk could outgrow the 12.5 % slack of ensure() and make it reallocate -- a device
+// synchronisation -- with chunks in flight).
 int32_t pipe_prepare(msm_ctx* c, size_t n_real, size_t plan_n, uint32_t extra_flags, hipStream_t st, PipeState* ps, uint32_t table_c = 0,
-                     uint32_t table_f = 1, uint32_t fixed_chunk_len = 0) {
+                     uint32_t table_f = 1, const PipeState* first = nullptr) {
     if (trace_enabled() && c->flags_clean) c->t_prepare = std::chrono::steady_clock::now();  // (flags_clean: first prepare of a call)
     if (n_real > 0x3FFFFFFFull) return fail(c, MSM_ERR_BAD_ARG, "n = %zu exceeds 2^30-1 points per context call", n_real);
     // (a table call re-derives the plan its upload made: same width, and the split wherever make_table_plan allowed it -- the caller
@@ -355,55 +345,25 @@ int32_t pipe_prepare(msm_ctx* c, size_t n_real, size_t plan_n, uint32_t extra_fl
     ps->kb_lo = ps->rkb / 2, ps->kb_hi = ps->rkb - ps->kb_lo;  // bucket index inside a (pseudo-)window = hi * n_lo + lo
     ps->n_lo = 1u << ps->kb_lo, ps->n_hi = 1u << ps->kb_hi;
     const uint32_t ntiles = (uint32_t)((tb + msmk::SCAN_TILE - 1) / msmk::SCAN_TILE);
-    // sorted entries folded by one k_accumulate thread: ~2^19 chunks per call (2.7 rounds of the 196608 threads that
-    // 3 wavefronts/SIMD hold) keep the tail short, and the chunk grows with N so that buckets (mean n / nb entries)
-    // are cut into few pieces for k_combine.  Measured sweep at N = 2^20: L = 32 (profiles/NOTES_r1.md).
-    // 16 from 2^13 points up (8 loses there: more buckets are cut 3+ times than the finer granularity wins back); tiny instances
-    // (<= 2^17 sorted entries: a quarter of the SIMDs would hold a wavefront at 16) take 8: 0.262 vs 0.296 ms at 2^10
-    // (round 2, tools/chunk_len_sweep.py: up to 2^21 sorted entries -- 2^17 points with the GLV split -- L = 8 beats 16 by ~20 us:
-    // 2^16 0.403 vs 0.425 ms, 2^17 0.490 vs 0.509; from 2^22 entries on 16 wins because the buckets cut three and more times
-    // cost k_combine more than the finer granularity saves in k_accumulate)
-    // -- only where buckets are short, though: 2^14 points on c = 10 windows (64 entries per bucket) turn every bucket into a long one)
-    // (round 2, after the planner moved 2^14 and 2^15 points to c = 16: one or two entries per bucket there, and L = 4 fills
-    // twice the lanes: 2^14 0.329 -> 0.307 ms, 2^15 0.347 -> 0.341)
-    const size_t occ = ps->sn / nb;  // mean entries per bucket
-    uint32_t chunk_len = (pairs <= ((size_t)1 << 17) || (pairs <= ((size_t)1 << 21) && occ <= 8)) ? (occ <= 2 && pairs > ((size_t)1 << 17) ? 4 : 8) : 16;
-    // ... and from there the chunk follows the mean bucket occupancy n/nb (32 at 2^20 unsplit, 64 with the GLV split: measured
-    // 1.728 ms at L = 32 against 1.698 at 64), as long as ~2^17 chunks remain to fill the chip
-    while (chunk_len < 1024 && chunk_len < occ && pairs / (chunk_len * 2) >= 131072) chunk_len *= 2;
-    // (round 3, one shared array of a split window table at 2^17 points: 64 entries per bucket in 2^21 sorted entries -- at L = 16 every
-    // bucket is cut three times and k_combine's listed-bucket path costs more than the half-filled SIMDs of L = 32: single resident calls
-    // 0.493-0.508 -> 0.462-0.476 ms; at 2^16 (32 per bucket) and 2^18 (L = 32 already) nothing changes: profiles/r3_table_chunk_len.txt)
-    if (pairs <= ((size_t)1 << 21) && chunk_len * 4 <= occ && pairs / (chunk_len * 2) >= 65536) chunk_len *= 2;
-    if (c->knobs.chunk_rounds) chunk_len = msmplan::fit_chunk_to_rounds(pairs, chunk_len, c->num_cus, c->acc_wgs_per_cu);
-    if (fixed_chunk_len) chunk_len = fixed_chunk_len;
-    if (c->knobs.chunk_len) chunk_len = c->knobs.chunk_len;  // MSM_HIP_CHUNK_LEN at context creation (any value >= 1 is correct)
-    // PIECES (round 4, default): work items are whole buckets, or runs of at most pmax entries of the buckets that are longer than that --
-    // 4 x the mean occupancy, so uniform scalars never split one (the short top window of an unsplit plan holds ~2.7 x the mean) -- sorted by
-    // length.  pmax also stays small enough that an instance made of long buckets only (tiny windows, skewed scalars) still yields ~2^17 pieces.
-    ps->pieces = !c->knobs.acc_chunks;
-    if (ps->pieces) {
-        uint32_t pmax = (uint32_t)std::min<size_t>(msmk::PIECE_BINS, std::max<size_t>(32, 4 * occ));
-        while (pmax > 8 && pairs / pmax < 131072) pmax /= 2;
-        if (fixed_chunk_len) pmax = fixed_chunk_len;
-        if (c->knobs.chunk_len) pmax = std::min<uint32_t>(c->knobs.chunk_len, msmk::PIECE_BINS);  // MSM_HIP_CHUNK_LEN (tests force 1, 7, 26, 35)
-        ps->pmax = chunk_len = pmax;
-        ps->maxpieces = std::min(pairs, tb + pairs / pmax) + 1;
-        ps->maxpartials = std::min(pairs, 2 * (pairs / pmax) + 2) + 1;
+    // k_accumulate_pieces' work items (msmplan::make_piece_plan): whole buckets up to pmax entries, runs of psplit entries of longer ones
+    {
+        msmplan::piece_plan fp;
+        if (first) fp.pmax = first->pmax, fp.psplit = first->psplit;
+        const msmplan::piece_plan pp = msmplan::make_piece_plan(pairs, ps->sn / nb, tb, c->knobs.piece_len, first ? &fp : nullptr);
+        ps->pmax = pp.pmax, ps->psplit = pp.psplit, ps->maxpieces = pp.max_pieces, ps->maxpartials = pp.max_partials;
     }
-    ps->chunk_len = chunk_len;
-    const size_t nchunks_max = ps->nchunks_max = ps->pieces ? ps->maxpartials : (pairs + chunk_len - 1) / chunk_len;
+    const size_t maxpartials = ps->maxpartials;
     if ((rc = ensure(c, c->digits, pairs * 4))) return rc;
     if ((rc = ensure(c, c->sorted, pairs * 4))) return rc;
     if ((rc = ensure(c, c->hist, tb * 4))) return rc;
     if ((rc = ensure(c, c->offsets, (tb + 1) * 4))) return rc;
     if ((rc = ensure(c, c->blocksums, ((size_t)ntiles + 1) * 4))) return rc;
     if ((rc = ensure(c, c->buckets, tb * XB))) return rc;
-    if (ps->pieces) {
-        if ((rc = ensure(c, c->heads, pairs * 4))) return rc;  // stages the 2-level sort
-        if ((rc = ensure(c, c->partials, ps->maxpartials * XB))) return rc;
-        if ((rc = ensure(c, c->plist, ps->maxpieces * 16))) return rc;
-        if ((rc = ensure(c, c->pbase, tb * 4))) return rc;
+    if ((rc = ensure(c, c->sorttmp, pairs * 4))) return rc;  // stages the two-level sort
+    if ((rc = ensure(c, c->partials, maxpartials * XB))) return rc;
+    if ((rc = ensure(c, c->plist, ps->maxpieces * 16))) return rc;
+    if ((rc = ensure(c, c->pbase, tb * 4))) return rc;
+    {
         const bool fresh = !c->phist.p || !c->pcursor.p;
         if ((rc = ensure(c, c->phist, (msmk::PIECE_BINS + 1) * 4))) return rc;
         if ((rc = ensure(c, c->pcursor, (msmk::PIECE_BINS + 1) * 4))) return rc;
@@ -411,20 +371,15 @@ int32_t pipe_prepare(msm_ctx* c, size_t n_real, size_t plan_n, uint32_t extra_fl
             HIPCHK(c, hipMemsetAsync(c->phist.p, 0, c->phist.cap, st));
             HIPCHK(c, hipMemsetAsync(c->pcursor.p, 0, c->pcursor.cap, st));
         }
-    } else {
-        if ((rc = ensure(c, c->heads, nchunks_max * XB > pairs * 4 ? nchunks_max * XB : pairs * 4))) return rc;  // also stages the 2-level sort
-        if ((rc = ensure(c, c->tails, nchunks_max * XB))) return rc;
-        if ((rc = ensure(c, c->chunkmap, nchunks_max * 4))) return rc;
     }
-    {   // a long bucket owns >= LONG_SPAN chunks and gets one (bucket, segment) entry per LONG_SEG pieces
-        const size_t entries = nchunks_max / msmk::LONG_SPAN + nchunks_max / msmk::LONG_SEG + 32;
+    {   // a long bucket owns >= LONG_SPAN partial sums and gets one (bucket, segment) entry per LONG_SEG of them
+        const size_t entries = maxpartials / msmk::LONG_SPAN + maxpartials / msmk::LONG_SEG + 32;
         if ((rc = ensure(c, c->longlist, entries * 8))) return rc;
         const size_t had = c->longdone.cap;
         if ((rc = ensure(c, c->longdone, entries * 4))) return rc;
         if (c->longdone.cap != had) HIPCHK(c, hipMemsetAsync(c->longdone.p, 0, c->longdone.cap, st));  // self-cleaning afterwards
     }
-    if ((rc = ensure(c, c->midlist, (nchunks_max / 2 + 16) * 4))) return rc;                  // a listed bucket owns >= 2 chunk borders
-    if (!ps->pieces && (rc = ensure(c, c->oncelist, (std::min(nchunks_max, tb) + 16) * 4))) return rc;  // a once-cut bucket owns one chunk border
+    if ((rc = ensure(c, c->midlist, (maxpartials / 2 + 16) * 4))) return rc;  // a listed bucket owns >= 2 partial sums
     if ((rc = ensure(c, c->rc, (tb + tb / 2 + 4) * XB))) return rc;  // two families x (1/2 + 1/4) ping-pong levels
     if ((rc = ensure(c, c->flags, 64))) return rc;
     return MSM_OK;
@@ -523,7 +478,7 @@ int32_t enqueue_sort(msm_ctx* c, const PipeState& ps, hipStream_t st, bool into)
         uint32_t* counts = (uint32_t*)c->ccounts.p;
         uint32_t* rtotal = (uint32_t*)c->cregion.p;
         uint32_t* rstart = rtotal + nregions;
-        uint32_t* tmp = (uint32_t*)c->heads.p;  // staging copy; k_accumulate only writes heads later
+        uint32_t* tmp = (uint32_t*)c->sorttmp.p;  // staging copy of the two-level sort
         msmk::k_coarse_hist<<<dim3(NS, sW), msmk::TILE_BLOCK, 0, st>>>(digits, counts, (uint32_t)sn, fine_bits, ncoarse, NS, flags);
         msmk::k_coarse_prefix<<<grid1(nregions, msmk::PREFIX_REGIONS), 1024, 0, st>>>(counts, rtotal, NS, ncoarse, nregions);
         // regions too large for one workgroup's staging area are cut into batches that worker blocks share (skewed scalars)
@@ -577,16 +532,11 @@ int32_t enqueue_sort(msm_ctx* c, const PipeState& ps, hipStream_t st, bool into)
         }
     }
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_SORT], st));
-    if (ps.pieces) {  // the piece list, longest first (k_accumulate_pieces zeroes the histogram and the cursors again)
-        msmk::k_piece_count<<<grid1(tb, 1024), 1024, 0, st>>>(offsets, (uint32_t)tb, ps.pmax, (uint32_t*)c->phist.p, flags, (uint32_t*)c->longlist.p,
-                                                            (uint32_t*)c->midlist.p, (uint32_t*)c->pbase.p, (uint32_t*)c->buckets.p, into ? 1u : 0u);
-        msmk::k_piece_scatter<<<grid1(tb, 1024), 1024, 0, st>>>(offsets, (uint32_t)tb, ps.pmax, (const uint32_t*)c->phist.p, (uint32_t*)c->pcursor.p,
-                                                              (const uint32_t*)c->pbase.p, (uint4*)c->plist.p, flags);
-        return MSM_OK;
-    }
-    msmk::k_chunk_map<<<grid1(tb, 1024), 1024, 0, st>>>(offsets, (uint32_t*)c->chunkmap.p, (uint32_t)tb, ps.chunk_len, flags,
-                                                      (uint32_t*)c->longlist.p, (uint32_t*)c->midlist.p, (uint32_t*)c->oncelist.p,
-                                                      (uint32_t*)c->buckets.p, into ? 1u : 0u);  // accumulating INTO the buckets
+    // the piece list, longest first (k_accumulate_pieces zeroes the histogram and the cursors again)
+    msmk::k_piece_count<<<grid1(tb, 1024), 1024, 0, st>>>(offsets, (uint32_t)tb, ps.pmax, ps.psplit, (uint32_t*)c->phist.p, flags, (uint32_t*)c->longlist.p,
+                                                        (uint32_t*)c->midlist.p, (uint32_t*)c->pbase.p, (uint32_t*)c->buckets.p, into ? 1u : 0u);
+    msmk::k_piece_scatter<<<grid1(tb, 1024), 1024, 0, st>>>(offsets, (uint32_t)tb, ps.pmax, ps.psplit, (const uint32_t*)c->phist.p, (uint32_t*)c->pcursor.p,
+                                                          (const uint32_t*)c->pbase.p, (uint4*)c->plist.p, flags);
     return MSM_OK;
 }
 
@@ -607,37 +557,20 @@ int32_t enqueue_accumulate(msm_ctx* c, const PipeState& ps, const uint32_t* d_ba
     Range r_("msm:accumulate");
     uint32_t* flags = (uint32_t*)c->flags.p;
     uint32_t* offsets = (uint32_t*)c->offsets.p;
-    const size_t tb = ps.tb;
     if (bases_ready) HIPCHK(c, hipStreamWaitEvent(st, bases_ready, 0));  // d_bases is being converted on another stream
     HIPCHK(c, hipEventRecord(c->ev[EV_ACC0], st));
-    if (ps.pieces) {
-        const dim3 gp = grid1(ps.maxpieces, 256);
-        const uint32_t *srt_ = (const uint32_t*)c->sorted.p, *np = flags + msmk::FLAG_ONCE;
-        const uint4* pl_ = (const uint4*)c->plist.p;
-        uint32_t *bk_ = (uint32_t*)c->buckets.p, *pt = (uint32_t*)c->partials.p, *hs = (uint32_t*)c->phist.p, *cu = (uint32_t*)c->pcursor.p;
-        unsigned long long* clk_ = (unsigned long long*)c->clk.p;
-        if (into) msmk::k_accumulate_pieces<true, true><<<gp, 256, 0, st>>>(d_bases, srt_, pl_, np, bk_, pt, hs, cu, ps.pmax, clk_);
-        else if (chunked) msmk::k_accumulate_pieces<false, true><<<gp, 256, 0, st>>>(d_bases, srt_, pl_, np, bk_, pt, hs, cu, ps.pmax, clk_);
-        else msmk::k_accumulate_pieces<false, false><<<gp, 256, 0, st>>>(d_bases, srt_, pl_, np, bk_, pt, hs, cu, ps.pmax, clk_);
-        HIPCHK(c, hipEventRecord(c->ev[EV_ACC1], st));
-        msmk::k_combine_pieces<<<dim3(msmk::LONG_BLOCKS + msmk::MID_BLOCKS), 512, 0, st>>>(
-            offsets, pt, bk_, ps.pmax, (const uint32_t*)c->pbase.p, flags + msmk::FLAG_MID, (const uint32_t*)c->midlist.p, flags + msmk::FLAG_LONG,
-            (const uint32_t*)c->longlist.p, (uint32_t*)c->longdone.p);
-        return MSM_OK;
-    }
-    const dim3 ga = grid1(ps.nchunks_max, 256);  // (64- and 128-thread workgroups: no difference at any size, tools/env_sweep.py)
-    const uint32_t *srt = (const uint32_t*)c->sorted.p, *cm = (const uint32_t*)c->chunkmap.p, *tp = flags + msmk::FLAG_PAIRS;
-    uint32_t *bk = (uint32_t*)c->buckets.p, *hd = (uint32_t*)c->heads.p, *tl = (uint32_t*)c->tails.p;
+    const dim3 gp = grid1(ps.maxpieces, 256);  // (threads beyond the number of pieces, known on the device only, leave at once)
+    const uint32_t *srt = (const uint32_t*)c->sorted.p, *np = flags + msmk::FLAG_PIECES;
+    const uint4* pl = (const uint4*)c->plist.p;
+    uint32_t *bk = (uint32_t*)c->buckets.p, *pt = (uint32_t*)c->partials.p, *hs = (uint32_t*)c->phist.p, *cu = (uint32_t*)c->pcursor.p;
     unsigned long long* clk = (unsigned long long*)c->clk.p;  // clock probe of the launch's first workgroup (msm_get_clock_stats)
-    if (into) msmk::k_accumulate<true, true><<<ga, 256, 0, st>>>(d_bases, srt, offsets, cm, bk, hd, tl, tp, ps.chunk_len, (uint32_t)tb, clk);
-    else if (chunked) msmk::k_accumulate<false, true><<<ga, 256, 0, st>>>(d_bases, srt, offsets, cm, bk, hd, tl, tp, ps.chunk_len, (uint32_t)tb, clk);
-    else msmk::k_accumulate<false, false><<<ga, 256, 0, st>>>(d_bases, srt, offsets, cm, bk, hd, tl, tp, ps.chunk_len, (uint32_t)tb, clk);
+    if (into) msmk::k_accumulate_pieces<true, true><<<gp, 256, 0, st>>>(d_bases, srt, pl, np, bk, pt, hs, cu, ps.pmax, clk);
+    else if (chunked) msmk::k_accumulate_pieces<false, true><<<gp, 256, 0, st>>>(d_bases, srt, pl, np, bk, pt, hs, cu, ps.pmax, clk);
+    else msmk::k_accumulate_pieces<false, false><<<gp, 256, 0, st>>>(d_bases, srt, pl, np, bk, pt, hs, cu, ps.pmax, clk);
     HIPCHK(c, hipEventRecord(c->ev[EV_ACC1], st));
-    const size_t once_max = std::min(ps.nchunks_max, tb);  // a once-cut bucket owns one chunk border
-    msmk::k_combine<<<dim3(msmk::LONG_BLOCKS + msmk::MID_BLOCKS + (unsigned)((once_max + 511) / 512)), 512, 0, st>>>(
-        offsets, (uint32_t*)c->heads.p, (uint32_t*)c->tails.p, (uint32_t*)c->buckets.p, ps.chunk_len, flags + msmk::FLAG_MID,
-        (uint32_t*)c->midlist.p, flags + msmk::FLAG_ONCE, (uint32_t*)c->oncelist.p, flags + msmk::FLAG_LONG, (uint32_t*)c->longlist.p,
-        (uint32_t*)c->longdone.p);
+    msmk::k_combine_pieces<<<dim3(msmk::LONG_BLOCKS + msmk::MID_BLOCKS), 512, 0, st>>>(
+        offsets, pt, bk, ps.pmax, ps.psplit, (const uint32_t*)c->pbase.p, flags + msmk::FLAG_MID, (const uint32_t*)c->midlist.p, flags + msmk::FLAG_LONG,
+        (const uint32_t*)c->longlist.p, (uint32_t*)c->longdone.p);
     return MSM_OK;
 }
 
@@ -772,9 +705,9 @@ void trace_line(const msm_ctx* c, const char* entry, const PipeState& ps) {
     if (!trace_enabled()) return;
     const msm_timings_t& t = c->tm;
     std::fprintf(stderr,
-                 "[msm_hip] %s dev %d n %zu c %u W %u nb %u glv %u sort_path %u chunk_len %u stream_chunks %u | h2d %.3f convert %.3f "
+                 "[msm_hip] %s dev %d n %zu c %u W %u nb %u glv %u sort_path %u pieces <= %u / split %u stream_chunks %u | h2d %.3f convert %.3f "
                  "decompose %.3f sort %.3f accumulate %.3f reduce %.3f finish %.3f total %.3f ms (host enqueue %.3f ms), %llu adds\n",
-                 entry, c->device, (size_t)t.num_points, ps.cbits, ps.W, ps.nb, ps.pl.glv, c->last_sort_path, ps.chunk_len, t.stream_chunks,
+                 entry, c->device, (size_t)t.num_points, ps.cbits, ps.W, ps.nb, ps.pl.glv, c->last_sort_path, ps.pmax, ps.psplit, t.stream_chunks,
                  t.h2d_ms, t.convert_ms, t.decompose_ms, t.sort_ms, t.accumulate_ms, t.reduce_ms, t.finish_ms, t.total_ms,
                  c->enqueue_ms, (unsigned long long)t.num_adds);
 }
@@ -839,11 +772,11 @@ int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, 
     const size_t dchunk = dev_chunk_log2 ? (size_t)1 << dev_chunk_log2 : 0;
     if (table_f <= 1 && dchunk && n >= 2 * dchunk && !plan_glv(c, n, extra_flags)) {
         if ((rc = pipe_prepare(c, dchunk, n, extra_flags, st, &ps))) return rc;
-        const uint32_t range_chunk_len = ps.chunk_len;  // fixed by the first, largest range
+        const PipeState ps_first = ps;  // piece lengths: fixed by the first, largest range
         uint32_t nch = 0;
         for (size_t lo = 0; lo < n; lo += dchunk, nch++) {
             const size_t cnt = std::min(dchunk, n - lo);
-            if ((rc = pipe_prepare(c, cnt, n, extra_flags, st, &ps, 0, 1, range_chunk_len))) return rc;
+            if ((rc = pipe_prepare(c, cnt, n, extra_flags, st, &ps, 0, 1, &ps_first))) return rc;
             if ((rc = enqueue_digits_sort(c, ps, d_inf ? d_inf + lo : nullptr, d_scalars + lo * 8, scalars_mont, st, lo == 0))) return rc;
             if ((rc = enqueue_accumulate(c, ps, d_bases + lo * 16, st, lo == 0 ? bases_ready : nullptr, lo > 0, true))) return rc;
         }
@@ -1006,7 +939,7 @@ int32_t run_streamed(msm_ctx* c, const HostInput& in, size_t n, const std::vecto
     hipStream_t st = c->stream, cs = c->copy_stream;
     PipeState ps;
     if ((rc = pipe_prepare(c, chunk, n, 0, st, &ps))) return rc;  // workspace for the largest chunk before anything is in flight
-    const uint32_t stream_chunk_len = ps.chunk_len;                // k_accumulate's chunk length: fixed by the largest chunk
+    const PipeState ps_first = ps;                                 // piece lengths: fixed by the largest chunk
     size_t lo = 0;
     for (size_t j = 0; j < sizes.size(); j++) {
         const int s = (int)(j & 1);
@@ -1024,7 +957,7 @@ int32_t run_streamed(msm_ctx* c, const HostInput& in, size_t n, const std::vecto
         // carries the infinity flags inside the base records, which k_decompose reads: there the sort waits for the whole chunk.)
         const bool early_sort = in.kind != KIND_ARK;
         HIPCHK(c, hipStreamWaitEvent(st, early_sort ? c->ev_scal[s] : c->ev_copied[s], 0));
-        if ((rc = pipe_prepare(c, cnt, n, 0, st, &ps, 0, 1, stream_chunk_len))) return rc;
+        if ((rc = pipe_prepare(c, cnt, n, 0, st, &ps, 0, 1, &ps_first))) return rc;
         if ((rc = enqueue_digits_sort(c, ps, d_inf, (const uint32_t*)c->sscalars[s].p, in.scalars_mont, st, j == 0))) return rc;
         if ((rc = enqueue_accumulate(c, ps, (const uint32_t*)c->sibases[s].p, st, early_sort ? c->ev_copied[s] : nullptr, j > 0, true))) return rc;
         HIPCHK(c, hipEventRecord(c->ev_free[s], st));
@@ -1176,12 +1109,6 @@ static int32_t ctx_create_impl(const msm_config_t* cfg, msm_ctx** out, int main_
         e = least != greatest ? hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, greatest)
                               : hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
     }
-    if (e == hipSuccess) {
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)msmk::k_accumulate<false, false>, 256, 0) == hipSuccess && per_cu > 0)
-            c->acc_wgs_per_cu = (uint32_t)per_cu;
-        (void)hipGetLastError();
-    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_bases, hipEventDisableTiming);
     for (int i = 0; i < 2 && e == hipSuccess; i++) {
@@ -1256,7 +1183,7 @@ void msm_ctx_destroy(msm_ctx* c) {
         if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
         DevBuf* bufs[] = {&c->bases,   &c->inf,       &c->scalars, &c->digits,  &c->ranks,  &c->sorted, &c->hist,
                           &c->offsets, &c->blocksums, &c->buckets, &c->rc,      &c->flags,  &c->pow2,
-                          &c->heads,   &c->tails,     &c->chunkmap, &c->tilecounts, &c->ibases, &c->longlist, &c->longdone, &c->midlist, &c->oncelist, &c->ccounts, &c->cregion, &c->bigslot, &c->big,
+                          &c->sorttmp, &c->tilecounts, &c->ibases, &c->longlist, &c->longdone, &c->midlist, &c->ccounts, &c->cregion, &c->bigslot, &c->big,
                           &c->rbases,  &c->rinf,      &c->clk,     &c->phist,   &c->pcursor, &c->pbase,  &c->plist,  &c->partials};
         for (DevBuf* b : bufs) release(*b);
         if (c->h_qsums) (void)hipHostFree(c->h_qsums);

@@ -6,8 +6,8 @@
 //   K2 transpose (ONE thread per window, serial 2N+C loop) -> two-level counting sort in LDS: k_coarse_hist, k_coarse_prefix,
 //        k_coarse_starts, k_coarse_scatter, k_fine_sort (fallbacks: k_tile_* for n > 2^24, device-scope atomics in
 //        k_decompose + k_scan_* + k_scatter for windows of more than 2^17 buckets)
-//   K3 smvp (full 16-mul Jacobian add, one thread per bucket pair) -> k_chunk_map, k_accumulate (XYZZ mixed add over
-//        fixed-length chunks), k_combine (buckets cut by chunk borders: once / 3+ times / long, one launch)
+//   K3 smvp (full 16-mul Jacobian add, one thread per bucket pair) -> k_piece_count + k_piece_scatter (work items = whole buckets,
+//        sorted by length), k_accumulate_pieces (XYZZ mixed add, one thread per piece), k_combine_pieces (buckets split by skew)
 //   K4/K5 bpr_stage_1/2 -> k_pair_level / k_pair_level_wide (row/column plain sums, dense pairwise levels) +
 //        k_reduce_bits_wide (per-bit sums, LDS trees of eight-lane additions; k_reduce_bits = the one-lane fallback)
 //   final_reduction (CPU) -> stays on the CPU: host_g1.hpp
@@ -21,7 +21,8 @@
 //   offsets  W*nb + 1 exclusive prefix sum of bucket sizes == CSC column pointer of the reference
 //   sorted   W x n    point index | sign<<31 grouped by bucket        == val_idxs of the reference
 //   buckets  W*nb x 36  XYZZ bucket sums, 4 coordinates x 9 limbs of 29 bits (144 B);
-//   heads/tails  ceil(n*W/L) x 36  partial sums of buckets cut by chunk borders
+//   plist    pieces x 4     (bucket, first sorted entry, length | flags, partial slot), longest pieces first
+//   partials  x 36          partial sums of buckets longer than 4 x the mean occupancy (skewed scalars only)
 #pragma once
 #include "ec_bn254.hpp"
 #include "ec_wide.hpp"
@@ -36,9 +37,8 @@ constexpr int SCALAR_BITS = 254;
 
 constexpr int XW = 36;  // words per XYZZ record in HBM: 4 coordinates x 9 limbs
 // flags (u32 words, one set per context): [0] error bits  [4] sorted entries of this (chunk of an) MSM  [6,7] running 64-bit total of
-// sorted entries over the chunks of a streamed MSM  [8] long-list entries  [9] mid-list entries  [10] once-cut-list entries
-constexpr uint32_t FLAG_ERR = 0, FLAG_PAIRS = 4, FLAG_ADDS64 = 6, FLAG_LONG = 8, FLAG_MID = 9, FLAG_ONCE = 10, FLAG_PARTIALS = 11;
-// (pieces form of the accumulation: FLAG_ONCE holds the number of pieces, FLAG_PARTIALS the partial-sum slots reserved by split buckets)
+// sorted entries over the chunks of a streamed MSM  [8] long-list entries  [9] mid-list entries  [10] pieces  [11] partial-sum slots
+constexpr uint32_t FLAG_ERR = 0, FLAG_PAIRS = 4, FLAG_ADDS64 = 6, FLAG_LONG = 8, FLAG_MID = 9, FLAG_PIECES = 10, FLAG_PARTIALS = 11;
 
 // packed 8-word field element (canonical value) -> 9 x 29-bit limbs
 __device__ __forceinline__ fp load_fp_packed(const uint32_t* p) {
@@ -92,24 +92,6 @@ __device__ __forceinline__ void store_xyzz(uint32_t* p, const xyzz& v) {
     uint4* q = reinterpret_cast<uint4*>(p);
 #pragma unroll
     for (int i = 0; i < XW / 4; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
-}
-// streaming variants (experiment ACC_NT): the record is written once and read once by a later kernel, the index stream is read once
-typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store_xyzz_nt(uint32_t* p, const xyzz& v) {
-    uint32_t w[XW];
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-        w[i] = v.x.v[i];
-        w[9 + i] = v.y.v[i];
-        w[18 + i] = v.zz.v[i];
-        w[27 + i] = v.zzz.v[i];
-    }
-    v4u32* q = reinterpret_cast<v4u32*>(p);
-#pragma unroll
-    for (int i = 0; i < XW / 4; i++) {
-        v4u32 t = {w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]};
-        __builtin_nontemporal_store(t, q + i);
-    }
 }
 // one coordinate (0 = X, 1 = Y, 2 = ZZ, 3 = ZZZ) of an XYZZ record, HBM or LDS
 __device__ __forceinline__ fp load_coord(const uint32_t* rec, uint32_t coord) {
@@ -390,7 +372,7 @@ __global__ void k_decompose(const uint32_t* __restrict__ scalars, const uint8_t*
                             uint32_t* __restrict__ digits, uint32_t* __restrict__ ranks, uint32_t* __restrict__ err,
                             uint32_t scalars_mont, uint32_t top_shift) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) err[FLAG_LONG] = 0, err[FLAG_MID] = 0, err[FLAG_ONCE] = 0, err[FLAG_PARTIALS] = 0;  // list counters of this (chunk of an) MSM: k_chunk_map / k_piece_count fill them later in the stream
+    if (i == 0) err[FLAG_LONG] = 0, err[FLAG_MID] = 0, err[FLAG_PIECES] = 0, err[FLAG_PARTIALS] = 0;  // list counters of this (chunk of an) MSM: k_piece_count fills them later in the stream
     if (i >= n) return;
     const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
     uint4 a = sp[0], b = sp[1];
@@ -444,7 +426,7 @@ __global__ void k_decompose_glv(const uint32_t* __restrict__ scalars, const uint
                                 uint32_t W, uint32_t* __restrict__ digits, uint32_t* __restrict__ err, uint32_t scalars_mont,
                                 uint32_t top_shift) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) err[FLAG_LONG] = 0, err[FLAG_MID] = 0, err[FLAG_ONCE] = 0, err[FLAG_PARTIALS] = 0;  // list counters of this (chunk of an) MSM: k_chunk_map / k_piece_count fill them later in the stream
+    if (i == 0) err[FLAG_LONG] = 0, err[FLAG_MID] = 0, err[FLAG_PIECES] = 0, err[FLAG_PARTIALS] = 0;  // list counters of this (chunk of an) MSM: k_piece_count fills them later in the stream
     if (i >= n) return;
     const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
     uint4 a = sp[0], b = sp[1];
@@ -645,9 +627,9 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_coarse_hist(const uint32_t* __re
                                                             uint32_t* __restrict__ flags) {
     __shared__ uint32_t s_h[COARSE_BINS_MAX];
     const uint32_t st = blockIdx.x, w = blockIdx.y;
-    // list counters of THIS sort call (k_chunk_map fills them later in the stream; k_decompose zeroes them too -- kept here so that a
+    // list counters of THIS sort call (k_piece_count fills them later in the stream; k_decompose zeroes them too -- kept here so that a
     // sort never depends on which kernel ran before it)
-    if (st == 0 && w == 0 && threadIdx.x == 0) flags[FLAG_LONG] = 0, flags[FLAG_MID] = 0, flags[FLAG_ONCE] = 0, flags[FLAG_PARTIALS] = 0;
+    if (st == 0 && w == 0 && threadIdx.x == 0) flags[FLAG_LONG] = 0, flags[FLAG_MID] = 0, flags[FLAG_PIECES] = 0, flags[FLAG_PARTIALS] = 0;
     if (threadIdx.x < COARSE_BINS_MAX) s_h[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t i0 = st * SUBTILE, i1 = min(n, i0 + SUBTILE);
@@ -1056,318 +1038,48 @@ __global__ void k_scatter(const uint32_t* __restrict__ digits, const uint32_t* _
 }
 
 // ---------------------------------------------------------------------------------------------
-// K3: bucket accumulation.  The sorted (point, sign) array is cut into fixed-length CHUNKS of L entries and
-// every thread folds exactly one chunk, so all 64 lanes of a wavefront run the same number of mixed adds
-// whatever the bucket-size distribution is (Poisson sizes, the short top window whose buckets are ~5x
-// longer, or adversarial inputs with one huge bucket).  The reference gives one thread a whole bucket pair
-// (smvp.metal:46-71) and serialises on the longest.
-//   * a bucket lying inside one chunk is written straight to buckets[k];
-//   * a bucket cut by chunk borders leaves partial sums: tails[t] (it starts in chunk t and runs on) and
-//     heads[t] (it started before chunk t); k_combine adds them: B_k = tails[t0] + heads[t0+1] + ... + heads[t1].
-// Each point is gathered as one 64-byte affine record and folded into an XYZZ accumulator in registers.
-
-// chunk_bucket[t] = bucket that owns sorted entry t*L  (one thread per bucket writes the chunks it starts)
-// Buckets cut into LONG_SPAN or more chunks (tiny top windows, adversarial scalars) are listed for k_combine's long workgroups,
-// buckets cut into 3..LONG_SPAN-1 chunks for k_combine_mid; k_combine itself only meets buckets cut once, so that
-// every one of its wavefronts runs exactly one XYZZ add (a few 3-chunk buckets per wavefront used to double its time).
-constexpr uint32_t LONG_SPAN = 8;
-constexpr uint32_t LONG_SEG = 2048;  // pieces of a long bucket folded by one long workgroup of k_combine
-__global__ void __launch_bounds__(1024) k_chunk_map(const uint32_t* __restrict__ offsets, uint32_t* __restrict__ chunk_bucket,
-                                                   uint32_t total_buckets, uint32_t L, uint32_t* __restrict__ flags,
-                                                   uint32_t* __restrict__ long_list, uint32_t* __restrict__ mid_list,
-                                                   uint32_t* __restrict__ once_list, uint32_t* __restrict__ buckets, uint32_t into) {
-    uint32_t* const long_count = flags + FLAG_LONG;
-    uint32_t* const mid_count = flags + FLAG_MID;
-    uint32_t* const once_count = flags + FLAG_ONCE;
-    __shared__ uint32_t s_n[3], s_base[3];  // [0] mid, [1] long, [2] cut once: list slots are reserved once per workgroup
-    if (threadIdx.x < 3) s_n[threadIdx.x] = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0)  // mixed additions executed so far (msm_timings_t.num_adds), all chunks of a streamed MSM
-        *reinterpret_cast<unsigned long long*>(flags + FLAG_ADDS64) += (unsigned long long)flags[FLAG_PAIRS];
-    __syncthreads();
-    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t kindl = 3, slot = 0, nseg = 1;  // 0 = mid list, 1 = long list, 2 = once-cut list, 3 = none
-    if (k < total_buckets) {
-        uint32_t beg = offsets[k], end = offsets[k + 1];
-        if (beg != end) {
-            uint32_t tf = (beg + L - 1) / L, tl = (end - 1) / L;
-            const uint32_t span = tl - beg / L;  // chunk borders inside the bucket; the bucket has span + 1 pieces
-            if (span >= LONG_SPAN) {
-                kindl = 1;
-                nseg = (span + 1 + LONG_SEG - 1) / LONG_SEG;
-            } else if (span >= 2) {
-                kindl = 0;
-            } else if (span == 1) {
-                kindl = 2;
-            }
-            for (uint32_t t = tf; t <= tl; t++) chunk_bucket[t] = k;
-        } else if (!into) {
-            store_xyzz(buckets + (size_t)k * XW, xyzz_identity());  // empty bucket (into: it keeps the earlier chunks' sum)
-        }
-    }
-    if (kindl < 3) slot = atomicAdd(&s_n[kindl], nseg);  // LDS
-    __syncthreads();
-    if (threadIdx.x == 0 && s_n[0]) s_base[0] = atomicAdd(mid_count, s_n[0]);
-    if (threadIdx.x == 1 && s_n[1]) s_base[1] = atomicAdd(long_count, s_n[1]);
-    if (threadIdx.x == 2 && s_n[2]) s_base[2] = atomicAdd(once_count, s_n[2]);
-    __syncthreads();
-    if (kindl == 0) {
-        mid_list[s_base[0] + slot] = k;
-    } else if (kindl == 2) {
-        once_list[s_base[2] + slot] = k;
-    } else if (kindl == 1) {  // one entry per LONG_SEG pieces: (bucket, segment | first entry of the bucket)
-        for (uint32_t j = 0; j < nseg; j++) {
-            long_list[2 * (size_t)(s_base[1] + slot + j)] = k;
-            long_list[2 * (size_t)(s_base[1] + slot + j) + 1] = j;
-        }
-    }
-}
-
-// INTO = true (chunks 2.. of a streamed MSM, run_streamed): the bucket array already holds the sums of the earlier chunks; the
-// thread in whose chunk a bucket STARTS folds the old value in (it becomes the first term of that bucket's first piece), and
-// k_combine leaves buckets that this chunk does not touch alone.  One reduction and one host finish per MSM, however many chunks.
-// CHUNK only names the launch: the chunks of a streamed host call (first: <false, true>, later: <true, true>) show up in a
-// kernel trace under their own symbols, apart from the whole-MSM launch <false, false> that bench.py times and grades.
-template <bool INTO, bool CHUNK>
-__global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
-                                                    const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ chunk_bucket,
-                                                    uint32_t* __restrict__ buckets, uint32_t* __restrict__ heads,
-                                                    uint32_t* __restrict__ tails, const uint32_t* __restrict__ total_pairs_ptr,
-                                                    uint32_t L, uint32_t total_buckets, unsigned long long* __restrict__ clk) {
-    const uint32_t total_pairs = *total_pairs_ptr;  // non-zero digits, known only on the device (k_scan_block_sums)
-    // Clock probe (msm_get_clock_stats): the first workgroup of every launch brackets its own chunk with the shader-cycle counter
-    // (s_memtime: counts at whatever frequency the device sustains) and the constant-rate counter (s_memrealtime); the ratio of the two
-    // deltas is the shader clock the kernel really ran at, and the cycle delta says whether two boxes execute the same instruction
-    // stream in the same number of cycles.  Both values live in scalar registers; the cost is two atomics per launch.
-    const bool probe = blockIdx.x == 0;
-    long long clk_c0 = 0, clk_w0 = 0;
-    if (probe) clk_c0 = clock64(), clk_w0 = wall_clock64();
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t j0 = t * L;
-    if (j0 >= total_pairs) return;
-    uint32_t j1 = min(total_pairs, j0 + L);
-    uint32_t k = chunk_bucket[t];
-    uint32_t seg_end = offsets[k + 1];
-    bool is_head = offsets[k] < j0;  // the first bucket of this chunk began in an earlier chunk
-    xyzz acc = xyzz_identity();
-    if (INTO && !is_head) acc = load_xyzz(buckets + (size_t)k * XW);
-    // Software pipeline: the 64-byte record of entry j+1, the index of entry j+2 and a bucket end two buckets ahead are in flight
-    // while entry j is folded.  Only ONE raw record is kept: it is unpacked to 29-bit limbs before the next gather is issued.
-    // Round 3: every one of these loads is UNCONDITIONAL and is issued at the top of the iteration, IN FRONT of the bucket switch and
-    // its stores (the last entry of a chunk fetches its own record once more, indices are clamped).  gfx950 counts loads and stores
-    // with ONE in-order counter (vmcnt): a wait on any load also waits for every memory instruction issued before it.  The compiler
-    // used to close the conditional prefetch with register copies of the freshly loaded words (s_waitcnt vmcnt(1) a few instructions
-    // after the gather was issued, in every iteration), and the bucket switch waited for offsets[k + 1] -- and with it for the gather
-    // issued just before, then for its own nine 16-byte stores.  That put the whole memory latency on the critical path of the
-    // wavefront in ~9 of 10 iterations (some lane switches buckets); with a window table (832 MB of records instead of 64 MB that live
-    // in the Infinity Cache) that latency is HBM's.  Now a switch reads registers only -- seg_end and end1 = offsets[k + 2] are kept
-    // one bucket ahead, refilled from the load `ahead` = offsets[k + 3] of the iteration before -- and the only waits sit at the top
-    // of an iteration, one whole mixed addition after everything was issued.
-#ifdef ACC_NT
-#define ACC_LD_SORTED(i) __builtin_nontemporal_load(sorted + (i))
-#define ACC_STORE store_xyzz_nt
-#else
-#define ACC_LD_SORTED(i) sorted[i]
-#define ACC_STORE store_xyzz
-#endif
-    uint32_t e_cur = ACC_LD_SORTED(j0);
-    uint32_t e_nxt = ACC_LD_SORTED(min(j0 + 1, j1 - 1));
-    uint32_t end1 = offsets[min(k + 2, total_buckets)];  // seg_end of the bucket after this one
-    uint32_t ahead = 0;                                     // offsets[k + 3] as of the previous iteration: the next end1 after a switch
-    bool switched = false;
-    uint4 g[4];
-    {
-        const uint4* bp = reinterpret_cast<const uint4*>(bases + (size_t)(e_cur & ~SIGN_BIT) * 16);
-#pragma unroll
-        for (int i = 0; i < 4; i++) g[i] = bp[i];
-    }
-#ifdef ACC_PF2  // experiment: the record of entry j+2 is in flight as well (16 more VGPRs)
-    uint4 g2[4];
-    uint32_t e_nn = ACC_LD_SORTED(min(j0 + 2, j1 - 1));
-    {
-        const uint4* bp = reinterpret_cast<const uint4*>(bases + (size_t)(e_nxt & ~SIGN_BIT) * 16);
-#pragma unroll
-        for (int i = 0; i < 4; i++) g2[i] = bp[i];
-    }
-#endif
-    for (uint32_t j = j0; j < j1; j++) {
-        affine q;
-        {
-            uint32_t wx[8] = {g[0].x, g[0].y, g[0].z, g[0].w, g[1].x, g[1].y, g[1].z, g[1].w};
-            uint32_t wy[8] = {g[2].x, g[2].y, g[2].z, g[2].w, g[3].x, g[3].y, g[3].z, g[3].w};
-            q.x = fp_unpack(wx);
-            q.y = fp_unpack(wy);
-        }
-        if (e_cur & SIGN_BIT) q.y = fp_neg_raw<2>(q.y);  // raw: only ever a multiplier in xyzz_madd
-        if (switched) end1 = ahead;                      // the previous iteration moved to bucket k: its offsets[k_old + 3] is offsets[k + 2]
-#ifdef ACC_PF2
-#pragma unroll
-        for (int i = 0; i < 4; i++) g[i] = g2[i];        // record of entry j+1 (loaded one iteration ago)
-        {
-            const uint4* bp = reinterpret_cast<const uint4*>(bases + (size_t)(e_nn & ~SIGN_BIT) * 16);
-#pragma unroll
-            for (int i = 0; i < 4; i++) g2[i] = bp[i];   // record of entry j+2
-        }
-        const uint32_t e_n3 = ACC_LD_SORTED(min(j + 3, j1 - 1));
-#else
-        {
-            const uint4* bp = reinterpret_cast<const uint4*>(bases + (size_t)(e_nxt & ~SIGN_BIT) * 16);
-#pragma unroll
-            for (int i = 0; i < 4; i++) g[i] = bp[i];
-        }
-        const uint32_t e_nn = ACC_LD_SORTED(min(j + 2, j1 - 1));
-#endif
-        ahead = offsets[min(k + 3, total_buckets)];
-        switched = false;
-        if (j == seg_end) {  // bucket k is finished: flush and move to the bucket that owns entry j
-            ACC_STORE((is_head ? heads + (size_t)t * XW : buckets + (size_t)k * XW), acc);
-            k++;
-            seg_end = end1;  // == offsets[k + 1]
-            switched = true;
-            if (seg_end <= j) {  // empty buckets follow: binary-search the bucket that owns entry j (skewed scalars
-                                 // leave thousands of empty buckets between two occupied ones)
-                uint32_t lo = k + 1, hi = total_buckets - 1;
-                while (lo < hi) {
-                    uint32_t mid = (lo + hi) >> 1;
-                    if (offsets[mid + 1] > j) hi = mid;
-                    else lo = mid + 1;
-                }
-                k = lo;
-                seg_end = offsets[k + 1];
-                end1 = offsets[min(k + 2, total_buckets)];
-                switched = false;  // `ahead` belongs to the bucket we left
-                // the rare path waits for its own loads HERE: left pending, they make the compiler wait at the join below -- on the
-                // common path too, where that wait covers the gather and the stores just issued
-                asm volatile("" ::"v"(seg_end), "v"(end1));
-            }
-            is_head = false;
-            if (INTO) acc = load_xyzz(buckets + (size_t)k * XW);
-            else acc = xyzz_identity();
-        }
-        xyzz_madd(acc, q);
-        e_cur = e_nxt;
-        e_nxt = e_nn;
-#ifdef ACC_PF2
-        e_nn = e_n3;
-#endif
-    }
-    uint32_t* dst = is_head ? heads + (size_t)t * XW : (seg_end == j1 ? buckets + (size_t)k * XW : tails + (size_t)t * XW);
-    ACC_STORE(dst, acc);
-#undef ACC_LD_SORTED
-#undef ACC_STORE
-    if (probe && threadIdx.x == 0) {  // [0] shader cycles, [1] constant-rate ticks, [2] samples, [3] mixed additions of the sampled thread
-        atomicAdd(clk + 0, (unsigned long long)(clock64() - clk_c0));
-        atomicAdd(clk + 1, (unsigned long long)(wall_clock64() - clk_w0));
-        atomicAdd(clk + 2, 1ull);
-        atomicAdd(clk + 3, (unsigned long long)(j1 - j0));
-    }
-}
-
-// Long buckets (cut into LONG_SPAN or more pieces: tiny top windows, skewed scalars).  Pieces e(0) = tails[t0],
-// e(i) = heads[t0+i].  One 512-thread workgroup per SEGMENT of LONG_SEG pieces: staged in LDS (more than 256: threads
-// 0..255 first fold strided, scalar) and folded by a pairwise tree of WIDE additions.  A bucket of several segments
-// (one bucket holding most of a window) is finished by whichever of its workgroups arrives last: segment sums are
-// parked in the segment's first piece, a device-scope counter per bucket tells the last one (threadfence reduction).
-__device__ __forceinline__ const uint32_t* long_piece(const uint32_t* heads, const uint32_t* tails, uint32_t t0, uint32_t i) {
-    return i == 0 ? tails + (size_t)t0 * XW : heads + (size_t)(t0 + i) * XW;
-}
-// fold pieces first, first+stride, ... (count of them) into e[0]; whole workgroup
-__device__ __forceinline__ void long_fold(uint32_t* e, const uint32_t* heads, const uint32_t* tails, uint32_t t0, uint32_t first,
-                                          uint32_t stride, uint32_t count) {
-    constexpr uint32_t CAP = WIDE_TREE_MAX;
-    __syncthreads();  // e is reused
-    if (count <= CAP) {
-        for (uint32_t i = threadIdx.x >> 2; i < count; i += blockDim.x >> 2) {
-            const uint32_t co = threadIdx.x & 3u;
-            store_coord(e + (size_t)i * XW, co, load_coord(long_piece(heads, tails, t0, first + i * stride), co));
-        }
-    } else if (threadIdx.x < CAP) {
-        xyzz acc = xyzz_identity();
-#pragma unroll 1
-        for (uint32_t i = threadIdx.x; i < count; i += CAP) acc = xyzz_add(acc, load_xyzz(long_piece(heads, tails, t0, first + i * stride)));
-        store_xyzz(e + (size_t)threadIdx.x * XW, acc);
-    }
-    lds_tree_wide(e, count < CAP ? count : CAP);
-}
-// ONE launch for every bucket cut by chunk borders, three kinds of 512-thread workgroups -- the ones with the longest dependent chains
-// come FIRST in the grid and run beside the single-add bulk instead of after it:
-//   blockIdx <  LONG_BLOCKS              : long buckets (LONG_SPAN or more pieces), one workgroup per (bucket, segment) item, grid-stride
-//   next MID_BLOCKS workgroups           : one thread per LISTED bucket (cut into 3..LONG_SPAN-1 chunks), grid-stride over the list
-//   the rest                             : one thread per bucket of the ONCE-CUT list: tails[t0] + heads[t1].  The list (k_chunk_map) makes
-//                                          these wavefronts dense -- with one thread per bucket ~40 % of the lanes idled through the addition
-// (Round 3: the long buckets had a launch of their own, k_combine_long -- 5 us per MSM for a list that is empty on uniform scalars.)
-constexpr uint32_t LONG_BLOCKS = 512, MID_BLOCKS = 128;
-__global__ void __launch_bounds__(512) k_combine(const uint32_t* __restrict__ offsets, uint32_t* __restrict__ heads, uint32_t* __restrict__ tails,
-                                                 uint32_t* __restrict__ buckets, uint32_t L, const uint32_t* __restrict__ mid_count,
-                                                 const uint32_t* __restrict__ mid_list, const uint32_t* __restrict__ once_count,
-                                                 const uint32_t* __restrict__ once_list, const uint32_t* __restrict__ long_count,
-                                                 const uint32_t* __restrict__ long_list, uint32_t* __restrict__ long_done) {
-    if (blockIdx.x >= LONG_BLOCKS) {
-        const uint32_t b = blockIdx.x - LONG_BLOCKS;
-        if (b < MID_BLOCKS) {
-            const uint32_t nmid = *mid_count;
-            for (uint32_t i = b * blockDim.x + threadIdx.x; i < nmid; i += MID_BLOCKS * blockDim.x) {
-                const uint32_t k = mid_list[i];
-                const uint32_t t0 = offsets[k] / L, t1 = (offsets[k + 1] - 1) / L;
-                xyzz acc = load_xyzz(tails + (size_t)t0 * XW);
-                for (uint32_t t = t0 + 1; t <= t1; t++) acc = xyzz_add(acc, load_xyzz(heads + (size_t)t * XW));
-                store_xyzz(buckets + (size_t)k * XW, acc);
-            }
-            return;
-        }
-        const uint32_t i = (b - MID_BLOCKS) * blockDim.x + threadIdx.x;
-        if (i >= *once_count) return;
-        const uint32_t k = once_list[i];
-        const uint32_t t0 = offsets[k] / L;
-        store_xyzz(buckets + (size_t)k * XW, xyzz_add(load_xyzz(tails + (size_t)t0 * XW), load_xyzz(heads + (size_t)(t0 + 1) * XW)));
-        return;
-    }
-    __shared__ uint32_t e[WIDE_TREE_MAX * XW];
-    __shared__ uint32_t s_last;
-    const uint32_t nlong = *long_count;
-    for (uint32_t item = blockIdx.x; item < nlong; item += LONG_BLOCKS) {
-        const uint32_t k = long_list[2 * (size_t)item], seg = long_list[2 * (size_t)item + 1];
-        const uint32_t beg = offsets[k], end = offsets[k + 1];
-        const uint32_t t0 = beg / L, t1 = (end - 1) / L;
-        const uint32_t cnt = t1 - t0 + 1, nseg = (cnt + LONG_SEG - 1) / LONG_SEG;
-        const uint32_t first = seg * LONG_SEG, count = min(LONG_SEG, cnt - first);
-        long_fold(e, heads, tails, t0, first, 1, count);
-        if (nseg == 1) {
-            if (threadIdx.x < 4) store_coord(buckets + (size_t)k * XW, threadIdx.x, load_coord(e, threadIdx.x));
-            continue;
-        }
-        // park the segment sum in the segment's first piece (only this workgroup ever read it), then count in
-        uint32_t* park = const_cast<uint32_t*>(long_piece(heads, tails, t0, first));
-        if (threadIdx.x < 4) store_coord(park, threadIdx.x, load_coord(e, threadIdx.x));
-        __threadfence();
-        __syncthreads();
-        if (threadIdx.x == 0) s_last = atomicAdd(&long_done[item - seg], 1u) == nseg - 1 ? 1u : 0u;
-        __syncthreads();
-        if (!s_last) continue;  // uniform
-        __threadfence();        // see the other segments' sums
-        long_fold(e, heads, tails, t0, 0, LONG_SEG, nseg);
-        if (threadIdx.x < 4) store_coord(buckets + (size_t)k * XW, threadIdx.x, load_coord(e, threadIdx.x));
-        if (threadIdx.x == 0) long_done[item - seg] = 0;  // ready for the next call
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// K3, second form (round 4): PIECES SORTED BY LENGTH instead of fixed-length chunks.
+// K3: bucket accumulation (round 4 form: PIECES SORTED BY LENGTH).
 //
-// The chunk form above gives every thread exactly L sorted entries, whatever buckets they belong to.  That balances any distribution,
-// but (i) almost every bucket is cut by a chunk border (mean bucket = L entries at 2^20 points), so k_combine has to add ~one pair of
-// partial sums per bucket (54 us at 2^20, 46 us at 2^17) after heads and tails travelled through HBM, and (ii) the launch is 1.33 rounds
-// of identical workgroups, whose last wavefront per SIMD runs alone for a whole chunk (measured round 4, tools/ab_libs.py chunk sweep:
-// 2.47 Mcycles at L = 64 against 2.28 at L = 22, where k_combine then costs 0.44 ms instead of 0.20).
-// Here a work item is a PIECE: a whole bucket, or -- only for buckets longer than `pmax` entries (4 x the mean occupancy: skewed scalars,
-// never uniform ones) -- a run of at most pmax entries of one.  The pieces are counting-sorted by length, longest first, so the 64 lanes
-// of a wavefront run the same trip count (the property the chunks were built for), the long items start first and the launch ends on its
-// shortest ones (LPT order), a bucket that is one piece is written straight to its slot, and nothing is left to combine on uniform
-// scalars.  Split buckets leave partial sums in `partials` and are listed for k_combine_pieces exactly like cut buckets were for k_combine
+// Rounds 1-3 cut the sorted (point, sign) array into fixed-length CHUNKS of L entries, one per thread, whatever buckets they belonged to
+// (the reference gives one thread a whole bucket pair, smvp.metal:46-71, and serialises on the longest).  That balances any distribution,
+// but (i) almost every bucket is cut by a chunk border (mean bucket = L entries at 2^20 points), so a k_combine pass had to add ~one pair
+// of partial sums per bucket (54 us at 2^20, 46 us at 2^17) after heads and tails travelled through HBM, and (ii) the launch was 1.33 rounds
+// of identical workgroups, whose last wavefront per SIMD ran alone for a whole chunk (tools/ab_libs.py chunk sweep, profiles/
+// r4_pieces_vs_chunks.txt: 2.47 Mcycles at L = 64 against 2.28 at L = 22, where k_combine then cost 0.44 ms instead of 0.20).
+// Here a work item is a PIECE: a whole bucket, or a part of one that is longer than `pmax` entries (2 x the mean occupancy: the buckets of a
+// plan's short top window, which hold 2-4 x the mean, become runs of pmax and a short rest; on uniform scalars nothing else is cut) -- runs
+// of pmax up to 8 x pmax, runs of `psplit` entries beyond (skewed scalars: psplit plays the part the chunk length used to, short enough that
+// an instance made of long buckets only still yields ~2^19 pieces and that the longest item of an under-filled launch does not run alone
+// for long).  pmax must stay well below a SIMD lane's share of the launch (256 entries at 2^20): the resident workgroups of the first
+// round are placed three per CU whatever their lengths, and with whole top-window buckets of ~128-175 entries among ordinary ones of ~64
+// the heaviest CUs carried 13 % more than the mean (2.78 against 2.43 Mcycles, profiles/r4_pieces_vs_chunks.txt).  The pieces are counting-sorted by
+// length, longest first, so the 64 lanes of a wavefront run the same trip count (the property the chunks were built for), the long items
+// start first and the launch ends on its shortest ones (LPT order), a bucket that is one piece is written straight to its slot, and
+// nothing is left to combine on uniform scalars.  Split buckets leave partial sums in `partials` and are listed for k_combine_pieces
 // (2..7 pieces: one thread per bucket; 8 or more: LDS trees of eight-lane additions per 2048-piece segment).
-constexpr uint32_t PIECE_BINS = 1024;                 // pmax <= PIECE_BINS: one histogram bin per piece length
+// Measured against the chunk form, same build, one box (profiles/r4_pieces_vs_chunks.txt): 2^20 1.557 -> 1.488 ms, 2^17 0.470 -> 0.440,
+// 2^22 5.32 -> 5.00.
+constexpr uint32_t LONG_SPAN = 8;     // split buckets of this many pieces or more are folded by whole workgroups (k_combine_pieces)
+constexpr uint32_t LONG_SEG = 2048;   // pieces of a long bucket folded by one workgroup
+constexpr uint32_t LONG_BLOCKS = 512, MID_BLOCKS = 128;
+constexpr uint32_t PIECE_BINS = 1024;                 // pmax <= PIECE_BINS: one histogram bin per piece length (== msmplan::PIECE_BINS_MAX)
 constexpr uint32_t PF_WHOLE = 0x80000000u;            // piece.z: the bucket is this one piece -> the sum goes to buckets[k]
 constexpr uint32_t PF_FIRST = 0x40000000u;            // piece.z: first piece of a split bucket (INTO: starts from the bucket's old value)
 constexpr uint32_t PF_LEN_MASK = 0x00FFFFFFu;
+
+// how a bucket of sz entries is cut: 1 piece up to pmax entries; up to LONG_SPAN * pmax entries into runs of pmax and a remainder (the
+// short top window of a plan: buckets of ~2x the mean -> pmax + a short rest, one addition to fold them -- the short rests are what the
+// launch ends on: cut into EQUAL halves instead, the same buckets cost k_accumulate_pieces 2.63 instead of 2.40 Mcycles at 2^20, the
+// smallest items then being ~35 entries long); beyond that into runs of psplit.
+// Returns the number of pieces m; pieces 0 .. m-2 hold *q entries, the last one the rest.
+__device__ __forceinline__ uint32_t piece_split(uint32_t sz, uint32_t pmax, uint32_t psplit, uint32_t* q) {
+    if (sz <= pmax) {
+        *q = sz;
+        return 1u;
+    }
+    *q = sz <= LONG_SPAN * pmax ? pmax : psplit;
+    return (sz + *q - 1) / *q;
+}
 
 // exclusive scan over the 1024 threads of a workgroup (v -> sum of the values of lower threads); *total = sum of all
 __device__ __forceinline__ uint32_t block1024_exclusive_scan(uint32_t v, uint32_t* s_wsum /* 16 words of LDS */, uint32_t* total) {
@@ -1393,7 +1105,7 @@ __device__ __forceinline__ uint32_t block1024_exclusive_scan(uint32_t v, uint32_
 
 // pass 1: histogram of the piece lengths (LDS per workgroup, one global add per non-empty bin), the identity for empty buckets, a run of
 // partial-sum slots and a list entry for every split bucket.  One thread per bucket.
-__global__ void __launch_bounds__(1024) k_piece_count(const uint32_t* __restrict__ offsets, uint32_t total_buckets, uint32_t pmax,
+__global__ void __launch_bounds__(1024) k_piece_count(const uint32_t* __restrict__ offsets, uint32_t total_buckets, uint32_t pmax, uint32_t psplit,
                                                      uint32_t* __restrict__ hist, uint32_t* __restrict__ flags, uint32_t* __restrict__ long_list,
                                                      uint32_t* __restrict__ mid_list, uint32_t* __restrict__ pbase, uint32_t* __restrict__ buckets,
                                                      uint32_t into) {
@@ -1411,12 +1123,13 @@ __global__ void __launch_bounds__(1024) k_piece_count(const uint32_t* __restrict
         if (sz == 0) {
             if (!into) store_xyzz(buckets + (size_t)k * XW, xyzz_identity());  // (into: the bucket keeps the earlier chunks' sum)
         } else {
-            m = (sz + pmax - 1) / pmax;
+            uint32_t q;
+            m = piece_split(sz, pmax, psplit, &q);
             if (m == 1) {
                 atomicAdd(&s_hist[sz], 1u);
             } else {
-                atomicAdd(&s_hist[pmax], m - 1);
-                atomicAdd(&s_hist[sz - (m - 1) * pmax], 1u);
+                atomicAdd(&s_hist[q], m - 1);
+                atomicAdd(&s_hist[sz - (m - 1) * q], 1u);
                 pbase[k] = atomicAdd(flags + FLAG_PARTIALS, m);  // device-scope, split buckets only
                 if (m >= LONG_SPAN) {
                     kindl = 1;
@@ -1447,7 +1160,7 @@ __global__ void __launch_bounds__(1024) k_piece_count(const uint32_t* __restrict
 // pass 2: the piece list, longest pieces first.  Every workgroup derives the bins' start positions from the global histogram (an
 // exclusive prefix in DESCENDING length order), reserves its share of every bin with one device-scope add per non-empty bin and places
 // its pieces with LDS cursors.  piece = (bucket, first sorted entry, length | flags, partial slot).
-__global__ void __launch_bounds__(1024) k_piece_scatter(const uint32_t* __restrict__ offsets, uint32_t total_buckets, uint32_t pmax,
+__global__ void __launch_bounds__(1024) k_piece_scatter(const uint32_t* __restrict__ offsets, uint32_t total_buckets, uint32_t pmax, uint32_t psplit,
                                                        const uint32_t* __restrict__ hist, uint32_t* __restrict__ cursor,
                                                        const uint32_t* __restrict__ pbase, uint4* __restrict__ plist, uint32_t* __restrict__ flags) {
     __shared__ uint32_t s_start[PIECE_BINS + 1], s_cnt[PIECE_BINS + 1], s_cur[PIECE_BINS + 1];
@@ -1458,19 +1171,19 @@ __global__ void __launch_bounds__(1024) k_piece_scatter(const uint32_t* __restri
         uint32_t total;
         const uint32_t ex = block1024_exclusive_scan(h, s_wsum, &total);
         if (len) s_start[len] = ex;
-        if (blockIdx.x == 0 && threadIdx.x == 0) flags[FLAG_ONCE] = total;  // number of pieces: k_accumulate_pieces' trip count
+        if (blockIdx.x == 0 && threadIdx.x == 0) flags[FLAG_PIECES] = total;  // number of pieces: k_accumulate_pieces' trip count
     }
     for (uint32_t i = threadIdx.x; i <= pmax; i += blockDim.x) s_cnt[i] = 0, s_cur[i] = 0;
     __syncthreads();
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t beg = 0, sz = 0, m = 0, rem = 0;
+    uint32_t beg = 0, sz = 0, m = 0, rem = 0, q = 0;
     if (k < total_buckets) {
         beg = offsets[k];
         sz = offsets[k + 1] - beg;
         if (sz) {
-            m = (sz + pmax - 1) / pmax;
-            rem = sz - (m - 1) * pmax;
-            if (m > 1) atomicAdd(&s_cnt[pmax], m - 1);
+            m = piece_split(sz, pmax, psplit, &q);
+            rem = sz - (m - 1) * q;  // (m == 1: q == sz, rem == sz)
+            if (m > 1) atomicAdd(&s_cnt[q], m - 1);
             atomicAdd(&s_cnt[rem], 1u);
         }
     }
@@ -1483,14 +1196,14 @@ __global__ void __launch_bounds__(1024) k_piece_scatter(const uint32_t* __restri
         plist[pos] = make_uint4(k, beg, sz | PF_WHOLE, 0u);
     } else if (m > 1) {
         const uint32_t pb = pbase[k];
-        uint32_t pos = s_start[pmax] + atomicAdd(&s_cur[pmax], m - 1);  // the m - 1 full pieces: one reservation
-        for (uint32_t p = 0; p + 1 < m; p++) plist[pos + p] = make_uint4(k, beg + p * pmax, pmax | (p == 0 ? PF_FIRST : 0u), pb + p);
+        uint32_t pos = s_start[q] + atomicAdd(&s_cur[q], m - 1);  // the m - 1 full pieces: one reservation
+        for (uint32_t p = 0; p + 1 < m; p++) plist[pos + p] = make_uint4(k, beg + p * q, q | (p == 0 ? PF_FIRST : 0u), pb + p);
         pos = s_start[rem] + atomicAdd(&s_cur[rem], 1u);
-        plist[pos] = make_uint4(k, beg + (m - 1) * pmax, rem, pb + m - 1);
+        plist[pos] = make_uint4(k, beg + (m - 1) * q, rem, pb + m - 1);
     }
 }
 
-// one thread per piece: the loop of k_accumulate without bucket switches.  INTO: a whole bucket, or the first piece of a split one, starts
+// one thread per piece, a loop without bucket switches.  INTO: a whole bucket, or the first piece of a split one, starts
 // from the value the bucket holds (earlier chunks of a streamed host call / point ranges of a device-resident instance).
 // Workgroup 0 also zeroes the histogram and the bin cursors for the next plan (they are only read by the two plan kernels, which
 // precede this launch in stream order).
@@ -1500,7 +1213,11 @@ __global__ void __launch_bounds__(256) k_accumulate_pieces(const uint32_t* __res
                                                            uint32_t* __restrict__ buckets, uint32_t* __restrict__ partials,
                                                            uint32_t* __restrict__ hist, uint32_t* __restrict__ cursor, uint32_t pmax,
                                                            unsigned long long* __restrict__ clk) {
-    const bool probe = blockIdx.x == 0;  // clock probe: see k_accumulate
+    // Clock probe (msm_get_clock_stats): the first workgroup of every launch brackets its own pieces with the shader-cycle counter
+    // (s_memtime: counts at whatever frequency the device sustains) and the constant-rate counter (s_memrealtime); the ratio of the two
+    // deltas is the shader clock the kernel really ran at, and the cycle delta says whether two boxes execute the same instruction
+    // stream in the same number of cycles.  Both values live in scalar registers; the cost is four atomics per launch.
+    const bool probe = blockIdx.x == 0;
     long long clk_c0 = 0, clk_w0 = 0;
     if (probe) {
         clk_c0 = clock64(), clk_w0 = wall_clock64();
@@ -1513,8 +1230,12 @@ __global__ void __launch_bounds__(256) k_accumulate_pieces(const uint32_t* __res
     const bool whole = (pc.z & PF_WHOLE) != 0;
     xyzz acc = xyzz_identity();
     if (INTO && (pc.z & (PF_WHOLE | PF_FIRST))) acc = load_xyzz(buckets + (size_t)k * XW);
-    // software pipeline as in k_accumulate: the record of entry j+1 and the index of entry j+2 are in flight while entry j is folded;
-    // every load is unconditional (the last entry fetches its own record once more) and issued at the top of the iteration
+    // Software pipeline: the 64-byte record of entry j+1 and the index of entry j+2 are in flight while entry j is folded; only ONE raw
+    // record is kept, unpacked to 29-bit limbs before the next gather is issued.  Every load is UNCONDITIONAL (the last entry of a piece
+    // fetches its own record once more, indices are clamped) and issued at the top of the iteration: gfx950 counts loads and stores with
+    // ONE in-order counter (vmcnt), and a conditional prefetch used to be closed by the compiler with an s_waitcnt a few instructions
+    // after the gather was issued (round 3, profiles/NOTES_r3.md section 1).  The only wait sits at the top of the next iteration, one
+    // whole mixed addition after everything was issued.
     uint32_t e_cur = sorted[j0];
     uint32_t e_nxt = sorted[min(j0 + 1, j1 - 1)];
     uint4 g[4];
@@ -1551,8 +1272,7 @@ __global__ void __launch_bounds__(256) k_accumulate_pieces(const uint32_t* __res
     }
 }
 
-// Split buckets (longer than pmax entries: skewed scalars, tiny top windows): partial sums partials[pbase[k] .. + m).  ONE launch, the
-// two kinds of k_combine that remain: the leading LONG_BLOCKS workgroups take the long list -- (bucket, segment) items of buckets with
+// Split buckets (longer than pmax entries: skewed scalars, tiny top windows): partial sums partials[pbase[k] .. + m).  ONE launch, two kinds of workgroups: the leading LONG_BLOCKS workgroups take the long list -- (bucket, segment) items of buckets with
 // LONG_SPAN or more pieces: LDS trees of eight-lane additions per 2048-piece segment, the last-arriving workgroup of a bucket folds the
 // segment sums -- the others one bucket of 2..LONG_SPAN-1 pieces per thread.  On uniform scalars both lists are empty.
 __device__ __forceinline__ void fold_partials(uint32_t* e, const uint32_t* partials, uint32_t base, uint32_t first, uint32_t stride,
@@ -1573,7 +1293,7 @@ __device__ __forceinline__ void fold_partials(uint32_t* e, const uint32_t* parti
     lds_tree_wide(e, count < CAP ? count : CAP);
 }
 __global__ void __launch_bounds__(512) k_combine_pieces(const uint32_t* __restrict__ offsets, uint32_t* __restrict__ partials,
-                                                        uint32_t* __restrict__ buckets, uint32_t pmax, const uint32_t* __restrict__ pbase,
+                                                        uint32_t* __restrict__ buckets, uint32_t pmax, uint32_t psplit, const uint32_t* __restrict__ pbase,
                                                         const uint32_t* __restrict__ mid_count, const uint32_t* __restrict__ mid_list,
                                                         const uint32_t* __restrict__ long_count, const uint32_t* __restrict__ long_list,
                                                         uint32_t* __restrict__ long_done) {
@@ -1581,7 +1301,8 @@ __global__ void __launch_bounds__(512) k_combine_pieces(const uint32_t* __restri
         const uint32_t nmid = *mid_count;
         for (uint32_t i = (blockIdx.x - LONG_BLOCKS) * blockDim.x + threadIdx.x; i < nmid; i += MID_BLOCKS * blockDim.x) {
             const uint32_t k = mid_list[i];
-            const uint32_t m = (offsets[k + 1] - offsets[k] + pmax - 1) / pmax, base = pbase[k];
+            uint32_t q;
+            const uint32_t m = piece_split(offsets[k + 1] - offsets[k], pmax, psplit, &q), base = pbase[k];
             xyzz acc = load_xyzz(partials + (size_t)base * XW);
             for (uint32_t p = 1; p < m; p++) acc = xyzz_add(acc, load_xyzz(partials + (size_t)(base + p) * XW));
             store_xyzz(buckets + (size_t)k * XW, acc);
@@ -1593,7 +1314,8 @@ __global__ void __launch_bounds__(512) k_combine_pieces(const uint32_t* __restri
     const uint32_t nlong = *long_count;
     for (uint32_t item = blockIdx.x; item < nlong; item += LONG_BLOCKS) {
         const uint32_t k = long_list[2 * (size_t)item], seg = long_list[2 * (size_t)item + 1];
-        const uint32_t cnt = (offsets[k + 1] - offsets[k] + pmax - 1) / pmax, nseg = (cnt + LONG_SEG - 1) / LONG_SEG, base = pbase[k];
+        uint32_t q;
+        const uint32_t cnt = piece_split(offsets[k + 1] - offsets[k], pmax, psplit, &q), nseg = (cnt + LONG_SEG - 1) / LONG_SEG, base = pbase[k];
         const uint32_t first = seg * LONG_SEG, count = min(LONG_SEG, cnt - first);
         fold_partials(e, partials, base, first, 1, count);
         if (nseg == 1) {

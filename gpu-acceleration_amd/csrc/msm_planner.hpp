@@ -149,34 +149,29 @@ inline uint32_t table_top_shift(const msm_plan_t& pl, uint32_t tf) {
     return top_bits < pl.window_bits - 1 ? pl.window_bits - 1 - top_bits : 0u;
 }
 
-// k_accumulate keeps 3 wavefronts per SIMD (141 VGPRs), i.e. 3 workgroups of 256 threads per CU, and every thread folds the same number L of
-// sorted entries, so the workgroups run in ROUNDS of 3 x CUs; the last, partial round keeps ceil(r / CUs) wavefronts per SIMD busy for a
-// whole chunk (a lone wavefront already fills its SIMD's multiplier).  Wall time in units of one addition of a lone wavefront:
-//     T(L) = L * (3 * full_rounds + ceil(r / CUs))
-// 8 x 2^21 entries at L = 64 are 1024 workgroups = one round + 256: every SIMD busy to the end, T = 256 = entries / lanes, nothing lost --
-// but the 13 x 2^20 entries of a window table at L = 32 are 1664 = two rounds + 128: half the CUs idle through the last chunk (T = 224 against
-// 208), and 2^19 + 12345 points (1049 workgroups) pay a whole extra chunk for 25 workgroups.  The length moves by up to a quarter to the
-// value with the smallest T (ties: closest to L0) -- while the rounds are still rounds (at most three full ones: behind that the workgroups
-// have drifted apart and a shorter chunk only costs k_combine more) and the model promises 2 % or more.  Measured (profiles/
-// r3_chunk_rounds.txt): k_accumulate with the table 2^20 0.883 -> 0.81-0.84 ms, 2^21 1.98-2.00 -> 1.87; device calls on 536 633 points
-// 1.073 -> 0.959 ms, 600 000 1.214 -> 1.039, 3 000 000 3.92 -> 3.75; powers of two without a table were whole rounds already.
-// (per_cu: resident k_accumulate workgroups per CU -- 3 for the 143-VGPR build; the context asks hipOccupancyMaxActiveBlocksPerMultiprocessor)
-inline uint64_t chunk_rounds_cost(size_t pairs, uint32_t L, uint32_t cus, uint32_t per_cu = 3) {
-    const size_t wgs = ((pairs + L - 1) / L + 255) / 256, slots = (size_t)per_cu * cus;
-    return (uint64_t)L * (per_cu * (wgs / slots) + (wgs % slots + cus - 1) / cus);
-}
-inline uint32_t fit_chunk_to_rounds(size_t pairs, uint32_t L0, uint32_t cus, uint32_t per_cu = 3) {
-    if (cus == 0 || per_cu == 0 || L0 < 8 || pairs == 0) return L0;
-    if (((pairs + L0 - 1) / L0 + 255) / 256 / ((size_t)per_cu * cus) > 3) return L0;
-    uint32_t best = L0;
-    uint64_t best_t = chunk_rounds_cost(pairs, L0, cus, per_cu);
-    const uint64_t t0 = best_t;
-    for (uint32_t d = 1; d <= L0 / 4; d++)
-        for (uint32_t L : {L0 - d, L0 + d}) {
-            const uint64_t t = chunk_rounds_cost(pairs, L, cus, per_cu);
-            if (t < best_t) best = L, best_t = t;
-        }
-    return best_t * 100 <= t0 * 98 ? best : L0;
+// Work items of k_accumulate_pieces (msm_kernels.hpp): a bucket of at most pmax entries is ONE piece; a longer one is cut into runs of pmax
+// entries and a rest (up to 8 x pmax) or into runs of psplit entries (beyond).  pmax = 2 x the mean occupancy: Poisson buckets stay whole,
+// the short top window of a plan (2-4 x the mean) is cut into two to four -- whole, those buckets were items of half a SIMD lane's share of
+// the launch and the first round of workgroups, placed three per CU whatever their lengths, left the heaviest CUs 13 % above the mean
+// (profiles/r4_pieces_vs_chunks.txt).  At least 16, at most the 1024 histogram bins of the piece sort.  psplit makes an instance of long
+// buckets only yield ~2^19 pieces (2.7 rounds of resident workgroups), at least 8 entries per piece.  max_pieces / max_partials bound what
+// ANY bucket-size distribution over `pairs` sorted entries and `total_buckets` buckets can produce (workspace sizes).
+constexpr uint32_t PIECE_BINS_MAX = 1024;
+struct piece_plan {
+    uint32_t pmax = 0, psplit = 0;
+    size_t max_pieces = 0, max_partials = 0;
+};
+inline piece_plan make_piece_plan(size_t pairs, size_t mean_occupancy, size_t total_buckets, uint32_t forced_len = 0, const piece_plan* first = nullptr) {
+    piece_plan p;
+    p.pmax = (uint32_t)std::min<size_t>(PIECE_BINS_MAX, std::max<size_t>(16, 2 * mean_occupancy));
+    p.psplit = (uint32_t)std::min<size_t>(p.pmax, std::max<size_t>(8, pairs >> 19));
+    if (first) p.pmax = first->pmax, p.psplit = first->psplit;  // a later chunk of an instance: the lengths of its first, largest chunk
+    if (forced_len) p.pmax = p.psplit = std::min<uint32_t>(forced_len, PIECE_BINS_MAX);
+    // every non-empty bucket is a piece, a split bucket of sz > pmax entries adds at most sz / psplit more (runs of pmax: ceil(sz / pmax) <=
+    // sz / psplit + 1 as well); partial sums: split buckets only (at most sz / psplit + 1 each, and fewer than pairs / pmax buckets can be split)
+    p.max_pieces = std::min(pairs, total_buckets + pairs / p.psplit) + 1;
+    p.max_partials = std::min(pairs, pairs / p.psplit + pairs / ((size_t)p.pmax + 1) + 2) + 1;
+    return p;
 }
 
 }  // namespace msmplan

@@ -510,16 +510,14 @@ def test_resident_bases_with_scalars_in_hbm(hk, flags):
         assert e.value.code == mh.ERR_BAD_ARG
 
 
-@pytest.mark.parametrize("chunk_len", ["1", "7", "26", "35", "rounds-off"])
-def test_chunk_lengths_that_are_not_powers_of_two(monkeypatch, hk, chunk_len):
-    """k_accumulate's fixed-length chunks: the length is fitted to whole rounds of workgroups (13 x 2^k entries of a window table take
-    26 or 35 instead of 32), so every kernel that divides by it (k_chunk_map, k_accumulate, k_combine) sees odd values.  Forced lengths
-    incl. 1 (every bucket with two entries is a cut bucket) and 7, plain + GLV + window table + batch, against the closed form."""
+@pytest.mark.parametrize("chunk_len", ["1", "2", "7", "26", "35", "1024"])
+def test_forced_piece_lengths(monkeypatch, hk, chunk_len):
+    """k_accumulate_pieces' work items: whole buckets up to pmax entries, runs of psplit entries of longer ones, counting-sorted by length
+    (k_piece_count / k_piece_scatter), split buckets folded by k_combine_pieces (2..7 pieces: one thread; 8+: LDS trees, 2048-piece
+    segments).  MSM_HIP_PIECE_LEN forces pmax = psplit: 1 (every entry its own piece, every bucket of two entries split), 2, 7, odd values,
+    and 1024 (the largest bin; the long bucket below is still split) -- plain + GLV + window table + batch, against the closed form."""
     import torch
-    if chunk_len == "rounds-off":
-        monkeypatch.setenv("MSM_HIP_CHUNK_ROUNDS", "0")
-    else:
-        monkeypatch.setenv("MSM_HIP_CHUNK_LEN", chunk_len)
+    monkeypatch.setenv("MSM_HIP_PIECE_LEN", chunk_len)
     n = (1 << 16) + 4321
     dev = torch.device("cuda:0")
     d_bases = torch.empty(n * 16, dtype=torch.int32, device=dev)

@@ -186,30 +186,60 @@ static int check_partitions() {
     return 0;
 }
 
-static int check_chunk_fit() {
-    // whole rounds already: nothing moves
-    REQUIRE(msmplan::fit_chunk_to_rounds((size_t)8 << 21, 64, 256) == 64);
-    REQUIRE(msmplan::fit_chunk_to_rounds((size_t)15 << 21, 32, 256) == 32);
-    // 13 x 2^20 entries of a window table: 1664 workgroups at 32 -> 2048 at 26 (T 224 -> 208 = entries / lanes)
-    REQUIRE(msmplan::fit_chunk_to_rounds((size_t)13 << 20, 32, 256) == 26);
-    REQUIRE(msmplan::chunk_rounds_cost((size_t)13 << 20, 32, 256) == 224 && msmplan::chunk_rounds_cost((size_t)13 << 20, 26, 256) == 208);
-    REQUIRE(msmplan::fit_chunk_to_rounds((size_t)13 << 21, 64, 256) == 52);
-    // more than three full rounds, tiny lengths, unknown device: untouched
-    REQUIRE(msmplan::fit_chunk_to_rounds((size_t)15 * (((size_t)1 << 20) + 1), 16, 256) == 16);
-    REQUIRE(msmplan::fit_chunk_to_rounds((size_t)1 << 16, 4, 256) == 4 && msmplan::fit_chunk_to_rounds((size_t)13 << 20, 32, 0) == 32);
-    // never worse than L0 by its own model, always within a quarter of L0, for a spread of sizes and CU counts
-    for (uint32_t cus : {64u, 104u, 256u, 304u})
-        for (size_t pairs = 1000; pairs < ((size_t)1 << 27); pairs = pairs * 5 / 3 + 17)
-            for (uint32_t L0 : {8u, 16u, 32u, 64u, 128u}) {
-                const uint32_t L = msmplan::fit_chunk_to_rounds(pairs, L0, cus);
-                REQUIRE(L >= L0 - L0 / 4 && L <= L0 + L0 / 4);
-                REQUIRE(msmplan::chunk_rounds_cost(pairs, L, cus) <= msmplan::chunk_rounds_cost(pairs, L0, cus));
+static int check_piece_plan() {
+    // the BASELINE shape: 8 windows x 2^21 entries over 8 x 32768 buckets (mean 64): whole buckets up to 128 entries, runs of 32
+    {
+        const msmplan::piece_plan p = msmplan::make_piece_plan((size_t)8 << 21, 64, (size_t)8 << 15);
+        REQUIRE(p.pmax == 128 && p.psplit == 32);
+    }
+    // tiny instance, forced lengths, a later chunk keeps its first chunk's lengths
+    REQUIRE(msmplan::make_piece_plan(1000, 0, 512).pmax == 16 && msmplan::make_piece_plan(1000, 0, 512).psplit == 8);
+    REQUIRE(msmplan::make_piece_plan((size_t)1 << 24, 600, 4096).pmax == 1024);
+    REQUIRE(msmplan::make_piece_plan((size_t)1 << 20, 64, 4096, 7).pmax == 7 && msmplan::make_piece_plan((size_t)1 << 20, 64, 4096, 7).psplit == 7);
+    {
+        const msmplan::piece_plan a = msmplan::make_piece_plan((size_t)15 << 22, 64, (size_t)15 << 16);
+        const msmplan::piece_plan b = msmplan::make_piece_plan((size_t)15 << 20, 16, (size_t)15 << 16, 0, &a);
+        REQUIRE(b.pmax == a.pmax && b.psplit == a.psplit && b.max_pieces <= a.max_pieces && b.max_partials <= a.max_partials);
+    }
+    // the bounds hold for ANY distribution: simulate bucket sizes (uniform, one huge bucket, many medium ones, everything just above pmax)
+    uint64_t st = 88172645463325252ull;
+    auto rnd = [&]() { st ^= st << 13, st ^= st >> 7, st ^= st << 17; return st; };
+    for (int rep = 0; rep < 200; rep++) {
+        const size_t tb = 1 + rnd() % 5000;
+        std::vector<size_t> sz(tb, 0);
+        const int kind = rep % 4;
+        size_t pairs = 0;
+        for (size_t k = 0; k < tb; k++) {
+            size_t v = kind == 0 ? rnd() % 100 : kind == 1 ? (k == 0 ? 200000 : rnd() % 3) : kind == 2 ? (rnd() % 7 == 0 ? 500 + rnd() % 3000 : 0) : 0;
+            sz[k] = v, pairs += v;
+        }
+        if (pairs == 0) continue;
+        const uint32_t forced = rep % 5 == 0 ? 1 + (uint32_t)(rnd() % 40) : 0;
+        const msmplan::piece_plan p = msmplan::make_piece_plan(pairs, pairs / tb, tb, forced);
+        if (kind == 3) {  // worst case for the partial-sum bound: every bucket one entry above pmax
+            pairs = 0;
+            for (size_t k = 0; k < tb; k++) sz[k] = p.pmax + 1, pairs += sz[k];
+        }
+        const msmplan::piece_plan q = kind == 3 ? msmplan::make_piece_plan(pairs, pairs / tb, tb, forced) : p;
+        size_t pieces = 0, partials = 0;
+        for (size_t k = 0; k < tb; k++) {
+            if (!sz[k]) continue;
+            size_t m = 1;  // msmk::piece_split
+            if (sz[k] > q.pmax) {
+                const size_t run = sz[k] <= (size_t)8 * q.pmax ? q.pmax : q.psplit;
+                m = (sz[k] + run - 1) / run;
             }
+            pieces += m;
+            if (m > 1) partials += m;
+        }
+        REQUIRE(q.psplit >= 1 && q.psplit <= q.pmax && q.pmax <= msmplan::PIECE_BINS_MAX);
+        REQUIRE(pieces <= q.max_pieces && partials <= q.max_partials);
+    }
     return 0;
 }
 
 int main() {
-    if (check_planner() || check_table_planner() || check_chunk_fit() || check_pool() || check_g1() || check_glv() || check_partitions()) return 1;
-    std::puts("host runtime: planner, window-table planner, chunk fit, pool, host_g1, glv split, partitions clean under ASan/UBSan");
+    if (check_planner() || check_table_planner() || check_piece_plan() || check_pool() || check_g1() || check_glv() || check_partitions()) return 1;
+    std::puts("host runtime: planner, window-table planner, piece plan, pool, host_g1, glv split, partitions clean under ASan/UBSan");
     return 0;
 }
