@@ -1061,7 +1061,7 @@ __global__ void k_scatter(const uint32_t* __restrict__ digits, const uint32_t* _
 // 2^22 5.32 -> 5.00.
 constexpr uint32_t LONG_SPAN = 8;     // split buckets of this many pieces or more are folded by whole workgroups (k_combine_pieces)
 constexpr uint32_t LONG_SEG = 2048;   // pieces of a long bucket folded by one workgroup
-constexpr uint32_t LONG_BLOCKS = 512, MID_BLOCKS = 128;
+constexpr uint32_t LONG_BLOCKS = 1024, MID_BLOCKS = 128;  // k_combine_pieces' grid: (bucket, segment) items grid-stride over the first, listed buckets over the rest
 constexpr uint32_t PIECE_BINS = 1024;                 // pmax <= PIECE_BINS: one histogram bin per piece length (== msmplan::PIECE_BINS_MAX)
 constexpr uint32_t PF_WHOLE = 0x80000000u;            // piece.z: the bucket is this one piece -> the sum goes to buckets[k]
 constexpr uint32_t PF_FIRST = 0x40000000u;            // piece.z: first piece of a split bucket (INTO: starts from the bucket's old value)
@@ -1191,15 +1191,36 @@ __global__ void __launch_bounds__(1024) k_piece_scatter(const uint32_t* __restri
     for (uint32_t i = threadIdx.x; i <= pmax; i += blockDim.x)
         if (s_cnt[i]) s_start[i] += atomicAdd(&cursor[i], s_cnt[i]);  // this workgroup's run inside bin i
     __syncthreads();
+    // a bucket of many pieces (skewed scalars: all scalars equal -> 16 buckets of 2^20 entries = 32768 pieces each) is written out by the
+    // whole workgroup: its owner only reserves the run and lists it (one thread writing 32768 records took 1 ms)
+    constexpr uint32_t COOP_MIN = 64, COOP_MAX = 64;
+    __shared__ uint32_t s_nco;
+    __shared__ uint4 s_co[COOP_MAX];  // (bucket, first entry, pieces - 1, position of the run)
+    if (threadIdx.x == 0) s_nco = 0;
+    __syncthreads();
     if (m == 1) {
         const uint32_t pos = s_start[sz] + atomicAdd(&s_cur[sz], 1u);
         plist[pos] = make_uint4(k, beg, sz | PF_WHOLE, 0u);
     } else if (m > 1) {
         const uint32_t pb = pbase[k];
         uint32_t pos = s_start[q] + atomicAdd(&s_cur[q], m - 1);  // the m - 1 full pieces: one reservation
-        for (uint32_t p = 0; p + 1 < m; p++) plist[pos + p] = make_uint4(k, beg + p * q, q | (p == 0 ? PF_FIRST : 0u), pb + p);
+        uint32_t slot = COOP_MAX;
+        if (m >= COOP_MIN) slot = atomicAdd(&s_nco, 1u);
+        if (slot < COOP_MAX) {
+            s_co[slot] = make_uint4(k, beg, m - 1, pos);
+        } else {
+            for (uint32_t p = 0; p + 1 < m; p++) plist[pos + p] = make_uint4(k, beg + p * q, q | (p == 0 ? PF_FIRST : 0u), pb + p);
+        }
         pos = s_start[rem] + atomicAdd(&s_cur[rem], 1u);
         plist[pos] = make_uint4(k, beg + (m - 1) * q, rem, pb + m - 1);
+    }
+    __syncthreads();
+    const uint32_t nco = min(s_nco, COOP_MAX);
+    for (uint32_t i = 0; i < nco; i++) {  // uniform
+        const uint4 co = s_co[i];
+        const uint32_t pb = pbase[co.x];
+        for (uint32_t p = threadIdx.x; p < co.z; p += blockDim.x)  // (listed buckets are long ones: runs of psplit)
+            plist[co.w + p] = make_uint4(co.x, co.y + p * psplit, psplit | (p == 0 ? PF_FIRST : 0u), pb + p);
     }
 }
 
