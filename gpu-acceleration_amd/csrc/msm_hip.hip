@@ -17,6 +17,7 @@
 //     shared bucket array.
 // There is NO CPU fallback: without a HIP device every compute entry point returns MSM_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <dlfcn.h>
 
@@ -102,15 +103,8 @@ struct Knobs {
     uint32_t piece_len = 0;                    // MSM_HIP_PIECE_LEN: longest whole bucket = split length of k_accumulate_pieces' work items; 0 = by size (tests force 1, 7, 26, 35)
     bool direct_scatter = false;               // MSM_HIP_DIRECT_SCATTER: skip the two-level LDS sort
     uint32_t device_chunk_log2 = 22;           // MSM_HIP_DEVICE_CHUNK_LOG2: point ranges of device-resident instances; 0 = never cut
-    uint32_t stream_min_log2 = 19;             // MSM_HIP_STREAM_MIN_LOG2: host calls are streamed from this size on
     uint32_t stream_chunk_log2 = 0;            // MSM_HIP_STREAM_CHUNK_LOG2: 0 = by size
-    bool copy_priority = true;                 // MSM_HIP_COPY_PRIORITY=0: the copy stream is a plain stream
     int host_threads = -1;                     // MSM_HIP_HOST_THREADS: CPU finish threads incl. the caller; -1 = default (2)
-    size_t wide_max = 40960;                   // MSM_HIP_WIDE_MAX: pairwise levels up to this many additions use 8 lanes per addition; 0 = never
-    bool reduce_v1 = false;                    // MSM_HIP_REDUCE_V1: one launch per pairwise level (round 1)
-    uint32_t pair8_lanes = 0;                  // MSM_HIP_PAIR8_LANES: lanes per output of k_pair_level8 (1, 2, 4; 0 = by size)
-    int batch_copy_own = 0;                    // MSM_HIP_BATCH_COPY=0: each batch pipeline uploads on its own copy stream
-    int lane_priority = 1;                     // MSM_HIP_LANE_PRIORITY: low (1, default) | high (2) | normal (0)
     msmplan::table_knobs table;                // MSM_HIP_TABLE_C / MSM_HIP_TABLE_F / MSM_HIP_TABLE_MAX_GB (window table of a resident set)
     static Knobs from_env() {
         Knobs k;
@@ -119,30 +113,15 @@ struct Knobs {
             if (!e || !*e) return dflt;
             return std::max(lo, std::min(hi, std::atol(e)));
         };
-        auto on = [](const char* name) {
-            const char* e = std::getenv(name);
-            return e && *e && *e != '0';
-        };
         k.glv_max = msmplan::glv_max_from_env();
         k.piece_len = (uint32_t)num("MSM_HIP_PIECE_LEN", 0, msmk::PIECE_BINS, 0);
-        k.direct_scatter = std::getenv("MSM_HIP_DIRECT_SCATTER") != nullptr;
+        k.direct_scatter = std::getenv("MSM_HIP_DIRECT_SCATTER") != nullptr;  // (tests: the one-level LDS / global-atomic sort fallbacks)
         k.device_chunk_log2 = (uint32_t)num("MSM_HIP_DEVICE_CHUNK_LOG2", 0, 30, 22);
-        k.stream_min_log2 = (uint32_t)num("MSM_HIP_STREAM_MIN_LOG2", 9, 31, 19);
         k.stream_chunk_log2 = std::getenv("MSM_HIP_STREAM_CHUNK_LOG2") ? (uint32_t)num("MSM_HIP_STREAM_CHUNK_LOG2", 8, 28, 0) : 0u;
-        if (const char* e = std::getenv("MSM_HIP_COPY_PRIORITY")) k.copy_priority = e[0] != '0';
         if (std::getenv("MSM_HIP_HOST_THREADS")) k.host_threads = (int)num("MSM_HIP_HOST_THREADS", 0, 64, 2);
-        k.wide_max = (size_t)num("MSM_HIP_WIDE_MAX", 0, 1 << 30, 40960);
-        k.reduce_v1 = on("MSM_HIP_REDUCE_V1");
-        {
-            const long v = num("MSM_HIP_PAIR8_LANES", 0, 4, 0);
-            k.pair8_lanes = v == 1 || v == 2 || v == 4 ? (uint32_t)v : 0u;
-        }
-        if (const char* e = std::getenv("MSM_HIP_BATCH_COPY")) k.batch_copy_own = e[0] == '0';
-        if (const char* e = std::getenv("MSM_HIP_LANE_PRIORITY")) k.lane_priority = !strcmp(e, "high") ? 2 : !strcmp(e, "normal") ? 0 : 1;
         k.table.c = (uint32_t)num("MSM_HIP_TABLE_C", 0, 20, 0);
         k.table.f = (uint32_t)num("MSM_HIP_TABLE_F", 0, 128, 0);
         k.table.max_bytes = (size_t)num("MSM_HIP_TABLE_MAX_GB", 0, 1024, 64) << 30;
-        if (std::getenv("MSM_HIP_TABLE_GLV_MAX_LOG2")) k.table.glv_max = (size_t)1 << num("MSM_HIP_TABLE_GLV_MAX_LOG2", 0, 23, 18);
         return k;
     }
 };
@@ -257,6 +236,8 @@ inline bool plan_glv(const msm_ctx* c, size_t n, uint32_t extra_flags = 0) {
 }
 constexpr size_t XB = msmk::XW * 4;               // bytes per XYZZ record (4 coordinates x 9 x 29-bit limbs)
 constexpr size_t LDS_HIST_BYTES = 128 * 1024;   // one window's bucket histogram must fit here for the LDS sort path
+constexpr size_t WIDE_MAX_ADDS = 40960;     // pairwise levels of at most this many additions use eight lanes per addition (k_pair_level_wide)
+constexpr uint32_t STREAM_MIN_LOG2 = 19;     // host-pointer calls are streamed in chunks from this many points on
 constexpr size_t MAX_QSUM_POINTS = 4096;  // (pseudo-)windows x (rkb + 1) bit sums: c = 2: 128 x 2; c = 20 unsigned: 13 x 16 slices x 17 = 3536
 
 uint32_t ilog2(uint32_t v) {
@@ -558,16 +539,17 @@ int32_t enqueue_accumulate(msm_ctx* c, const PipeState& ps, const uint32_t* d_ba
     uint32_t* flags = (uint32_t*)c->flags.p;
     uint32_t* offsets = (uint32_t*)c->offsets.p;
     if (bases_ready) HIPCHK(c, hipStreamWaitEvent(st, bases_ready, 0));  // d_bases is being converted on another stream
-    HIPCHK(c, hipEventRecord(c->ev[EV_ACC0], st));
+    // The graded kernel's own pair of events rides on its DISPATCH (hipExtLaunchKernelGGL: start / stop are the kernel's begin and end
+    // timestamps, no barrier packets): two hipEventRecord calls around it cost ~6 us of stream time each (kernel traces of rounds 1-3).
     const dim3 gp = grid1(ps.maxpieces, 256);  // (threads beyond the number of pieces, known on the device only, leave at once)
     const uint32_t *srt = (const uint32_t*)c->sorted.p, *np = flags + msmk::FLAG_PIECES;
     const uint4* pl = (const uint4*)c->plist.p;
     uint32_t *bk = (uint32_t*)c->buckets.p, *pt = (uint32_t*)c->partials.p, *hs = (uint32_t*)c->phist.p, *cu = (uint32_t*)c->pcursor.p;
     unsigned long long* clk = (unsigned long long*)c->clk.p;  // clock probe of the launch's first workgroup (msm_get_clock_stats)
-    if (into) msmk::k_accumulate_pieces<true, true><<<gp, 256, 0, st>>>(d_bases, srt, pl, np, bk, pt, hs, cu, ps.pmax, clk);
-    else if (chunked) msmk::k_accumulate_pieces<false, true><<<gp, 256, 0, st>>>(d_bases, srt, pl, np, bk, pt, hs, cu, ps.pmax, clk);
-    else msmk::k_accumulate_pieces<false, false><<<gp, 256, 0, st>>>(d_bases, srt, pl, np, bk, pt, hs, cu, ps.pmax, clk);
-    HIPCHK(c, hipEventRecord(c->ev[EV_ACC1], st));
+    const hipEvent_t e0 = c->ev[EV_ACC0], e1 = c->ev[EV_ACC1];
+    if (into) hipExtLaunchKernelGGL((msmk::k_accumulate_pieces<true, true>), gp, dim3(256), 0, st, e0, e1, 0, d_bases, srt, pl, np, bk, pt, hs, cu, ps.pmax, clk);
+    else if (chunked) hipExtLaunchKernelGGL((msmk::k_accumulate_pieces<false, true>), gp, dim3(256), 0, st, e0, e1, 0, d_bases, srt, pl, np, bk, pt, hs, cu, ps.pmax, clk);
+    else hipExtLaunchKernelGGL((msmk::k_accumulate_pieces<false, false>), gp, dim3(256), 0, st, e0, e1, 0, d_bases, srt, pl, np, bk, pt, hs, cu, ps.pmax, clk);
     msmk::k_combine_pieces<<<dim3(msmk::LONG_BLOCKS + msmk::MID_BLOCKS), 512, 0, st>>>(
         offsets, pt, bk, ps.pmax, ps.psplit, (const uint32_t*)c->pbase.p, flags + msmk::FLAG_MID, (const uint32_t*)c->midlist.p, flags + msmk::FLAG_LONG,
         (const uint32_t*)c->longlist.p, (uint32_t*)c->longdone.p);
@@ -595,16 +577,15 @@ int32_t enqueue_reduce(msm_ctx* c, const PipeState& ps, hipStream_t st, uint32_t
     // 15 x 65536 buckets: there its strided record reads lose 20-35 us to the pairwise levels).  A matching single launch for the
     // LAST levels (one LDS tree of eight-lane additions per output) was slower than the launch-bound k_pair_level_wide levels it
     // replaced (2^20: 52 vs 37 us: a tree's upper levels leave most lanes of its wavefront idle): profiles/NOTES_r2.md.
-    // MSM_HIP_REDUCE_V1=1 at context creation = one launch per level throughout (round 1; A/B knob).
     uint32_t l = 0;
-    if (!c->knobs.reduce_v1 && levels >= 3 && kb_lo >= 3 && tb * XB <= ((size_t)100 << 20)) {
+    if (levels >= 3 && kb_lo >= 3 && tb * XB <= ((size_t)100 << 20)) {
         rn = tb / 8, cn = tb / 8;
         // lanes per output: one lane while every SIMD has a wavefront of outputs (the kernel is multiplier bound then: 8 x 32768 buckets,
         // 2^14 .. 2^20 points: 1 / 2 / 4 lanes 0.471 / 0.470 / 0.487 ms at 2^17); below that the seven dependent additions of an output are
         // what the kernel waits for and 2 or 4 lanes cut the chain to 4 or 3 (2^12: 0.307 / 0.283 / 0.275 ms; one shared array of 2^15 buckets
         // of a window table: profiles/r3_pair8_lanes_ab.txt)
         const size_t outs = rn + cn;
-        const uint32_t lanes = c->knobs.pair8_lanes ? c->knobs.pair8_lanes : outs >= 65536 ? 1u : outs * 2 >= 65536 ? 2u : 4u;
+        const uint32_t lanes = outs >= 65536 ? 1u : outs * 2 >= 65536 ? 2u : 4u;
         if (lanes == 1) msmk::k_pair_level8<1><<<grid1(outs, 256), 256, 0, st>>>(bk, rbuf[0], cbuf[0], (uint32_t)rn, n_lo);
         else if (lanes == 2) msmk::k_pair_level8<2><<<grid1(outs * 2, 256), 256, 0, st>>>(bk, rbuf[0], cbuf[0], (uint32_t)rn, n_lo);
         else msmk::k_pair_level8<4><<<grid1(outs * 4, 256), 256, 0, st>>>(bk, rbuf[0], cbuf[0], (uint32_t)rn, n_lo);
@@ -625,7 +606,7 @@ int32_t enqueue_reduce(msm_ctx* c, const PipeState& ps, hipStream_t st, uint32_t
         }
         // levels with fewer additions than an eighth of the lanes the chip keeps resident: eight lanes per addition
         const size_t nadds = (size_t)ja.n_out + jb.n_out;
-        if (nadds <= c->knobs.wide_max) msmk::k_pair_level_wide<<<grid1(nadds * msmk::WIDE_LANES, 256), 256, 0, st>>>(ja, jb);
+        if (nadds <= WIDE_MAX_ADDS) msmk::k_pair_level_wide<<<grid1(nadds * msmk::WIDE_LANES, 256), 256, 0, st>>>(ja, jb);
         else msmk::k_pair_level<<<grid1(nadds, 256), 256, 0, st>>>(ja, jb);
     }
     // the bit sums (and the flag words) are written by the kernel straight into the caller's PINNED host buffers:
@@ -633,7 +614,7 @@ int32_t enqueue_reduce(msm_ctx* c, const PipeState& ps, hipStream_t st, uint32_t
     uint32_t *q_dev = nullptr, *f_dev = nullptr;
     HIPCHK(c, hipHostGetDevicePointer((void**)&q_dev, h_qsums_dst, 0));
     HIPCHK(c, hipHostGetDevicePointer((void**)&f_dev, h_flags_dst, 0));
-    if (c->knobs.wide_max && n_hi / 2 <= msmk::WIDE_TREE_MAX && n_lo <= msmk::WIDE_TREE_MAX)
+    if (n_hi / 2 <= msmk::WIDE_TREE_MAX && n_lo <= msmk::WIDE_TREE_MAX)
         msmk::k_reduce_bits_wide<<<W * (kb + 1), 512, 0, st>>>(rin, cin, q_dev, n_hi, n_lo, kb_lo, kb, flags, f_dev);
     else
         msmk::k_reduce_bits<<<W * (kb + 1), 64, 0, st>>>(rin, cin, q_dev, n_hi, n_lo, kb_lo, kb, flags, f_dev);
@@ -986,7 +967,7 @@ std::vector<size_t> stream_schedule(const msm_ctx* c, size_t n) {
     // after the last byte, cost more in fixed per-chunk work than they hide (measured: 2^20 in 4 chunks 2.89 ms, 3 x 2^18 +
     // 2^17 + 2 x 2^16: 3.48 ms -- profiles/NOTES_r2.md; round 3, with the sort already overlapped: the last chunk halved once / twice /
     // three times costs +0.12 / +0.24 / +0.41 ms at 2^20, profiles/r3_stream_tail_split.txt).  A remainder below half a chunk joins the last chunk.
-    const uint32_t min_log2 = c->knobs.stream_min_log2;
+    const uint32_t min_log2 = STREAM_MIN_LOG2;
     uint32_t lg = n < ((size_t)1 << 21) ? 18u : n < ((size_t)1 << 23) ? 19u : 20u;
     if (c->knobs.stream_chunk_log2) lg = c->knobs.stream_chunk_log2;
     const size_t chunk = (size_t)1 << lg;
@@ -1105,7 +1086,6 @@ static int32_t ctx_create_impl(const msm_config_t* cfg, msm_ctx** out, int main_
         // one queue, the barrier packets of their cross-stream event waits executed in queue order and every chunk upload waited
         // for the PREVIOUS chunk's kernels (rocprofv3 kernel trace: one Queue_Id, profiles/NOTES_r2.md).  A stream of another
         // priority comes from another pool.
-        if (!knobs.copy_priority) least = greatest;  // MSM_HIP_COPY_PRIORITY=0 (experiment): a plain stream
         e = least != greatest ? hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, greatest)
                               : hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
     }
@@ -1404,8 +1384,7 @@ static int32_t resident_on_lane(msm_ctx* w, const msm_ctx* owner, const uint32_t
         // (shared: BOTH pipelines upload through the owner's copy stream.  Uploads queued on the second pipeline's own copy stream
         // slowed the kernels running beside them 1.4-4.6x -- k_coarse_scatter 33 -> 47 us, k_fine_sort 42 -> 85, k_chunk_map 18 -> 84 --
         // while the owner's did not: 1.61-1.62 -> 1.51-1.58 ms per MSM at 2^20, NOTES_r2.md section 7)
-        // (MSM_HIP_BATCH_COPY=0 at context creation, A/B: each pipeline's own copy stream)
-        hipStream_t cs = shared ? (o->knobs.batch_copy_own ? w->copy_stream : o->copy_stream) : w->stream;
+        hipStream_t cs = shared ? o->copy_stream : w->stream;
         hipStream_t st = shared ? o->stream : w->stream;
         {
             std::lock_guard<std::mutex> cp(o->copy_mu);
@@ -1487,7 +1466,7 @@ static int32_t resident_batch_locked(msm_ctx* c, const uint32_t* const* scalars,
         msm_config_t cfg = c->cfg;
         cfg.device = c->device;
         cfg.max_points = 0;
-        int32_t rc = ctx_create_impl(&cfg, &c->lane1, c->knobs.lane_priority, &c->knobs);  // (MSM_HIP_LANE_PRIORITY: low by default)
+        int32_t rc = ctx_create_impl(&cfg, &c->lane1, 1 /* a stream of the low-priority pool */, &c->knobs);
         if (rc) return fail(c, rc, "second pipeline: %s", msm_last_error(nullptr));
         c->batch_pool = new (std::nothrow) HostPool(1);
         if (!c->batch_pool) return fail(c, MSM_ERR_OOM, "host allocation failed");
@@ -1511,7 +1490,7 @@ static int32_t resident_batch_locked(msm_ctx* c, const uint32_t* const* scalars,
     // (include/msm_hip.h MSM_BATCH_LAYOUT_*).  A pure function of the configuration, the tuned choice and the CLAMPED n: round 3 timed the
     // first four batch calls of a context to choose, and one noisy call decided for the context's life.
     const uint32_t layout = forced_layout ? forced_layout : batch_layout_for(c, std::min(n, c->resident_n));
-    const bool red_ok = count > 1 && c->knobs.copy_priority && !c->knobs.batch_copy_own;  // the reduce stream is the second pipeline's copy stream
+    const bool red_ok = count > 1;  // the reduce stream is the second pipeline's copy stream
     c->batch_shared_stream = layout != MSM_BATCH_LAYOUT_TWO_STREAMS;
     c->red_active = layout == MSM_BATCH_LAYOUT_ONE_STREAM_REDUCE && red_ok;
     c->last_batch_layout = layout;

@@ -1110,14 +1110,14 @@ __global__ void __launch_bounds__(1024) k_piece_count(const uint32_t* __restrict
                                                      uint32_t* __restrict__ mid_list, uint32_t* __restrict__ pbase, uint32_t* __restrict__ buckets,
                                                      uint32_t into) {
     __shared__ uint32_t s_hist[PIECE_BINS + 1];
-    __shared__ uint32_t s_n[2], s_base[2];  // [0] mid list, [1] long list: slots are reserved once per workgroup
+    __shared__ uint32_t s_n[3], s_base[3];  // [0] mid list, [1] long list, [2] partial-sum slots: reserved once per workgroup
     for (uint32_t i = threadIdx.x; i <= pmax; i += blockDim.x) s_hist[i] = 0;
-    if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
+    if (threadIdx.x < 3) s_n[threadIdx.x] = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0)  // mixed additions executed so far (msm_timings_t.num_adds), all chunks of a streamed MSM
         *reinterpret_cast<unsigned long long*>(flags + FLAG_ADDS64) += (unsigned long long)flags[FLAG_PAIRS];
     __syncthreads();
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t kindl = 2, slot = 0, nseg = 1, m = 0;  // 0 = mid list, 1 = long list, 2 = none
+    uint32_t kindl = 2, slot = 0, nseg = 1, m = 0, pslot = 0;  // 0 = mid list, 1 = long list, 2 = none
     if (k < total_buckets) {
         const uint32_t beg = offsets[k], sz = offsets[k + 1] - beg;
         if (sz == 0) {
@@ -1130,7 +1130,8 @@ __global__ void __launch_bounds__(1024) k_piece_count(const uint32_t* __restrict
             } else {
                 atomicAdd(&s_hist[q], m - 1);
                 atomicAdd(&s_hist[sz - (m - 1) * q], 1u);
-                pbase[k] = atomicAdd(flags + FLAG_PARTIALS, m);  // device-scope, split buckets only
+                pslot = atomicAdd(&s_n[2], m);  // (LDS; the short top window of a small instance splits ~8000 buckets: one device-scope
+                                                // add each on ONE word took k_piece_count 19 us at 2^17 where 2^20 takes 8)
                 if (m >= LONG_SPAN) {
                     kindl = 1;
                     nseg = (m + LONG_SEG - 1) / LONG_SEG;
@@ -1144,9 +1145,11 @@ __global__ void __launch_bounds__(1024) k_piece_count(const uint32_t* __restrict
     __syncthreads();
     if (threadIdx.x == 0 && s_n[0]) s_base[0] = atomicAdd(flags + FLAG_MID, s_n[0]);
     if (threadIdx.x == 1 && s_n[1]) s_base[1] = atomicAdd(flags + FLAG_LONG, s_n[1]);
+    if (threadIdx.x == 2 && s_n[2]) s_base[2] = atomicAdd(flags + FLAG_PARTIALS, s_n[2]);
     for (uint32_t i = threadIdx.x; i <= pmax; i += blockDim.x)
         if (s_hist[i]) atomicAdd(&hist[i], s_hist[i]);
     __syncthreads();
+    if (m > 1) pbase[k] = s_base[2] + pslot;
     if (kindl == 0) {
         mid_list[s_base[0] + slot] = k;
     } else if (kindl == 1) {  // one entry per LONG_SEG pieces: (bucket, segment)

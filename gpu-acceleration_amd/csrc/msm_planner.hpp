@@ -98,7 +98,7 @@ inline int32_t make_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_pla
 struct table_knobs {
     uint32_t c = 0, f = 0;                // MSM_HIP_TABLE_C / MSM_HIP_TABLE_F: force the width / the factor (0 = planner)
     size_t max_bytes = (size_t)64 << 30;  // MSM_HIP_TABLE_MAX_GB: no table beyond this
-    size_t glv_max = 0;                   // MSM_HIP_TABLE_GLV_MAX_LOG2: table plans split up to this many points (0 = TABLE_GLV_MAX_POINTS)
+    size_t glv_max = 0;                   // table plans split up to this many points (0 = TABLE_GLV_MAX_POINTS; tools/ only)
 };
 // A table is made while ONE sort covers the shared array and the table pays: up to 2^21 points (13 x 2^21 = 27 M entries; the regions of
 // the fine sort hold entries / 1024 and are sorted by their owner workgroup up to four LDS staging areas of 16384).  At 2^22 points
