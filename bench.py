@@ -49,7 +49,7 @@ def words_to_ints(a):
     return out
 
 
-# one mixed addition (ec_bn254.hpp xyzz_madd): 6 fp_mul + 2 fp_sqr + 1 fused fp_mul_add
+# one mixed addition (ec_bn254.hpp xyzz_madd, the loop body of k_accumulate_pieces): 6 fp_mul + 2 fp_sqr + 1 fused fp_mul_add
 MADS_PER_ADD = 6 * 162 + 2 * 126 + 243           # v_mad_u64_u32 instructions
 FPMUL_EQ_PER_ADD = (6 * 171 + 2 * 135 + 252) / 171.0  # in units of one fp_mul (162 mads + 9 Montgomery-digit multiplications)
 
@@ -60,7 +60,7 @@ def valu_roofline(num_adds, acc_ms, mad_peak, fpmul_peak):
     t = acc_ms * 1e-3
     mads = num_adds * MADS_PER_ADD / t
     fpm = num_adds * FPMUL_EQ_PER_ADD / t
-    out = {"bound": "valu", "kernel": "k_accumulate", "mixed_additions_per_launch": num_adds,
+    out = {"bound": "valu", "kernel": "k_accumulate_pieces", "mixed_additions_per_launch": num_adds,
            "achieved": round(fpm / 1e9, 2), "peak": round(fpmul_peak / 1e9, 2), "unit": "G field-mul/s", "frac": round(fpm / fpmul_peak, 4),
            "mad_u64_achieved_G_per_s": round(mads / 1e9, 1), "mad_u64_peak_G_per_s": round(mad_peak / 1e9, 1),
            "mad_u64_frac": round(mads / mad_peak, 4),
@@ -249,9 +249,9 @@ def main():
     elapsed = time.perf_counter() - t0
     clk_loop = clk_single = None
     if ctx is not None:
-        clk_loop = ctx.clock_stats()  # k_accumulate's own cycle / constant-rate counters over the timed launches
+        clk_loop = ctx.clock_stats()  # k_accumulate_pieces' own cycle / constant-rate counters over the timed launches
         acc_avg_ms, acc_launches = ctx.accumulate_kernel_stats()
-        # instances cut into point ranges (device inputs from 2^23 points, streamed host inputs) launch k_accumulate once per range:
+        # instances cut into point ranges (device inputs from 2^23 points, streamed host inputs) launch k_accumulate_pieces once per range:
         # the roofline prices the MSM's accumulation = all of a step's launches together, against the whole instance's bytes
         # (the context's statistic holds the LAST range's launch of every call; the ranges are equal: 2^22 points each)
         launches_per_step = 1 if args.streamed else max(1, int(ctx.timings().get("stream_chunks", 0)))
@@ -396,16 +396,16 @@ def main():
             "bit_exact": bit_exact,
             "bit_exact_steps": {"checked": len(step_jac), "equal_to_closed_form": steps_ok,
                                 "distinct_jacobian_representations": len({bytes(jw.tobytes()) for jw in step_jac})},
-            # Is a slower line a slower kernel or a slower box?  k_accumulate's first workgroup reads the shader-cycle counter and the
+            # Is a slower line a slower kernel or a slower box?  k_accumulate_pieces' first workgroup reads the shader-cycle counter and the
             # constant-rate counter around its chunk in EVERY launch: the GHz the kernel really sustained, and shader cycles per mixed
             # addition of one wavefront -- equal on two boxes that run the same instruction stream, whatever their clocks.
             "clock": ({"sclk_ghz_timed_loop": round(clk_loop["sclk_ghz"], 4), "sclk_ghz_single_step": round(clk_single["sclk_ghz"], 4) if clk_single else None,
                        "cycles_per_addition_timed_loop": round(clk_loop["cycles_per_addition"], 1),
                        "cycles_per_addition_single_step": round(clk_single["cycles_per_addition"], 1) if clk_single else None,
                        "k_accumulate_mcycles": round(acc_avg_ms * 1e-3 * clk_loop["sclk_ghz"] * 1e3, 3), "launches_sampled": int(clk_loop["samples"]),
-                       "note": "k_accumulate_mcycles = avg_kernel_ms x sclk_ghz_timed_loop (10^6 shader cycles per launch); cycles per addition are those of "
-                               "the launch's first wavefront, which shares its SIMD with two others"} if clk_loop and clk_loop["samples"] else None),
-            "roofline": {"bound": "hbm", "kernel": "k_accumulate", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
+                       "note": "k_accumulate_mcycles = avg_kernel_ms x sclk_ghz_timed_loop (10^6 shader cycles per launch of k_accumulate_pieces); cycles per "
+                               "addition are those of the launch's first wavefront (its longest pieces), which shares its SIMD with two others"} if clk_loop and clk_loop["samples"] else None),
+            "roofline": {"bound": "hbm", "kernel": "k_accumulate_pieces", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_over_algorithmic": round(traffic / alg_bytes, 3) if traffic else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_ms": round(acc_avg_ms, 4), "launches_per_step": launches_per_step,
@@ -482,7 +482,7 @@ def main():
             legs["resident_batch_layout"] = LAYOUT_NAMES.get(ctx.timings()["batch_layout"])  # AUTO: deterministic, by size
             ok = ok and all(bool((x.affine_std == exp).all()) for x in r)
             # ... and after the explicit, opt-in measurement of the three stream layouts on this context (msm_tune_batch)
-            chosen, tune_ms = ctx.tune_batch([hspn] * 4, reps=2)
+            chosen, tune_ms = ctx.tune_batch([hspn] * K, reps=3)
             r, avg, _ = timed_calls(lambda: ctx.msm_resident_batch([hspn] * K), 3)
             legs["resident_batch_tuned_ms_per_msm"] = round(avg / K, 4)
             legs["resident_batch_tuned_layout"] = LAYOUT_NAMES.get(chosen)
@@ -505,7 +505,7 @@ def main():
                 r, avg, _ = timed_calls(lambda: tctx.msm_resident_batch([hspn] * K), 3)
                 legs["resident_table_batch_ms_per_msm"] = round(avg / K, 4)
                 ok = ok and all(bool((x.affine_std == exp).all()) for x in r)
-                chosen, _tm = tctx.tune_batch([hspn] * 4, reps=2)
+                chosen, _tm = tctx.tune_batch([hspn] * K, reps=3)
                 r, avg, _ = timed_calls(lambda: tctx.msm_resident_batch([hspn] * K), 3)
                 legs["resident_table_batch_tuned_ms_per_msm"] = round(avg / K, 4)
                 legs["resident_table_batch_tuned_layout"] = LAYOUT_NAMES.get(chosen)

@@ -103,6 +103,7 @@ struct Knobs {
     uint32_t piece_len = 0;                    // MSM_HIP_PIECE_LEN: longest whole bucket = split length of k_accumulate_pieces' work items; 0 = by size (tests force 1, 7, 26, 35)
     bool direct_scatter = false;               // MSM_HIP_DIRECT_SCATTER: skip the two-level LDS sort
     uint32_t device_chunk_log2 = 22;           // MSM_HIP_DEVICE_CHUNK_LOG2: point ranges of device-resident instances; 0 = never cut
+    uint32_t stream_min_log2 = 19;             // MSM_HIP_STREAM_MIN_LOG2: host calls are streamed from this size on (tools/host_path_sweep.py)
     uint32_t stream_chunk_log2 = 0;            // MSM_HIP_STREAM_CHUNK_LOG2: 0 = by size
     int host_threads = -1;                     // MSM_HIP_HOST_THREADS: CPU finish threads incl. the caller; -1 = default (2)
     msmplan::table_knobs table;                // MSM_HIP_TABLE_C / MSM_HIP_TABLE_F / MSM_HIP_TABLE_MAX_GB (window table of a resident set)
@@ -117,11 +118,13 @@ struct Knobs {
         k.piece_len = (uint32_t)num("MSM_HIP_PIECE_LEN", 0, msmk::PIECE_BINS, 0);
         k.direct_scatter = std::getenv("MSM_HIP_DIRECT_SCATTER") != nullptr;  // (tests: the one-level LDS / global-atomic sort fallbacks)
         k.device_chunk_log2 = (uint32_t)num("MSM_HIP_DEVICE_CHUNK_LOG2", 0, 30, 22);
+        k.stream_min_log2 = (uint32_t)num("MSM_HIP_STREAM_MIN_LOG2", 9, 31, 19);
         k.stream_chunk_log2 = std::getenv("MSM_HIP_STREAM_CHUNK_LOG2") ? (uint32_t)num("MSM_HIP_STREAM_CHUNK_LOG2", 8, 28, 0) : 0u;
         if (std::getenv("MSM_HIP_HOST_THREADS")) k.host_threads = (int)num("MSM_HIP_HOST_THREADS", 0, 64, 2);
         k.table.c = (uint32_t)num("MSM_HIP_TABLE_C", 0, 20, 0);
         k.table.f = (uint32_t)num("MSM_HIP_TABLE_F", 0, 128, 0);
         k.table.max_bytes = (size_t)num("MSM_HIP_TABLE_MAX_GB", 0, 1024, 64) << 30;
+        if (std::getenv("MSM_HIP_TABLE_GLV_MAX_LOG2")) k.table.glv_max = (size_t)1 << num("MSM_HIP_TABLE_GLV_MAX_LOG2", 0, 23, 18);  // (tools/table_sweep.py)
         return k;
     }
 };
@@ -237,7 +240,6 @@ inline bool plan_glv(const msm_ctx* c, size_t n, uint32_t extra_flags = 0) {
 constexpr size_t XB = msmk::XW * 4;               // bytes per XYZZ record (4 coordinates x 9 x 29-bit limbs)
 constexpr size_t LDS_HIST_BYTES = 128 * 1024;   // one window's bucket histogram must fit here for the LDS sort path
 constexpr size_t WIDE_MAX_ADDS = 40960;     // pairwise levels of at most this many additions use eight lanes per addition (k_pair_level_wide)
-constexpr uint32_t STREAM_MIN_LOG2 = 19;     // host-pointer calls are streamed in chunks from this many points on
 constexpr size_t MAX_QSUM_POINTS = 4096;  // (pseudo-)windows x (rkb + 1) bit sums: c = 2: 128 x 2; c = 20 unsigned: 13 x 16 slices x 17 = 3536
 
 uint32_t ilog2(uint32_t v) {
@@ -967,7 +969,7 @@ std::vector<size_t> stream_schedule(const msm_ctx* c, size_t n) {
     // after the last byte, cost more in fixed per-chunk work than they hide (measured: 2^20 in 4 chunks 2.89 ms, 3 x 2^18 +
     // 2^17 + 2 x 2^16: 3.48 ms -- profiles/NOTES_r2.md; round 3, with the sort already overlapped: the last chunk halved once / twice /
     // three times costs +0.12 / +0.24 / +0.41 ms at 2^20, profiles/r3_stream_tail_split.txt).  A remainder below half a chunk joins the last chunk.
-    const uint32_t min_log2 = STREAM_MIN_LOG2;
+    const uint32_t min_log2 = c->knobs.stream_min_log2;
     uint32_t lg = n < ((size_t)1 << 21) ? 18u : n < ((size_t)1 << 23) ? 19u : 20u;
     if (c->knobs.stream_chunk_log2) lg = c->knobs.stream_chunk_log2;
     const size_t chunk = (size_t)1 << lg;

@@ -98,7 +98,7 @@ inline int32_t make_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_pla
 struct table_knobs {
     uint32_t c = 0, f = 0;                // MSM_HIP_TABLE_C / MSM_HIP_TABLE_F: force the width / the factor (0 = planner)
     size_t max_bytes = (size_t)64 << 30;  // MSM_HIP_TABLE_MAX_GB: no table beyond this
-    size_t glv_max = 0;                   // table plans split up to this many points (0 = TABLE_GLV_MAX_POINTS; tools/ only)
+    size_t glv_max = 0;                   // MSM_HIP_TABLE_GLV_MAX_LOG2: table plans split up to this many points (0 = TABLE_GLV_MAX_POINTS)
 };
 // A table is made while ONE sort covers the shared array and the table pays: up to 2^21 points (13 x 2^21 = 27 M entries; the regions of
 // the fine sort hold entries / 1024 and are sorted by their owner workgroup up to four LDS staging areas of 16384).  At 2^22 points
@@ -164,6 +164,9 @@ struct piece_plan {
 inline piece_plan make_piece_plan(size_t pairs, size_t mean_occupancy, size_t total_buckets, uint32_t forced_len = 0, const piece_plan* first = nullptr) {
     piece_plan p;
     p.pmax = (uint32_t)std::min<size_t>(PIECE_BINS_MAX, std::max<size_t>(16, 2 * mean_occupancy));
+    // tiny instances (2^10 .. 2^13 points on 10-bit windows: a few thousand buckets of 16-64 entries) would be a few thousand pieces -- a
+    // wavefront on a tenth of the SIMDs, each walking its piece alone; there the pieces shrink until ~2^15 of them exist (at least 8 entries)
+    p.pmax = (uint32_t)std::min<size_t>(p.pmax, std::max<size_t>(8, pairs >> 15));
     p.psplit = (uint32_t)std::min<size_t>(p.pmax, std::max<size_t>(8, pairs >> 19));
     if (first) p.pmax = first->pmax, p.psplit = first->psplit;  // a later chunk of an instance: the lengths of its first, largest chunk
     if (forced_len) p.pmax = p.psplit = std::min<uint32_t>(forced_len, PIECE_BINS_MAX);

@@ -15,8 +15,8 @@ known = {"k_stream": 1 << 30, "k_gather": (1 << 22) * 64, "k_store36": (1 << 21)
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     b = per_kernel(f"{d}/bench_{c}/**/*counter_collection.csv")
     k = per_kernel(f"{d}/calib_{c}/**/*counter_collection.csv")
-    res[c] = {"k_accumulate_kib_per_launch": sum(b.get("k_accumulate", [0])) / max(1, len(b.get("k_accumulate", [1]))),
-              "launches": len(b.get("k_accumulate", [])),
+    res[c] = {"k_accumulate_kib_per_launch": sum(b.get("k_accumulate_pieces", [0])) / max(1, len(b.get("k_accumulate_pieces", [1]))),
+              "launches": len(b.get("k_accumulate_pieces", [])),
               "calib_counter_kib": {n: sum(v) / len(v) for n, v in k.items()},
               "calib_known_bytes": known}
 f, w = res["FETCH_SIZE"], res["WRITE_SIZE"]

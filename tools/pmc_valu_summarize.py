@@ -14,7 +14,7 @@ for f in glob.glob(f"{d}/**/*kernel_trace.csv", recursive=True):
         k = r["Kernel_Name"].split("(")[0].split("::")[-1].split("<")[0]
         dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 out = {}
-for k in ("k_accumulate", "k_pair_level", "k_combine", "k_fine_sort", "k_coarse_scatter"):
+for k in ("k_accumulate_pieces", "k_pair_level8", "k_combine_pieces", "k_fine_sort", "k_coarse_scatter"):
     if k not in vals: continue
     c = {n: sum(v) / len(v) for n, v in vals[k].items()}
     us = sum(dur[k]) / max(1, len(dur[k]))
@@ -34,7 +34,7 @@ for k in ("k_accumulate", "k_pair_level", "k_combine", "k_fine_sort", "k_coarse_
     out[k] = e
 res = {"kernels": out, "source": "tools/pmc_valu.sh: rocprofv3 --pmc (SQ_* / GRBM_GUI_ACTIVE), --kernel-trace only, python3 bench.py --steps 3 --warmup 1 directly after `--`; "
                                    "SQ_ACTIVE_INST_* and SQ_WAVE_CYCLES count quad-cycles (MI355X_MICROARCH.md)"}
-a = out.get("k_accumulate", {})
+a = out.get("k_accumulate_pieces", {})
 for k in ("valu_busy_frac", "valu_util_frac"):
     if k in a: res[k] = a[k]
 res["build"] = sys.argv[2] if len(sys.argv) > 2 else "?"
