@@ -164,9 +164,10 @@ struct piece_plan {
 inline piece_plan make_piece_plan(size_t pairs, size_t mean_occupancy, size_t total_buckets, uint32_t forced_len = 0, const piece_plan* first = nullptr) {
     piece_plan p;
     p.pmax = (uint32_t)std::min<size_t>(PIECE_BINS_MAX, std::max<size_t>(16, 2 * mean_occupancy));
-    // tiny instances (2^10 .. 2^13 points on 10-bit windows: a few thousand buckets of 16-64 entries) would be a few thousand pieces -- a
-    // wavefront on a tenth of the SIMDs, each walking its piece alone; there the pieces shrink until ~2^15 of them exist (at least 8 entries)
-    p.pmax = (uint32_t)std::min<size_t>(p.pmax, std::max<size_t>(8, pairs >> 15));
+    // FEW buckets (tiny instances on 10-bit windows: a few thousand buckets of 16-64 entries; the shared array of a split window table: 2^15
+    // buckets for eight windows' entries) would be as few pieces -- a wavefront on a fraction of the SIMDs, each walking its piece alone; there
+    // the pieces shrink until ~2^17 of them exist (at least 8 entries each).  2^17 points with the table: k_accumulate_pieces 0.257 -> 0.149 ms, profiles/r4_table_small.txt
+    if (total_buckets < ((size_t)1 << 17)) p.pmax = (uint32_t)std::min<size_t>(p.pmax, std::max<size_t>(8, pairs >> 17));
     p.psplit = (uint32_t)std::min<size_t>(p.pmax, std::max<size_t>(8, pairs >> 19));
     if (first) p.pmax = first->pmax, p.psplit = first->psplit;  // a later chunk of an instance: the lengths of its first, largest chunk
     if (forced_len) p.pmax = p.psplit = std::min<uint32_t>(forced_len, PIECE_BINS_MAX);

@@ -195,7 +195,8 @@ static int check_piece_plan() {
     // tiny instance, forced lengths, a later chunk keeps its first chunk's lengths
     REQUIRE(msmplan::make_piece_plan(1000, 0, 512).pmax == 8 && msmplan::make_piece_plan(1000, 0, 512).psplit == 8);
     REQUIRE(msmplan::make_piece_plan((size_t)1 << 21, 8, (size_t)8 << 15).pmax == 16);  // 2^17 points, GLV: unchanged by the tiny-instance rule
-    REQUIRE(msmplan::make_piece_plan((size_t)1 << 28, 600, (size_t)1 << 18).pmax == 1024 && msmplan::make_piece_plan((size_t)1 << 24, 600, 4096).pmax == 512);
+    REQUIRE(msmplan::make_piece_plan((size_t)1 << 28, 600, (size_t)1 << 18).pmax == 1024 && msmplan::make_piece_plan((size_t)1 << 24, 600, 4096).pmax == 128);
+    REQUIRE(msmplan::make_piece_plan((size_t)1 << 21, 64, (size_t)1 << 15).pmax == 16);  // 2^17 points, split window table: one array of 2^15 buckets
     REQUIRE(msmplan::make_piece_plan((size_t)1 << 20, 64, 4096, 7).pmax == 7 && msmplan::make_piece_plan((size_t)1 << 20, 64, 4096, 7).psplit == 7);
     {
         const msmplan::piece_plan a = msmplan::make_piece_plan((size_t)15 << 22, 64, (size_t)15 << 16);
