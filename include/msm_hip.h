@@ -168,7 +168,7 @@ int32_t msm_bn254_g1_resident(msm_ctx *ctx, const uint32_t *scalars, size_t n, u
 /* the same with the scalars already in HBM (ABI 4): d_scalars = n x 8 words of device memory, e.g. the witness of a prover whose
  * earlier stages ran on the GPU; hip_stream = the hipStream_t that produced them (NULL = the context's stream).  Nothing crosses
  * PCIe but the 96-byte result, the bases are not converted again (msm_bn254_g1_device converts its bases on every call), and a
- * context created with MSM_FLAG_WINDOW_TABLE uses the table: 2^20 points 1.29 ms against the 1.50 of msm_bn254_g1_device in the same run (1.46 without the table).
+ * context created with MSM_FLAG_WINDOW_TABLE uses the table: 2^20 points 1.27 ms against the 1.46 of msm_bn254_g1_device in the same run (1.42 without the table).
  * Blocks until the result is on the host. */
 int32_t msm_bn254_g1_resident_device(msm_ctx *ctx, const void *d_scalars, size_t n, void *hip_stream,
                                      uint32_t out_jacobian_mont[24], uint32_t out_affine_std[16], uint8_t *out_is_inf);
@@ -181,7 +181,7 @@ int32_t msm_bn254_g1_resident_device(msm_ctx *ctx, const void *d_scalars, size_t
  * below, where no kernel fills the GPU, each keeps its own stream and the kernels overlap.  Which of the three layouts a call runs
  * under is decided by msm_config_t.batch_layout (see MSM_BATCH_LAYOUT_*), deterministically; msm_get_timings().batch_layout reports it.
  * n is clamped to the resident set; a window table (MSM_FLAG_WINDOW_TABLE) serves calls on the WHOLE set only.
- * Per MSM, single calls -> batch: 2^14 0.40 -> 0.24 ms, 2^17 0.56 -> 0.40, 2^20 2.28 -> 1.63, 2^22 8.54 -> 5.80.
+ * Per MSM, single calls -> batch (round 4): 2^14 0.32 -> 0.21 ms, 2^17 0.50 -> 0.35, 2^20 2.1 -> 1.49, 2^22 7.75 -> 5.80.
  * Results are identical to `count` msm_bn254_g1_resident calls; on an error the first failing code is returned. */
 int32_t msm_bn254_g1_resident_batch(msm_ctx *ctx, const uint32_t *const *scalars, size_t n, size_t count,
                                     uint32_t *out_jacobian_mont, uint32_t *out_affine_std, uint8_t *out_is_inf);
