@@ -282,6 +282,8 @@ struct PipeState {
     uint32_t tf = 1, sW = 0;
     size_t sn = 0;
     uint32_t top_shift = 0;  // full table (tf == W): the short top window's digits enter as d * 2^top_shift (table_top_shift)
+    uint32_t top_bits = 0;   // == pl.top_digit_bits: index bits of the top window that carry the digit; the kb - top_bits above it carry point-index
+                             // bits (split plans: msmplan::glv_top_digit_bits), which host_finish leaves out
     // REDUCTION view: arrays of more than 2^17 buckets are reduced as 2^pw_bits PSEUDO-windows of 2^rkb buckets each (bucket index
     // b = q * 2^rkb + b'); the host adds q * 2^rkb * (plain sum of pseudo-window q) back in (host_finish).  rW = sW << pw_bits.
     uint32_t rW = 0, rkb = 0, pw_bits = 0, kb_lo = 0, kb_hi = 0, n_lo = 0, n_hi = 0;
@@ -318,6 +320,8 @@ int32_t pipe_prepare(msm_ctx* c, size_t n_real, size_t plan_n, uint32_t extra_fl
     ps->sW = W / ps->tf;
     ps->sn = (size_t)ps->tf * n;
     ps->top_shift = table_top_shift(pl, ps->tf);
+    if (ps->tf > 1) ps->pl.top_digit_bits = ilog2(nb);  // (make_plan does not know of the table: its top window is spread by top_shift)
+    ps->top_bits = pl.top_digit_bits;
     const size_t pairs = ps->pairs = (size_t)W * n, tb = ps->tb = (size_t)ps->sW * nb;
     if (pairs > 0xFFFFFFFFull) return fail(c, MSM_ERR_BAD_ARG, "n*W = %zu does not fit 32-bit offsets", pairs);
     ps->kb = ilog2(nb);
@@ -424,10 +428,11 @@ int32_t enqueue_decompose(msm_ctx* c, const PipeState& ps, const uint8_t* d_inf,
     uint32_t *dg = (uint32_t*)c->digits.p, *rk = (uint32_t*)c->ranks.p;
     dim3 g = grid1(n_real, 256);
     const uint32_t nr = (uint32_t)n_real;
+    const uint32_t spread_mask = ps.top_bits < ps.kb ? (1u << (ps.kb - ps.top_bits)) - 1u : 0u;  // (split plans without a table)
     if (pl.glv) {
         if (!sg.lds_counts) return fail(c, MSM_ERR_BAD_ARG, "window_bits %u needs the non-GLV path (MSM_FLAG_NO_GLV)", cbits);
-        if (pl.signed_digits) msmk::k_decompose_glv<true><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, dg, flags, scalars_mont, ps.top_shift);
-        else msmk::k_decompose_glv<false><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, dg, flags, scalars_mont, ps.top_shift);
+        if (pl.signed_digits) msmk::k_decompose_glv<true><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, dg, flags, scalars_mont, ps.top_shift, ps.top_bits, spread_mask);
+        else msmk::k_decompose_glv<false><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, dg, flags, scalars_mont, ps.top_shift, ps.top_bits, spread_mask);
     } else if (pl.signed_digits && sg.lds_counts) msmk::k_decompose<true, false><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, nb, hist, dg, rk, flags, scalars_mont, ps.top_shift);
     else if (pl.signed_digits) msmk::k_decompose<true, true><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, nb, hist, dg, rk, flags, scalars_mont, ps.top_shift);
     else if (sg.lds_counts) msmk::k_decompose<false, false><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, nb, hist, dg, rk, flags, scalars_mont, ps.top_shift);
@@ -646,7 +651,9 @@ hostg1::Jac host_finish(msm_ctx* c, const uint32_t* h_qsums, const PipeState& g)
         for (uint32_t p = hi; p-- > lo;) {
             acc = hostg1::jdbl(acc);
             const uint32_t v = p / spacing, u = p % spacing;
-            if (u < rkb)
+            if (v == V - 1 && u >= g.top_bits) {
+                // index bits of a spread top window that hold point-index bits, not the digit (msmplan::glv_top_digit_bits): no weight
+            } else if (u < rkb)
                 for (uint32_t q = 0; q < PW; q++) acc = hostg1::jadd(acc, qsum(v, q, u));
             else if (u < kb)
                 for (uint32_t q = 0; q < PW; q++)
@@ -680,7 +687,7 @@ hostg1::Jac host_finish(msm_ctx* c, const uint32_t* h_qsums, const PipeState& g)
 int32_t check_flags(msm_ctx* c, const uint32_t* h_flags) {
     if (h_flags[0] & 1u) return fail(c, MSM_ERR_BAD_ARG, "a scalar is >= 2^254 (not a canonical Fr element)");
     if (h_flags[0] & 2u) return fail(c, MSM_ERR_HIP, "internal: signed-digit carry out of the top window");
-    if (h_flags[0] & 4u) return fail(c, MSM_ERR_HIP, "internal: a GLV half exceeds 127 bits");
+    if (h_flags[0] & 4u) return fail(c, MSM_ERR_HIP, "internal: a GLV half exceeds its bound (7 * 2^123)");
     return MSM_OK;
 }
 

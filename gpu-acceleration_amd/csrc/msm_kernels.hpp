@@ -418,13 +418,16 @@ __device__ __forceinline__ uint32_t window128(const uint32_t s[4], uint32_t off,
     uint64_t hi = (wi + 1 < 4) ? s[wi + 1] : 0u;
     return (uint32_t)(((lo | (hi << 32)) >> sh)) & ((1u << c) - 1u);
 }
-// k_decompose with the GLV split (glv_bn254.hpp): scalar k_i -> (k1, k2), |k_j| < 2^127; the digits of |k1| go to virtual point
+// k_decompose with the GLV split (glv_bn254.hpp): scalar k_i -> (k1, k2), |k_j| < 7 * 2^123; the digits of |k1| go to virtual point
 // i, those of |k2| to virtual point n + i (the record of phi(P_i)), the sign of k_j is folded into every digit's negate flag.
 // digits: W x 2n, window-major.
+// spread_mask != 0 (msmplan::glv_top_digit_bits): the top window's magnitudes are at most 2^top_bits, fewer than the window has buckets;
+// its bucket index is (magnitude - 1) | (i & spread_mask) << top_bits -- the same digit in 2^spread buckets, chosen by the point index, so
+// that the top window's buckets are no fuller than the others'.  The host ignores the bit sums of the index bits above top_bits.
 template <bool SIGNED>
 __global__ void k_decompose_glv(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_mask, uint32_t n, uint32_t c,
                                 uint32_t W, uint32_t* __restrict__ digits, uint32_t* __restrict__ err, uint32_t scalars_mont,
-                                uint32_t top_shift) {
+                                uint32_t top_shift, uint32_t top_bits, uint32_t spread_mask) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) err[FLAG_LONG] = 0, err[FLAG_MID] = 0, err[FLAG_PIECES] = 0, err[FLAG_PARTIALS] = 0;  // list counters of this (chunk of an) MSM: k_piece_count fills them later in the stream
     if (i >= n) return;
@@ -436,9 +439,10 @@ __global__ void k_decompose_glv(const uint32_t* __restrict__ scalars, const uint
     const bool skip = inf_mask != nullptr && inf_mask[i] != 0;
     uint32_t k[2][4];
     bool kneg[2];
-    if (!glv::split(s, k[0], kneg[0], k[1], kneg[1])) atomicOr(err, 4u);  // a half beyond 127 bits: cannot happen below 2^254
+    if (!glv::split(s, k[0], kneg[0], k[1], kneg[1])) atomicOr(err, 4u);  // a half beyond 126 bits: cannot happen below 2^254
     const uint32_t H = 1u << (c - 1);
     const size_t row = 2 * (size_t)n;
+    const uint32_t spread = (i & spread_mask) << top_bits;
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         uint32_t carry = 0;
@@ -455,8 +459,16 @@ __global__ void k_decompose_glv(const uint32_t* __restrict__ scalars, const uint
                     carry = 0;
                 }
             }
-            if (w == W - 1) mag <<= top_shift;  // (window table, shared bucket array: see k_decompose)
-            digits[(size_t)w * row + (size_t)h * n + i] = (mag == 0 || skip) ? DIGIT_SKIP : ((mag - 1) | (neg ? SIGN_BIT : 0u));
+            uint32_t bkt = mag - 1;
+            if (w == W - 1) {
+                if (spread_mask) {
+                    if (mag > (1u << top_bits)) atomicOr(err, 4u);  // cannot happen: halves < 7 * 2^123
+                    bkt |= spread;
+                } else {
+                    bkt = (mag << top_shift) - 1;  // (window table, shared bucket array: see k_decompose)
+                }
+            }
+            digits[(size_t)w * row + (size_t)h * n + i] = (mag == 0 || skip) ? DIGIT_SKIP : (bkt | (neg ? SIGN_BIT : 0u));
         }
         if (SIGNED && carry) atomicOr(err, 2u);
     }

@@ -11,6 +11,21 @@
 namespace msmplan {
 
 constexpr uint32_t GLV_SPLIT_BITS = 127;  // == glv::SPLIT_BITS (glv_bn254.hpp); asserted in msm_hip.hip
+// The halves of a split scalar are below 7 * 2^123 (= 2^125.81; glv_bn254.hpp HALF_BOUND_*, proved by tools/gen_glv_constants.py), so the TOP
+// window of a split plan holds few digit values: 14336 of 32768 at c = 16 (eight windows, 14 bits left), 56 of 512 at c = 10.  Its buckets
+// would be 2-10x as full as every other window's -- at 2^20 points 16384 buckets of ~128 entries among 229376 of ~64, which the
+// accumulation had to cut into pieces and fold again.  The decomposition therefore SPREADS the top window: bucket index =
+// (digit magnitude - 1) | (low bits of the point index) << top_digit_bits.  The reduction is unchanged (it sums by index bits); the host
+// leaves the bit sums of the spread bits out (host_finish).  top_digit_bits = the smallest t with max magnitude <= 2^t.
+inline uint32_t glv_top_digit_bits(uint32_t c, uint32_t W, bool is_signed, uint32_t kb) {
+    const uint32_t low = c * (W - 1);
+    if (low >= 127) return kb;
+    const unsigned __int128 bound = ((unsigned __int128)7 << 123) - 1;  // largest half
+    const uint64_t maxmag = (uint64_t)(bound >> low) + (is_signed ? 1u : 0u);  // (the signed form's carry)
+    uint32_t t = 0;
+    while (((uint64_t)1 << t) < maxmag) t++;
+    return t < kb ? t : kb;
+}
 
 // ---- planner: replaces the N -> window_size / scale_factor tables (metal_msm.rs:661-691).  The cuZK cost model
 // (utils/window_size_optimizer.rs:38-51: per window N mixed adds plus ~2 full adds per bucket) gives the shape, but two
@@ -86,6 +101,10 @@ inline int32_t make_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_pla
     out->table_factor = 1;
     out->bucket_arrays = out->num_windows;
     out->table_bytes = 0;
+    uint32_t kb = 0;
+    while ((1u << kb) < out->num_buckets) kb++;
+    out->top_digit_bits = use_glv ? glv_top_digit_bits(c, out->num_windows, is_signed, kb) : kb;
+    out->reserved = 0;
     return MSM_OK;
 }
 
@@ -131,6 +150,9 @@ inline int32_t make_table_plan(size_t n, uint32_t window_bits, uint32_t flags, m
     const uint64_t bytes = (uint64_t)f * t.virtual_points * 64;
     if (bytes > tk.max_bytes || (uint64_t)f * t.virtual_points > TABLE_MAX_ENTRIES) return rc;
     t.table_factor = f;
+    uint32_t kb = 0;
+    while ((1u << kb) < t.num_buckets) kb++;
+    t.top_digit_bits = kb;  // (a table's short top window is spread by its table level instead: table_top_shift)
     t.bucket_arrays = t.num_windows / f;
     t.table_bytes = bytes;
     const size_t tb = (size_t)t.bucket_arrays * t.num_buckets, pairs = (size_t)t.num_windows * (size_t)t.virtual_points;
@@ -150,12 +172,19 @@ inline uint32_t table_top_shift(const msm_plan_t& pl, uint32_t tf) {
 }
 
 // Work items of k_accumulate_pieces (msm_kernels.hpp): a bucket of at most pmax entries is ONE piece; a longer one is cut into runs of pmax
-// entries and a rest (up to 8 x pmax) or into runs of psplit entries (beyond).  pmax = 2 x the mean occupancy: Poisson buckets stay whole,
-// the short top window of a plan (2-4 x the mean) is cut into two to four -- whole, those buckets were items of half a SIMD lane's share of
-// the launch and the first round of workgroups, placed three per CU whatever their lengths, left the heaviest CUs 13 % above the mean
-// (profiles/r4_pieces_vs_chunks.txt).  At least 16, at most the 1024 histogram bins of the piece sort.  psplit makes an instance of long
-// buckets only yield ~2^19 pieces (2.7 rounds of resident workgroups), at least 8 entries per piece.  max_pieces / max_partials bound what
-// ANY bucket-size distribution over `pairs` sorted entries and `total_buckets` buckets can produce (workspace sizes).
+// entries and a rest (up to 8 x pmax) or into runs of psplit entries (beyond).
+// pmax = mean occupancy + max(8, 2 sqrt(mean)) -- two standard deviations of a Poisson bucket above the mean: the few per cent of the buckets
+// beyond it are cut, and their RESTS (1 .. ~20 entries) are what the launch ends on.  The pieces run longest first, 1.33 rounds of resident
+// workgroups at 2^20 points; with whole buckets only, the last workgroups still walk 40-50 entries each while the rest of the chip idles.
+// Measured (profiles/r4_top_window_spread.txt; k_accumulate_pieces Mcycles / ms per MSM): 2^20 (mean 64) cap 128: 2.455 / 1.480, 112: 2.461,
+// 96: 2.373 / 1.444, 88: 2.340, 80: 2.313 / 1.423, 72: 2.311 / 1.422 (k_combine_pieces +16 us);  2^19 (32) cap 64: 1.281, 48: 1.193, 40:
+// 1.175, 36: 1.171;  2^18 (16) cap 32: 0.628 / 0.580, 28: 0.610, 24: 0.596 / 0.563, 20: 0.589 / 0.565;  2^17 (8) 16: 0.311 / 0.415, 12: 0.301 /
+// 0.420, 10: 0.294 / 0.421 (the folding costs what the balance gains);  2^16 (4) 16: 0.213 / 0.372, 12: 0.180 / 0.343, 8: 0.152 / 0.345;  unsplit
+// 2^21 (32) 64: 4.305 / 2.859, 43: 4.147 / 2.826;  2^22, 2^24 (64, 256): no difference (6+ rounds).
+// Round 4 before the top window of split plans was spread (glv_top_digit_bits): pmax = 2 x the mean, and the rests of the top window's
+// twice-as-full buckets were that tail.  At most the 1024 histogram bins of the piece sort.  psplit makes an instance of long buckets only
+// yield ~2^19 pieces (2.7 rounds of resident workgroups), at least 8 entries per piece.  max_pieces / max_partials bound what ANY
+// bucket-size distribution over `pairs` sorted entries and `total_buckets` buckets can produce (workspace sizes).
 constexpr uint32_t PIECE_BINS_MAX = 1024;
 struct piece_plan {
     uint32_t pmax = 0, psplit = 0;
@@ -163,7 +192,9 @@ struct piece_plan {
 };
 inline piece_plan make_piece_plan(size_t pairs, size_t mean_occupancy, size_t total_buckets, uint32_t forced_len = 0, const piece_plan* first = nullptr) {
     piece_plan p;
-    p.pmax = (uint32_t)std::min<size_t>(PIECE_BINS_MAX, std::max<size_t>(16, 2 * mean_occupancy));
+    size_t two_sigma = 0;
+    while ((two_sigma + 1) * (two_sigma + 1) <= 4 * mean_occupancy) two_sigma++;  // floor(2 sqrt(mean))
+    p.pmax = (uint32_t)std::min<size_t>(PIECE_BINS_MAX, mean_occupancy + std::max<size_t>(8, two_sigma));
     // FEW buckets (tiny instances on 10-bit windows: a few thousand buckets of 16-64 entries; the shared array of a split window table: 2^15
     // buckets for eight windows' entries) would be as few pieces -- a wavefront on a fraction of the SIMDs, each walking its piece alone; there
     // the pieces shrink until ~2^17 of them exist (at least 8 entries each).  2^17 points with the table: k_accumulate_pieces 0.257 -> 0.149 ms, profiles/r4_table_small.txt

@@ -59,7 +59,7 @@ class Plan(C.Structure):
     _fields_ = [("window_bits", C.c_uint32), ("num_windows", C.c_uint32), ("num_buckets", C.c_uint32),
                 ("signed_digits", C.c_uint32), ("workspace_bytes", C.c_uint64), ("virtual_points", C.c_uint64),
                 ("glv", C.c_uint32), ("scalar_bits", C.c_uint32), ("table_factor", C.c_uint32), ("bucket_arrays", C.c_uint32),
-                ("table_bytes", C.c_uint64)]
+                ("table_bytes", C.c_uint64), ("top_digit_bits", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class Timings(C.Structure):

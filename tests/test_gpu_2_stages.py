@@ -334,3 +334,53 @@ def test_stages_glv_plan_sort_invariants_and_result():
             assert same_point(d.bit_sums[w, u], exp_q[w, u])
     aff, _ = orc.g1_to_affine_std(d.jacobian)
     assert (aff == g["expected"]).all()
+
+
+R_ORDER = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+
+
+@pytest.mark.parametrize("wb,name", [(0, "rand_n4096"), (16, "rand_n1024"), (13, "rand_n1024"), (9, "rand_n1024")])
+def test_stages_glv_digits_rebuild_the_halves_and_the_top_window_is_spread(wb, name):
+    """split plans, decompose stage: the digit codes of virtual points i and n + i rebuild k1 and k2 with k1 + lambda k2 = k (mod r) and
+    |k_j| < 7 * 2^123; in the TOP window the bucket index carries the magnitude in its low msm_plan_t.top_digit_bits bits and the low bits
+    of the point index above them (csrc/msm_planner.hpp glv_top_digit_bits: its buckets as full as the other windows')."""
+    import json
+    import os
+    lam = int(json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "glv_constants.json")))["lambda"], 16)
+    g = load_golden(name)
+    n = g["scalars"].shape[0]
+    with th.HooksContext(window_bits=wb) as c:
+        d = c.stage_dump(g["bases"], g["scalars"], mh.FORM_STD, g["inf"])
+    pl = d.plan
+    assert pl.glv == 1 and d.nv == 2 * n
+    W, kb, t, cb = d.W, d.kb, pl.top_digit_bits, pl.window_bits
+    # the planner's rule, restated: the halves are below 7 * 2^123
+    maxmag = (((7 << 123) - 1) >> (cb * (W - 1))) + 1
+    assert t == min(kb, max(0, (maxmag - 1).bit_length())) and maxmag <= 1 << t
+    live_pts = np.ones(n, bool) if g["inf"] is None else (np.asarray(g["inf"]) == 0)
+    halves = np.zeros((2, n), object)
+    for w in range(W):
+        code = d.digits[w].astype(np.int64)
+        live = code != SKIP
+        idx = code & 0x7FFFFFFF
+        neg = (code & SIGN) != 0
+        if w == W - 1 and t < kb:
+            pt = np.tile(np.arange(n), 2)
+            assert ((idx >> t)[live] == (pt & ((1 << (kb - t)) - 1))[live]).all(), "spread bits are the low bits of the point index"
+            idx = idx & ((1 << t) - 1)
+            if live.sum() >= 16 << (kb - t):  # the spread reaches the top of the window's index range
+                assert (code[live] & 0x7FFFFFFF).max() >> t == (1 << (kb - t)) - 1
+        mag = np.where(live, idx + 1, 0)
+        dig = np.where(neg, -mag, mag)
+        for h in range(2):
+            for i in range(n):
+                halves[h, i] += int(dig[h * n + i]) << (cb * w)
+    for i in range(n):
+        if not live_pts[i]:
+            assert halves[0, i] == 0 and halves[1, i] == 0
+            continue
+        k = orc.words_to_int(g["scalars"][i])
+        assert (halves[0, i] + lam * halves[1, i] - k) % R_ORDER == 0, i
+        assert abs(halves[0, i]) < 7 << 123 and abs(halves[1, i]) < 7 << 123
+    aff, _ = orc.g1_to_affine_std(d.jacobian)
+    assert (aff == g["expected"]).all()

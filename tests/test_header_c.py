@@ -44,7 +44,8 @@ int main(void) {
     printf("msm_plan_t %zu\n", sizeof(msm_plan_t));
     F(msm_plan_t, window_bits); F(msm_plan_t, num_windows); F(msm_plan_t, num_buckets); F(msm_plan_t, signed_digits);
     F(msm_plan_t, workspace_bytes); F(msm_plan_t, virtual_points); F(msm_plan_t, glv); F(msm_plan_t, scalar_bits);
-    F(msm_plan_t, table_factor); F(msm_plan_t, bucket_arrays); F(msm_plan_t, table_bytes);
+    F(msm_plan_t, table_factor); F(msm_plan_t, bucket_arrays); F(msm_plan_t, table_bytes); F(msm_plan_t, top_digit_bits);
+    F(msm_plan_t, reserved);
     printf("msm_timings_t %zu\n", sizeof(msm_timings_t));
     F(msm_timings_t, h2d_ms); F(msm_timings_t, convert_ms); F(msm_timings_t, decompose_ms); F(msm_timings_t, sort_ms);
     F(msm_timings_t, accumulate_ms); F(msm_timings_t, reduce_ms); F(msm_timings_t, finish_ms); F(msm_timings_t, total_ms);

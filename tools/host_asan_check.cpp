@@ -151,8 +151,26 @@ static int check_glv() {
         if (it == 1) std::memset(k, 0xFF, sizeof k), k[7] = 0x3FFFFFFFu;
         uint32_t k1[4], k2[4];
         bool n1, n2;
-        REQUIRE(glv::split(k, k1, n1, k2, n2));          // both halves below 2^127 for every scalar below 2^254
-        REQUIRE((k1[3] >> 31) == 0 && (k2[3] >> 31) == 0);
+        REQUIRE(glv::split(k, k1, n1, k2, n2));          // both halves below 7 * 2^123 for every scalar below 2^254
+        REQUIRE((k1[3] >> 27) < 7 && (k2[3] >> 27) < 7);
+    }
+    // the top window of a split plan (msmplan::glv_top_digit_bits): c = 16: 8 windows, magnitudes <= 14336 -> 14 of 15 index bits; c = 10:
+    // 13 windows, <= 56 -> 6 of 9; c = 9: 15 windows, only the carry -> 0 of 8; unsigned c = 15: 9 windows, <= 55 -> 6 of 15
+    REQUIRE(msmplan::glv_top_digit_bits(16, 8, true, 15) == 14 && msmplan::glv_top_digit_bits(10, 13, true, 9) == 6);
+    REQUIRE(msmplan::glv_top_digit_bits(9, 15, true, 8) == 0 && msmplan::glv_top_digit_bits(15, 9, false, 15) == 6);
+    REQUIRE(msmplan::glv_top_digit_bits(13, 10, true, 12) == 9 && msmplan::glv_top_digit_bits(17, 8, true, 16) == 7);
+    for (size_t n : {(size_t)1 << 10, (size_t)1 << 14, (size_t)1 << 20, (size_t)1 << 22}) {
+        msm_plan_t p;
+        REQUIRE(msmplan::make_plan(n, 0, 0, &p) == MSM_OK);
+        uint32_t kb = 0;
+        while ((1u << kb) < p.num_buckets) kb++;
+        REQUIRE(p.glv ? p.top_digit_bits < kb : p.top_digit_bits == kb);
+        REQUIRE(msmplan::make_plan(n, 0, MSM_FLAG_WINDOW_TABLE, &p) == MSM_OK);
+        msmplan::table_knobs tk;
+        REQUIRE(msmplan::make_table_plan(n, 0, MSM_FLAG_WINDOW_TABLE, &p, msmplan::GLV_MAX_POINTS, tk) == MSM_OK);
+        kb = 0;
+        while ((1u << kb) < p.num_buckets) kb++;
+        REQUIRE(p.table_factor == 1 || p.top_digit_bits == kb);
     }
     return 0;
 }
@@ -190,12 +208,12 @@ static int check_piece_plan() {
     // the BASELINE shape: 8 windows x 2^21 entries over 8 x 32768 buckets (mean 64): whole buckets up to 128 entries, runs of 32
     {
         const msmplan::piece_plan p = msmplan::make_piece_plan((size_t)8 << 21, 64, (size_t)8 << 15);
-        REQUIRE(p.pmax == 128 && p.psplit == 32);
+        REQUIRE(p.pmax == 80 && p.psplit == 32);
     }
     // tiny instance, forced lengths, a later chunk keeps its first chunk's lengths
     REQUIRE(msmplan::make_piece_plan(1000, 0, 512).pmax == 8 && msmplan::make_piece_plan(1000, 0, 512).psplit == 8);
     REQUIRE(msmplan::make_piece_plan((size_t)1 << 21, 8, (size_t)8 << 15).pmax == 16);  // 2^17 points, GLV: unchanged by the tiny-instance rule
-    REQUIRE(msmplan::make_piece_plan((size_t)1 << 28, 600, (size_t)1 << 18).pmax == 1024 && msmplan::make_piece_plan((size_t)1 << 24, 600, 4096).pmax == 128);
+    REQUIRE(msmplan::make_piece_plan((size_t)1 << 28, 600, (size_t)1 << 18).pmax == 648 && msmplan::make_piece_plan((size_t)1 << 28, 4000, (size_t)1 << 18).pmax == 1024 && msmplan::make_piece_plan((size_t)1 << 24, 600, 4096).pmax == 128);
     REQUIRE(msmplan::make_piece_plan((size_t)1 << 21, 64, (size_t)1 << 15).pmax == 16);  // 2^17 points, split window table: one array of 2^15 buckets
     REQUIRE(msmplan::make_piece_plan((size_t)1 << 20, 64, 4096, 7).pmax == 7 && msmplan::make_piece_plan((size_t)1 << 20, 64, 4096, 7).psplit == 7);
     {
