@@ -926,6 +926,9 @@ int32_t run_streamed(msm_ctx* c, const HostInput& in, size_t n, const std::vecto
         if (in.carries_inf() && (rc = ensure(c, c->sinf[s], chunk))) return rc;
         if ((rc = ensure(c, c->sibases[s], (glv ? 2 : 1) * chunk * 64))) return rc;
     }
+    // ONE copy stream for scalars and bases: on two streams (two SDMA queues) the transfers of a chunk share the link at a LOWER combined
+    // rate (24 MB in 0.61 ms instead of 0.47) -- the 16-20 us of command turnaround between two transfers of one queue cost less
+    // (round 4, profiles/r4_host_call_timeline.txt)
     hipStream_t st = c->stream, cs = c->copy_stream;
     PipeState ps;
     if ((rc = pipe_prepare(c, chunk, n, 0, st, &ps))) return rc;  // workspace for the largest chunk before anything is in flight
@@ -940,16 +943,23 @@ int32_t run_streamed(msm_ctx* c, const HostInput& in, size_t n, const std::vecto
             if (j >= 2) HIPCHK(c, hipStreamWaitEvent(cs, c->ev_free[s], 0));  // the pipeline that read this slot is done
             if ((rc = feed_scalars(c, in, lo, cnt, c->sscalars[s].p, d_inf, cs))) return rc;
             HIPCHK(c, hipEventRecord(c->ev_scal[s], cs));
-            if ((rc = feed_bases(c, in, lo, cnt, c->sbases[s].p, (uint32_t*)c->sibases[s].p, d_inf, glv, cs))) return rc;
+            // the copy stream carries COPIES only: with the conversion kernel between two chunks' transfers the link idled ~40 us per
+            // chunk -- and the link is what a host-pointer call waits for
+            if ((rc = h2d(c, c->sbases[s].p, in.bases + lo * in.stride, cnt * in.stride, cs))) return rc;
             HIPCHK(c, hipEventRecord(c->ev_copied[s], cs));
         }
         // the sort only needs the scalars (a third of the chunk's bytes): it starts while the bases still travel.  (The struct form
         // carries the infinity flags inside the base records, which k_decompose reads: there the sort waits for the whole chunk.)
         const bool early_sort = in.kind != KIND_ARK;
-        HIPCHK(c, hipStreamWaitEvent(st, early_sort ? c->ev_scal[s] : c->ev_copied[s], 0));
         if ((rc = pipe_prepare(c, cnt, n, 0, st, &ps, 0, 1, &ps_first))) return rc;
-        if ((rc = enqueue_digits_sort(c, ps, d_inf, (const uint32_t*)c->sscalars[s].p, in.scalars_mont, st, j == 0))) return rc;
-        if ((rc = enqueue_accumulate(c, ps, (const uint32_t*)c->sibases[s].p, st, early_sort ? c->ev_copied[s] : nullptr, j > 0, true))) return rc;
+        HIPCHK(c, hipStreamWaitEvent(st, c->ev_scal[s], 0));
+        if (early_sort) {
+            if ((rc = enqueue_digits_sort(c, ps, d_inf, (const uint32_t*)c->sscalars[s].p, in.scalars_mont, st, j == 0))) return rc;
+        }
+        HIPCHK(c, hipStreamWaitEvent(st, c->ev_copied[s], 0));
+        launch_convert(in, c->sbases[s].p, cnt, (uint32_t*)c->sibases[s].p, d_inf, glv, st);
+        if (!early_sort && (rc = enqueue_digits_sort(c, ps, d_inf, (const uint32_t*)c->sscalars[s].p, in.scalars_mont, st, j == 0))) return rc;
+        if ((rc = enqueue_accumulate(c, ps, (const uint32_t*)c->sibases[s].p, st, nullptr, j > 0, true))) return rc;
         HIPCHK(c, hipEventRecord(c->ev_free[s], st));
         lo += cnt;
     }
@@ -975,7 +985,8 @@ std::vector<size_t> stream_schedule(const msm_ctx* c, size_t n) {
     // longer.  Uniform chunks of 2^18 points (2^19 / 2^20 for large instances): shorter chunks at the end, meant to leave less work
     // after the last byte, cost more in fixed per-chunk work than they hide (measured: 2^20 in 4 chunks 2.89 ms, 3 x 2^18 +
     // 2^17 + 2 x 2^16: 3.48 ms -- profiles/NOTES_r2.md; round 3, with the sort already overlapped: the last chunk halved once / twice /
-    // three times costs +0.12 / +0.24 / +0.41 ms at 2^20, profiles/r3_stream_tail_split.txt).  A remainder below half a chunk joins the last chunk.
+    // three times costs +0.12 / +0.24 / +0.41 ms at 2^20, profiles/r3_stream_tail_split.txt; round 4, copy stream without the conversion
+    // kernels: halved once / twice +0.15 / +0.25 ms, uniform 2^17 +0.3 ms).  A remainder below half a chunk joins the last chunk.
     const uint32_t min_log2 = c->knobs.stream_min_log2;
     uint32_t lg = n < ((size_t)1 << 21) ? 18u : n < ((size_t)1 << 23) ? 19u : 20u;
     if (c->knobs.stream_chunk_log2) lg = c->knobs.stream_chunk_log2;
@@ -1415,7 +1426,7 @@ static int32_t resident_on_lane(msm_ctx* w, const msm_ctx* owner, const uint32_t
             // 2.85 -> 2.75 (profiles/r3_batch_reduce_stream.txt).  The priority is what makes it work: on a plain stream -- also one with
             // a hardware queue of its own (full CU mask) -- the levels queue behind the next accumulation's workgroups and the batch
             // LOSES 10-18 %; leaving 8-32 CUs out of the shared stream's CU mask for them loses 5-10 %; k_combine moved along: no gain.
-            // (o->red_active: msm_bn254_g1_resident_batch measures the mechanism once per context and drops it where it is slower.)
+            // (o->red_active: set by the batch call for MSM_BATCH_LAYOUT_ONE_STREAM_REDUCE -- msm_config_t.batch_layout or msm_tune_batch.)
             hipStream_t rs = st;
             if (shared && o->red_active && o->lane1 && w->ev_body) {
                 rs = o->lane1->copy_stream;

@@ -67,7 +67,11 @@ inline uint32_t plan_window_bits_glv(size_t n, bool is_signed) {
     // Re-measured after k_accumulate lost 11 % of its instructions (round 2, tools/sweep_c.py, ramped-up clock, ms): 2^13 c = 10 0.337,
     // 13 0.327, 16 0.331; 2^14 10 0.362-0.369, 13 0.363, 16 0.331; 2^15 12 0.406-0.409, 15 0.390, 16 0.336-0.346; 2^16 16 0.378-0.382
     // (15: 0.446); 2^17 16 0.451 (13: 0.552); 2^18 16 0.613 (13: 0.760); 2^19 16 0.937 (13: 1.201)  => 16 from 2^14 points on.
-    uint32_t c = n < ((size_t)1 << 14) ? 10u : 16u;
+    // Round 4, with the top window spread over all of its buckets (glv_top_digit_bits: a 9-bit top window of c = 13 no longer piles 2n points
+    // into 448 buckets; tools/r4_sweep_c.sh, profiles/r4_window_width_sweep.txt, ms): 2^11 c = 10 0.246-0.261, 13 0.227; 2^12 10 0.272-0.276, 12 0.240,
+    // 13 0.232; 2^13 10 0.310, 12 0.270, 13 0.247, 16 0.293; 2^14 13 0.278, 14 0.289, 16 0.291-0.297; 2^15 13 0.323, 16 0.307-0.319; 2^16 13 0.371, 15 0.367,
+    // 16 0.336; 2^17 15 0.463, 16 0.415; 2^19 13 1.059, 16 0.846; 2^8..2^10: 0.20-0.23 whatever the width  => 13 from 2^11 to below 2^15 points.
+    uint32_t c = n < ((size_t)1 << 11) ? 10u : n < ((size_t)1 << 15) ? 13u : 16u;
     if (!is_signed && c > 15u) c = 15u;
     return c;
 }
