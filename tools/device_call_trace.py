@@ -31,7 +31,7 @@ n = 1 << lg
 gen = th.HooksContext()
 d_b = torch.empty(n * 16, dtype=torch.int32, device="cuda:0"); d_s = torch.empty(n * 8, dtype=torch.int32, device="cuda:0")
 gen.generate_device(1, 2, n, d_b.data_ptr(), d_s.data_ptr()); torch.cuda.synchronize()
-c = mh.MsmContext(max_points=n)
+c = mh.MsmContext(max_points=n, window_bits=int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 t0 = time.perf_counter()
 while time.perf_counter() - t0 < 0.2: c.msm_device(d_b.data_ptr(), d_s.data_ptr(), n)
 ts = []
