@@ -129,6 +129,10 @@ struct Knobs {
     }
 };
 
+// Chunks of a streamed host call in flight: the transfer of chunk j + STREAM_SLOTS reuses the raw buffers of chunk j and waits for its
+// accumulation.  With two slots the link stalls when a chunk's transfer is shorter than the accumulation of the chunk two before it (the two
+// half-size chunks a ragged instance ends on); three cost one more chunk of HBM.
+constexpr int STREAM_SLOTS = 3;
 struct msm_ctx {
     std::mutex mu;
     Knobs knobs;
@@ -141,10 +145,10 @@ struct msm_ctx {
     uint32_t tuned_layout[2] = {0, 0};     // msm_tune_batch: the measured MSM_BATCH_LAYOUT_* per size class (below / from 2^19 points); 0 = not tuned
     uint32_t last_batch_layout = 0;        // what the last batch call ran under (msm_timings_t.batch_layout)
     bool red_active = false;               // the reduce stream is in use by the batch call that is running
-    hipEvent_t ev_copied[2]{}, ev_free[2]{}, ev_scal[2]{};  // streamed host call: slot's bases+scalars there / slot free again / its scalars there
+    hipEvent_t ev_copied[STREAM_SLOTS]{}, ev_free[STREAM_SLOTS]{}, ev_scal[STREAM_SLOTS]{};  // streamed host call: slot's bases+scalars there / slot free again / its scalars there
     hipEvent_t ev_fork = nullptr, ev_bases = nullptr;  // base conversion runs on copy_stream beside the sort kernels
-    DevBuf sbases[2], sscalars[2], sinf[2];  // double-buffered raw inputs of the streamed path
-    DevBuf sibases[2];                        // ... and of the converted bases (the conversion of chunk j+1 runs beside the accumulation of chunk j)
+    DevBuf sbases[STREAM_SLOTS], sscalars[STREAM_SLOTS], sinf[STREAM_SLOTS];  // raw inputs of the streamed path, one set per chunk in flight
+    DevBuf sibases;                           // the converted bases of the chunk being accumulated (conversion and accumulation share the compute stream)
     msm_config_t cfg{};
     std::string err;
     hipEvent_t ev[EV_COUNT]{};
@@ -912,20 +916,22 @@ int32_t run_single(msm_ctx* c, const HostInput& in, size_t n, uint32_t* out_jac,
 // range is cut into chunks; chunk j+1 travels host->HBM and is converted on the copy stream while chunk j is sorted and
 // accumulated on the compute stream.  MSM is linear in the points, so every chunk adds into the SAME bucket array
 // (k_accumulate<INTO>, one plan for the whole instance): ONE bucket reduction, ONE host finish and W*(kb+1) bit sums back,
-// however many chunks.  Raw and converted inputs are double-buffered.  Transfer (96 B per point at ~56 GB/s from pinned, ~40 GB/s
-// from pageable memory) and per-chunk work (~0.47 ms per 2^18 points) are about level: the call costs the first transfer, then
-// the slower of the two per chunk, then the reduction and the host finish (2^20: 2.7-2.9 ms against 1.7 resident).
+// however many chunks.  Raw inputs live in STREAM_SLOTS buffers; the conversion runs on the compute stream right before the chunk's
+// accumulation (the copy stream carries copies only).  Transfer (96 B per point at 52-56 GB/s from pinned, ~40 GB/s from pageable memory:
+// 0.48 ms per 2^18 points) and per-chunk work (sort 0.09 + conversion 0.02 + accumulation INTO the buckets 0.29-0.31 + fold 0.02 = 0.43 ms)
+// are about level: the call costs the first transfer, then the slower of the two per chunk, then the last chunk's work, the reduction
+// and the host finish (2^20: 2.43-2.53 ms pinned against 1.45 resident; timeline in profiles/r4_host_call_timeline.txt).
 int32_t run_streamed(msm_ctx* c, const HostInput& in, size_t n, const std::vector<size_t>& sizes, uint32_t* out_jac,
                      uint32_t* out_aff, uint8_t* out_inf) {
     int32_t rc;
     const bool glv = plan_glv(c, n);  // of the WHOLE instance: all chunks share one bucket array
     const size_t chunk = *std::max_element(sizes.begin(), sizes.end());
-    for (int s = 0; s < 2; s++) {
+    for (int s = 0; s < STREAM_SLOTS; s++) {
         if ((rc = ensure(c, c->sbases[s], chunk * in.stride))) return rc;
         if ((rc = ensure(c, c->sscalars[s], chunk * 32))) return rc;
         if (in.carries_inf() && (rc = ensure(c, c->sinf[s], chunk))) return rc;
-        if ((rc = ensure(c, c->sibases[s], (glv ? 2 : 1) * chunk * 64))) return rc;
     }
+    if ((rc = ensure(c, c->sibases, (glv ? 2 : 1) * chunk * 64))) return rc;
     // ONE copy stream for scalars and bases: on two streams (two SDMA queues) the transfers of a chunk share the link at a LOWER combined
     // rate (24 MB in 0.61 ms instead of 0.47) -- the 16-20 us of command turnaround between two transfers of one queue cost less
     // (round 4, profiles/r4_host_call_timeline.txt)
@@ -935,12 +941,12 @@ int32_t run_streamed(msm_ctx* c, const HostInput& in, size_t n, const std::vecto
     const PipeState ps_first = ps;                                 // piece lengths: fixed by the largest chunk
     size_t lo = 0;
     for (size_t j = 0; j < sizes.size(); j++) {
-        const int s = (int)(j & 1);
+        const int s = (int)(j % STREAM_SLOTS);
         const size_t cnt = sizes[j];
         uint8_t* d_inf = in.carries_inf() ? (uint8_t*)c->sinf[s].p : nullptr;
         {
             Range r_("msm:h2d chunk");
-            if (j >= 2) HIPCHK(c, hipStreamWaitEvent(cs, c->ev_free[s], 0));  // the pipeline that read this slot is done
+            if (j >= (size_t)STREAM_SLOTS) HIPCHK(c, hipStreamWaitEvent(cs, c->ev_free[s], 0));  // the pipeline that read this slot is done
             if ((rc = feed_scalars(c, in, lo, cnt, c->sscalars[s].p, d_inf, cs))) return rc;
             HIPCHK(c, hipEventRecord(c->ev_scal[s], cs));
             // the copy stream carries COPIES only: with the conversion kernel between two chunks' transfers the link idled ~40 us per
@@ -957,9 +963,9 @@ int32_t run_streamed(msm_ctx* c, const HostInput& in, size_t n, const std::vecto
             if ((rc = enqueue_digits_sort(c, ps, d_inf, (const uint32_t*)c->sscalars[s].p, in.scalars_mont, st, j == 0))) return rc;
         }
         HIPCHK(c, hipStreamWaitEvent(st, c->ev_copied[s], 0));
-        launch_convert(in, c->sbases[s].p, cnt, (uint32_t*)c->sibases[s].p, d_inf, glv, st);
+        launch_convert(in, c->sbases[s].p, cnt, (uint32_t*)c->sibases.p, d_inf, glv, st);
         if (!early_sort && (rc = enqueue_digits_sort(c, ps, d_inf, (const uint32_t*)c->sscalars[s].p, in.scalars_mont, st, j == 0))) return rc;
-        if ((rc = enqueue_accumulate(c, ps, (const uint32_t*)c->sibases[s].p, st, nullptr, j > 0, true))) return rc;
+        if ((rc = enqueue_accumulate(c, ps, (const uint32_t*)c->sibases.p, st, nullptr, j > 0, true))) return rc;
         HIPCHK(c, hipEventRecord(c->ev_free[s], st));
         lo += cnt;
     }
@@ -986,7 +992,9 @@ std::vector<size_t> stream_schedule(const msm_ctx* c, size_t n) {
     // after the last byte, cost more in fixed per-chunk work than they hide (measured: 2^20 in 4 chunks 2.89 ms, 3 x 2^18 +
     // 2^17 + 2 x 2^16: 3.48 ms -- profiles/NOTES_r2.md; round 3, with the sort already overlapped: the last chunk halved once / twice /
     // three times costs +0.12 / +0.24 / +0.41 ms at 2^20, profiles/r3_stream_tail_split.txt; round 4, copy stream without the conversion
-    // kernels: halved once / twice +0.15 / +0.25 ms, uniform 2^17 +0.3 ms).  A remainder below half a chunk joins the last chunk.
+    // kernels and three slots: halved once / twice / three times +0.08 / +0.2 / +0.3 ms -- a 2^17-point chunk still costs 0.30 ms of
+    // sort + accumulation INTO 2^18 buckets, two of them 0.17 ms more than the chunk they replace, and the compute stream has no slack
+    // left to hide it).  A remainder below half a chunk joins the last chunk.
     const uint32_t min_log2 = c->knobs.stream_min_log2;
     uint32_t lg = n < ((size_t)1 << 21) ? 18u : n < ((size_t)1 << 23) ? 19u : 20u;
     if (c->knobs.stream_chunk_log2) lg = c->knobs.stream_chunk_log2;
@@ -1111,7 +1119,7 @@ static int32_t ctx_create_impl(const msm_config_t* cfg, msm_ctx** out, int main_
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_bases, hipEventDisableTiming);
-    for (int i = 0; i < 2 && e == hipSuccess; i++) {
+    for (int i = 0; i < STREAM_SLOTS && e == hipSuccess; i++) {
         e = hipEventCreateWithFlags(&c->ev_copied[i], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_free[i], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_scal[i], hipEventDisableTiming);
@@ -1188,11 +1196,11 @@ void msm_ctx_destroy(msm_ctx* c) {
         for (DevBuf* b : bufs) release(*b);
         if (c->h_qsums) (void)hipHostFree(c->h_qsums);
         if (c->h_flags) (void)hipHostFree(c->h_flags);
-        for (int i = 0; i < 2; i++) {
+        release(c->sibases);
+        for (int i = 0; i < STREAM_SLOTS; i++) {
             release(c->sbases[i]);
             release(c->sscalars[i]);
             release(c->sinf[i]);
-            release(c->sibases[i]);
             if (c->ev_copied[i]) (void)hipEventDestroy(c->ev_copied[i]);
             if (c->ev_free[i]) (void)hipEventDestroy(c->ev_free[i]);
             if (c->ev_scal[i]) (void)hipEventDestroy(c->ev_scal[i]);
