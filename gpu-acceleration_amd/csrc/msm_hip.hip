@@ -432,15 +432,15 @@ int32_t enqueue_decompose(msm_ctx* c, const PipeState& ps, const uint8_t* d_inf,
     uint32_t *dg = (uint32_t*)c->digits.p, *rk = (uint32_t*)c->ranks.p;
     dim3 g = grid1(n_real, 256);
     const uint32_t nr = (uint32_t)n_real;
-    const uint32_t spread_mask = ps.top_bits < ps.kb ? (1u << (ps.kb - ps.top_bits)) - 1u : 0u;  // (split plans without a table)
+    const uint32_t spread_mask = ps.top_bits < ps.kb ? (1u << (ps.kb - ps.top_bits)) - 1u : 0u;  // (plans without a table)
     if (pl.glv) {
         if (!sg.lds_counts) return fail(c, MSM_ERR_BAD_ARG, "window_bits %u needs the non-GLV path (MSM_FLAG_NO_GLV)", cbits);
         if (pl.signed_digits) msmk::k_decompose_glv<true><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, dg, flags, scalars_mont, ps.top_shift, ps.top_bits, spread_mask);
         else msmk::k_decompose_glv<false><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, dg, flags, scalars_mont, ps.top_shift, ps.top_bits, spread_mask);
-    } else if (pl.signed_digits && sg.lds_counts) msmk::k_decompose<true, false><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, nb, hist, dg, rk, flags, scalars_mont, ps.top_shift);
-    else if (pl.signed_digits) msmk::k_decompose<true, true><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, nb, hist, dg, rk, flags, scalars_mont, ps.top_shift);
-    else if (sg.lds_counts) msmk::k_decompose<false, false><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, nb, hist, dg, rk, flags, scalars_mont, ps.top_shift);
-    else msmk::k_decompose<false, true><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, nb, hist, dg, rk, flags, scalars_mont, ps.top_shift);
+    } else if (pl.signed_digits && sg.lds_counts) msmk::k_decompose<true, false><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, nb, hist, dg, rk, flags, scalars_mont, ps.top_shift, ps.top_bits, spread_mask);
+    else if (pl.signed_digits) msmk::k_decompose<true, true><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, nb, hist, dg, rk, flags, scalars_mont, ps.top_shift, ps.top_bits, spread_mask);
+    else if (sg.lds_counts) msmk::k_decompose<false, false><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, nb, hist, dg, rk, flags, scalars_mont, ps.top_shift, ps.top_bits, spread_mask);
+    else msmk::k_decompose<false, true><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, nb, hist, dg, rk, flags, scalars_mont, ps.top_shift, ps.top_bits, spread_mask);
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_DECOMP], st));
     return MSM_OK;
 }

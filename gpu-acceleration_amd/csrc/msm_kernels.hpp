@@ -370,7 +370,7 @@ template <bool SIGNED, bool HIST>
 __global__ void k_decompose(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_mask, uint32_t n,
                             uint32_t c, uint32_t W, uint32_t nb, uint32_t* __restrict__ hist,
                             uint32_t* __restrict__ digits, uint32_t* __restrict__ ranks, uint32_t* __restrict__ err,
-                            uint32_t scalars_mont, uint32_t top_shift) {
+                            uint32_t scalars_mont, uint32_t top_shift, uint32_t top_bits, uint32_t spread_mask) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) err[FLAG_LONG] = 0, err[FLAG_MID] = 0, err[FLAG_PIECES] = 0, err[FLAG_PARTIALS] = 0;  // list counters of this (chunk of an) MSM: k_piece_count fills them later in the stream
     if (i >= n) return;
@@ -403,6 +403,9 @@ __global__ void k_decompose(const uint32_t* __restrict__ scalars, const uint8_t*
             digits[o] = DIGIT_SKIP;
         } else {
             uint32_t bkt = mag - 1;
+            // the top window of a plan holds 254 - c*(W-1) bits: magnitudes up to 2^top_bits.  spread_mask != 0 (msmplan::top_digit_bits): the index
+            // bits above them carry low bits of the point index, so that the window's entries use all of its buckets (see k_decompose_glv)
+            if (w == W - 1 && spread_mask) bkt |= (i & spread_mask) << top_bits;
             if (HIST) ranks[o] = atomicAdd(&hist[(size_t)w * nb + bkt], 1u);
             digits[o] = bkt | neg;
         }

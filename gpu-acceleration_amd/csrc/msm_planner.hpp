@@ -107,7 +107,9 @@ inline int32_t make_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_pla
     out->table_bytes = 0;
     uint32_t kb = 0;
     while ((1u << kb) < out->num_buckets) kb++;
-    out->top_digit_bits = use_glv ? glv_top_digit_bits(c, out->num_windows, is_signed, kb) : kb;
+    // unsplit: scalars below 2^254 (checked on the device) leave the top window 254 - c*(W-1) bits: magnitudes up to 2^that (signed carry included)
+    const uint32_t top_plain = std::min(kb, 254u - c * (out->num_windows - 1));
+    out->top_digit_bits = use_glv ? glv_top_digit_bits(c, out->num_windows, is_signed, kb) : top_plain;
     out->reserved = 0;
     return MSM_OK;
 }

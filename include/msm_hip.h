@@ -114,9 +114,9 @@ typedef struct {
     uint32_t bucket_arrays;  /* num_windows / table_factor bucket arrays of num_buckets buckets each         */
     uint64_t table_bytes;    /* HBM the window table of the resident set takes (0 without one)               */
     uint32_t top_digit_bits; /* the TOP window's bucket index holds the digit magnitude - 1 in its low top_digit_bits bits; when that is
-                                less than log2(num_buckets) -- split plans: the halves are below 2^125.81, the top window has few digit
-                                values -- the bits above hold low bits of the point index, so that its buckets are as full as every
-                                other window's (csrc/msm_planner.hpp glv_top_digit_bits)                       */
+                                less than log2(num_buckets) -- the top window only holds 254 - c*(W-1) bits (split plans: the halves are
+                                below 2^125.81) -- the bits above hold low bits of the point index, so that its buckets are as full as
+                                every other window's (csrc/msm_planner.hpp)                                    */
     uint32_t reserved;
 } msm_plan_t;
 

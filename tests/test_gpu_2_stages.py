@@ -43,8 +43,25 @@ def signed_digits(scalars, c, W, signed=True):
     return out
 
 
+def placed(d, digits_signed):
+    """where the engine PUTS a digit: bucket index + 1 with the digit's sign.  Every window but the top one: the digit itself.  The top
+    window holds 254 - c*(W-1) bits (msm_plan_t.top_digit_bits = t): its bucket index is (|digit| - 1) | (point index mod 2^(kb-t)) << t, so
+    that its entries use all of the window's buckets (csrc/msm_planner.hpp, k_decompose); the host leaves the bit sums u >= t out."""
+    t, kb = d.plan.top_digit_bits, d.kb
+    if t >= kb:
+        return digits_signed
+    out = digits_signed.copy()
+    top = out[d.W - 1]
+    mag = np.abs(top)
+    assert (mag <= 1 << t).all(), "top window magnitude beyond 2^top_digit_bits"
+    spread = (np.arange(top.shape[0]) & ((1 << (kb - t)) - 1)) << t
+    out[d.W - 1] = np.where(mag > 0, np.sign(top) * (((mag - 1) | spread) + 1), 0)
+    return out
+
+
 def check_sort(d, digits_signed, inf=None):
     """offsets / sorted against the digits (transpose.rs:95-118: stable counting sort; here grouped, order inside a bucket free)"""
+    digits_signed = placed(d, digits_signed)
     W, nb, nv = d.W, d.nb, d.nv
     assert d.offsets[0] == 0
     total = 0
@@ -78,7 +95,7 @@ def same_point(a, b):
 
 
 def check_buckets_and_bits(d, bases, form, digits_signed, inf, expected_affine):
-    exp_b = orc.bucket_sums(bases, digits_signed, d.nb, form, inf)
+    exp_b = orc.bucket_sums(bases, placed(d, digits_signed), d.nb, form, inf)
     for k in range(d.W * d.nb):
         assert same_point(d.buckets[k], exp_b[k]), ("bucket sum", k // d.nb, k % d.nb)
     exp_q = orc.bit_sums(exp_b, d.W, d.nb)

@@ -159,6 +159,13 @@ static int check_glv() {
     REQUIRE(msmplan::glv_top_digit_bits(16, 8, true, 15) == 14 && msmplan::glv_top_digit_bits(10, 13, true, 9) == 6);
     REQUIRE(msmplan::glv_top_digit_bits(9, 15, true, 8) == 0 && msmplan::glv_top_digit_bits(15, 9, false, 15) == 6);
     REQUIRE(msmplan::glv_top_digit_bits(13, 10, true, 12) == 9 && msmplan::glv_top_digit_bits(17, 8, true, 16) == 7);
+    {   // unsplit plans: the top window holds 254 - c*(W-1) bits
+        msm_plan_t p;
+        REQUIRE(msmplan::make_plan((size_t)1 << 20, 16, MSM_FLAG_NO_GLV, &p) == MSM_OK && p.num_windows == 16 && p.top_digit_bits == 14);
+        REQUIRE(msmplan::make_plan((size_t)1 << 20, 20, MSM_FLAG_NO_GLV, &p) == MSM_OK && p.num_windows == 13 && p.top_digit_bits == 14);
+        REQUIRE(msmplan::make_plan((size_t)1 << 20, 17, MSM_FLAG_NO_GLV, &p) == MSM_OK && p.num_windows == 15 && p.top_digit_bits == 16);
+        REQUIRE(msmplan::make_plan((size_t)1 << 20, 9, MSM_FLAG_NO_GLV | MSM_FLAG_UNSIGNED_DIGITS, &p) == MSM_OK && p.num_windows == 29 && p.top_digit_bits == 2);
+    }
     for (size_t n : {(size_t)1 << 10, (size_t)1 << 14, (size_t)1 << 20, (size_t)1 << 22}) {
         msm_plan_t p;
         REQUIRE(msmplan::make_plan(n, 0, 0, &p) == MSM_OK);
