@@ -376,7 +376,7 @@ int32_t pipe_prepare(msm_ctx* c, size_t n_real, size_t plan_n, uint32_t extra_fl
     return MSM_OK;
 }
 
-// K1b: digits + signed recode of one (chunk of an) MSM on stream st (with the GLV split: two 127-bit halves per scalar, 2*n_real digit
+// K1b: digits + signed recode of one (chunk of an) MSM on stream st (with the GLV split: two halves below 7 * 2^123 per scalar, 2*n_real digit
 // columns).  Needs the scalars (and the infinity mask), NOT the bases.  first = false: a later chunk of a streamed MSM (error bits and
 // the running count of additions survive).
 struct SortGeom {  // counting-sort plan of (sW sort windows, sn entries each, nb buckets per window)

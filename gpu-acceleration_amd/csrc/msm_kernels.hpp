@@ -22,7 +22,7 @@
 //   sorted   W x n    point index | sign<<31 grouped by bucket        == val_idxs of the reference
 //   buckets  W*nb x 36  XYZZ bucket sums, 4 coordinates x 9 limbs of 29 bits (144 B);
 //   plist    pieces x 4     (bucket, first sorted entry, length | flags, partial slot), longest pieces first
-//   partials  x 36          partial sums of buckets longer than 4 x the mean occupancy (skewed scalars only)
+//   partials  x 36          partial sums of the pieces of buckets longer than the cap (mean + 2 sigma: msmplan::make_piece_plan)
 #pragma once
 #include "ec_bn254.hpp"
 #include "ec_wide.hpp"
@@ -1061,16 +1061,17 @@ __global__ void k_scatter(const uint32_t* __restrict__ digits, const uint32_t* _
 // of partial sums per bucket (54 us at 2^20, 46 us at 2^17) after heads and tails travelled through HBM, and (ii) the launch was 1.33 rounds
 // of identical workgroups, whose last wavefront per SIMD ran alone for a whole chunk (tools/ab_libs.py chunk sweep, profiles/
 // r4_pieces_vs_chunks.txt: 2.47 Mcycles at L = 64 against 2.28 at L = 22, where k_combine then cost 0.44 ms instead of 0.20).
-// Here a work item is a PIECE: a whole bucket, or a part of one that is longer than `pmax` entries (2 x the mean occupancy: the buckets of a
-// plan's short top window, which hold 2-4 x the mean, become runs of pmax and a short rest; on uniform scalars nothing else is cut) -- runs
+// Here a work item is a PIECE: a whole bucket, or a part of one that is longer than `pmax` entries (mean occupancy + two standard
+// deviations, msmplan::make_piece_plan: the few per cent of Poisson buckets beyond it become a run of pmax and a short rest) -- runs
 // of pmax up to 8 x pmax, runs of `psplit` entries beyond (skewed scalars: psplit plays the part the chunk length used to, short enough that
 // an instance made of long buckets only still yields ~2^19 pieces and that the longest item of an under-filled launch does not run alone
 // for long).  pmax must stay well below a SIMD lane's share of the launch (256 entries at 2^20): the resident workgroups of the first
 // round are placed three per CU whatever their lengths, and with whole top-window buckets of ~128-175 entries among ordinary ones of ~64
 // the heaviest CUs carried 13 % more than the mean (2.78 against 2.43 Mcycles, profiles/r4_pieces_vs_chunks.txt).  The pieces are counting-sorted by
 // length, longest first, so the 64 lanes of a wavefront run the same trip count (the property the chunks were built for), the long items
-// start first and the launch ends on its shortest ones (LPT order), a bucket that is one piece is written straight to its slot, and
-// nothing is left to combine on uniform scalars.  Split buckets leave partial sums in `partials` and are listed for k_combine_pieces
+// start first and the launch ends on its shortest ones (LPT order: the rests of the cut buckets), and a bucket that is one piece is
+// written straight to its slot.  (First form: the top window of a plan was not spread yet and its twice-as-full buckets, cut at 2 x the mean,
+// supplied the rests; now the decomposition spreads it -- k_decompose(_glv) -- and the cap itself does.)  Split buckets leave partial sums in `partials` and are listed for k_combine_pieces
 // (2..7 pieces: one thread per bucket; 8 or more: LDS trees of eight-lane additions per 2048-piece segment).
 // Measured against the chunk form, same build, one box (profiles/r4_pieces_vs_chunks.txt): 2^20 1.557 -> 1.488 ms, 2^17 0.470 -> 0.440,
 // 2^22 5.32 -> 5.00.
@@ -1082,10 +1083,9 @@ constexpr uint32_t PF_WHOLE = 0x80000000u;            // piece.z: the bucket is 
 constexpr uint32_t PF_FIRST = 0x40000000u;            // piece.z: first piece of a split bucket (INTO: starts from the bucket's old value)
 constexpr uint32_t PF_LEN_MASK = 0x00FFFFFFu;
 
-// how a bucket of sz entries is cut: 1 piece up to pmax entries; up to LONG_SPAN * pmax entries into runs of pmax and a remainder (the
-// short top window of a plan: buckets of ~2x the mean -> pmax + a short rest, one addition to fold them -- the short rests are what the
-// launch ends on: cut into EQUAL halves instead, the same buckets cost k_accumulate_pieces 2.63 instead of 2.40 Mcycles at 2^20, the
-// smallest items then being ~35 entries long); beyond that into runs of psplit.
+// how a bucket of sz entries is cut: 1 piece up to pmax entries; up to LONG_SPAN * pmax entries into runs of pmax and a remainder (one
+// addition to fold them; the short rests are what the launch ends on: cut into EQUAL halves instead, buckets of twice the mean cost
+// k_accumulate_pieces 2.63 instead of 2.40 Mcycles at 2^20, the smallest items then being ~35 entries long); beyond that into runs of psplit.
 // Returns the number of pieces m; pieces 0 .. m-2 hold *q entries, the last one the rest.
 __device__ __forceinline__ uint32_t piece_split(uint32_t sz, uint32_t pmax, uint32_t psplit, uint32_t* q) {
     if (sz <= pmax) {

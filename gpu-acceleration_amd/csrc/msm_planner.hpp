@@ -51,7 +51,7 @@ inline uint32_t plan_window_bits(size_t n, bool is_signed) {
     if (!is_signed && c > 15u) c = 15u;
     return c;
 }
-// GLV (glv_bn254.hpp): 2n virtual points with 127-bit scalars -- the same additions in half the windows: half the buckets to
+// GLV (glv_bn254.hpp): 2n virtual points with half-length scalars (|k_j| < 7 * 2^123, windows over 127 bits) -- the same additions in half the windows: half the buckets to
 // reduce, half the host's Horner chain.  Interleaved A/B against the unsplit pipeline (tools/ab_glv.py): 2^10 -12.8 %, 2^14 -11.9 %,
 // 2^16 -12.3 %, 2^17 -12.2 %, 2^18 -9.6 %, 2^19 +1.1 %, 2^20 -0.4 %, 2^21 +9.2 %, 2^22 +6.8 % (twice the base records to gather
 // from, k_accumulate unchanged, and the fixed costs it halves no longer matter).  With the chunk length following the bucket
@@ -95,7 +95,7 @@ inline int32_t make_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_pla
     out->glv = use_glv ? 1u : 0u;
     out->scalar_bits = bits;
     out->virtual_points = use_glv ? 2 * (uint64_t)n : (uint64_t)n;
-    // signed: one spare window position so the top digit never overflows (r < 2^254, |k_j| < 2^127): W = floor(bits/c) + 1
+    // signed: one spare window position so the top digit never overflows (r < 2^254, |k_j| < 2^126): W = floor(bits/c) + 1
     out->num_windows = is_signed ? (bits / c + 1) : ((bits + c - 1) / c);
     out->num_buckets = is_signed ? (1u << (c - 1)) : (1u << c);
     size_t nv = (size_t)out->virtual_points;
