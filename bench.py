@@ -54,6 +54,24 @@ MADS_PER_ADD = 6 * 162 + 2 * 126 + 243           # v_mad_u64_u32 instructions
 FPMUL_EQ_PER_ADD = (6 * 171 + 2 * 135 + 252) / 171.0  # in units of one fp_mul (162 mads + 9 Montgomery-digit multiplications)
 
 
+# vector instructions of one mixed addition in k_accumulate_pieces' loop (disassembly of the round-4 build: 1468 v_mad_u64_u32, 81 v_mul_lo_u32, 150
+# v_lshrrev_b64, 201 v_and_b32, the rest adds / subs / unpack; rocprofv3 --pmc counts 2101 per addition and lane, profiles/accumulate_valu_pmc.json)
+VALU_INSTS_PER_ADD = 2126
+
+
+def issue_floor(num_adds, mcycles, simds):
+    """the hard bound of the kernel's instruction stream: a 64-lane wavefront occupies its 16-lane SIMD for >= 4 cycles per vector instruction"""
+    if not (num_adds and mcycles and simds):
+        return None
+    wave_adds_per_simd = num_adds / 64.0 / simds
+    cpi = mcycles * 1e6 / (wave_adds_per_simd * VALU_INSTS_PER_ADD)
+    return {"vector_instructions_per_addition": VALU_INSTS_PER_ADD, "simds": simds, "wavefront_additions_per_simd": round(wave_adds_per_simd, 1),
+            "floor_mcycles": round(wave_adds_per_simd * VALU_INSTS_PER_ADD * 4 / 1e6, 3), "measured_mcycles": mcycles,
+            "cycles_per_instruction": round(cpi, 3), "frac_of_issue_floor": round(4.0 / cpi, 4),
+            "note": "floor = 4 cycles per vector instruction and wavefront on a 16-lane SIMD; measured = live kernel ms x the shader clock the kernel "
+                    "measured for itself (clock.k_accumulate_mcycles)"}
+
+
 def valu_roofline(num_adds, acc_ms, mad_peak, fpmul_peak):
     if not (num_adds and acc_ms > 0 and mad_peak > 0 and fpmul_peak > 0):
         return None
@@ -421,6 +439,9 @@ def main():
             # the bound that actually holds: multiplier work of the launch against what two calibration
             # micro-kernels sustain on THIS device (dependent chains, 4 wavefronts per SIMD, like k_accumulate)
             "roofline_valu": valu_roofline(int(tm.get("num_adds", 0)), acc_avg_ms, mad_peak, fpmul_peak) if not args.streamed else None,
+            "issue_floor": (issue_floor(int(tm.get("num_adds", 0)), round(acc_avg_ms * 1e-3 * clk_loop["sclk_ghz"] * 1e3, 3),
+                                        4 * torch.cuda.get_device_properties(dev).multi_processor_count)
+                            if clk_loop and clk_loop["samples"] and not args.streamed else None),
             "stage_ms_untimed_diagnostic_step": {k: round(v, 4) for k, v in tm.items() if k.endswith("_ms")},
         }
         if exchange is not None:
