@@ -392,6 +392,17 @@ def main():
                 break
         sort_ms = float(tm.get("sort_ms", 0.0) or 0.0)
         sort_bytes = 8 * int(pl.virtual_points) * W  # per window N*(2 read + 2 read + 4 write)
+        sort_traffic, sort_traffic_src = None, None  # HBM bytes the six sort launches really move (same offline PMC passes, tools/pmc_sort_summarize.py)
+        for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "sort_pmc*.json"))):
+            try:
+                j = json.load(open(pmc))
+            except Exception:
+                continue
+            if j.get("n_local") == n_local and j.get("window_bits") == pl.window_bits and bool(j.get("glv_split")) == bool(pl.glv):
+                sort_traffic = j.get("sort_hbm_bytes")
+                sort_traffic_src = {"source": "file", "file": os.path.relpath(pmc, ROOT), "build": j.get("build"),
+                                    "detail": "offline rocprofv3 --pmc passes (tools/pmc_accumulate.sh + tools/pmc_sort_summarize.py); not measured in this run"}
+                break
         out = {
             "metric": "BN254 G1 MSM latency (ms) at N=2^%d, bit-exact vs arkworks-equivalent oracle" % args.log_n,
             "value": round(ms_per_step, 4), "unit": "ms", "n_gpus": nshards, "steps": args.steps, "warmup": args.warmup, "pre_warm_steps": pre_warm_steps,
@@ -435,7 +446,11 @@ def main():
             "roofline_sort": ({"bound": "hbm", "kernels": "k_coarse_hist+k_coarse_prefix+k_coarse_starts+k_coarse_scatter+k_fine_sort+k_big_place",
                                "algorithmic_bytes": sort_bytes, "ms": round(sort_ms, 4), "achieved": round(sort_bytes / (sort_ms * 1e-3) / 1e9, 1),
                                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(sort_bytes / (sort_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
-                               "note": "latency/LDS-atomic bound at this size (6 dependent launches over 64 MB of digits)"} if sort_ms > 0 else None),
+                               "traffic": sort_traffic, "traffic_source": sort_traffic_src,
+                               "traffic_GBps": round(sort_traffic / (sort_ms * 1e-3) / 1e9, 1) if sort_traffic else None,
+                               "note": "achieved = SURVEY's algorithmic bytes (one read + one write of the pairs) over the hipEvent time of the six launches; a "
+                                       "counting sort reads the digits three times and writes them twice (traffic: what the counters saw), and four of the "
+                                       "six launches are launch-bound (~5 us each)"} if sort_ms > 0 else None),
             # the bound that actually holds: multiplier work of the launch against what two calibration
             # micro-kernels sustain on THIS device (dependent chains, 4 wavefronts per SIMD, like k_accumulate)
             "roofline_valu": valu_roofline(int(tm.get("num_adds", 0)), acc_avg_ms, mad_peak, fpmul_peak) if not args.streamed else None,

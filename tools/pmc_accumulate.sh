@@ -16,5 +16,6 @@ for n in ${*:-20}; do
   done
   python3 tools/pmc_summarize.py $O "${BUILD:-round 4}" > $O/summary.txt
   cp $O/summary.json gpurun_out/accumulate_pmc_2p$n.json
+  python3 tools/pmc_sort_summarize.py $O "${BUILD:-round 4}" > $O/sort_summary.txt && cp $O/sort_summary.json gpurun_out/sort_pmc_2p$n.json
   python3 -c "import json; j=json.load(open('$O/summary.json')); print('2^$n: c', j['window_bits'], 'W', j.get('num_windows'), 'glv', j.get('glv_split'), 'HBM bytes per launch', j['hbm_bytes_per_launch'], 'algorithmic', j.get('algorithmic_bytes_per_launch'), 'ratio', j.get('traffic_over_algorithmic'))"
 done
