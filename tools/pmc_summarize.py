@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise tools/pmc_accumulate.sh output: per-dispatch FETCH_SIZE / WRITE_SIZE (KiB) of k_accumulate, the
 calibration factors measured with tools/calib_gather, and the corrected HBM bytes per launch.
-Writes <dir>/summary.json; copy it to profiles/accumulate_pmc.json to have bench.py report `roofline.traffic`."""
+Writes <dir>/summary.json; copy it to profiles/accumulate_pmc_2p<log_n>.json to have bench.py report `roofline.traffic`."""
 import csv, glob, json, sys, collections
 d = sys.argv[1]
 def per_kernel(pattern):
