@@ -251,10 +251,35 @@ __global__ void k_decompress(const uint32_t* __restrict__ rec, uint32_t n, uint3
     const fp x = fp_from_std(w);                                    // < 1.01p
     const fp three = fp_add(fp_dbl(fp_one()), fp_one());              // < 3p
     const fp rhs = fp_add(fp_mul(fp_sqr(x), x), three);              // < 4.01p
-    fp y = rhs;
-    for (int b = 250; b >= 0; b--) {                                  // top bit of the exponent consumed by y = rhs
-        y = fp_sqr(y);                                                // < 1.1p
-        if ((EXP[b >> 5] >> (b & 31)) & 1u) y = fp_mul(y, rhs);       // < 1.03p
+    // fixed 3-bit windows over the 252-bit exponent (84 of them): 7 table entries rhs^1 .. rhs^7 in registers, then per window three
+    // squarings and -- unless the window is zero -- one multiplication instead of the 251 + 126 of
+    // bit-by-bit square-and-multiply: 252 + 74 for this exponent (-16 % multiplier instructions).  The window value is a constant of the exponent: wave-uniform.
+    fp tab[7];
+    tab[0] = rhs;                              // < 4.01p: a product's operand, as in the bit-by-bit chain
+    tab[1] = fp_sqr(tab[0]);                   // ^2
+    tab[2] = fp_mul(tab[1], tab[0]);           // ^3
+    tab[3] = fp_sqr(tab[1]);                   // ^4
+    tab[4] = fp_mul(tab[3], tab[0]);           // ^5
+    tab[5] = fp_sqr(tab[2]);                   // ^6
+    tab[6] = fp_mul(tab[5], tab[0]);           // ^7
+    auto window = [&](int k) -> uint32_t {  // bits [3k, 3k+3) of the exponent
+        const int b = 3 * k, i = b >> 5;
+        const uint64_t lo = EXP[i], hi = i < 7 ? EXP[i + 1] : 0u;
+        return (uint32_t)(((hi << 32) | lo) >> (b & 31)) & 7u;
+    };
+    auto entry = [&](uint32_t d) {  // d in 1..7, uniform
+        fp r = tab[0];
+#pragma unroll
+        for (int k = 1; k < 7; k++)
+            if (d == (uint32_t)k + 1) r = tab[k];
+        return r;
+    };
+    fp y = entry(window(83));                  // the top window (bits 249..251) is not zero: bit 251 is set
+#pragma unroll 1
+    for (int k = 82; k >= 0; k--) {
+        y = fp_sqr(fp_sqr(fp_sqr(y)));                                // < 1.1p
+        const uint32_t d = window(k);
+        if (d) y = fp_mul(y, entry(d));                               // < 1.03p
     }
     const fp y2 = fp_canonical(fp_sqr(y)), r2 = fp_canonical(rhs);
     bool ok = true;
