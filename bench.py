@@ -49,6 +49,8 @@ def words_to_ints(a):
     return out
 
 
+EXTRAS_DEADLINE_S = int(os.environ.get("MSM_BENCH_EXTRAS_DEADLINE_S", "420"))  # the untimed legs of a default run take ~6 s
+
 # one mixed addition (ec_bn254.hpp xyzz_madd, the loop body of k_accumulate_pieces): 6 fp_mul + 2 fp_sqr + 1 fused fp_mul_add
 MADS_PER_ADD = 6 * 162 + 2 * 126 + 243           # v_mad_u64_u32 instructions
 FPMUL_EQ_PER_ADD = (6 * 171 + 2 * 135 + 252) / 171.0  # in units of one fp_mul (162 mads + 9 Montgomery-digit multiplications)
@@ -112,6 +114,8 @@ def timed_calls(fn, reps, warm=1, warm_s=0.1):
 
 
 def main():
+    import faulthandler
+    faulthandler.dump_traceback_later(1500, exit=True)  # a stalled run leaves the stacks of all threads on stderr instead of nothing
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -480,6 +484,24 @@ def main():
             except Exception:
                 pass
 
+        # ---- from here on: UNTIMED extras (host-pointer legs, resident / batch / table legs, the CPU baseline).  The measurement itself is
+        #      complete; a watchdog prints the line without whatever is still missing if the extras stall (one run in ~80 on the gpurun pool
+        #      sat for 20 minutes on a box that answered again afterwards -- cause unknown, never reproduced: 25 of 25 reruns took 8 s)
+        import threading
+
+        def _emit_without_extras():
+            late = dict(out)
+            late["bit_exact"] = bit_exact
+            late["extras_timed_out"] = "untimed legs did not finish within %d s; the timed measurement above is complete" % EXTRAS_DEADLINE_S
+            print(json.dumps(late))
+            sys.stdout.flush()
+            os._exit(0 if bit_exact else 1)
+
+        watchdog = threading.Timer(EXTRAS_DEADLINE_S, _emit_without_extras)
+        watchdog.daemon = True
+        if world == 1:
+            watchdog.start()
+
         # ---- host-pointer legs (the reference's own measurement shape: benches/e2e.rs:46-60 times the call from HOST slices);
         #      same instance, copied to the host once outside every timed region; never `value`
         if world == 1 and not in_proc and not args.no_host_legs and not args.streamed:
@@ -588,6 +610,7 @@ def main():
                                              % (lg, os.environ.get("OMP_PROC_BIND"), os.environ.get("OMP_PLACES"), -(-254 // c_ark), c_ark, threads),
                                    "agrees_with_gpu": cpu_ok}
             bit_exact = bit_exact and cpu_ok
+        watchdog.cancel()
         out["bit_exact"] = bit_exact
         print(json.dumps(out))
         sys.stdout.flush()
