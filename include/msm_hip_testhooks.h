@@ -55,7 +55,7 @@ int32_t msm_calibrate(msm_ctx *ctx, double *mad_per_s, double *fp_mul_per_s);
  *        offsets     W*nb + 1   exclusive prefix of the bucket sizes (CSC column pointer)
  *        sorted      W x nv     first offsets[W*nb] entries valid: virtual point index | negate << 31, grouped by bucket
  *        buckets     W*nb x 24  bucket sums, Jacobian Montgomery words (bucket b of window w holds the digit magnitude b + 1; in the TOP
- *                               window of a split plan the magnitude (b mod 2^t) + 1, t = msm_plan_t.top_digit_bits, the index bits above
+ *                               window, when t = msm_plan_t.top_digit_bits < kb, the magnitude (b mod 2^t) + 1, the index bits above
  *                               t being low bits of the point index)
  *        bit_sums    W x (kb+1) x 24   Q_{w,u} (u < kb: buckets whose index has bit u set) and Q_{w,kb} = all buckets
  *      With MSM_FLAG_WINDOW_TABLE in the context's flags the RESIDENT path runs (upload + window table, then the resident
