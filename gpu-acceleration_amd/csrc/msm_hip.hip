@@ -1036,7 +1036,7 @@ int32_t build_table_locked(msm_ctx* c, const msm_plan_t& pl) {
     uint32_t* t = (uint32_t*)c->rbases.p;
     const uint32_t top_shift = table_top_shift(pl, pl.table_factor);
     for (uint32_t j = 1; j < pl.table_factor; j++)  // (the top level of a full table: top_shift doublings fewer, see table_top_shift)
-        msmk::k_table_next<<<grid1(nv, 256), 256, 0, c->stream>>>(t + (size_t)(j - 1) * nv * 16, t + (size_t)j * nv * 16, (uint32_t)nv,
+        msmk::k_table_next<<<grid1((nv + 1) / 2, 256), 256, 0, c->stream>>>(t + (size_t)(j - 1) * nv * 16, t + (size_t)j * nv * 16, (uint32_t)nv,
                                                                  pl.window_bits - (j + 1 == pl.table_factor ? top_shift : 0u));
     c->table_c = pl.window_bits, c->table_f = pl.table_factor;
     return MSM_OK;

@@ -62,7 +62,7 @@ extern "C" {
                                        set add a digit of window j as +-T_j[i] into ONE bucket array shared by all windows: the buckets are
                                        reduced once per MSM instead of once per window, which moves the optimum to wider windows (c = 20
                                        at 2^20 points: 13 windows instead of 16, 19 % fewer additions, a 19-position host chain instead of
-                                       254).  Memory: W x 64 bytes per (virtual) point -- 872 MB at 2^20 -- see msm_plan_t.table_bytes; build 39 ms at
+                                       254).  Memory: W x 64 bytes per (virtual) point -- 872 MB at 2^20 -- see msm_plan_t.table_bytes; build 28 ms at
                                        2^20 (what ~300 MSMs gain: for base sets that outlive many calls, e.g. a proving key); none above 2^21.
                                        Every other entry point, and a resident call on fewer scalars than bases, is unaffected.
                                        Results are the same group element either way (bit-exact affine coordinates).            */
