@@ -173,7 +173,7 @@ int32_t msm_bn254_g1_resident(msm_ctx *ctx, const uint32_t *scalars, size_t n, u
 /* the same with the scalars already in HBM (ABI 4): d_scalars = n x 8 words of device memory, e.g. the witness of a prover whose
  * earlier stages ran on the GPU; hip_stream = the hipStream_t that produced them (NULL = the context's stream).  Nothing crosses
  * PCIe but the 96-byte result, the bases are not converted again (msm_bn254_g1_device converts its bases on every call), and a
- * context created with MSM_FLAG_WINDOW_TABLE uses the table: 2^20 points 1.27 ms against the 1.40 of msm_bn254_g1_device in the same run (1.35 without the table).
+ * context created with MSM_FLAG_WINDOW_TABLE uses the table: 2^20 points 1.28 ms against the 1.41 of msm_bn254_g1_device in the same run (1.35 without the table).
  * Blocks until the result is on the host. */
 int32_t msm_bn254_g1_resident_device(msm_ctx *ctx, const void *d_scalars, size_t n, void *hip_stream,
                                      uint32_t out_jacobian_mont[24], uint32_t out_affine_std[16], uint8_t *out_is_inf);
