@@ -61,6 +61,15 @@ int main() {
         if (!same(to_host_mont256(fp_sub<3>(a, b)), hostg1::sub(ha, hb))) { printf("sub mismatch\n"); return 1; }
         if (!same(to_host_mont256(fp_mul_add(a, b, b, fp_neg<3>(a))), hostg1::sub(hostg1::mul(ha, hb), hostg1::mul(hb, ha)))) { printf("mul_add mismatch\n"); return 1; }
         checks += 5;
+        if (it % 100 == 0) {  // the windowed Fermat inversion (fp_inv) against the host's bit-by-bit one; 0 -> 0
+            if (!same(to_host_mont256(fp_inv(a)), hostg1::inv(ha))) { printf("inv mismatch\n"); return 1; }
+            checks++;
+        }
+    }
+    {
+        uint32_t z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const fp zero = fp_from_mont256(z);
+        if (!same(to_host_mont256(fp_inv(zero)), hostg1::load_words(z))) { printf("inv(0) != 0\n"); return 1; }
     }
     // 2. long chains of group operations on arbitrary field values (bounds are what is being checked)
     for (int chain = 0; chain < 2000; chain++) {
