@@ -112,6 +112,43 @@ FP_HD void xyzz_madd(xyzz& acc, const affine& q) {
     acc.zz = fp_mul(acc.zz, pp);       // < 1.02
     acc.zzz = fp_mul(acc.zzz, ppp);    // < 1.02
 }
+// acc += +-(x2, y2) where the affine operand arrives as qx = 32 * X2, qy = 32 * Y2 (fp_unpack_shl5 of the caller's R = 2^256 Montgomery words:
+// congruent to the internal-domain coordinates, normalised limbs, value < 2^261 = 169.4p for ANY 256-bit words, < 32p for canonical ones) and
+// the sign of the digit is applied to S2 = Y2 * ZZZ1 instead of to y2 (a negated 32 * Y2 would need a pad of 170p).  Same instruction count as
+// xyzz_madd; bounds with the 169.4p multipliers:  U2, S2 < 169.4 * 2k + 1 = 3.0;  P < 11;  R < 4 + 6 = 10;  PP < 1.72;  PPP < 1.12;  Q < 1.08;
+// R^2 < 1.59, PPP + 2Q < 3.28 (< 4: fp_sub_b_2c);  X3 < 6.6 (< 7);  Y3 < (10 * 9.08 + 6 * 1.12)k + 1 < 1.58;  ZZ3, ZZZ3 < 1.03.
+// No k_convert_bases pass, no second copy of the bases in HBM (round 5).
+FP_HD void xyzz_madd_m32(xyzz& acc, const fp& qx, const fp& qy, bool neg) {
+    if (xyzz_is_identity(acc)) {  // (every piece starts here: two multiplications by one instead of a mixed addition)
+        const fp x = fp_mul(qx, fp_one()), y = fp_mul(qy, fp_one());  // < 169.4k + 1 < 2
+        acc = xyzz{x, neg ? fp_neg<4>(y) : y, fp_one(), fp_one()};   // Y < 4
+        return;
+    }
+    fp u2 = fp_mul(qx, acc.zz);        // < 3.0
+    fp s2 = fp_mul(qy, acc.zzz);       // < 3.0
+    fp s2s = s2;
+    if (neg) s2s = fp_neg_raw<4>(s2);  // raw: an addend of the next subtraction only (a branch, not selects: nine subtractions under the lane mask)
+    fp pp_ = fp_sub<8>(u2, acc.x);     // P: acc.x < 7;  P < 11
+    fp r = fp_sub<6>(s2s, acc.y);      // R: acc.y < 5;  R < 10   (s2s raw: limbs < 2^30, + pad < 2^31: fp_normalize's input range)
+    fp pp = fp_sqr(pp_);               // < 1.72
+    if (fp_is_zero_lt2p(pp)) {         // P == 0 (mod p): same x
+        if (fp_is_zero_lt2p(fp_sqr(r))) {  // same point
+            const fp x = fp_reduce_lt2p(fp_mul(qx, fp_one())), y = fp_reduce_lt2p(fp_mul(qy, fp_one()));  // canonical
+            acc = xyzz_dbl_affine(neg ? affine_neg(affine{x, y}) : affine{x, y});
+        } else {
+            acc = xyzz_identity();     // opposite points
+        }
+        return;
+    }
+    fp ppp = fp_mul(pp_, pp);          // < 1.12
+    fp qv = fp_mul(acc.x, pp);         // < 1.08
+    fp x3 = fp_sub_b_2c(fp_sqr(r), ppp, qv);  // r^2 < 1.59, ppp + 2 qv < 3.28;  x3 < 6.6
+    fp y3 = fp_mul_add(r, fp_sub_raw<8>(qv, x3), fp_neg_raw<6>(acc.y), ppp);  // r*(qv - x3) + (6p - y)*ppp: (10*9.08 + 6*1.12)k + 1 < 1.58
+    acc.x = x3;
+    acc.y = y3;
+    acc.zz = fp_mul(acc.zz, pp);       // < 1.03
+    acc.zzz = fp_mul(acc.zzz, ppp);    // < 1.03
+}
 // a + b, add-2008-s, 12M+2S, complete.
 FP_HD xyzz xyzz_add(const xyzz& a, const xyzz& b) {
     if (xyzz_is_identity(a)) return b;
@@ -133,6 +170,30 @@ FP_HD xyzz xyzz_add(const xyzz& a, const xyzz& b) {
     fp y3 = fp_mul_add(r, fp_sub_raw<8>(qv, x3), fp_neg_raw<3>(s1), ppp);  // r*(qv - x3) + (3p - s1)*ppp: (4.06*9.01 + 3*1.03)k + 1 < 1.24
     fp zz3 = fp_mul(fp_mul(a.zz, b.zz), pp);
     fp zzz3 = fp_mul(fp_mul(a.zzz, b.zzz), ppp);
+    return xyzz{x3, y3, zz3, zzz3};
+}
+
+// xyzz_add for kernels that run ONE wavefront per SIMD or fewer (the bucket reduction, k_combine_pieces): the fourteen products as six
+// interleaved pairs and one two-accumulator multiply-add (fp_mul2 / fp_sqr2 / fp_mul_add_2acc) -- the same values, the same bounds, about half
+// the dependency chain.  Not for k_accumulate_pieces-like occupancy, where the plain chain already issues at the SIMD's rate.
+FP_HD xyzz xyzz_add_ilp(const xyzz& a, const xyzz& b) {
+    if (xyzz_is_identity(a)) return b;
+    if (xyzz_is_identity(b)) return a;
+    fp u1, u2, s1, s2, pp, rr, ppp, qv, zzab, zzzab, zz3, zzz3;
+    fp_mul2(a.x, b.zz, b.x, a.zz, u1, u2);      // < 1.09
+    fp_mul2(a.y, b.zzz, b.y, a.zzz, s1, s2);    // < 1.06
+    fp pp_ = fp_sub<3>(u2, u1);                 // < 4.09
+    fp r = fp_sub<3>(s2, s1);                   // < 4.06
+    fp_sqr2(pp_, r, pp, rr);                    // < 1.1
+    if (fp_is_zero_lt2p(pp)) {
+        if (fp_is_zero_lt2p(rr)) return xyzz_dbl(a);
+        return xyzz_identity();
+    }
+    fp_mul2(pp_, pp, u1, pp, ppp, qv);          // < 1.03, < 1.01
+    fp_mul2(a.zz, b.zz, a.zzz, b.zzz, zzab, zzzab);
+    fp x3 = fp_sub_b_2c(rr, ppp, qv);           // x3 < 6.1
+    fp_mul2(zzab, pp, zzzab, ppp, zz3, zzz3);
+    fp y3 = fp_mul_add_2acc(r, fp_sub_raw<8>(qv, x3), fp_neg_raw<3>(s1), ppp);  // < 1.24
     return xyzz{x3, y3, zz3, zzz3};
 }
 

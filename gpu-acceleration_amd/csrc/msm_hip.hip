@@ -261,9 +261,28 @@ float stage_ms(const msm_ctx* c, int a, int b) {
 
 inline dim3 grid1(size_t n, unsigned block) { return dim3((unsigned)((n + block - 1) / block)); }
 
-void finish_outputs(const hostg1::Jac& r, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf) {
-    if (out_jac) hostg1::store_jac(out_jac, r);
+// canonical = MSM_FLAG_DETERMINISTIC: the Jacobian result is handed out as its Z = 1 representative (x*R, y*R, R), the identity as (R, R, 0)
+// -- the same 24 words for the same group element, whatever order the buckets were filled in (the sort places entries inside a bucket with
+// LDS atomics: the XYZZ sums, hence X : Y : Z, differ between identical calls; only the group element does not).  Costs the inversion the
+// affine output pays anyway (~10 us of host time), shared when both are asked for.
+void finish_outputs(const hostg1::Jac& r, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf, bool canonical = false) {
     if (out_inf) *out_inf = hostg1::is_identity(r) ? 1 : 0;
+    if (canonical && out_jac) {
+        if (hostg1::is_identity(r)) {
+            hostg1::store_jac(out_jac, hostg1::identity());
+            if (out_aff) std::memset(out_aff, 0, 64);
+            return;
+        }
+        const hostg1::Fq zi = hostg1::inv(r.z), zi2 = hostg1::sqr(zi);
+        const hostg1::Fq xm = hostg1::mul(r.x, zi2), ym = hostg1::mul(r.y, hostg1::mul(zi2, zi));
+        hostg1::store_jac(out_jac, hostg1::Jac{xm, ym, hostg1::ONE});
+        if (out_aff) {
+            hostg1::store_words(out_aff, hostg1::from_mont(xm));
+            hostg1::store_words(out_aff + 8, hostg1::from_mont(ym));
+        }
+        return;
+    }
+    if (out_jac) hostg1::store_jac(out_jac, r);
     if (out_aff) {  // the only inversion of the whole call (~10 us): callers that want the reference's result type
                     // (Jacobian, metal_msm.rs:228-241) pass NULL and skip it
         hostg1::Fq x, y;
@@ -271,6 +290,15 @@ void finish_outputs(const hostg1::Jac& r, uint32_t* out_jac, uint32_t* out_aff, 
         hostg1::store_words(out_aff, x);
         hostg1::store_words(out_aff + 8, y);
     }
+}
+// msm_bn254_g1_combine with the representative chosen by the caller's flags (the multi-GPU fold of a MSM_FLAG_DETERMINISTIC handle)
+int32_t combine_partials(const uint32_t* partials, size_t k, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf, bool canonical) {
+    if (!partials) return MSM_ERR_BAD_ARG;
+    if (k == 0) return MSM_ERR_EMPTY;
+    hostg1::Jac total = hostg1::identity();
+    for (size_t i = 0; i < k; i++) total = hostg1::jadd(total, hostg1::load_jac(partials + i * 24));  // fixed rank order
+    finish_outputs(total, out_jac, out_aff, out_inf, canonical);
+    return MSM_OK;
 }
 
 // Everything the three enqueue steps of one (chunk of an) MSM share.  The PLAN (window width, digit form, GLV split: what the
@@ -381,6 +409,8 @@ int32_t pipe_prepare(msm_ctx* c, size_t n_real, size_t plan_n, uint32_t extra_fl
 // the running count of additions survive).
 struct SortGeom {  // counting-sort plan of (sW sort windows, sn entries each, nb buckets per window)
     bool tiled = false, two_level = false, lds_counts = false;
+    bool d16 = false;   // the digits travel as 16-bit codes (msm_kernels.hpp DIGIT16_*): two-level sort, <= 2^15 buckets per window, no window table
+    uint32_t drow = 0;  // entries per row of the digit array (sn, padded to an even number for 16-bit codes)
     uint32_t coarse_bits = 0, fine_bits = 0, idx_bits = 0, ncoarse = 0, NS = 0, nsuper = 1;
 };
 SortGeom sort_geometry(const msm_ctx* c, const PipeState& ps) {
@@ -407,6 +437,12 @@ SortGeom sort_geometry(const msm_ctx* c, const PipeState& ps) {
     g.two_level = g.fine_bits <= 9 && g.nsuper <= msmk::SUPER_MAX && !c->knobs.direct_scatter;
     g.lds_counts = g.two_level || g.tiled;  // no device-scope histogram / rank atomics in k_decompose
     g.NS = (uint32_t)((sn + msmk::SUBTILE - 1) / msmk::SUBTILE);
+#ifdef MSM_AB_DIGITS32  // A/B builds only (tools/build_variant.sh): the 32-bit codes of rounds 1-4 everywhere
+    g.d16 = false;
+#else
+    g.d16 = g.two_level && ps.tf == 1 && kb <= 15;
+#endif
+    g.drow = (uint32_t)(g.d16 ? (sn + 1) & ~(size_t)1 : sn);  // (d16: tf == 1, a sort window is a decomposition window)
     return g;
 }
 
@@ -429,18 +465,27 @@ int32_t enqueue_decompose(msm_ctx* c, const PipeState& ps, const uint8_t* d_inf,
     if (first && !c->flags_clean) HIPCHK(c, hipMemsetAsync(flags, 0, 64, st));
     if (first) c->flags_clean = false;
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_CONVERT], st));
-    uint32_t *dg = (uint32_t*)c->digits.p, *rk = (uint32_t*)c->ranks.p;
+    void* dg = c->digits.p;
+    uint32_t *rk = (uint32_t*)c->ranks.p, *ph = (uint32_t*)c->phist.p, *pcu = (uint32_t*)c->pcursor.p;
     dim3 g = grid1(n_real, 256);
-    const uint32_t nr = (uint32_t)n_real;
+    const uint32_t nr = (uint32_t)n_real, drow = sg.d16 ? sg.drow : (uint32_t)ps.n;  // row of ONE window (a sort window is tf of them)
     const uint32_t spread_mask = ps.top_bits < ps.kb ? (1u << (ps.kb - ps.top_bits)) - 1u : 0u;  // (plans without a table)
+#define MSM_DECOMP_ARGS d_scalars, d_inf, nr, cbits, W, nb, hist, dg, drow, rk, flags, scalars_mont, ps.top_shift, ps.top_bits, spread_mask, ph, pcu
+#define MSM_DECOMP_GLV_ARGS d_scalars, d_inf, nr, cbits, W, dg, drow, flags, scalars_mont, ps.top_shift, ps.top_bits, spread_mask, ph, pcu
     if (pl.glv) {
         if (!sg.lds_counts) return fail(c, MSM_ERR_BAD_ARG, "window_bits %u needs the non-GLV path (MSM_FLAG_NO_GLV)", cbits);
-        if (pl.signed_digits) msmk::k_decompose_glv<true><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, dg, flags, scalars_mont, ps.top_shift, ps.top_bits, spread_mask);
-        else msmk::k_decompose_glv<false><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, dg, flags, scalars_mont, ps.top_shift, ps.top_bits, spread_mask);
-    } else if (pl.signed_digits && sg.lds_counts) msmk::k_decompose<true, false><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, nb, hist, dg, rk, flags, scalars_mont, ps.top_shift, ps.top_bits, spread_mask);
-    else if (pl.signed_digits) msmk::k_decompose<true, true><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, nb, hist, dg, rk, flags, scalars_mont, ps.top_shift, ps.top_bits, spread_mask);
-    else if (sg.lds_counts) msmk::k_decompose<false, false><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, nb, hist, dg, rk, flags, scalars_mont, ps.top_shift, ps.top_bits, spread_mask);
-    else msmk::k_decompose<false, true><<<g, 256, 0, st>>>(d_scalars, d_inf, nr, cbits, W, nb, hist, dg, rk, flags, scalars_mont, ps.top_shift, ps.top_bits, spread_mask);
+        if (pl.signed_digits && sg.d16) msmk::k_decompose_glv<true, true><<<g, 256, 0, st>>>(MSM_DECOMP_GLV_ARGS);
+        else if (pl.signed_digits) msmk::k_decompose_glv<true, false><<<g, 256, 0, st>>>(MSM_DECOMP_GLV_ARGS);
+        else if (sg.d16) msmk::k_decompose_glv<false, true><<<g, 256, 0, st>>>(MSM_DECOMP_GLV_ARGS);
+        else msmk::k_decompose_glv<false, false><<<g, 256, 0, st>>>(MSM_DECOMP_GLV_ARGS);
+    } else if (pl.signed_digits && sg.d16) msmk::k_decompose<true, false, true><<<g, 256, 0, st>>>(MSM_DECOMP_ARGS);
+    else if (pl.signed_digits && sg.lds_counts) msmk::k_decompose<true, false, false><<<g, 256, 0, st>>>(MSM_DECOMP_ARGS);
+    else if (pl.signed_digits) msmk::k_decompose<true, true, false><<<g, 256, 0, st>>>(MSM_DECOMP_ARGS);
+    else if (sg.d16) msmk::k_decompose<false, false, true><<<g, 256, 0, st>>>(MSM_DECOMP_ARGS);
+    else if (sg.lds_counts) msmk::k_decompose<false, false, false><<<g, 256, 0, st>>>(MSM_DECOMP_ARGS);
+    else msmk::k_decompose<false, true, false><<<g, 256, 0, st>>>(MSM_DECOMP_ARGS);
+#undef MSM_DECOMP_ARGS
+#undef MSM_DECOMP_GLV_ARGS
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_DECOMP], st));
     return MSM_OK;
 }
@@ -456,7 +501,7 @@ int32_t enqueue_sort(msm_ctx* c, const PipeState& ps, hipStream_t st, bool into)
     uint32_t* hist = (uint32_t*)c->hist.p;
     uint32_t* offsets = (uint32_t*)c->offsets.p;
     uint32_t* flags = (uint32_t*)c->flags.p;
-    const uint32_t* digits = (const uint32_t*)c->digits.p;
+    const uint32_t* digits = (const uint32_t*)c->digits.p;  // (32-bit codes on every path but the two-level sort with sg.d16)
     const SortGeom sg = sort_geometry(c, ps);
     const uint32_t coarse_bits = sg.coarse_bits, fine_bits = sg.fine_bits, idx_bits = sg.idx_bits, ncoarse = sg.ncoarse, NS = sg.NS;
     uint32_t T = 1, tile_len = (uint32_t)sn;
@@ -471,7 +516,9 @@ int32_t enqueue_sort(msm_ctx* c, const PipeState& ps, hipStream_t st, bool into)
         uint32_t* rtotal = (uint32_t*)c->cregion.p;
         uint32_t* rstart = rtotal + nregions;
         uint32_t* tmp = (uint32_t*)c->sorttmp.p;  // staging copy of the two-level sort
-        msmk::k_coarse_hist<<<dim3(NS, sW), msmk::TILE_BLOCK, 0, st>>>(digits, counts, (uint32_t)sn, fine_bits, ncoarse, NS, flags);
+        uint32_t *ph = (uint32_t*)c->phist.p, *pcu = (uint32_t*)c->pcursor.p;
+        if (sg.d16) msmk::k_coarse_hist<true><<<dim3(NS, sW), msmk::TILE_BLOCK, 0, st>>>(c->digits.p, sg.drow, counts, (uint32_t)sn, fine_bits, ncoarse, NS, flags, ph, pcu);
+        else msmk::k_coarse_hist<false><<<dim3(NS, sW), msmk::TILE_BLOCK, 0, st>>>(c->digits.p, sg.drow, counts, (uint32_t)sn, fine_bits, ncoarse, NS, flags, ph, pcu);
         msmk::k_coarse_prefix<<<grid1(nregions, msmk::PREFIX_REGIONS), 1024, 0, st>>>(counts, rtotal, NS, ncoarse, nregions);
         // regions too large for one workgroup's staging area are cut into batches that worker blocks share (skewed scalars)
         uint32_t fine_block = (sn >> coarse_bits) <= 1024 ? 256u : (sn >> coarse_bits) <= 2048 ? 512u : 1024u;
@@ -483,7 +530,8 @@ int32_t enqueue_sort(msm_ctx* c, const PipeState& ps, hipStream_t st, bool into)
         // path pays a global cursor add per bucket and batch and is meant for the few huge regions of skewed scalars -- with every
         // region ~3 x oversized (2^22 points x 13 windows in one array) it took 5 ms where the owners take 0.6)
         msmk::k_coarse_starts<<<1, msmk::SCAN_BLOCK, 0, st>>>(rtotal, rstart, nregions, flags + msmk::FLAG_PAIRS, offsets + tb, bigslot, big, 4 * fine_cap, fine_cap);
-        msmk::k_coarse_scatter<<<dim3(NS, sW), msmk::TILE_BLOCK, 0, st>>>(digits, counts, rstart, tmp, (uint32_t)sn, fine_bits, idx_bits, ncoarse, NS);
+        if (sg.d16) msmk::k_coarse_scatter<true><<<dim3(NS, sW), msmk::TILE_BLOCK, 0, st>>>(c->digits.p, sg.drow, counts, rstart, tmp, (uint32_t)sn, fine_bits, idx_bits, ncoarse, NS);
+        else msmk::k_coarse_scatter<false><<<dim3(NS, sW), msmk::TILE_BLOCK, 0, st>>>(c->digits.p, sg.drow, counts, rstart, tmp, (uint32_t)sn, fine_bits, idx_bits, ncoarse, NS);
         // workgroup size by mean region size (a workgroup stages up to 16 elements per thread); grid.x = the window's regions +
         // BIG_WORKERS_X worker blocks for the batches of oversized regions, which k_big_place then places
         const uint32_t wx = std::max(msmk::BIG_WORKERS_X, (msmk::BIG_WORKERS_MIN + sW - 1) / sW);  // worker blocks per sort window
@@ -524,7 +572,7 @@ int32_t enqueue_sort(msm_ctx* c, const PipeState& ps, hipStream_t st, bool into)
         }
     }
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_SORT], st));
-    // the piece list, longest first (k_accumulate_pieces zeroes the histogram and the cursors again)
+    // the piece list, longest first (its histogram and bin cursors were zeroed at the head of this chain: msmk::clear_piece_bins)
     msmk::k_piece_count<<<grid1(tb, 1024), 1024, 0, st>>>(offsets, (uint32_t)tb, ps.pmax, ps.psplit, (uint32_t*)c->phist.p, flags, (uint32_t*)c->longlist.p,
                                                         (uint32_t*)c->midlist.p, (uint32_t*)c->pbase.p, (uint32_t*)c->buckets.p, into ? 1u : 0u);
     msmk::k_piece_scatter<<<grid1(tb, 1024), 1024, 0, st>>>(offsets, (uint32_t)tb, ps.pmax, ps.psplit, (const uint32_t*)c->phist.p, (uint32_t*)c->pcursor.p,
@@ -540,11 +588,29 @@ int32_t enqueue_digits_sort(msm_ctx* c, const PipeState& ps, const uint8_t* d_in
     return enqueue_sort(c, ps, st, !first);
 }
 
+// Where k_accumulate_pieces gathers its base records from.  m256 = false: `rec` holds INTERNAL-domain packed records (with the GLV split
+// 2*n_real of them, phi(P_i) at index n_real + i) -- resident sets, window tables, standard-form and struct inputs (k_convert_bases /
+// k_import_ark / k_decompress wrote them).  m256 = true (round 5): `rec` are the CALLER's arkworks words (R = 2^256 Montgomery) as they
+// arrived, entries from nsplit on are phi records in the same form (k_phi_records; split plans only).
+struct BaseSrc {
+    const uint32_t* rec = nullptr;
+    const uint32_t* phi = nullptr;
+    uint32_t nsplit = 0xFFFFFFFFu;
+    bool m256 = false;
+    BaseSrc() = default;
+    BaseSrc(const uint32_t* internal_records) : rec(internal_records) {}  // NOLINT: the internal-domain form converts implicitly
+    BaseSrc shifted(size_t lo) const {  // the point range starting at lo (unsplit plans only)
+        BaseSrc s = *this;
+        s.rec = rec + lo * 16;
+        return s;
+    }
+};
+
 // K3: bucket accumulation (the graded kernel) -- bracketed by its own events on its own stream -- and the buckets cut by chunk
 // borders.  d_bases: INTERNAL-domain records; with the GLV split 2*n_real of them, phi(P_i) at index n_real + i.
 // into = true: the buckets keep what earlier chunks of the same MSM left in them (k_accumulate<true, true>); chunked: a chunk of a
 // streamed host call (own kernel symbol).
-int32_t enqueue_accumulate(msm_ctx* c, const PipeState& ps, const uint32_t* d_bases, hipStream_t st, hipEvent_t bases_ready, bool into,
+int32_t enqueue_accumulate(msm_ctx* c, const PipeState& ps, const BaseSrc& src, hipStream_t st, hipEvent_t bases_ready, bool into,
                            bool chunked = false) {
     Range r_("msm:accumulate");
     uint32_t* flags = (uint32_t*)c->flags.p;
@@ -555,12 +621,23 @@ int32_t enqueue_accumulate(msm_ctx* c, const PipeState& ps, const uint32_t* d_ba
     const dim3 gp = grid1(ps.maxpieces, 256);  // (threads beyond the number of pieces, known on the device only, leave at once)
     const uint32_t *srt = (const uint32_t*)c->sorted.p, *np = flags + msmk::FLAG_PIECES;
     const uint4* pl = (const uint4*)c->plist.p;
-    uint32_t *bk = (uint32_t*)c->buckets.p, *pt = (uint32_t*)c->partials.p, *hs = (uint32_t*)c->phist.p, *cu = (uint32_t*)c->pcursor.p;
+    uint32_t *bk = (uint32_t*)c->buckets.p, *pt = (uint32_t*)c->partials.p;
     unsigned long long* clk = (unsigned long long*)c->clk.p;  // clock probe of the launch's first workgroup (msm_get_clock_stats)
     const hipEvent_t e0 = c->ev[EV_ACC0], e1 = c->ev[EV_ACC1];
-    if (into) hipExtLaunchKernelGGL((msmk::k_accumulate_pieces<true, true>), gp, dim3(256), 0, st, e0, e1, 0, d_bases, srt, pl, np, bk, pt, hs, cu, ps.pmax, clk);
-    else if (chunked) hipExtLaunchKernelGGL((msmk::k_accumulate_pieces<false, true>), gp, dim3(256), 0, st, e0, e1, 0, d_bases, srt, pl, np, bk, pt, hs, cu, ps.pmax, clk);
-    else hipExtLaunchKernelGGL((msmk::k_accumulate_pieces<false, false>), gp, dim3(256), 0, st, e0, e1, 0, d_bases, srt, pl, np, bk, pt, hs, cu, ps.pmax, clk);
+#define MSM_ACC_LAUNCH(INTO, CHUNK, M256) \
+    hipExtLaunchKernelGGL((msmk::k_accumulate_pieces<INTO, CHUNK, M256>), gp, dim3(256), 0, st, e0, e1, 0, src.rec, phi_biased, src.nsplit, srt, pl, np, bk, pt, clk)
+    // the kernel indexes the phi records by the ENTRY (nsplit + i): hand it the array biased by -nsplit records (never dereferenced below nsplit)
+    const uint32_t* phi_biased = src.phi ? (const uint32_t*)((uintptr_t)src.phi - (uintptr_t)src.nsplit * 64u) : src.rec;
+    if (src.m256) {
+        if (into) MSM_ACC_LAUNCH(true, true, true);
+        else if (chunked) MSM_ACC_LAUNCH(false, true, true);
+        else MSM_ACC_LAUNCH(false, false, true);
+    } else {
+        if (into) MSM_ACC_LAUNCH(true, true, false);
+        else if (chunked) MSM_ACC_LAUNCH(false, true, false);
+        else MSM_ACC_LAUNCH(false, false, false);
+    }
+#undef MSM_ACC_LAUNCH
     msmk::k_combine_pieces<<<dim3(msmk::LONG_BLOCKS + msmk::MID_BLOCKS), 512, 0, st>>>(
         offsets, pt, bk, ps.pmax, ps.psplit, (const uint32_t*)c->pbase.p, flags + msmk::FLAG_MID, (const uint32_t*)c->midlist.p, flags + msmk::FLAG_LONG,
         (const uint32_t*)c->longlist.p, (uint32_t*)c->longdone.p);
@@ -692,6 +769,7 @@ int32_t check_flags(msm_ctx* c, const uint32_t* h_flags) {
     if (h_flags[0] & 1u) return fail(c, MSM_ERR_BAD_ARG, "a scalar is >= 2^254 (not a canonical Fr element)");
     if (h_flags[0] & 2u) return fail(c, MSM_ERR_HIP, "internal: signed-digit carry out of the top window");
     if (h_flags[0] & 4u) return fail(c, MSM_ERR_HIP, "internal: a GLV half exceeds its bound (7 * 2^123)");
+    if (h_flags[0] & 8u) return fail(c, MSM_ERR_HIP, "internal: a digit collides with the 16-bit skip code");
     return MSM_OK;
 }
 
@@ -719,7 +797,7 @@ int32_t finish_sync(msm_ctx* c, const PipeState& ps, size_t n_total, hipStream_t
     int32_t rc;
     if ((rc = check_flags(c, c->h_flags))) return rc;
     hostg1::Jac total = host_finish(c, c->h_qsums, ps);
-    finish_outputs(total, out_jac, out_aff, out_inf);
+    finish_outputs(total, out_jac, out_aff, out_inf, (c->cfg.flags & MSM_FLAG_DETERMINISTIC) != 0);
     auto t_fin1 = std::chrono::steady_clock::now();
     float ms = 0;
     msm_timings_t& tm = c->tm;
@@ -741,7 +819,7 @@ int32_t finish_sync(msm_ctx* c, const PipeState& ps, size_t n_total, hipStream_t
 // table, record j * n + i = 2^(c*j) P_i; the planner only makes tables whose shared array is sorted in ONE piece --
 // msmplan::TABLE_MAX_ENTRIES: cutting the windows into ranges that accumulate INTO the array was built, found bit-exact and 17 % slower
 // than no table at 2^22 points, profiles/r3_f4_shared_buckets.txt).
-int32_t enqueue_body(msm_ctx* c, const PipeState& ps, const uint32_t* d_bases, const uint8_t* d_inf, const uint32_t* d_scalars,
+int32_t enqueue_body(msm_ctx* c, const PipeState& ps, const BaseSrc& d_bases, const uint8_t* d_inf, const uint32_t* d_scalars,
                      uint32_t scalars_mont, hipStream_t st, hipEvent_t bases_ready) {
     int32_t rc;
     if ((rc = enqueue_decompose(c, ps, d_inf, d_scalars, scalars_mont, st, true))) return rc;
@@ -751,7 +829,7 @@ int32_t enqueue_body(msm_ctx* c, const PipeState& ps, const uint32_t* d_bases, c
 
 // The pipeline proper: everything in HBM, one stream.  d_bases: INTERNAL-domain packed coordinates (or the window table of the
 // resident set, table_f > 1: planned with table_c bits per window).
-int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, const uint32_t* d_scalars, size_t n,
+int32_t run_pipeline(msm_ctx* c, const BaseSrc& d_bases, const uint8_t* d_inf, const uint32_t* d_scalars, size_t n,
                      hipStream_t st, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf, uint32_t scalars_mont = 0,
                      hipEvent_t bases_ready = nullptr, uint32_t extra_flags = 0, PipeState* ps_out = nullptr, uint32_t table_c = 0,
                      uint32_t table_f = 1) {
@@ -772,7 +850,7 @@ int32_t run_pipeline(msm_ctx* c, const uint32_t* d_bases, const uint8_t* d_inf, 
             const size_t cnt = std::min(dchunk, n - lo);
             if ((rc = pipe_prepare(c, cnt, n, extra_flags, st, &ps, 0, 1, &ps_first))) return rc;
             if ((rc = enqueue_digits_sort(c, ps, d_inf ? d_inf + lo : nullptr, d_scalars + lo * 8, scalars_mont, st, lo == 0))) return rc;
-            if ((rc = enqueue_accumulate(c, ps, d_bases + lo * 16, st, lo == 0 ? bases_ready : nullptr, lo > 0, true))) return rc;
+            if ((rc = enqueue_accumulate(c, ps, d_bases.shifted(lo), st, lo == 0 ? bases_ready : nullptr, lo > 0, true))) return rc;
         }
         if ((rc = enqueue_reduce(c, ps, st, c->h_qsums, c->h_flags))) return rc;
         if (ps_out) *ps_out = ps;
@@ -832,15 +910,33 @@ int32_t h2d(msm_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t cs
     HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, cs));
     return MSM_OK;
 }
-// raw base records in HBM -> internal-domain records (+ infinity bytes for the struct form), on stream st
-void launch_convert(const HostInput& in, const void* d_raw, size_t cnt, uint32_t* d_ibases, uint8_t* d_inf, bool glv, hipStream_t st) {
-    if (in.kind == KIND_ARK)
+// K1's coordinate half for cnt raw base records that sit in HBM as the caller sent them, on stream st; returns what the accumulation gathers
+// from.  arkworks-form words (R = 2^256 Montgomery): the records stay where they are -- nothing to do for an unsplit plan, the phi records of a
+// split one go to d_out (k_phi_records, round 5).  Standard-form words and struct arrays: internal-domain records in d_out (+ infinity bytes
+// for the struct form).
+BaseSrc launch_convert(const HostInput& in, const void* d_raw, size_t cnt, uint32_t* d_out, uint8_t* d_inf, bool glv, hipStream_t st) {
+    if (in.kind == KIND_ARK) {
         msmk::k_import_ark<<<grid1(2 * cnt, 256), 256, 0, st>>>((const uint8_t*)d_raw, (uint64_t)in.stride, in.x_off, in.y_off,
                                                              in.has_inf_field ? in.inf_off : 0u, in.has_inf_field ? 1u : 0u, (uint32_t)cnt,
-                                                             d_ibases, d_inf, glv ? 1u : 0u);
-    else
-        msmk::k_convert_bases<<<grid1(2 * cnt, 256), 256, 0, st>>>((const uint32_t*)d_raw, d_ibases, (uint32_t)cnt,
-                                                                in.kind == KIND_MONT ? 1u : 0u, glv ? 1u : 0u);
+                                                             d_out, d_inf, glv ? 1u : 0u);
+        return BaseSrc(d_out);
+    }
+#ifndef MSM_AB_CONVERT  // (A/B builds only, tools/build_variant.sh: the conversion pass of rounds 1-4)
+    if (in.kind == KIND_MONT) {
+        BaseSrc src;
+        src.m256 = true;
+        src.rec = (const uint32_t*)d_raw;
+        if (glv) {
+            msmk::k_phi_records<<<grid1(cnt, 256), 256, 0, st>>>((const uint32_t*)d_raw, d_out, (uint32_t)cnt);
+            src.phi = d_out;
+            src.nsplit = (uint32_t)cnt;
+        }
+        return src;
+    }
+#endif
+    msmk::k_convert_bases<<<grid1(2 * cnt, 256), 256, 0, st>>>((const uint32_t*)d_raw, d_out, (uint32_t)cnt,
+                                                            in.kind == KIND_MONT ? 1u : 0u, glv ? 1u : 0u);
+    return BaseSrc(d_out);
 }
 
 // scalars (+ the infinity mask of the packed forms) of points [lo, lo+cnt) -> d_scalars / d_inf on stream s
@@ -853,10 +949,10 @@ int32_t feed_scalars(msm_ctx* c, const HostInput& in, size_t lo, size_t cnt, voi
 // base records of points [lo, lo+cnt) -> raw staging d_raw -> internal-domain records d_ibases (+ infinity bytes d_inf for the
 // struct form), all on stream s
 int32_t feed_bases(msm_ctx* c, const HostInput& in, size_t lo, size_t cnt, void* d_raw, uint32_t* d_ibases, uint8_t* d_inf, bool glv,
-                   hipStream_t s) {
+                   hipStream_t s, BaseSrc* src) {
     int32_t rc = h2d(c, d_raw, in.bases + lo * in.stride, cnt * in.stride, s);
     if (rc) return rc;
-    launch_convert(in, d_raw, cnt, d_ibases, d_inf, glv, s);
+    *src = launch_convert(in, d_raw, cnt, d_ibases, d_inf, glv, s);
     return MSM_OK;
 }
 
@@ -878,29 +974,30 @@ int32_t run_single(msm_ctx* c, const HostInput& in, size_t n, uint32_t* out_jac,
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_START], st));
     const uint8_t* d_inf = in.carries_inf() ? (const uint8_t*)c->inf.p : nullptr;
     uint32_t* ib = (uint32_t*)c->ibases.p;
+    BaseSrc src;
     {
         Range r_("msm:h2d");
         if (in.kind == KIND_ARK) {
-            if ((rc = feed_bases(c, in, 0, n, c->bases.p, ib, (uint8_t*)c->inf.p, glv, bs))) return rc;
+            if ((rc = feed_bases(c, in, 0, n, c->bases.p, ib, (uint8_t*)c->inf.p, glv, bs, &src))) return rc;
             if (overlap) HIPCHK(c, hipEventRecord(c->ev_bases, bs));
             if ((rc = feed_scalars(c, in, 0, n, c->scalars.p, nullptr, st))) return rc;
             if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_H2D], st));
             if (overlap) HIPCHK(c, hipStreamWaitEvent(st, c->ev_bases, 0));  // k_decompose reads the infinity bytes
             if ((rc = enqueue_digits_sort(c, ps, d_inf, (const uint32_t*)c->scalars.p, in.scalars_mont, st, true))) return rc;
-            if ((rc = enqueue_accumulate(c, ps, ib, st, nullptr, false))) return rc;
+            if ((rc = enqueue_accumulate(c, ps, src, st, nullptr, false))) return rc;
         } else {
             if ((rc = feed_scalars(c, in, 0, n, c->scalars.p, c->inf.p, st))) return rc;
             if (overlap) {
                 // queue the sort BEFORE the bases are touched: a copy from pageable memory blocks the host, the GPU sorts meanwhile
                 if ((rc = enqueue_digits_sort(c, ps, d_inf, (const uint32_t*)c->scalars.p, in.scalars_mont, st, true))) return rc;
-                if ((rc = feed_bases(c, in, 0, n, c->bases.p, ib, nullptr, glv, bs))) return rc;
+                if ((rc = feed_bases(c, in, 0, n, c->bases.p, ib, nullptr, glv, bs, &src))) return rc;
                 HIPCHK(c, hipEventRecord(c->ev_bases, bs));
-                if ((rc = enqueue_accumulate(c, ps, ib, st, c->ev_bases, false))) return rc;
+                if ((rc = enqueue_accumulate(c, ps, src, st, c->ev_bases, false))) return rc;
             } else {
-                if ((rc = feed_bases(c, in, 0, n, c->bases.p, ib, nullptr, glv, st))) return rc;
+                if ((rc = feed_bases(c, in, 0, n, c->bases.p, ib, nullptr, glv, st, &src))) return rc;
                 if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_H2D], st));
                 if ((rc = enqueue_digits_sort(c, ps, d_inf, (const uint32_t*)c->scalars.p, in.scalars_mont, st, true))) return rc;
-                if ((rc = enqueue_accumulate(c, ps, ib, st, nullptr, false))) return rc;
+                if ((rc = enqueue_accumulate(c, ps, src, st, nullptr, false))) return rc;
             }
         }
     }
@@ -963,9 +1060,9 @@ int32_t run_streamed(msm_ctx* c, const HostInput& in, size_t n, const std::vecto
             if ((rc = enqueue_digits_sort(c, ps, d_inf, (const uint32_t*)c->sscalars[s].p, in.scalars_mont, st, j == 0))) return rc;
         }
         HIPCHK(c, hipStreamWaitEvent(st, c->ev_copied[s], 0));
-        launch_convert(in, c->sbases[s].p, cnt, (uint32_t*)c->sibases.p, d_inf, glv, st);
+        const BaseSrc src = launch_convert(in, c->sbases[s].p, cnt, (uint32_t*)c->sibases.p, d_inf, glv, st);  // (arkworks words: gathered from the slot itself)
         if (!early_sort && (rc = enqueue_digits_sort(c, ps, d_inf, (const uint32_t*)c->sscalars[s].p, in.scalars_mont, st, j == 0))) return rc;
-        if ((rc = enqueue_accumulate(c, ps, (const uint32_t*)c->sibases.p, st, nullptr, j > 0, true))) return rc;
+        if ((rc = enqueue_accumulate(c, ps, src, st, nullptr, j > 0, true))) return rc;
         HIPCHK(c, hipEventRecord(c->ev_free[s], st));
         lo += cnt;
     }
@@ -1594,26 +1691,31 @@ int32_t msm_bn254_g1_device(msm_ctx* c, const void* d_bases_mont, const void* d_
     Range r_("msm_bn254_g1_device");
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
     auto t0 = std::chrono::steady_clock::now();
-    const uint32_t glv = plan_glv(c, n) ? 1u : 0u;
+    const bool glv = plan_glv(c, n);
     if ((rc = ensure(c, c->ibases, (glv ? 2 : 1) * n * 64))) return rc;  // scratch (the resident set has its own buffers)
     PipeState ps;
+    HostInput in;  // (only the kind matters here: the records are in HBM already)
+    in.kind = KIND_MONT;
+    uint32_t* ib = (uint32_t*)c->ibases.p;
+#ifndef MSM_AB_CONVERT
+    const bool nothing_to_convert = !glv;  // round 5: an unsplit plan gathers the caller's words as they are
+#else
+    const bool nothing_to_convert = false;
+#endif
     // Each event record / cross-stream wait costs ~6 us of stream time (measured gaps in the kernel trace), so the
     // conversion only moves to the second stream when it is longer than that (n > 2^18: 32 us at 2^20, 5 us at 2^16).
-    if (c->stage_timing || n <= ((size_t)1 << 18)) {  // serialised (also: so that convert_ms means something)
+    if (c->stage_timing || nothing_to_convert || n <= ((size_t)1 << 18)) {  // serialised (also: so that convert_ms means something)
         if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_H2D], st));
-        msmk::k_convert_bases<<<grid1(2 * n, 256), 256, 0, st>>>((const uint32_t*)d_bases_mont, (uint32_t*)c->ibases.p, (uint32_t)n, 1u, glv);
-        rc = run_pipeline(c, (const uint32_t*)c->ibases.p, (const uint8_t*)d_inf_mask, (const uint32_t*)d_scalars, n, st, out_jac,
-                          out_aff, out_inf, 0, nullptr, 0, &ps);
-    } else {  // the bases are not needed before k_accumulate: convert them on the second stream beside the sort
+        const BaseSrc src = launch_convert(in, d_bases_mont, n, ib, nullptr, glv, st);
+        rc = run_pipeline(c, src, (const uint8_t*)d_inf_mask, (const uint32_t*)d_scalars, n, st, out_jac, out_aff, out_inf, 0, nullptr, 0, &ps);
+    } else {  // the phi records are not needed before k_accumulate: they are made on the second stream beside the sort
         if (hip_stream) {  // the caller's stream may still be producing the inputs; the context's own stream is idle between calls
             HIPCHK(c, hipEventRecord(c->ev_fork, st));
             HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_fork, 0));
         }
-        msmk::k_convert_bases<<<grid1(2 * n, 256), 256, 0, c->copy_stream>>>((const uint32_t*)d_bases_mont, (uint32_t*)c->ibases.p,
-                                                                           (uint32_t)n, 1u, glv);
+        const BaseSrc src = launch_convert(in, d_bases_mont, n, ib, nullptr, glv, c->copy_stream);
         HIPCHK(c, hipEventRecord(c->ev_bases, c->copy_stream));
-        rc = run_pipeline(c, (const uint32_t*)c->ibases.p, (const uint8_t*)d_inf_mask, (const uint32_t*)d_scalars, n, st, out_jac,
-                          out_aff, out_inf, 0, c->ev_bases, 0, &ps);
+        rc = run_pipeline(c, src, (const uint8_t*)d_inf_mask, (const uint32_t*)d_scalars, n, st, out_jac, out_aff, out_inf, 0, c->ev_bases, 0, &ps);
     }
     if (rc) return rc;
     c->tm.h2d_ms = 0;
@@ -1625,12 +1727,7 @@ int32_t msm_bn254_g1_device(msm_ctx* c, const void* d_bases_mont, const void* d_
 
 int32_t msm_bn254_g1_combine(const uint32_t* partials, size_t k, uint32_t out_jac[24], uint32_t out_aff[16],
                              uint8_t* out_inf) {
-    if (!partials) return MSM_ERR_BAD_ARG;
-    if (k == 0) return MSM_ERR_EMPTY;
-    hostg1::Jac total = hostg1::identity();
-    for (size_t i = 0; i < k; i++) total = hostg1::jadd(total, hostg1::load_jac(partials + i * 24));  // fixed rank order
-    finish_outputs(total, out_jac, out_aff, out_inf);
-    return MSM_OK;
+    return combine_partials(partials, k, out_jac, out_aff, out_inf, false);
 }
 
 int32_t msm_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_plan_t* out) {

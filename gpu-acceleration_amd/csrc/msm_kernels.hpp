@@ -40,6 +40,35 @@ constexpr int XW = 36;  // words per XYZZ record in HBM: 4 coordinates x 9 limbs
 // sorted entries over the chunks of a streamed MSM  [8] long-list entries  [9] mid-list entries  [10] pieces  [11] partial-sum slots
 constexpr uint32_t FLAG_ERR = 0, FLAG_PAIRS = 4, FLAG_ADDS64 = 6, FLAG_LONG = 8, FLAG_MID = 9, FLAG_PIECES = 10, FLAG_PARTIALS = 11;
 
+// 16-BIT DIGIT CODES (round 5).  Where a window has at most 2^15 buckets and the two-level LDS sort runs (every default plan without a
+// window table: c <= 16 signed), a digit travels from k_decompose to the two sort kernels that read it as 16 bits: bucket index in bits
+// 0..14, bit 15 = negate, 0xFFFF = digit 0 / base at infinity.  0xFFFF is free: it would be bucket 2^15 - 1 NEGATED, i.e. the digit -2^15,
+// and the signed recode never produces it (v > H gives magnitude 2H - v <= H - 1); the spread top window of a split plan holds magnitudes
+// <= 7 * 2^(c-5) < 2^top_bits, so its spread code cannot end in all ones either (msmplan::digits16 spells the conditions out).
+// Halves the decomposition's write and the two reads of the coarse histogram / scatter: 100 MB of the sort stage's 351 MB at 2^20.
+// Rows of the digit array are padded to an even number of entries (digit_row_stride) so that a thread can load two digits as one word.
+constexpr uint32_t PIECE_BINS = 1024;  // k_piece_count / k_piece_scatter: one histogram bin per piece length (== msmplan::PIECE_BINS_MAX)
+constexpr uint32_t DIGIT16_SKIP = 0xFFFFu;
+__host__ __device__ __forceinline__ uint32_t digit16_widen(uint32_t h) {
+    return h == DIGIT16_SKIP ? DIGIT_SKIP : ((h & 0x7FFFu) | ((h & 0x8000u) << 16));
+}
+__host__ __device__ __forceinline__ uint32_t digit16_narrow(uint32_t d) {
+    return d == DIGIT_SKIP ? DIGIT16_SKIP : ((d & 0x7FFFu) | ((d >> 16) & 0x8000u));
+}
+// store digit code d (32-bit form) as entry o of a digit array of the given width
+template <bool D16>
+__device__ __forceinline__ void digit_store(void* __restrict__ digits, size_t o, uint32_t d) {
+    if (D16) reinterpret_cast<uint16_t*>(digits)[o] = (uint16_t)digit16_narrow(d);
+    else reinterpret_cast<uint32_t*>(digits)[o] = d;
+}
+// The piece-sort histogram and its bin cursors (k_piece_count / k_piece_scatter) are zeroed at the HEAD of every (chunk of an) MSM, by the
+// first workgroup of the decomposition and of the coarse histogram, next to the list counters: a sort never depends on the kernel that
+// ran before it.  (Round 4 left this to workgroup 0 of k_accumulate_pieces, i.e. to the PREVIOUS call having completed: an error between
+// a sort and its accumulation left them dirty for the next call -- ADVICE r4.)  PIECE_BINS + 1 words each.
+__device__ __forceinline__ void clear_piece_bins(uint32_t* __restrict__ phist, uint32_t* __restrict__ pcursor) {
+    for (uint32_t k = threadIdx.x; k <= PIECE_BINS; k += blockDim.x) phist[k] = 0, pcursor[k] = 0;
+}
+
 // packed 8-word field element (canonical value) -> 9 x 29-bit limbs
 __device__ __forceinline__ fp load_fp_packed(const uint32_t* p) {
     const uint4* q = reinterpret_cast<const uint4*>(p);
@@ -112,8 +141,17 @@ __device__ __forceinline__ void store_coord(uint32_t* rec, uint32_t coord, const
 // the rare pairs (an identity operand, equal or opposite points): the scalar complete addition.  ~40 KB of code wherever it is inlined:
 // a kernel keeps ONE eight-lane call site (the instruction cache is 64 KB for two CUs).  Out of line it would cost nothing in code, but
 // a callee's register needs become the kernel's: 248 VGPRs, two wavefronts per SIMD for every reduction kernel.
+// The complete addition of every kernel that runs one wavefront per SIMD or fewer (bucket reduction, k_combine_pieces): the paired-product
+// form (ec_bn254.hpp xyzz_add_ilp, round 5).  -DMSM_AB_NO_ILP: the single-chain form of rounds 1-4.
+__device__ __forceinline__ xyzz xyzz_add_lat(const xyzz& a, const xyzz& b) {
+#ifdef MSM_AB_NO_ILP
+    return xyzz_add(a, b);
+#else
+    return xyzz_add_ilp(a, b);
+#endif
+}
 __device__ __forceinline__ void add_records_complete(const uint32_t* a_rec, const uint32_t* b_rec, uint32_t* out_rec) {
-    store_xyzz(out_rec, xyzz_add(load_xyzz(a_rec), load_xyzz(b_rec)));
+    store_xyzz(out_rec, xyzz_add_lat(load_xyzz(a_rec), load_xyzz(b_rec)));
 }
 __device__ __forceinline__ void wide_add_records(const uint32_t* a_rec, const uint32_t* b_rec, uint32_t* out_rec) {
     const uint32_t role = threadIdx.x & (WIDE_LANES - 1);
@@ -190,6 +228,22 @@ __global__ void k_convert_bases(const uint32_t* __restrict__ in, uint32_t* __res
     fp v = load_fp_packed(in + (size_t)i * 8);
     v = fp_mul(v, mont_form ? fp_const(FP29_IN_MONT) : fp_const(FP29_IN_STD));  // < 1.01p
     store_coord_and_phi(out, i >> 1, i & 1u, n, v, glv);
+}
+
+// Round 5: the device and host-pointer calls on arkworks-form bases (R = 2^256 Montgomery words) no longer convert them at all --
+// k_accumulate_pieces<.., M256> gathers the caller's records as they are (fp_unpack_shl5: 32 * W is the internal-domain value, unreduced).
+// What is left of K1's coordinate half on that path is the phi half of a split plan: record i = (beta * x_i, y_i) in the SAME word form, one
+// multiplication and 128 bytes per point where k_convert_bases spent three and 192 (unsplit plans: nothing at all).
+__global__ void k_phi_records(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t w[8];
+    load_words8(w, in + (size_t)i * 16);
+    const fp bx = fp_reduce_lt2p(fp_mul(fp_unpack(w), fp_from_std(glv::BETA_STD)));  // X * beta (mod p), canonical: beta * x in R = 2^256 form
+    fp_pack(w, bx);
+    store_words8(out + (size_t)i * 16, w);
+    load_words8(w, in + (size_t)i * 16 + 8);
+    store_words8(out + (size_t)i * 16 + 8, w);
 }
 
 // Zero-copy ingestion of an array of arkworks `G1Affine` structs: the struct array is copied to
@@ -412,13 +466,16 @@ __device__ __forceinline__ void fr_from_mont(uint32_t s[8]) {
 
 // HIST = true also counts buckets with global atomics (fallback when a window's histogram does not fit LDS);
 // HIST = false only writes the digits and leaves counting to k_tile_hist.
-template <bool SIGNED, bool HIST>
+template <bool SIGNED, bool HIST, bool D16>
 __global__ void k_decompose(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_mask, uint32_t n,
                             uint32_t c, uint32_t W, uint32_t nb, uint32_t* __restrict__ hist,
-                            uint32_t* __restrict__ digits, uint32_t* __restrict__ ranks, uint32_t* __restrict__ err,
-                            uint32_t scalars_mont, uint32_t top_shift, uint32_t top_bits, uint32_t spread_mask) {
+                            void* __restrict__ digits, uint32_t drow, uint32_t* __restrict__ ranks, uint32_t* __restrict__ err,
+                            uint32_t scalars_mont, uint32_t top_shift, uint32_t top_bits, uint32_t spread_mask,
+                            uint32_t* __restrict__ phist, uint32_t* __restrict__ pcursor) {
+    static_assert(!(HIST && D16), "the global-atomic fallback keeps 32-bit digits");
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) err[FLAG_LONG] = 0, err[FLAG_MID] = 0, err[FLAG_PIECES] = 0, err[FLAG_PARTIALS] = 0;  // list counters of this (chunk of an) MSM: k_piece_count fills them later in the stream
+    if (blockIdx.x == 0) clear_piece_bins(phist, pcursor);
     if (i >= n) return;
     const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
     uint4 a = sp[0], b = sp[1];
@@ -440,20 +497,21 @@ __global__ void k_decompose(const uint32_t* __restrict__ scalars, const uint8_t*
                 carry = 0;
             }
         }
-        size_t o = (size_t)w * n + i;
+        size_t o = (size_t)w * drow + i;
         // window table with one shared bucket array: the short top window (14 bits of 20 at c = 20) would pile its digits into the
         // lowest buckets -- 32 of the sort's 1024 regions.  Its table level is 2^(c*(W-1) - top_shift) P instead, and the digit goes in
         // as d * 2^top_shift: the same group element, spread over every 2^top_shift-th bucket
         if (w == W - 1) mag <<= top_shift;
         if (mag == 0 || skip) {
-            digits[o] = DIGIT_SKIP;
+            digit_store<D16>(digits, o, DIGIT_SKIP);
         } else {
             uint32_t bkt = mag - 1;
             // the top window of a plan holds 254 - c*(W-1) bits: magnitudes up to 2^top_bits.  spread_mask != 0 (msmplan::top_digit_bits): the index
             // bits above them carry low bits of the point index, so that the window's entries use all of its buckets (see k_decompose_glv)
             if (w == W - 1 && spread_mask) bkt |= (i & spread_mask) << top_bits;
             if (HIST) ranks[o] = atomicAdd(&hist[(size_t)w * nb + bkt], 1u);
-            digits[o] = bkt | neg;
+            if (D16 && (bkt | neg) == (0x7FFFu | SIGN_BIT)) atomicOr(err, 8u);  // cannot happen: would read as the 16-bit skip code
+            digit_store<D16>(digits, o, bkt | neg);
         }
     }
     if (SIGNED && carry) atomicOr(err, 2u);  // cannot happen for scalars < 2^254 with W = 254/c + 1
@@ -473,12 +531,14 @@ __device__ __forceinline__ uint32_t window128(const uint32_t s[4], uint32_t off,
 // spread_mask != 0 (msmplan::glv_top_digit_bits): the top window's magnitudes are at most 2^top_bits, fewer than the window has buckets;
 // its bucket index is (magnitude - 1) | (i & spread_mask) << top_bits -- the same digit in 2^spread buckets, chosen by the point index, so
 // that the top window's buckets are no fuller than the others'.  The host ignores the bit sums of the index bits above top_bits.
-template <bool SIGNED>
+template <bool SIGNED, bool D16>
 __global__ void k_decompose_glv(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_mask, uint32_t n, uint32_t c,
-                                uint32_t W, uint32_t* __restrict__ digits, uint32_t* __restrict__ err, uint32_t scalars_mont,
-                                uint32_t top_shift, uint32_t top_bits, uint32_t spread_mask) {
+                                uint32_t W, void* __restrict__ digits, uint32_t drow, uint32_t* __restrict__ err, uint32_t scalars_mont,
+                                uint32_t top_shift, uint32_t top_bits, uint32_t spread_mask, uint32_t* __restrict__ phist,
+                                uint32_t* __restrict__ pcursor) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) err[FLAG_LONG] = 0, err[FLAG_MID] = 0, err[FLAG_PIECES] = 0, err[FLAG_PARTIALS] = 0;  // list counters of this (chunk of an) MSM: k_piece_count fills them later in the stream
+    if (blockIdx.x == 0) clear_piece_bins(phist, pcursor);
     if (i >= n) return;
     const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
     uint4 a = sp[0], b = sp[1];
@@ -490,7 +550,7 @@ __global__ void k_decompose_glv(const uint32_t* __restrict__ scalars, const uint
     bool kneg[2];
     if (!glv::split(s, k[0], kneg[0], k[1], kneg[1])) atomicOr(err, 4u);  // a half beyond 126 bits: cannot happen below 2^254
     const uint32_t H = 1u << (c - 1);
-    const size_t row = 2 * (size_t)n;
+    const size_t row = drow;  // >= 2n
     const uint32_t spread = (i & spread_mask) << top_bits;
 #pragma unroll
     for (int h = 0; h < 2; h++) {
@@ -500,7 +560,10 @@ __global__ void k_decompose_glv(const uint32_t* __restrict__ scalars, const uint
             uint32_t mag = v;
             bool neg = kneg[h];
             if (SIGNED) {
-                if (v > H) {
+                // v == H may go either way (+H, or -H with a carry).  It goes the way that leaves the FINAL digit (the half's sign folded
+                // in) in [-(H-1), H], the range of the unsplit form: a negative half recodes from v >= H on, a positive one from v > H.
+                // (Round 5: the 16-bit digit codes have no room for a negated magnitude H.)
+                if (v + (kneg[h] ? 1u : 0u) > H) {
                     mag = (2u * H) - v;
                     neg = !neg;
                     carry = 1;
@@ -517,7 +580,9 @@ __global__ void k_decompose_glv(const uint32_t* __restrict__ scalars, const uint
                     bkt = (mag << top_shift) - 1;  // (window table, shared bucket array: see k_decompose)
                 }
             }
-            digits[(size_t)w * row + (size_t)h * n + i] = (mag == 0 || skip) ? DIGIT_SKIP : (bkt | (neg ? SIGN_BIT : 0u));
+            const uint32_t code = (mag == 0 || skip) ? DIGIT_SKIP : (bkt | (neg ? SIGN_BIT : 0u));
+            if (D16 && code == (0x7FFFu | SIGN_BIT)) atomicOr(err, 8u);  // cannot happen: would read as the 16-bit skip code
+            digit_store<D16>(digits, (size_t)w * row + (size_t)h * n + i, code);
         }
         if (SIGNED && carry) atomicOr(err, 2u);
     }
@@ -683,25 +748,54 @@ __device__ __forceinline__ uint32_t lds_inc(uint32_t* ctr, uint32_t key) {
     return atomicAdd(&ctr[key], 1u);
 }
 
-__global__ void __launch_bounds__(TILE_BLOCK) k_coarse_hist(const uint32_t* __restrict__ digits, uint32_t* __restrict__ counts,
+// The SUBTILE / TILE_BLOCK = 16 digit codes (32-bit form) a thread of a level-1 workgroup owns, all loads in flight at once.  32-bit digits:
+// entry m is element i0 + tid + m * TILE_BLOCK.  16-bit digits: eight 4-byte loads of two codes each, entries 2k and 2k+1 are elements
+// i0 + 2 * (tid + k * TILE_BLOCK) and the one behind it (rows are padded to an even length and start 4-byte aligned: digit_row_stride).
+template <bool D16>
+__device__ __forceinline__ uint32_t subtile_element(uint32_t i0, int m) {
+    return D16 ? i0 + 2u * (threadIdx.x + (uint32_t)(m >> 1) * TILE_BLOCK) + (uint32_t)(m & 1) : i0 + threadIdx.x + (uint32_t)m * TILE_BLOCK;
+}
+template <bool D16>
+__device__ __forceinline__ void load_subtile_digits(const void* __restrict__ digits, size_t row, uint32_t i0, uint32_t i1,
+                                                    uint32_t (&dg)[SUBTILE / TILE_BLOCK]) {
+    if (D16) {
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(digits) + row + i0);
+#pragma unroll
+        for (int k = 0; k < SUBTILE / TILE_BLOCK / 2; k++) {
+            const uint32_t j = threadIdx.x + (uint32_t)k * TILE_BLOCK, i = i0 + 2u * j;
+            const uint32_t v = i < i1 ? p[j] : 0xFFFFFFFFu;
+            dg[2 * k] = digit16_widen(v & 0xFFFFu);
+            dg[2 * k + 1] = i + 1 < i1 ? digit16_widen(v >> 16) : DIGIT_SKIP;  // (the pad entry of an odd row is not a digit)
+        }
+    } else {
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(digits) + row;
+#pragma unroll
+        for (int k = 0; k < SUBTILE / TILE_BLOCK; k++) {
+            const uint32_t i = i0 + threadIdx.x + (uint32_t)k * TILE_BLOCK;
+            dg[k] = i < i1 ? p[i] : DIGIT_SKIP;
+        }
+    }
+}
+
+template <bool D16>
+__global__ void __launch_bounds__(TILE_BLOCK) k_coarse_hist(const void* __restrict__ digits, uint32_t drow, uint32_t* __restrict__ counts,
                                                             uint32_t n, uint32_t fine_bits, uint32_t ncoarse, uint32_t NS,
-                                                            uint32_t* __restrict__ flags) {
+                                                            uint32_t* __restrict__ flags, uint32_t* __restrict__ phist,
+                                                            uint32_t* __restrict__ pcursor) {
     __shared__ uint32_t s_h[COARSE_BINS_MAX];
     const uint32_t st = blockIdx.x, w = blockIdx.y;
-    // list counters of THIS sort call (k_piece_count fills them later in the stream; k_decompose zeroes them too -- kept here so that a
-    // sort never depends on which kernel ran before it)
-    if (st == 0 && w == 0 && threadIdx.x == 0) flags[FLAG_LONG] = 0, flags[FLAG_MID] = 0, flags[FLAG_PIECES] = 0, flags[FLAG_PARTIALS] = 0;
+    // list counters and piece bins of THIS sort call (k_piece_count fills them later in the stream; k_decompose zeroes them too -- kept
+    // here so that a sort never depends on which kernel ran before it)
+    if (st == 0 && w == 0) {
+        if (threadIdx.x == 0) flags[FLAG_LONG] = 0, flags[FLAG_MID] = 0, flags[FLAG_PIECES] = 0, flags[FLAG_PARTIALS] = 0;
+        clear_piece_bins(phist, pcursor);
+    }
     if (threadIdx.x < COARSE_BINS_MAX) s_h[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t i0 = st * SUBTILE, i1 = min(n, i0 + SUBTILE);
-    const size_t row = (size_t)w * n;
     // SUBTILE / TILE_BLOCK = 16 digits per thread: all loads in flight before the first LDS atomic
     uint32_t dg[SUBTILE / TILE_BLOCK];
-#pragma unroll
-    for (int k = 0; k < SUBTILE / TILE_BLOCK; k++) {
-        const uint32_t i = i0 + threadIdx.x + k * TILE_BLOCK;
-        dg[k] = i < i1 ? digits[row + i] : DIGIT_SKIP;
-    }
+    load_subtile_digits<D16>(digits, (size_t)w * drow, i0, i1, dg);
 #pragma unroll
     for (int k = 0; k < SUBTILE / TILE_BLOCK; k++)
         if (dg[k] != DIGIT_SKIP) lds_inc(s_h, (dg[k] & ~SIGN_BIT) >> fine_bits);
@@ -806,7 +900,8 @@ __global__ void k_coarse_starts(const uint32_t* __restrict__ region_total, uint3
     const uint32_t nslots = min(big[1], BIG_MAX_ITEMS);
     for (size_t q = threadIdx.x; q < (size_t)nslots * BIG_SLOT_WORDS; q += blockDim.x) big[BIG_TAB_OFF + q] = 0;
 }
-__global__ void __launch_bounds__(TILE_BLOCK) k_coarse_scatter(const uint32_t* __restrict__ digits, const uint32_t* __restrict__ counts,
+template <bool D16>
+__global__ void __launch_bounds__(TILE_BLOCK) k_coarse_scatter(const void* __restrict__ digits, uint32_t drow, const uint32_t* __restrict__ counts,
                                                                const uint32_t* __restrict__ region_start, uint32_t* __restrict__ tmp,
                                                                uint32_t n, uint32_t fine_bits, uint32_t idx_bits, uint32_t ncoarse,
                                                                uint32_t NS) {
@@ -816,13 +911,8 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_coarse_scatter(const uint32_t* _
     __shared__ uint32_t s_gbase[COARSE_BINS_MAX];        // where the run goes in tmp
     const uint32_t st = blockIdx.x, w = blockIdx.y;
     const uint32_t i0 = st * SUBTILE, i1 = min(n, i0 + SUBTILE);
-    const size_t row = (size_t)w * n;
     uint32_t dg[SUBTILE / TILE_BLOCK];
-#pragma unroll
-    for (int k = 0; k < SUBTILE / TILE_BLOCK; k++) {
-        const uint32_t i = i0 + threadIdx.x + k * TILE_BLOCK;
-        dg[k] = i < i1 ? digits[row + i] : DIGIT_SKIP;
-    }
+    load_subtile_digits<D16>(digits, (size_t)w * drow, i0, i1, dg);
     // this sub-tile's bin counts = differences of the prefixes over sub-tiles (last sub-tile: region total - prefix)
     uint32_t cnt = 0;
     if (threadIdx.x < ncoarse) {
@@ -862,7 +952,7 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_coarse_scatter(const uint32_t* _
     for (int k = 0; k < SUBTILE / TILE_BLOCK; k++) {
         const uint32_t d = dg[k];
         if (d == DIGIT_SKIP) continue;
-        const uint32_t i = i0 + threadIdx.x + k * TILE_BLOCK;
+        const uint32_t i = subtile_element<D16>(i0, k);
         uint32_t bkt = d & ~SIGN_BIT;
         uint32_t pos = lds_inc(s_cur, bkt >> fine_bits);
         s_stage[pos] = (i & ((1u << idx_bits) - 1u)) | ((bkt & fine_mask) << idx_bits) | (d & SIGN_BIT);
@@ -1124,7 +1214,7 @@ __global__ void k_scatter(const uint32_t* __restrict__ digits, const uint32_t* _
 constexpr uint32_t LONG_SPAN = 8;     // split buckets of this many pieces or more are folded by whole workgroups (k_combine_pieces)
 constexpr uint32_t LONG_SEG = 2048;   // pieces of a long bucket folded by one workgroup
 constexpr uint32_t LONG_BLOCKS = 1024, MID_BLOCKS = 128;  // k_combine_pieces' grid: (bucket, segment) items grid-stride over the first, listed buckets over the rest
-constexpr uint32_t PIECE_BINS = 1024;                 // pmax <= PIECE_BINS: one histogram bin per piece length (== msmplan::PIECE_BINS_MAX)
+// (PIECE_BINS, at the top of this file: pmax <= PIECE_BINS, one histogram bin per piece length)
 constexpr uint32_t PF_WHOLE = 0x80000000u;            // piece.z: the bucket is this one piece -> the sum goes to buckets[k]
 constexpr uint32_t PF_FIRST = 0x40000000u;            // piece.z: first piece of a split bucket (INTO: starts from the bucket's old value)
 constexpr uint32_t PF_LEN_MASK = 0x00FFFFFFu;
@@ -1290,13 +1380,15 @@ __global__ void __launch_bounds__(1024) k_piece_scatter(const uint32_t* __restri
 
 // one thread per piece, a loop without bucket switches.  INTO: a whole bucket, or the first piece of a split one, starts
 // from the value the bucket holds (earlier chunks of a streamed host call / point ranges of a device-resident instance).
-// Workgroup 0 also zeroes the histogram and the bin cursors for the next plan (they are only read by the two plan kernels, which
-// precede this launch in stream order).
-template <bool INTO, bool CHUNK>
-__global__ void __launch_bounds__(256) k_accumulate_pieces(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
+// (The piece histogram and the bin cursors are zeroed at the head of the NEXT chain -- clear_piece_bins -- not here.)
+// M256 (round 5): `bases` are the caller's arkworks words (R = 2^256 Montgomery, x || y) for entries below nsplit and `phi` (biased by -nsplit
+// records, see `record` below) holds the records nsplit + i of a split plan in the same form (k_phi_records); the record is unpacked with the x 2^5 folded into the shifts and the
+// digit's sign goes to S2 (xyzz_madd_m32).  Same instruction count per addition as the internal-domain form, no conversion pass before it.
+template <bool INTO, bool CHUNK, bool M256>
+__global__ void __launch_bounds__(256) k_accumulate_pieces(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ phi, uint32_t nsplit,
+                                                           const uint32_t* __restrict__ sorted,
                                                            const uint4* __restrict__ plist, const uint32_t* __restrict__ npieces_ptr,
                                                            uint32_t* __restrict__ buckets, uint32_t* __restrict__ partials,
-                                                           uint32_t* __restrict__ hist, uint32_t* __restrict__ cursor, uint32_t pmax,
                                                            unsigned long long* __restrict__ clk) {
     // Clock probe (msm_get_clock_stats): the first workgroup of every launch brackets its own pieces with the shader-cycle counter
     // (s_memtime: counts at whatever frequency the device sustains) and the constant-rate counter (s_memrealtime); the ratio of the two
@@ -1304,10 +1396,7 @@ __global__ void __launch_bounds__(256) k_accumulate_pieces(const uint32_t* __res
     // stream in the same number of cycles.  Both values live in scalar registers; the cost is four atomics per launch.
     const bool probe = blockIdx.x == 0;
     long long clk_c0 = 0, clk_w0 = 0;
-    if (probe) {
-        clk_c0 = clock64(), clk_w0 = wall_clock64();
-        for (uint32_t i = threadIdx.x; i <= pmax; i += blockDim.x) hist[i] = 0, cursor[i] = 0;
-    }
+    if (probe) clk_c0 = clock64(), clk_w0 = wall_clock64();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= *npieces_ptr) return;
     const uint4 pc = plist[t];
@@ -1321,30 +1410,35 @@ __global__ void __launch_bounds__(256) k_accumulate_pieces(const uint32_t* __res
     // ONE in-order counter (vmcnt), and a conditional prefetch used to be closed by the compiler with an s_waitcnt a few instructions
     // after the gather was issued (round 3, profiles/NOTES_r3.md section 1).  The only wait sits at the top of the next iteration, one
     // whole mixed addition after everything was issued.
+    // (M256: `phi` arrives BIASED by -nsplit records -- entry idx >= nsplit is record idx of it -- so the two sources differ by the base pointer only)
+    auto record = [&](uint32_t e) {
+        const uint32_t idx = e & ~SIGN_BIT;
+        const uint32_t* b0 = M256 && idx >= nsplit ? phi : bases;
+        return reinterpret_cast<const uint4*>(b0 + (size_t)idx * 16);
+    };
     uint32_t e_cur = sorted[j0];
     uint32_t e_nxt = sorted[min(j0 + 1, j1 - 1)];
     uint4 g[4];
     {
-        const uint4* bp = reinterpret_cast<const uint4*>(bases + (size_t)(e_cur & ~SIGN_BIT) * 16);
+        const uint4* bp = record(e_cur);
 #pragma unroll
         for (int i = 0; i < 4; i++) g[i] = bp[i];
     }
     for (uint32_t j = j0; j < j1; j++) {
+        uint32_t wx[8] = {g[0].x, g[0].y, g[0].z, g[0].w, g[1].x, g[1].y, g[1].z, g[1].w};
+        uint32_t wy[8] = {g[2].x, g[2].y, g[2].z, g[2].w, g[3].x, g[3].y, g[3].z, g[3].w};
         affine q;
+        q.x = M256 ? fp_unpack_shl5(wx) : fp_unpack(wx);
+        q.y = M256 ? fp_unpack_shl5(wy) : fp_unpack(wy);
+        if (!M256 && (e_cur & SIGN_BIT)) q.y = fp_neg_raw<2>(q.y);  // raw: only ever a multiplier in xyzz_madd
         {
-            uint32_t wx[8] = {g[0].x, g[0].y, g[0].z, g[0].w, g[1].x, g[1].y, g[1].z, g[1].w};
-            uint32_t wy[8] = {g[2].x, g[2].y, g[2].z, g[2].w, g[3].x, g[3].y, g[3].z, g[3].w};
-            q.x = fp_unpack(wx);
-            q.y = fp_unpack(wy);
-        }
-        if (e_cur & SIGN_BIT) q.y = fp_neg_raw<2>(q.y);  // raw: only ever a multiplier in xyzz_madd
-        {
-            const uint4* bp = reinterpret_cast<const uint4*>(bases + (size_t)(e_nxt & ~SIGN_BIT) * 16);
+            const uint4* bp = record(e_nxt);
 #pragma unroll
             for (int i = 0; i < 4; i++) g[i] = bp[i];
         }
         const uint32_t e_nn = sorted[min(j + 2, j1 - 1)];
-        xyzz_madd(acc, q);
+        if (M256) xyzz_madd_m32(acc, q.x, q.y, (e_cur & SIGN_BIT) != 0);
+        else xyzz_madd(acc, q);
         e_cur = e_nxt;
         e_nxt = e_nn;
     }
@@ -1372,7 +1466,7 @@ __device__ __forceinline__ void fold_partials(uint32_t* e, const uint32_t* parti
     } else if (threadIdx.x < CAP) {
         xyzz acc = xyzz_identity();
 #pragma unroll 1
-        for (uint32_t i = threadIdx.x; i < count; i += CAP) acc = xyzz_add(acc, load_xyzz(partials + (size_t)(base + first + i * stride) * XW));
+        for (uint32_t i = threadIdx.x; i < count; i += CAP) acc = xyzz_add_lat(acc, load_xyzz(partials + (size_t)(base + first + i * stride) * XW));
         store_xyzz(e + (size_t)threadIdx.x * XW, acc);
     }
     lds_tree_wide(e, count < CAP ? count : CAP);
@@ -1389,7 +1483,7 @@ __global__ void __launch_bounds__(512) k_combine_pieces(const uint32_t* __restri
             uint32_t q;
             const uint32_t m = piece_split(offsets[k + 1] - offsets[k], pmax, psplit, &q), base = pbase[k];
             xyzz acc = load_xyzz(partials + (size_t)base * XW);
-            for (uint32_t p = 1; p < m; p++) acc = xyzz_add(acc, load_xyzz(partials + (size_t)(base + p) * XW));
+            for (uint32_t p = 1; p < m; p++) acc = xyzz_add_lat(acc, load_xyzz(partials + (size_t)(base + p) * XW));
             store_xyzz(buckets + (size_t)k * XW, acc);
         }
         return;
@@ -1466,7 +1560,7 @@ __global__ void __launch_bounds__(256) k_pair_level(pair_job ja, pair_job jb) {
         if (t >= jb.n_out) return;
     }
     size_t i0 = (size_t)2 * (t / j.B) * j.B + (t % j.B);
-    xyzz r = xyzz_add(load_xyzz(j.in + i0 * XW), load_xyzz(j.in + (i0 + j.B) * XW));
+    xyzz r = xyzz_add_lat(load_xyzz(j.in + i0 * XW), load_xyzz(j.in + (i0 + j.B) * XW));
     store_xyzz(j.out + (size_t)t * XW, r);
 }
 
@@ -1523,7 +1617,7 @@ __global__ void __launch_bounds__(256) k_pair_level8(const uint32_t* __restrict_
             other = shfl_down_xyzz(acc, (int)d, G);
             if (sub >= d) other = xyzz_identity();  // spectator lanes: adding their own value would take the doubling branch
         }
-        acc = xyzz_add(acc, other);
+        acc = xyzz_add_lat(acc, other);
     }
     if (sub == 0) store_xyzz(out, acc);
 }
@@ -1617,7 +1711,7 @@ __global__ void __launch_bounds__(64) k_reduce_bits(const uint32_t* __restrict__
             other = shfl_down_xyzz(acc, d, 64);
             if (threadIdx.x >= d) other = xyzz_identity();
         }
-        acc = xyzz_add(acc, other);
+        acc = xyzz_add_lat(acc, other);
     }
     if (threadIdx.x == 0) {
         store_jacobian_mont256(q + (size_t)blockIdx.x * 24, xyzz_to_jacobian(acc));

@@ -83,7 +83,7 @@ inline size_t glv_max_from_env() {
     return GLV_MAX_POINTS;
 }
 inline int32_t make_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_plan_t* out, size_t glv_max = GLV_MAX_POINTS) {
-    if (flags & ~(MSM_FLAG_UNSIGNED_DIGITS | MSM_FLAG_NO_GLV | MSM_FLAG_WINDOW_TABLE)) return MSM_ERR_BAD_ARG;
+    if (flags & ~(MSM_FLAG_UNSIGNED_DIGITS | MSM_FLAG_NO_GLV | MSM_FLAG_WINDOW_TABLE | MSM_FLAG_DETERMINISTIC)) return MSM_ERR_BAD_ARG;
     bool is_signed = !(flags & MSM_FLAG_UNSIGNED_DIGITS);
     bool use_glv = !(flags & MSM_FLAG_NO_GLV) && n <= glv_max;
     uint32_t c = window_bits ? window_bits : (use_glv ? plan_window_bits_glv(n, is_signed) : plan_window_bits(n, is_signed));

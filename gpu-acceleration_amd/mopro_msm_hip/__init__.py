@@ -23,6 +23,7 @@ FORM_STD, FORM_MONT = 0, 1
 FLAG_UNSIGNED_DIGITS = 1
 FLAG_NO_GLV = 2
 FLAG_WINDOW_TABLE = 4  # resident sets carry their window table
+FLAG_DETERMINISTIC = 8  # jacobian_mont is the canonical Z = 1 representative: the same 24 words for the same group element (ABI 6)
 OK, ERR_EMPTY, ERR_BAD_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_STATE, ERR_INVALID_DATA = 0, -1, -2, -3, -4, -5, -6, -7
 
 # every symbol include/msm_hip.h declares (checked by tests/test_abi.py)

@@ -74,7 +74,7 @@ class HooksContext(MsmContext):
 
     def test_g1_op(self, op, a, b=None):
         a = _words(a, 24)
-        b = _words(b, 16 if op == 0 else 24) if b is not None else None
+        b = _words(b, 16 if op in (0, 5, 6) else 24) if b is not None else None  # (0, 5, 6: mixed additions, b affine)
         out = np.zeros_like(a)
         self._check(self._lib.msm_test_g1_op(self._h, op, _p32(a), _p32(b), _p32(out), a.shape[0]))
         return out

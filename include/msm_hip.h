@@ -21,6 +21,16 @@
  * MSM_FORM_MONT coordinates are bit-identical to arkworks' internal `Fq.0.0` limbs, so the shim
  * can hand them over without the 3N CPU-side Montgomery reductions of pack_affine_and_scalars.
  *
+ * Determinism.  out_affine_std (and out_is_inf) are CANONICAL: the same inputs give the same bits on every call, every entry point, every
+ * plan and any number of GPUs -- this is what "bit-exact against arkworks" means here and what every parity test compares.
+ * out_jacobian_mont -- the reference's result type, G::new(x, y, z) (metal_msm.rs:228-241) -- is a projective REPRESENTATIVE of that group
+ * element: X : Y : Z depends on the order in which the points of a bucket were added, and the counting sort places the entries of a bucket
+ * with LDS atomics, so the 24 words generally DIFFER BETWEEN TWO IDENTICAL CALLS (arkworks compares projectively: `==` on G1Projective
+ * holds).  The reference's own sort is serial (shader/cuzk/transpose.metal:8-65), so its limbs repeat; a caller that hashes or memcmp's
+ * the Jacobian words must either use out_affine_std or create the context with MSM_FLAG_DETERMINISTIC, which returns the Z = 1
+ * representative.  (A deterministic PLACEMENT -- every bucket's run sorted by point index in the fine sort's LDS staging -- was measured in
+ * round 5 and is not the default: profiles/NOTES_r5.md.)
+ *
  * Threading: a context serialises its own calls with an internal mutex; different contexts are
  * independent.  No caller pointer is retained after a call returns.  Nothing aborts or panics:
  * every failure is a negative status plus msm_last_error().
@@ -34,7 +44,7 @@
 extern "C" {
 #endif
 
-#define MSM_HIP_ABI_VERSION 5u
+#define MSM_HIP_ABI_VERSION 6u
 
 /* status codes */
 #define MSM_OK 0
@@ -66,6 +76,11 @@ extern "C" {
                                        2^20 (what ~300 MSMs gain: for base sets that outlive many calls, e.g. a proving key); none above 2^21.
                                        Every other entry point, and a resident call on fewer scalars than bases, is unaffected.
                                        Results are the same group element either way (bit-exact affine coordinates).            */
+
+#define MSM_FLAG_DETERMINISTIC 8u     /* out_jacobian_mont is the CANONICAL representative of the result: (x*R, y*R, R), the identity (R, R, 0) -- the
+                                       same 24 words for the same group element.  Without it the words are A representative that MAY DIFFER
+                                       BETWEEN IDENTICAL CALLS (see "Determinism" below).  Costs one field inversion on the host (~10 us;
+                                       shared with out_affine_std when both are asked for).  ABI 6.                              */
 
 typedef struct msm_ctx msm_ctx;
 
@@ -148,7 +163,7 @@ uint32_t msm_abi_version(void);
 /* replaces metal_variable_base_msm (metal_msm.rs:642-695).  bases: n x 16 words; inf_mask: n bytes
  * (non-zero = point at infinity, arkworks G1Affine.infinity) or NULL; scalars: n x 8 words.
  * Any of the three outputs may be NULL.  out_jacobian_mont is the reference's own result type (G::new(x, y, z),
- * metal_msm.rs:228-241).  out_affine_std = canonical affine, standard form (0,0 when the result is the identity and
+ * metal_msm.rs:228-241): a representative that may differ between identical calls unless the context has MSM_FLAG_DETERMINISTIC.  out_affine_std = canonical affine, standard form (0,0 when the result is the identity and
  * *out_is_inf = 1); it costs the call's only field inversion (~10 us on the host) -- pass NULL to skip it and normalise
  * later with msm_bn254_g1_combine(partial, 1, ...) if needed. */
 int32_t msm_bn254_g1(msm_ctx *ctx, const uint32_t *bases_xy, uint32_t base_form, const uint8_t *inf_mask,
@@ -236,8 +251,9 @@ int32_t msm_bn254_g1_combine(const uint32_t *partials_jacobian_mont, size_t k, u
  *        MSM_MULTI_EXCHANGE_RCCL  ncclAllGather of 24 words per rank over RCCL/xGMI (librccl is dlopen'ed: no link-time
  *                                 dependency), every rank folds in rank order, rank 0's bits are returned;
  *        MSM_MULTI_EXCHANGE_HOST  the partials already sit in pinned host memory: the calling thread folds them.
- *      AUTO picks RCCL when librccl loads, ndev > 1 and the device list has no duplicates, HOST otherwise.  Identical bits
- *      either way (fixed rank order).  A device may be listed more than once (tests on a 1-GPU box: {0, 0}). ---------- */
+ *      AUTO picks RCCL when librccl loads, ndev > 1 and the device list has no duplicates, HOST otherwise.  The two exchanges fold
+ *      the same partials in the same rank order: identical out_affine_std bits either way, and identical out_jacobian_mont for identical
+ *      PARTIALS -- which, like every Jacobian result, repeat between calls only under MSM_FLAG_DETERMINISTIC (see "Determinism").  A device may be listed more than once (tests on a 1-GPU box: {0, 0}). ---------- */
 #define MSM_MULTI_EXCHANGE_AUTO 0u
 #define MSM_MULTI_EXCHANGE_RCCL 1u
 #define MSM_MULTI_EXCHANGE_HOST 2u

@@ -35,3 +35,19 @@ def golden_cases():
 def load_golden(name):
     import numpy as np
     return np.load(os.path.join(GOLDEN, f"msm_{name}.npz"))
+
+
+def load_zkey_points():
+    """tests/golden/zkey_g1_points.json (tools/extract_zkey_points.py): the G1 entries of the reference's own Groth16 proving key
+    (example-app/test-vectors/circom/multiplier2_final.zkey) -- the only POINTS the reference tree holds -- as arkworks / MSM_FORM_MONT words.
+    Returns (bases_mont [n,16] u32, inf [n] u8, scalars [n,8] u32, expected affine standard-form words [16] u32, the json)."""
+    import json
+    import numpy as np
+    d = json.load(open(os.path.join(GOLDEN, "zkey_g1_points.json")))
+    pts = d["points"]
+    bases = np.stack([np.frombuffer(bytes.fromhex(p["mont_le_hex"]), dtype="<u4") for p in pts]).astype(np.uint32)
+    inf = np.array([1 if p["infinity"] else 0 for p in pts], np.uint8)
+    words = lambda v: np.frombuffer(int(v, 16).to_bytes(32, "little"), dtype="<u4").astype(np.uint32)
+    scalars = np.stack([words(k) for k in d["scalars_hex"]])
+    expected = np.concatenate([words(v) for v in d["expected_msm_affine_std_hex"]])
+    return bases, inf, scalars, expected, d

@@ -93,26 +93,54 @@ def test_struct_layouts_match_the_ctypes_mirrors(tmp_path):
 RUST_TYPES = {"i32": 4, "u32": 4, "u64": 8, "i64": 8, "f32": 4, "usize": 8, "u8": 1}
 
 
-def test_struct_layouts_match_the_rust_shim(tmp_path):
-    """the shim cannot be compiled here (no cargo): its #[repr(C)] mirror of msm_config_t is parsed and laid out by the C rules"""
-    sizes, fields, _ = _c_layout(tmp_path)
-    txt = open(os.path.join(ROOT, "rust", "mopro-msm-hip", "src", "lib.rs")).read()
+def _check_rust_binding(txt, where, sizes, fields, min_externs):
+    """a Rust source text (the shim, or a ```rust fence of a document): its #[repr(C)] MsmConfig laid out by the C rules must be gcc's
+    msm_config_t, and every `fn msm_*` of its extern "C" block must be declared by include/msm_hip.h with the same NUMBER of parameters"""
     m = re.search(r"#\[repr\(C\)\]\s*struct MsmConfig \{(.*?)\}", txt, re.S)
-    assert m, "MsmConfig mirror not found in the Rust shim"
+    assert m, f"MsmConfig mirror not found in {where}"
     off, got, align = 0, [], 1
-    for name, ty in re.findall(r"(\w+):\s*(\w+),", m.group(1)):
+    for name, ty in re.findall(r"(\w+):\s*(\w+)\s*[,}\n]", m.group(1) + "\n"):
         sz = RUST_TYPES[ty]
         off = (off + sz - 1) // sz * sz
         got.append((name, off, sz))
         off += sz
         align = max(align, sz)
-    assert got == fields["msm_config_t"], (got, fields["msm_config_t"])
-    assert (off + align - 1) // align * align == sizes["msm_config_t"]
-    # every extern "C" function the shim declares exists in the header
+    assert got == fields["msm_config_t"], (where, got, fields["msm_config_t"])
+    assert (off + align - 1) // align * align == sizes["msm_config_t"], where
     block = txt[txt.index('extern "C"'):]
     block = block[:block.index("\n}\n")]  # the extern block only: methods of the shim's own types are not ABI symbols
-    decl = set(re.findall(r"\bfn (msm_[a-z0-9_]+)\s*\(", block))
-    assert len(decl) >= 10
-    hdr = open(os.path.join(INC, "msm_hip.h")).read()
-    for f in decl:
-        assert re.search(r"\b%s\s*\(" % f, hdr), f"{f} declared by the Rust shim but not by include/msm_hip.h"
+    decl = re.findall(r"\bfn (msm_[a-z0-9_]+)\s*\((.*?)\)\s*(?:->\s*[^;]+)?;", block, re.S)
+    assert len(decl) >= min_externs, (where, len(decl))
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(INC, "msm_hip.h")).read(), flags=re.S)
+    for f, params in decl:
+        h = re.search(r"\b%s\s*\((.*?)\)\s*;" % f, hdr, re.S)
+        assert h, f"{f} declared by {where} but not by include/msm_hip.h"
+        n_rust = len([a for a in params.split(",") if a.strip()])
+        n_c = 0 if h.group(1).strip() in ("", "void") else len(h.group(1).split(","))
+        assert n_rust == n_c, f"{f}: {n_rust} parameters in {where}, {n_c} in include/msm_hip.h"
+    return {f for f, _ in decl}
+
+
+def test_struct_layouts_match_the_rust_shim(tmp_path):
+    """the shim cannot be compiled here (no cargo): its #[repr(C)] mirror of msm_config_t is parsed and laid out by the C rules"""
+    sizes, fields, _ = _c_layout(tmp_path)
+    txt = open(os.path.join(ROOT, "rust", "mopro-msm-hip", "src", "lib.rs")).read()
+    _check_rust_binding(txt, "rust/mopro-msm-hip/src/lib.rs", sizes, fields, 10)
+
+
+def test_integration_md_prints_the_real_binding(tmp_path):
+    """INTEGRATION.md section 2 is what a maintainer copies: round 4 shipped it with the 24-byte ABI-4 MsmConfig while the header's had grown
+    to 32.  Every ```rust fence of the document that declares MsmConfig or an extern "C" block is held to the same rules as
+    lib.rs, and the extern block must be the shim's own (same functions)."""
+    sizes, fields, _ = _c_layout(tmp_path)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    fences = re.findall(r"```rust\n(.*?)```", doc, re.S)
+    binding = [f for f in fences if "struct MsmConfig" in f or 'extern "C"' in f]
+    assert binding, "INTEGRATION.md no longer shows the binding"
+    shim = open(os.path.join(ROOT, "rust", "mopro-msm-hip", "src", "lib.rs")).read()
+    shim_decl = _check_rust_binding(shim, "lib.rs", sizes, fields, 10)
+    for k, f in enumerate(binding):
+        assert "struct MsmConfig" in f and 'extern "C"' in f, "a binding fence must show the struct AND the externs it is passed to"
+        assert _check_rust_binding(f, f"INTEGRATION.md rust fence {k}", sizes, fields, 10) == shim_decl
+    # no other place of the document spells the struct's fields out (a second, stale copy)
+    assert len(re.findall(r"struct MsmConfig\s*\{", doc)) == len(binding)

@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, golden_cases, load_golden
+from conftest import GOLDEN, golden_cases, load_golden, load_zkey_points
 from oracle import bn254_oracle as orc
 
 P, R = orc.P, orc.R_ORDER
@@ -142,3 +142,35 @@ def test_synthetic_generator_closed_form():
     assert inf == einf == 0 and (out == exp).all()
     # element i depends only on (seed, i)
     assert (orc.gen_scalars(0xB2540002, 10) == s[:10]).all()
+
+
+def test_reference_zkey_points_pin_the_montgomery_word_format():
+    """The one file of the reference that holds G1 POINTS (example-app/test-vectors/circom/multiplier2_final.zkey, extracted as data by
+    tools/extract_zkey_points.py): 64-byte entries of little-endian R = 2^256 Montgomery words, infinity as zeros.  The oracle's
+    fq_from_mont must put every non-zero entry on y^2 = x^3 + 3, its MSM over them in MONT form must equal the pure-Python known answer,
+    and the same call on the standard-form images must give the same words -- which pins what include/msm_hip.h calls MSM_FORM_MONT
+    ("bit-identical to arkworks Fq.0") against bytes the reference itself ships."""
+    bases, inf, scalars, expected, d = load_zkey_points()
+    assert int(d["q_hex"], 16) == P and int(d["r_hex"], 16) == R
+    assert bases.shape == (19, 16) and int(inf.sum()) == 4
+    std = np.zeros_like(bases)
+    for i in range(bases.shape[0]):
+        if inf[i]:
+            assert not bases[i].any()
+            continue
+        x, y = orc.fq_from_mont(bases[i, :8]), orc.fq_from_mont(bases[i, 8:])
+        xi, yi = orc.words_to_int(x), orc.words_to_int(y)
+        assert xi < P and yi < P and (yi * yi - xi * xi * xi - 3) % P == 0, ("not on the curve after fq_from_mont", i)
+        assert (orc.fq_to_mont(x) == bases[i, :8]).all() and (orc.fq_to_mont(y) == bases[i, 8:]).all()
+        std[i, :8], std[i, 8:] = x, y
+    for label, fn in (("pippenger/mont", lambda: orc.msm_pippenger(bases, scalars, orc.FORM_MONT, inf)),
+                      ("naive/mont", lambda: orc.msm_naive(bases, scalars, orc.FORM_MONT, inf)),
+                      ("cuzk/mont", lambda: orc.msm_cuzk(bases, scalars, orc.FORM_MONT, inf)),
+                      ("pippenger/std", lambda: orc.msm_pippenger(std, scalars, orc.FORM_STD, inf))):
+        out, is_inf, _ = fn()
+        assert is_inf == 0 and (out == expected).all(), label
+    ones = np.zeros_like(scalars)
+    ones[:, 0] = 1
+    out, is_inf, _ = orc.msm_naive(bases, ones, orc.FORM_MONT, inf)
+    exp_sum = np.concatenate([np.frombuffer(int(v, 16).to_bytes(32, "little"), dtype="<u4") for v in d["expected_sum_of_points_affine_std_hex"]])
+    assert is_inf == 0 and (out == exp_sum).all()

@@ -61,6 +61,20 @@ int main() {
         if (!same(to_host_mont256(fp_sub<3>(a, b)), hostg1::sub(ha, hb))) { printf("sub mismatch\n"); return 1; }
         if (!same(to_host_mont256(fp_mul_add(a, b, b, fp_neg<3>(a))), hostg1::sub(hostg1::mul(ha, hb), hostg1::mul(hb, ha)))) { printf("mul_add mismatch\n"); return 1; }
         checks += 5;
+        {   // round 5: the paired / two-accumulator forms give the SAME limbs as the plain chains (same column sums, split differently)
+            fp p1, p2, q1, q2;
+            fp_mul2(a, b, b, fp_neg<3>(a), p1, p2);
+            fp_sqr2(a, fp_sub<3>(a, b), q1, q2);
+            const fp e1 = fp_mul(a, b), e2 = fp_mul(b, fp_neg<3>(a)), f1 = fp_sqr(a), f2 = fp_sqr(fp_sub<3>(a, b));
+            const fp g1 = fp_mul_2acc(a, fp_sub_raw<3>(a, b)), g2 = fp_sqr_2acc(fp_sub<3>(a, b)), g3 = fp_mul_add_2acc(a, fp_sub_raw<3>(b, a), fp_neg_raw<3>(a), b);
+            const fp h1 = fp_mul(a, fp_sub_raw<3>(a, b)), h3 = fp_mul_add(a, fp_sub_raw<3>(b, a), fp_neg_raw<3>(a), b);
+            for (int i = 0; i < 9; i++)
+                if (p1.v[i] != e1.v[i] || p2.v[i] != e2.v[i] || q1.v[i] != f1.v[i] || q2.v[i] != f2.v[i] || g1.v[i] != h1.v[i] || g2.v[i] != f2.v[i] || g3.v[i] != h3.v[i]) {
+                    printf("paired / 2acc product differs from the plain one (it=%d)\n", it);
+                    return 1;
+                }
+            checks += 7;
+        }
         if (it % 100 == 0) {  // the windowed Fermat inversion (fp_inv) against the host's bit-by-bit one; 0 -> 0
             if (!same(to_host_mont256(fp_inv(a)), hostg1::inv(ha))) { printf("inv mismatch\n"); return 1; }
             checks++;
@@ -128,6 +142,62 @@ int main() {
         xyzz bi{add_kp(b.x, 6), add_kp(b.y, 4), add_kp(b.zz, 1), add_kp(b.zzz, 1)};
         if (!same_xyzz(xyzz_add(a, b), xyzz_add(ai, bi))) { printf("add: inflated operands change the residues\n"); return 1; }
         if (!same_xyzz(xyzz_add(a, bi), xyzz_add(ai, b))) { printf("add (mixed): inflated operands change the residues\n"); return 1; }
+        if (!same_xyzz(xyzz_add(a, b), xyzz_add_ilp(ai, bi)) || !same_xyzz(xyzz_add(a, a), xyzz_add_ilp(ai, a))) { printf("add_ilp differs from add\n"); return 1; }
+        checks += 4;
+    }
+    // 4. round 5: the mixed addition on the caller's R = 2^256 Montgomery words as they are (fp_unpack_shl5 + xyzz_madd_m32) against the
+    //    normalised one on converted operands -- canonical words, ANY 256-bit words (all ones: the largest multiplier, 2^261 - 32), reduced and
+    //    inflated accumulators, both signs, the identity start and the doubling / cancelling branches
+    for (int it = 0; it < 200000; it++) {
+        uint32_t w[6][8];
+        for (int j = 0; j < 6; j++) rand_words(w[j], (it + j) % 19 == 0 ? 1 : (it + j) % 23 == 0 ? 2 : 0);
+        if ((w[2][0] | w[2][1] | w[2][7]) == 0) w[2][0] = 5;
+        if (it % 3 == 1) for (int j = 4; j < 6; j++) for (int k = 0; k < 8; k++) w[j][k] = (uint32_t)rng();  // not canonical: any 256 bits
+        if (it % 1000 == 7) for (int j = 4; j < 6; j++) for (int k = 0; k < 8; k++) w[j][k] = 0xFFFFFFFFu;
+        xyzz a{fp_from_mont256(w[0]), fp_from_mont256(w[1]), fp_from_mont256(w[2]), fp_from_mont256(w[3])};
+        if (it % 50 == 0) a = xyzz_identity();
+        const xyzz ai = xyzz_is_identity(a) ? a : xyzz{add_kp(a.x, 6), add_kp(a.y, 4), add_kp(a.zz, 1), add_kp(a.zzz, 1)};
+        const bool ng = (it >> 1) & 1;
+        const fp qx = fp_unpack_shl5(w[4]), qy = fp_unpack_shl5(w[5]);
+        for (int i = 0; i < 8; i++)
+            if (qx.v[i] > FP_MASK || qy.v[i] > FP_MASK) { printf("unpack_shl5: limb not normalised\n"); return 1; }
+        affine q{fp_from_mont256(w[4]), fp_from_mont256(w[5])};  // (fp_mul takes any 256-bit words: the value mod p)
+        q.x = fp_reduce_lt2p(q.x), q.y = fp_reduce_lt2p(q.y);
+        if (!same_residue(qx, q.x) || !same_residue(qy, q.y)) { printf("unpack_shl5: 32 * W is not the internal-domain value\n"); return 1; }
+        if (ng) q.y = fp_neg<2>(q.y);
+        xyzz r0 = a, r1 = a, r2 = ai;
+        xyzz_madd_plain(r0, q);
+        xyzz_madd_m32(r1, qx, qy, ng);
+        xyzz_madd_m32(r2, qx, qy, ng);
+        if (!same_xyzz(r0, r1) || !same_xyzz(r0, r2) || xyzz_is_identity(r0) != xyzz_is_identity(r1) || xyzz_is_identity(r0) != xyzz_is_identity(r2)) {
+            printf("madd_m32 differs from the plain mixed addition (it=%d)\n", it);
+            return 1;
+        }
+        // same point again (doubling branch), then its inverse (cancels to the identity)
+        xyzz d0 = r0, d1 = r1;
+        xyzz_madd_plain(d0, q);
+        xyzz_madd_m32(d1, qx, qy, ng);
+        if (xyzz_is_identity(a)) {  // a was the identity: r = q, so this was q + q
+            if (!same_xyzz(d0, d1)) { printf("madd_m32: doubling branch differs (it=%d)\n", it); return 1; }
+            xyzz c1 = r1;
+            xyzz_madd_m32(c1, qx, qy, !ng);
+            const bool y_zero = fp_is_zero_lt2p(fp_mul(qy, fp_one()));  // (y = 0 is its own inverse -- not a curve point, but a boundary operand here)
+            if (!y_zero && !xyzz_is_identity(c1)) { printf("madd_m32: q + (-q) is not the identity (it=%d)\n", it); return 1; }
+        }
+        // a long chain keeps the bounds
+        if (it % 100 == 0) {
+            xyzz c0 = r0, c1 = r1;
+            for (int s = 0; s < 200; s++) {
+                uint32_t u[2][8];
+                for (int j = 0; j < 2; j++) for (int k = 0; k < 8; k++) u[j][k] = (s % 3) ? (uint32_t)rng() : 0xFFFFFFFFu - (uint32_t)(rng() % 4);
+                affine t{fp_reduce_lt2p(fp_from_mont256(u[0])), fp_reduce_lt2p(fp_from_mont256(u[1]))};
+                const bool g2 = rng() & 1;
+                if (g2) t.y = fp_neg<2>(t.y);
+                xyzz_madd_plain(c0, t);
+                xyzz_madd_m32(c1, fp_unpack_shl5(u[0]), fp_unpack_shl5(u[1]), g2);
+            }
+            if (!same_xyzz(c0, c1)) { printf("madd_m32: chain differs (it=%d)\n", it); return 1; }
+        }
         checks += 4;
     }
     printf("fp_bounds_check: %ld checked operations, no bound violated, field results identical to the 4x64 host arithmetic\n", checks);

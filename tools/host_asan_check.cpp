@@ -86,7 +86,7 @@ static int check_planner() {
     msm_plan_t p;
     REQUIRE(msmplan::make_plan(16, 1, 0, &p) == MSM_ERR_BAD_ARG);
     REQUIRE(msmplan::make_plan(16, 21, 0, &p) == MSM_ERR_BAD_ARG);
-    REQUIRE(msmplan::make_plan(16, 0, 8, &p) == MSM_ERR_BAD_ARG);
+    REQUIRE(msmplan::make_plan(16, 0, 16, &p) == MSM_ERR_BAD_ARG);
     return 0;
 }
 
