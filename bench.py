@@ -49,6 +49,19 @@ def words_to_ints(a):
     return out
 
 
+def kernel_source_hash():
+    """sha256 (16 hex digits) over the kernel / host-runtime sources the product library is built from: the committed counter passes
+    (profiles/*_pmc_*.json) carry the hash of the build they measured, and a line that quotes them for a different build says so"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "gpu-acceleration_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hpp")) + glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.inc"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 EXTRAS_DEADLINE_S = int(os.environ.get("MSM_BENCH_EXTRAS_DEADLINE_S", "420"))  # the untimed legs of a default run take ~6 s
 
 # one mixed addition (ec_bn254.hpp xyzz_madd, the loop body of k_accumulate_pieces): 6 fp_mul + 2 fp_sqr + 1 fused fp_mul_add
@@ -56,22 +69,31 @@ MADS_PER_ADD = 6 * 162 + 2 * 126 + 243           # v_mad_u64_u32 instructions
 FPMUL_EQ_PER_ADD = (6 * 171 + 2 * 135 + 252) / 171.0  # in units of one fp_mul (162 mads + 9 Montgomery-digit multiplications)
 
 
-# vector instructions of one mixed addition in k_accumulate_pieces' loop (disassembly of the round-4 build: 1468 v_mad_u64_u32, 81 v_mul_lo_u32, 150
-# v_lshrrev_b64, 201 v_and_b32, the rest adds / subs / unpack; rocprofv3 --pmc counts 2101 per addition and lane, profiles/accumulate_valu_pmc.json)
+# vector instructions of one mixed addition in k_accumulate_pieces<.., M256>'s loop (disassembly of the round-5 build: 1468 v_mad_u64_u32, 81
+# v_mul_lo_u32, 144 v_lshrrev_b64, 194 v_and_b32, the rest adds / subs / unpack / the digit's sign: 2117 in the loop body + 9 under the sign's
+# lane mask; rocprofv3 --pmc counted 2101 per addition and lane for the round-4 loop of 2126, profiles/accumulate_valu_pmc.json)
 VALU_INSTS_PER_ADD = 2126
+# the same stream priced class by class at the stand-alone rates of profiles/microbench_r1_instruction_rates.txt (DESIGN.md section 4.1,
+# yardstick i): multiplier instructions 4.8 cycles, 64-bit shifts / alignbit 4.5, VOP2 masks / adds / shifts 2.4
+CLASS_PRICED_CYCLES_PER_ADD = (1468 + 81) * 4.8 + (144 + 23 + 2 + 1) * 4.5 + (VALU_INSTS_PER_ADD - 1468 - 81 - 170) * 2.4
 
 
 def issue_floor(num_adds, mcycles, simds):
-    """the hard bound of the kernel's instruction stream: a 64-lane wavefront occupies its 16-lane SIMD for >= 4 cycles per vector instruction"""
+    """two YARDSTICKS for the kernel's instruction stream (neither is a hard bound: VOP2 instructions issue faster than 4 cycles when
+    several wavefronts share a SIMD, multiplier instructions slower)"""
     if not (num_adds and mcycles and simds):
         return None
     wave_adds_per_simd = num_adds / 64.0 / simds
     cpi = mcycles * 1e6 / (wave_adds_per_simd * VALU_INSTS_PER_ADD)
+    priced = wave_adds_per_simd * CLASS_PRICED_CYCLES_PER_ADD / 1e6
     return {"vector_instructions_per_addition": VALU_INSTS_PER_ADD, "simds": simds, "wavefront_additions_per_simd": round(wave_adds_per_simd, 1),
             "floor_mcycles": round(wave_adds_per_simd * VALU_INSTS_PER_ADD * 4 / 1e6, 3), "measured_mcycles": mcycles,
             "cycles_per_instruction": round(cpi, 3), "frac_of_issue_floor": round(4.0 / cpi, 4),
-            "note": "floor = 4 cycles per vector instruction and wavefront on a 16-lane SIMD; measured = live kernel ms x the shader clock the kernel "
-                    "measured for itself (clock.k_accumulate_mcycles)"}
+            "class_priced_mcycles": round(priced, 3), "measured_over_class_priced": round(mcycles / priced, 4),
+            "note": "YARDSTICKS, not bounds.  floor_mcycles = 4 cycles per vector instruction and wavefront on a 16-lane SIMD (VOP2 adds / masks issue "
+                    "faster with several wavefronts per SIMD: 2.2-2.6 cycles measured; the guide lists v_fma_f32 wave64 at 2); class_priced_mcycles = every "
+                    "instruction class at its measured stand-alone rate (multiplier 4.8, 64-bit shifts 4.5, VOP2 2.4 cycles; profiles/"
+                    "microbench_r1_instruction_rates.txt).  measured = live kernel ms x the shader clock the kernel measured for itself (clock.k_accumulate_mcycles)"}
 
 
 def valu_roofline(num_adds, acc_ms, mad_peak, fpmul_peak):
@@ -114,8 +136,6 @@ def timed_calls(fn, reps, warm=1, warm_s=0.1):
 
 
 def main():
-    import faulthandler
-    faulthandler.dump_traceback_later(1500, exit=True)  # a stalled run leaves the stacks of all threads on stderr instead of nothing
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -133,6 +153,9 @@ def main():
                          "with the accumulation) instead of the resident call; value then includes PCIe")
     ap.add_argument("--in-process", action="store_true",
                     help="N GPUs driven by ONE process through msm_multi (context + host thread per device, in-library RCCL exchange)")
+    ap.add_argument("--exchange", choices=["auto", "rccl", "host"], default="auto",
+                    help="--in-process only: the exchange of msm_multi (MSM_MULTI_EXCHANGE_*): auto = measured when the handle is created, "
+                         "rccl = in-library ncclAllGather, host = the calling thread folds the partials")
     ap.add_argument("--debug-same-device", action="store_true",
                     help="functional check of the N>1 path on a 1-GPU box: every rank uses cuda:0 and the exchange runs over gloo / the host fold")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launched torchrun (0 = a free one)")
@@ -152,8 +175,10 @@ def main():
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         env = dict(os.environ)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        sys.exit(subprocess.call(cmd, env=env))
+        sys.exit(subprocess.call(cmd, env=env))  # (no watchdog in this parent: exiting it would orphan the ranks)
 
+    import faulthandler
+    faulthandler.dump_traceback_later(1500, exit=True)  # a stalled run leaves the stacks of all threads on stderr instead of nothing
     import torch
     import torch.distributed as dist
     import mopro_msm_hip as mh
@@ -205,7 +230,8 @@ def main():
 
     multi = None
     if in_proc:
-        multi = mh.MsmMulti(devices=[devs[g].index for g in my_shards], window_bits=args.window_bits, flags=ctx_flags)
+        multi = mh.MsmMulti(devices=[devs[g].index for g in my_shards], window_bits=args.window_bits, flags=ctx_flags,
+                            exchange={"auto": mh.EXCHANGE_AUTO, "rccl": mh.EXCHANGE_RCCL, "host": mh.EXCHANGE_HOST}[args.exchange])
         ctx = None
     else:
         ctx = mh.MsmContext(device=local_rank, window_bits=args.window_bits, flags=ctx_flags, max_points=n_local)
@@ -329,7 +355,10 @@ def main():
                     "note": "exchange ms = host wall clock of the 100-byte all-gather incl. its two copies and the wait for the slowest rank"}
     elif in_proc:
         ex_ms, sh = multi.exchange_stats()
+        p_rccl, p_host = multi.exchange_probe()
         exchange = {"backend": {1: "rccl (in-library, ncclCommInitAll)", 2: "host fold"}.get(multi.exchange, "?"),
+                    "requested": args.exchange,
+                    "auto_probe_ms": {"rccl": round(p_rccl, 4), "host": round(p_host, 4)} if (p_rccl or p_host) else None,
                     "world_seen": multi.num_devices, "devices_seen": sorted({devs[g].index for g in my_shards}),
                     "payload_bytes_per_rank": 96, "ms_per_step": round(ex_ms, 4), "shard_ms_max": round(max(sh), 4),
                     "shard_ms_min": round(min(sh), 4), "note": "last step; shard ms = wall clock of each rank's local MSM on its host thread"}
@@ -382,6 +411,7 @@ def main():
         # HBM traffic of one k_accumulate launch: PMC counters cannot be read from inside this process, so the figure comes from the
         # committed offline passes (tools/pmc_accumulate.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, corrected as the
         # microarchitecture guide prescribes) of the SAME shape -- profiles/accumulate_pmc*.json, one file per shard size -- and says so
+        src_hash = kernel_source_hash()
         traffic, traffic_src = None, {"source": "none", "detail": "no committed PMC pass for n_local %d, c %d" % (n_local, pl.window_bits)}
         import glob
         for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "accumulate_pmc*.json"))):
@@ -392,7 +422,9 @@ def main():
             if j.get("n_local") == n_local and j.get("window_bits") == pl.window_bits and j.get("num_windows", W) == W:
                 traffic = j.get("hbm_bytes_per_launch")
                 traffic_src = {"source": "file", "file": os.path.relpath(pmc, ROOT), "build": j.get("build", "round 2"),
-                               "detail": "offline rocprofv3 --pmc passes on the same box class (tools/pmc_accumulate.sh); not measured in this run"}
+                               "source_hash_of_measured_build": j.get("source_hash"), "traffic_stale": j.get("source_hash") != src_hash,
+                               "detail": "offline rocprofv3 --pmc passes on the same box class (tools/pmc_accumulate.sh); not measured in this run; "
+                                         "traffic_stale = the kernel sources have changed since the counters were collected"}
                 break
         sort_ms = float(tm.get("sort_ms", 0.0) or 0.0)
         sort_bytes = 8 * int(pl.virtual_points) * W  # per window N*(2 read + 2 read + 4 write)
@@ -405,6 +437,7 @@ def main():
             if j.get("n_local") == n_local and j.get("window_bits") == pl.window_bits and bool(j.get("glv_split")) == bool(pl.glv):
                 sort_traffic = j.get("sort_hbm_bytes")
                 sort_traffic_src = {"source": "file", "file": os.path.relpath(pmc, ROOT), "build": j.get("build"),
+                                    "source_hash_of_measured_build": j.get("source_hash"), "traffic_stale": j.get("source_hash") != src_hash,
                                     "detail": "offline rocprofv3 --pmc passes (tools/pmc_accumulate.sh + tools/pmc_sort_summarize.py); not measured in this run"}
                 break
         out = {
@@ -412,7 +445,7 @@ def main():
             "value": round(ms_per_step, 4), "unit": "ms", "n_gpus": nshards, "steps": args.steps, "warmup": args.warmup, "pre_warm_steps": pre_warm_steps,
             "step_after_0.2s_idle_ms": round(after_idle_ms, 4) if after_idle_ms is not None else None,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
-            "dtype": "u32", "data": "synthetic",
+            "dtype": "u32", "data": "synthetic", "source_hash": src_hash,
             "config": {"workload": "BN254 G1 variable-base MSM, N=2^%d, dynamic window + signed-digit buckets "
                                    "(BASELINE.json configs[%d]); bases k_i*G and scalars %s, "
                                    "point-range shards + all-gather of 96-byte partials"
@@ -472,7 +505,10 @@ def main():
             try:
                 stj = json.load(open(st_file))
                 tms = {int(k): float(v) for k, v in stj["device_call_ms_by_log2_points"].items()}
-                ex_est = exchange["ms_per_step"] if exchange and world > 1 else float(stj.get("exchange_ms_estimate", 0.04))
+                # the exchange term: what THIS run measured when it ran on more than one rank; else an ESTIMATE -- the largest exchange this repo has
+                # measured end to end (0.12 ms: two gloo ranks on one device, profiles/r4_final_bench_torchrun_2x_same_device.json), never less
+                ex_meas = bool(exchange and world > 1)
+                ex_est = exchange["ms_per_step"] if ex_meas else max(0.12, float(stj.get("exchange_ms_estimate", 0.12)))
                 if args.log_n in tms:
                     proj = {}
                     for g in (2, 4, 8):
@@ -480,7 +516,10 @@ def main():
                         if lg in tms:
                             proj["x%d" % g] = {"ms": round(tms[lg] + ex_est, 4), "speedup": round(tms[args.log_n] / (tms[lg] + ex_est), 2)}
                     out["projected_strong_scaling"] = {"from": "profiles/shard_times.json (single-GPU device calls, %s)" % stj.get("build", "?"),
-                                                       "exchange_ms_used": round(ex_est, 4), "one_gpu_ms": tms[args.log_n], **proj}
+                                                       "exchange_ms_used": round(ex_est, 4),
+                                                       "exchange_ms_is": "measured in this run" if ex_meas else "ESTIMATE (no multi-GPU run: the largest exchange measured on one device)",
+                                                       "one_gpu_ms": tms[args.log_n], **proj,
+                                                       "note": "an estimate built on single-GPU shard times: no scaling curve has been measured on hardware"}
             except Exception:
                 pass
 
@@ -489,13 +528,21 @@ def main():
         #      sat for 20 minutes on a box that answered again afterwards -- cause unknown, never reproduced: 25 of 25 reruns took 8 s)
         import threading
 
+        import threading
+        emit_lock = threading.Lock()  # the line is printed ONCE: by the watchdog (from a snapshot taken before the extras) or by the main thread
+        emitted = [False]
+        snapshot = json.dumps(dict(out, bit_exact=bit_exact,
+                                   extras_timed_out="untimed legs did not finish within %d s; the timed measurement above is complete" % EXTRAS_DEADLINE_S))
+        snapshot_ok = bit_exact
+
         def _emit_without_extras():
-            late = dict(out)
-            late["bit_exact"] = bit_exact
-            late["extras_timed_out"] = "untimed legs did not finish within %d s; the timed measurement above is complete" % EXTRAS_DEADLINE_S
-            print(json.dumps(late))
-            sys.stdout.flush()
-            os._exit(0 if bit_exact else 1)
+            with emit_lock:
+                if emitted[0]:
+                    return
+                emitted[0] = True
+                print(snapshot)
+                sys.stdout.flush()
+            os._exit(0 if snapshot_ok else 1)
 
         watchdog = threading.Timer(EXTRAS_DEADLINE_S, _emit_without_extras)
         watchdog.daemon = True
@@ -612,8 +659,11 @@ def main():
             bit_exact = bit_exact and cpu_ok
         watchdog.cancel()
         out["bit_exact"] = bit_exact
-        print(json.dumps(out))
-        sys.stdout.flush()
+        with emit_lock:
+            if not emitted[0]:
+                emitted[0] = True
+                print(json.dumps(out))
+                sys.stdout.flush()
     if ctx is not None:
         ctx.close()
     if multi is not None:

@@ -173,30 +173,6 @@ FP_HD xyzz xyzz_add(const xyzz& a, const xyzz& b) {
     return xyzz{x3, y3, zz3, zzz3};
 }
 
-// xyzz_add for kernels that run ONE wavefront per SIMD or fewer (the bucket reduction, k_combine_pieces): the fourteen products as six
-// interleaved pairs and one two-accumulator multiply-add (fp_mul2 / fp_sqr2 / fp_mul_add_2acc) -- the same values, the same bounds, about half
-// the dependency chain.  Not for k_accumulate_pieces-like occupancy, where the plain chain already issues at the SIMD's rate.
-FP_HD xyzz xyzz_add_ilp(const xyzz& a, const xyzz& b) {
-    if (xyzz_is_identity(a)) return b;
-    if (xyzz_is_identity(b)) return a;
-    fp u1, u2, s1, s2, pp, rr, ppp, qv, zzab, zzzab, zz3, zzz3;
-    fp_mul2(a.x, b.zz, b.x, a.zz, u1, u2);      // < 1.09
-    fp_mul2(a.y, b.zzz, b.y, a.zzz, s1, s2);    // < 1.06
-    fp pp_ = fp_sub<3>(u2, u1);                 // < 4.09
-    fp r = fp_sub<3>(s2, s1);                   // < 4.06
-    fp_sqr2(pp_, r, pp, rr);                    // < 1.1
-    if (fp_is_zero_lt2p(pp)) {
-        if (fp_is_zero_lt2p(rr)) return xyzz_dbl(a);
-        return xyzz_identity();
-    }
-    fp_mul2(pp_, pp, u1, pp, ppp, qv);          // < 1.03, < 1.01
-    fp_mul2(a.zz, b.zz, a.zzz, b.zzz, zzab, zzzab);
-    fp x3 = fp_sub_b_2c(rr, ppp, qv);           // x3 < 6.1
-    fp_mul2(zzab, pp, zzzab, ppp, zz3, zzz3);
-    fp y3 = fp_mul_add_2acc(r, fp_sub_raw<8>(qv, x3), fp_neg_raw<3>(s1), ppp);  // < 1.24
-    return xyzz{x3, y3, zz3, zzz3};
-}
-
 // XYZZ -> Jacobian without inversion: Z = ZZ*ZZZ, X' = X*ZZ^4, Y' = Y*ZZZ^4
 // (then X'/Z^2 = X*ZZ^4/(ZZ^2*ZZZ^2) = X*ZZ^4/ZZ^5 = X/ZZ and Y'/Z^3 = Y*ZZZ^4/ZZZ^5 = Y/ZZZ).
 FP_HD jacobian xyzz_to_jacobian(const xyzz& p) {

@@ -27,18 +27,6 @@ __device__ __forceinline__ uint32_t wide_opa_coord(uint32_t role) { return (0x0E
 __device__ __forceinline__ uint32_t wide_opb_rec(uint32_t role) { return (0x35u >> role) & 1u; }          // 1,0,1,0,1,1,0,0
 __device__ __forceinline__ uint32_t wide_opb_coord(uint32_t role) { return (0x0EFAu >> (2 * role)) & 3u; }  // 2,2,3,3,2,3,0,0
 
-// Exchanges between the roles of a group.  Round 5: DPP row shifts (v_mov_b32_dpp row_shl / row_shr: a VALU move whose source lane is a
-// fixed distance away inside the 16-lane row; a group is half a row and every exchange below stays inside its group) instead of
-// __shfl = ds_bpermute_b32 (an LDS-pipe round trip per limb).  -DMSM_AB_NO_ILP builds the round-4 form (bpermute exchanges, single-chain products).
-template <int SHIFT>  // lane i <- lane i + SHIFT (SHIFT > 0: row_shl) or lane i - (-SHIFT) (row_shr); lanes whose source leaves the row keep their value
-__device__ __forceinline__ fp wide_from(const fp& a) {
-    static_assert(SHIFT != 0 && SHIFT > -16 && SHIFT < 16, "row shifts move 1..15 lanes");
-    constexpr int ctrl = SHIFT > 0 ? (0x100 | SHIFT) : (0x110 | -SHIFT);
-    fp r;
-#pragma unroll
-    for (int i = 0; i < 9; i++) r.v[i] = (uint32_t)__builtin_amdgcn_update_dpp((int)a.v[i], (int)a.v[i], ctrl, 0xF, 0xF, false);
-    return r;
-}
 __device__ __forceinline__ fp wide_shfl(const fp& a, int src_lane) {
     fp r;
 #pragma unroll
@@ -56,34 +44,25 @@ __device__ __forceinline__ fp wide_select(bool c, const fp& a, const fp& b) {
 // normalised).  operand_is_identity: role 4 passes (ZZ1 == 0 || ZZ2 == 0), other roles false.
 // Returns true (group-uniform) if the pair needs the scalar complete addition; otherwise
 //   role 1: out0 = X3 (< 7p), out1 = Y3 (< 5p)      role 4: out0 = ZZ3 (< 2p)      role 5: out0 = ZZZ3 (< 2p)
-// The products are the two-accumulator forms (fp_mul_2acc / fp_sqr_2acc, fp_bn254.hpp): a lane has ONE product per stage and the additions
-// this function serves are chains of dependent ones run by a handful of wavefronts -- the product's own dependency chain is what they wait for.
 __device__ __forceinline__ bool xyzz_add_wide(const fp& opa, const fp& opb, bool operand_is_identity, fp& out0, fp& out1) {
     const int lane = (int)(threadIdx.x & 63u);
     const int base = lane & ~(WIDE_LANES - 1);
     const uint32_t role = (uint32_t)lane & (WIDE_LANES - 1);
-#ifdef MSM_AB_NO_ILP
+
     // stage 1: r0 U1, r1 U2, r2 S1, r3 S2, r4 Za, r5 Zb                       (operands < 7p, < 2p -> products < 1.09p)
     const fp s1 = fp_mul(opa, opb);
+
     // stage 2: r0 PP = (U2-U1)^2, r1 RR = (S2-S1)^2
     const fp g1 = wide_shfl(s1, base + (role == 0 ? 1 : role == 1 ? 2 : (int)role));  // r0 <- U2, r1 <- S1
     const fp g2 = wide_shfl(s1, base + (role == 1 ? 3 : (int)role));                   // r1 <- S2
     const fp pr = role == 0 ? fp_sub<3>(g1, s1) : fp_sub<3>(g2, g1);  // r0: P = U2-U1, r1: R = S2-S1 (< 4.09p); others: unused
     const fp s2 = fp_sqr(pr);                                           // r0 PP, r1 RR  (< 1.1p)
-#else
-    const fp s1 = fp_mul_2acc(opa, opb);
-    const fp g1 = wide_from<1>(s1);  // r0 <- U2 (r1), r1 <- S1 (r2)
-    const fp g2 = wide_from<2>(s1);  // r1 <- S2 (r3)
-    const fp pr = role == 0 ? fp_sub<3>(g1, s1) : fp_sub<3>(g2, g1);
-    const fp s2 = fp_sqr_2acc(pr);
-#endif
 
     // P == 0 (same x: doubling or inverse points) or an identity operand -> scalar path for this pair
     const bool mine = (role == 0 && fp_is_zero_lt2p(s2)) || (role == 4 && operand_is_identity);
     const unsigned long long votes = __ballot(mine);
     if ((votes >> base) & 0xFFull) return true;
 
-#ifdef MSM_AB_NO_ILP
     // stage 3: r0 PPP = P*PP, r2 Q = U1*PP, r4 ZZ3 = Za*PP
     const fp pp = wide_shfl(s2, base);  // PP to everyone
     const fp u1 = wide_shfl(s1, base);  // U1 to everyone (r2 needs it)
@@ -99,23 +78,6 @@ __device__ __forceinline__ bool xyzz_add_wide(const fp& opa, const fp& opb, bool
     const fp s4 = fp_mul(a4, b4);                            // r1 T1 (< 1.22p), r2 T2 (< 1.01p), r5 ZZZ3
 
     const fp t2 = wide_shfl(s4, base + 2);
-#else
-    // stage 3: r0 PPP = P*PP, r2 Q = U1*PP, r4 ZZ3 = Za*PP
-    const fp pp = wide_select(role == 0, s2, wide_select(role == 2, wide_from<-2>(s2), wide_from<-4>(s2)));  // PP (r0) to r2 and r4
-    const fp u1 = wide_from<-2>(s1);                                                                            // U1 (r0) to r2
-    const fp a3 = role == 0 ? pr : role == 2 ? u1 : s1;  // r4: Za = its own stage-1 product
-    const fp s3 = fp_mul_2acc(a3, pp);                   // r0 PPP (< 1.03p), r2 Q (< 1.01p), r4 ZZ3
-
-    // stage 4: r1 T1 = R*(Q - X3), r2 T2 = S1*PPP, r5 ZZZ3 = Zb*PPP
-    const fp ppp = wide_select(role == 1, wide_from<-1>(s3), wide_select(role == 2, wide_from<-2>(s3), wide_from<-5>(s3)));  // PPP (r0) to r1, r2, r5
-    const fp q = wide_from<2 - 1>(s3);                    // Q (r2) to r1
-    const fp x3 = fp_sub<5>(s2, fp_add(ppp, fp_dbl(q)));  // r1: RR - (PPP + 2Q): subtrahend < 3.05p; X3 < 6.1p
-    const fp a4 = role == 1 ? pr : s1;                       // r1: R;  r2: S1;  r5: Zb
-    const fp b4 = role == 1 ? fp_sub<8>(q, x3) : ppp;        // r1: Q - X3 (< 9.01p)
-    const fp s4 = fp_mul_2acc(a4, b4);                       // r1 T1 (< 1.22p), r2 T2 (< 1.01p), r5 ZZZ3
-
-    const fp t2 = wide_from<1>(s4);  // T2 (r2) to r1
-#endif
     out0 = role == 1 ? x3 : role == 4 ? s3 : s4;  // r1 X3, r4 ZZ3, r5 ZZZ3
     out1 = fp_sub<3>(s4, t2);                     // r1: Y3 = T1 - T2 (< 4.3p)
     return false;

@@ -50,7 +50,7 @@ struct DevBuf {
     size_t cap = 0;
 };
 
-enum { EV_START, EV_H2D, EV_CONVERT, EV_DECOMP, EV_SORT, EV_ACC0, EV_ACC1, EV_REDUCE, EV_COUNT };
+enum { EV_START, EV_H2D, EV_CONVERT, EV_DECOMP, EV_SORT, EV_PLAN, EV_ACC0, EV_ACC1, EV_COMBINE, EV_REDUCE, EV_COUNT };
 
 // ---- observability (reference counterpart: LOG_DEBUG in build.rs:134-138 and the Metal capture scopes of
 // host/gpu.rs:34-114).  MSM_HIP_ROCTX=1: every stage is bracketed by a roctx range (librocprofiler-sdk-roctx / libroctx64 is
@@ -95,20 +95,24 @@ bool trace_enabled() {
 
 }  // namespace
 
-// Every MSM_HIP_* tuning / A-B switch, read ONCE when a context is created (INTEGRATION.md lists them): a call never looks at the
-// environment, so an upload and the resident calls after it, or the two pipelines of a batch, cannot see different plans.
-// (MSM_HIP_TRACE / MSM_HIP_ROCTX are per process; MSM_HIP_DEVICES / MSM_HIP_MULTI_VERIFY belong to msm_multi_create.)
+// Test / A-B knobs of the HOOKS build (libmsm_hip_hooks.so, -DMSM_HIP_TEST_HOOKS), read ONCE when a context is created: a call never looks
+// at the environment, so an upload and the resident calls after it, or the two pipelines of a batch, cannot see different plans.
+// The PRODUCT library reads none of them (round 5; the reference's whole configuration surface is one struct, metal_msm.rs:16-28): what a
+// caller may choose is in msm_config_t (window width, flags, stream chunk, workspace pre-sizing, batch layout, host threads); the product's
+// only environment variables are MSM_HIP_TRACE / MSM_HIP_ROCTX (observability, per process) and MSM_HIP_DEVICES / MSM_HIP_MULTI_TIMEOUT_S
+// (msm_multi_create: deployment).
 struct Knobs {
     size_t glv_max = msmplan::GLV_MAX_POINTS;  // MSM_HIP_GLV_MAX_LOG2
     uint32_t piece_len = 0;                    // MSM_HIP_PIECE_LEN: longest whole bucket = split length of k_accumulate_pieces' work items; 0 = by size (tests force 1, 7, 26, 35)
     bool direct_scatter = false;               // MSM_HIP_DIRECT_SCATTER: skip the two-level LDS sort
     uint32_t device_chunk_log2 = 22;           // MSM_HIP_DEVICE_CHUNK_LOG2: point ranges of device-resident instances; 0 = never cut
     uint32_t stream_min_log2 = 19;             // MSM_HIP_STREAM_MIN_LOG2: host calls are streamed from this size on (tools/host_path_sweep.py)
-    uint32_t stream_chunk_log2 = 0;            // MSM_HIP_STREAM_CHUNK_LOG2: 0 = by size
-    int host_threads = -1;                     // MSM_HIP_HOST_THREADS: CPU finish threads incl. the caller; -1 = default (2)
-    msmplan::table_knobs table;                // MSM_HIP_TABLE_C / MSM_HIP_TABLE_F / MSM_HIP_TABLE_MAX_GB (window table of a resident set)
+    uint32_t stream_chunk_log2 = 0;            // MSM_HIP_STREAM_CHUNK_LOG2: 0 = by size (product: msm_config_t.stream_chunk_log2)
+    int host_threads = -1;                     // MSM_HIP_HOST_THREADS: CPU finish threads incl. the caller; -1 = msm_config_t.host_threads
+    msmplan::table_knobs table;                // MSM_HIP_TABLE_C / MSM_HIP_TABLE_F / MSM_HIP_TABLE_MAX_GB / MSM_HIP_TABLE_GLV_MAX_LOG2 (window table of a resident set)
     static Knobs from_env() {
         Knobs k;
+#ifdef MSM_HIP_TEST_HOOKS
         auto num = [](const char* name, long lo, long hi, long dflt) {
             const char* e = std::getenv(name);
             if (!e || !*e) return dflt;
@@ -125,6 +129,7 @@ struct Knobs {
         k.table.f = (uint32_t)num("MSM_HIP_TABLE_F", 0, 128, 0);
         k.table.max_bytes = (size_t)num("MSM_HIP_TABLE_MAX_GB", 0, 1024, 64) << 30;
         if (std::getenv("MSM_HIP_TABLE_GLV_MAX_LOG2")) k.table.glv_max = (size_t)1 << num("MSM_HIP_TABLE_GLV_MAX_LOG2", 0, 23, 18);  // (tools/table_sweep.py)
+#endif
         return k;
     }
 };
@@ -577,6 +582,7 @@ int32_t enqueue_sort(msm_ctx* c, const PipeState& ps, hipStream_t st, bool into)
                                                         (uint32_t*)c->midlist.p, (uint32_t*)c->pbase.p, (uint32_t*)c->buckets.p, into ? 1u : 0u);
     msmk::k_piece_scatter<<<grid1(tb, 1024), 1024, 0, st>>>(offsets, (uint32_t)tb, ps.pmax, ps.psplit, (const uint32_t*)c->phist.p, (uint32_t*)c->pcursor.p,
                                                           (const uint32_t*)c->pbase.p, (uint4*)c->plist.p, flags);
+    if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_PLAN], st));  // msm_timings_t.plan_ms
     return MSM_OK;
 }
 
@@ -641,6 +647,7 @@ int32_t enqueue_accumulate(msm_ctx* c, const PipeState& ps, const BaseSrc& src, 
     msmk::k_combine_pieces<<<dim3(msmk::LONG_BLOCKS + msmk::MID_BLOCKS), 512, 0, st>>>(
         offsets, pt, bk, ps.pmax, ps.psplit, (const uint32_t*)c->pbase.p, flags + msmk::FLAG_MID, (const uint32_t*)c->midlist.p, flags + msmk::FLAG_LONG,
         (const uint32_t*)c->longlist.p, (uint32_t*)c->longdone.p);
+    if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_COMBINE], st));  // msm_timings_t.combine_ms
     return MSM_OK;
 }
 
@@ -808,7 +815,10 @@ int32_t finish_sync(msm_ctx* c, const PipeState& ps, size_t n_total, hipStream_t
     tm.accumulate_ms = ms;
     c->acc_ms_sum += ms;
     c->acc_launches += 1;
-    tm.reduce_ms = stage_ms(c, EV_ACC1, EV_REDUCE);
+    tm.plan_ms = stage_ms(c, EV_SORT, EV_PLAN);
+    tm.combine_ms = stage_ms(c, EV_ACC1, EV_COMBINE);
+    tm.reduce_ms = stage_ms(c, EV_COMBINE, EV_REDUCE);
+    tm.batch_layout = c->last_batch_layout;  // (of the last BATCH call: a single call in between does not reset it -- ADVICE r4)
     tm.finish_ms = std::chrono::duration<float, std::milli>(t_fin1 - t_fin0).count();
     tm.num_points = n_total;
     tm.num_adds = (uint64_t)c->h_flags[msmk::FLAG_ADDS64] | ((uint64_t)c->h_flags[msmk::FLAG_ADDS64 + 1] << 32);
@@ -1188,6 +1198,7 @@ static int32_t ctx_create_impl(const msm_config_t* cfg, msm_ctx** out, int main_
     if (c0.stream_chunk_log2 && (c0.stream_chunk_log2 < 8 || c0.stream_chunk_log2 > 28))
         return fail(nullptr, MSM_ERR_BAD_ARG, "stream_chunk_log2 = %u out of range [8, 28]", c0.stream_chunk_log2);
     if (c0.batch_layout > MSM_BATCH_LAYOUT_TWO_STREAMS) return fail(nullptr, MSM_ERR_BAD_ARG, "unknown batch_layout %u", c0.batch_layout);
+    if (c0.host_threads > 64) return fail(nullptr, MSM_ERR_BAD_ARG, "host_threads = %u out of range [0, 64]", c0.host_threads);
     int dev = c0.device;
     if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return fail(nullptr, MSM_ERR_NO_DEVICE, "hipGetDevice failed");
     if (dev >= ndev) return fail(nullptr, MSM_ERR_NO_DEVICE, "device %d out of range (%d visible)", dev, ndev);
@@ -1265,7 +1276,8 @@ static int32_t ctx_create_impl(const msm_config_t* cfg, msm_ctx** out, int main_
         if (want > 1) want = 1;  // the calling thread + ONE worker: measured over 1500 calls at 2^17 (tools/step_jitter.py),
                                  // mean latency 0.608 / 0.575 / 0.588 / 0.590 ms with 1 / 2 / 3 / 4 threads -- the median keeps
                                  // falling (0.606 / 0.570 / 0.556 / 0.555) but 3+ threads bring 2-8 ms outliers in ~1.3 % of the calls
-        if (knobs.host_threads >= 0) want = knobs.host_threads - 1;  // MSM_HIP_HOST_THREADS
+        if (c0.host_threads) want = (int)c0.host_threads - 1;        // msm_config_t.host_threads: the caller included
+        if (knobs.host_threads >= 0) want = knobs.host_threads - 1;  // MSM_HIP_HOST_THREADS (hooks build)
         if (want >= 1) c->pool = new (std::nothrow) HostPool(want);
     }
     *out = c;

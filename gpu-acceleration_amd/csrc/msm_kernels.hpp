@@ -141,17 +141,8 @@ __device__ __forceinline__ void store_coord(uint32_t* rec, uint32_t coord, const
 // the rare pairs (an identity operand, equal or opposite points): the scalar complete addition.  ~40 KB of code wherever it is inlined:
 // a kernel keeps ONE eight-lane call site (the instruction cache is 64 KB for two CUs).  Out of line it would cost nothing in code, but
 // a callee's register needs become the kernel's: 248 VGPRs, two wavefronts per SIMD for every reduction kernel.
-// The complete addition of every kernel that runs one wavefront per SIMD or fewer (bucket reduction, k_combine_pieces): the paired-product
-// form (ec_bn254.hpp xyzz_add_ilp, round 5).  -DMSM_AB_NO_ILP: the single-chain form of rounds 1-4.
-__device__ __forceinline__ xyzz xyzz_add_lat(const xyzz& a, const xyzz& b) {
-#ifdef MSM_AB_NO_ILP
-    return xyzz_add(a, b);
-#else
-    return xyzz_add_ilp(a, b);
-#endif
-}
 __device__ __forceinline__ void add_records_complete(const uint32_t* a_rec, const uint32_t* b_rec, uint32_t* out_rec) {
-    store_xyzz(out_rec, xyzz_add_lat(load_xyzz(a_rec), load_xyzz(b_rec)));
+    store_xyzz(out_rec, xyzz_add(load_xyzz(a_rec), load_xyzz(b_rec)));
 }
 __device__ __forceinline__ void wide_add_records(const uint32_t* a_rec, const uint32_t* b_rec, uint32_t* out_rec) {
     const uint32_t role = threadIdx.x & (WIDE_LANES - 1);
@@ -1103,6 +1094,37 @@ __global__ void __launch_bounds__(FINE_BLOCK) k_fine_sort(const uint32_t* __rest
             s_out[pos] = ((e[k] & idx_mask) + sort_hi_of(hi, s_bnd, threadIdx.x + k * FINE_BLOCK, idx_bits)) | (e[k] & SIGN_BIT);
         }
         __syncthreads();
+#ifdef MSM_AB_SORTED_BUCKETS
+        // EXPERIMENT (round 5; A/B builds only): a deterministic PLACEMENT.  Every staged bucket's run is put in ascending
+        // point-index order: an element's slot = bucket start + the number of entries of its bucket with a smaller index (a bucket holds ~64
+        // entries: ~64 LDS reads per element, lanes of a wavefront mostly on the same address).  With it the XYZZ bucket sums, and the 24
+        // Jacobian words of the result, repeat between identical calls on uniform scalars (regions that fit the staging area).  Cost: see
+        // profiles/NOTES_r5.md -- the product gives the same guarantee with MSM_FLAG_DETERMINISTIC for one host inversion instead.
+        {
+            uint32_t val[FINE_PER_THREAD], dst[FINE_PER_THREAD];
+#pragma unroll 1
+            for (int k = 0; k < FINE_PER_THREAD; k++) {
+                const uint32_t p = threadIdx.x + k * FINE_BLOCK;
+                dst[k] = 0xFFFFFFFFu;
+                if (p >= S) continue;
+                uint32_t lo = 0, hi_f = nfine;  // the bucket of slot p: the first f with s_cur[f] (= its end) > p
+                while (lo < hi_f) {
+                    const uint32_t mid = (lo + hi_f) >> 1;
+                    if (s_cur[mid] > p) hi_f = mid; else lo = mid + 1;
+                }
+                const uint32_t b0 = lo ? s_cur[lo - 1] : 0u, b1 = s_cur[lo];
+                const uint32_t v = s_out[p], key = v & ~SIGN_BIT;
+                uint32_t below = 0;
+                for (uint32_t j = b0; j < b1; j++) below += (s_out[j] & ~SIGN_BIT) < key ? 1u : 0u;
+                val[k] = v, dst[k] = b0 + below;
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int k = 0; k < FINE_PER_THREAD; k++)
+                if (dst[k] != 0xFFFFFFFFu) s_out[dst[k]] = val[k];
+            __syncthreads();
+        }
+#endif
         for (uint32_t k = threadIdx.x; k < S; k += FINE_BLOCK) sorted[rs + k] = s_out[k];
     } else {  // skewed data: the region does not fit LDS, place directly (aggregated cursors hand consecutive lanes
               // consecutive slots, so the stores of a hot bucket are still coalesced)
@@ -1466,7 +1488,7 @@ __device__ __forceinline__ void fold_partials(uint32_t* e, const uint32_t* parti
     } else if (threadIdx.x < CAP) {
         xyzz acc = xyzz_identity();
 #pragma unroll 1
-        for (uint32_t i = threadIdx.x; i < count; i += CAP) acc = xyzz_add_lat(acc, load_xyzz(partials + (size_t)(base + first + i * stride) * XW));
+        for (uint32_t i = threadIdx.x; i < count; i += CAP) acc = xyzz_add(acc, load_xyzz(partials + (size_t)(base + first + i * stride) * XW));
         store_xyzz(e + (size_t)threadIdx.x * XW, acc);
     }
     lds_tree_wide(e, count < CAP ? count : CAP);
@@ -1483,7 +1505,7 @@ __global__ void __launch_bounds__(512) k_combine_pieces(const uint32_t* __restri
             uint32_t q;
             const uint32_t m = piece_split(offsets[k + 1] - offsets[k], pmax, psplit, &q), base = pbase[k];
             xyzz acc = load_xyzz(partials + (size_t)base * XW);
-            for (uint32_t p = 1; p < m; p++) acc = xyzz_add_lat(acc, load_xyzz(partials + (size_t)(base + p) * XW));
+            for (uint32_t p = 1; p < m; p++) acc = xyzz_add(acc, load_xyzz(partials + (size_t)(base + p) * XW));
             store_xyzz(buckets + (size_t)k * XW, acc);
         }
         return;
@@ -1560,7 +1582,7 @@ __global__ void __launch_bounds__(256) k_pair_level(pair_job ja, pair_job jb) {
         if (t >= jb.n_out) return;
     }
     size_t i0 = (size_t)2 * (t / j.B) * j.B + (t % j.B);
-    xyzz r = xyzz_add_lat(load_xyzz(j.in + i0 * XW), load_xyzz(j.in + (i0 + j.B) * XW));
+    xyzz r = xyzz_add(load_xyzz(j.in + i0 * XW), load_xyzz(j.in + (i0 + j.B) * XW));
     store_xyzz(j.out + (size_t)t * XW, r);
 }
 
@@ -1617,7 +1639,7 @@ __global__ void __launch_bounds__(256) k_pair_level8(const uint32_t* __restrict_
             other = shfl_down_xyzz(acc, (int)d, G);
             if (sub >= d) other = xyzz_identity();  // spectator lanes: adding their own value would take the doubling branch
         }
-        acc = xyzz_add_lat(acc, other);
+        acc = xyzz_add(acc, other);
     }
     if (sub == 0) store_xyzz(out, acc);
 }
@@ -1711,7 +1733,7 @@ __global__ void __launch_bounds__(64) k_reduce_bits(const uint32_t* __restrict__
             other = shfl_down_xyzz(acc, d, 64);
             if (threadIdx.x >= d) other = xyzz_identity();
         }
-        acc = xyzz_add_lat(acc, other);
+        acc = xyzz_add(acc, other);
     }
     if (threadIdx.x == 0) {
         store_jacobian_mont256(q + (size_t)blockIdx.x * 24, xyzz_to_jacobian(acc));

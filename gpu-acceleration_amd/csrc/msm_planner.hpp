@@ -68,18 +68,58 @@ inline uint32_t plan_window_bits_glv(size_t n, bool is_signed) {
     // 13 0.327, 16 0.331; 2^14 10 0.362-0.369, 13 0.363, 16 0.331; 2^15 12 0.406-0.409, 15 0.390, 16 0.336-0.346; 2^16 16 0.378-0.382
     // (15: 0.446); 2^17 16 0.451 (13: 0.552); 2^18 16 0.613 (13: 0.760); 2^19 16 0.937 (13: 1.201)  => 16 from 2^14 points on.
     // Round 4, with the top window spread over all of its buckets (glv_top_digit_bits: a 9-bit top window of c = 13 no longer piles 2n points
-    // into 448 buckets; tools/r4_sweep_c.sh, profiles/r4_window_width_sweep.txt, ms): 2^11 c = 10 0.246-0.261, 13 0.227; 2^12 10 0.272-0.276, 12 0.240,
+    // into 448 buckets; tools/sweep_window_widths.sh, profiles/r4_window_width_sweep.txt, ms): 2^11 c = 10 0.246-0.261, 13 0.227; 2^12 10 0.272-0.276, 12 0.240,
     // 13 0.232; 2^13 10 0.310, 12 0.270, 13 0.247, 16 0.293; 2^14 13 0.278, 14 0.289, 16 0.291-0.297; 2^15 13 0.323, 16 0.307-0.319; 2^16 13 0.371, 15 0.367,
     // 16 0.336; 2^17 15 0.463, 16 0.415; 2^19 13 1.059, 16 0.846; 2^8..2^10: 0.20-0.23 whatever the width  => 13 from 2^11 to below 2^15 points.
     uint32_t c = n < ((size_t)1 << 11) ? 10u : n < ((size_t)1 << 15) ? 13u : 16u;
     if (!is_signed && c > 15u) c = 15u;
     return c;
 }
-// MSM_HIP_GLV_MAX_LOG2 (A/B knob).  Read where a CONTEXT is created (msm_ctx.knobs) and by the context-free
+// Work items of k_accumulate_pieces (msm_kernels.hpp): a bucket of at most pmax entries is ONE piece; a longer one is cut into runs of pmax
+// entries and a rest (up to 8 x pmax) or into runs of psplit entries (beyond).
+// pmax = mean occupancy + max(8, 2 sqrt(mean)) -- two standard deviations of a Poisson bucket above the mean: the few per cent of the buckets
+// beyond it are cut, and their RESTS (1 .. ~20 entries) are what the launch ends on.  The pieces run longest first, 1.33 rounds of resident
+// workgroups at 2^20 points; with whole buckets only, the last workgroups still walk 40-50 entries each while the rest of the chip idles.
+// Measured (profiles/r4_top_window_spread.txt; k_accumulate_pieces Mcycles / ms per MSM): 2^20 (mean 64) cap 128: 2.455 / 1.480, 112: 2.461,
+// 96: 2.373 / 1.444, 88: 2.340, 80: 2.313 / 1.423, 72: 2.311 / 1.422 (k_combine_pieces +16 us);  2^19 (32) cap 64: 1.281, 48: 1.193, 40:
+// 1.175, 36: 1.171;  2^18 (16) cap 32: 0.628 / 0.580, 28: 0.610, 24: 0.596 / 0.563, 20: 0.589 / 0.565;  2^17 (8) 16: 0.311 / 0.415, 12: 0.301 /
+// 0.420, 10: 0.294 / 0.421 (the folding costs what the balance gains);  2^16 (4) 16: 0.213 / 0.372, 12: 0.180 / 0.343, 8: 0.152 / 0.345;  unsplit
+// 2^21 (32) 64: 4.305 / 2.859, 43: 4.147 / 2.826;  2^22, 2^24 (64, 256): no difference (6+ rounds).
+// Round 4 before the top window of split plans was spread (glv_top_digit_bits): pmax = 2 x the mean, and the rests of the top window's
+// twice-as-full buckets were that tail.  At most the 1024 histogram bins of the piece sort.  psplit makes an instance of long buckets only
+// yield ~2^19 pieces (2.7 rounds of resident workgroups), at least 8 entries per piece.  max_pieces / max_partials bound what ANY
+// bucket-size distribution over `pairs` sorted entries and `total_buckets` buckets can produce (workspace sizes).
+constexpr uint32_t PIECE_BINS_MAX = 1024;
+struct piece_plan {
+    uint32_t pmax = 0, psplit = 0;
+    size_t max_pieces = 0, max_partials = 0;
+};
+inline piece_plan make_piece_plan(size_t pairs, size_t mean_occupancy, size_t total_buckets, uint32_t forced_len = 0, const piece_plan* first = nullptr) {
+    piece_plan p;
+    size_t two_sigma = 0;
+    while ((two_sigma + 1) * (two_sigma + 1) <= 4 * mean_occupancy) two_sigma++;  // floor(2 sqrt(mean))
+    p.pmax = (uint32_t)std::min<size_t>(PIECE_BINS_MAX, mean_occupancy + std::max<size_t>(8, two_sigma));
+    // FEW buckets (tiny instances on 10-bit windows: a few thousand buckets of 16-64 entries; the shared array of a split window table: 2^15
+    // buckets for eight windows' entries) would be as few pieces -- a wavefront on a fraction of the SIMDs, each walking its piece alone; there
+    // the pieces shrink until ~2^17 of them exist (at least 8 entries each).  2^17 points with the table: k_accumulate_pieces 0.257 -> 0.149 ms, profiles/r4_table_small.txt
+    if (total_buckets < ((size_t)1 << 17)) p.pmax = (uint32_t)std::min<size_t>(p.pmax, std::max<size_t>(8, pairs >> 17));
+    p.psplit = (uint32_t)std::min<size_t>(p.pmax, std::max<size_t>(8, pairs >> 19));
+    if (first) p.pmax = first->pmax, p.psplit = first->psplit;  // a later chunk of an instance: the lengths of its first, largest chunk
+    if (forced_len) p.pmax = p.psplit = std::min<uint32_t>(forced_len, PIECE_BINS_MAX);
+    // every non-empty bucket is a piece, a split bucket of sz > pmax entries adds at most sz / psplit more (runs of pmax: ceil(sz / pmax) <=
+    // sz / psplit + 1 as well); partial sums: split buckets only (at most sz / psplit + 1 each, and fewer than pairs / pmax buckets can be split)
+    p.max_pieces = std::min(pairs, total_buckets + pairs / p.psplit) + 1;
+    p.max_partials = std::min(pairs, pairs / p.psplit + pairs / ((size_t)p.pmax + 1) + 2) + 1;
+    return p;
+}
+
+// MSM_HIP_GLV_MAX_LOG2 (A/B knob of the HOOKS build).  Read where a CONTEXT is created (msm_ctx.knobs) and by the context-free
 // msm_plan(); never inside make_plan, which a call evaluates several times and which must give an upload and the resident calls
 // that follow it the same answer.
 inline size_t glv_max_from_env() {
+#ifdef MSM_HIP_TEST_HOOKS  // (the product library reads no planner knob from the environment)
     if (const char* e = std::getenv("MSM_HIP_GLV_MAX_LOG2")) return (size_t)1 << std::min(23, std::max(0, std::atoi(e)));
+#endif
     return GLV_MAX_POINTS;
 }
 inline int32_t make_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_plan_t* out, size_t glv_max = GLV_MAX_POINTS) {
@@ -101,7 +141,10 @@ inline int32_t make_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_pla
     size_t nv = (size_t)out->virtual_points;
     size_t pairs = (size_t)out->num_windows * nv;
     size_t tb = (size_t)out->num_windows * out->num_buckets;
-    out->workspace_bytes = nv * 64 + n * (32 + 1) + pairs * 12 + tb * (8 + 144) + tb * 144 * 3 / 2;
+    {   // records, scalars + infinity bytes, digits / sorted / staging, offsets + bucket sums, reduction levels, the piece list and the partial sums
+        const piece_plan pp = make_piece_plan(pairs, nv / out->num_buckets, tb);
+        out->workspace_bytes = nv * 64 + n * (32 + 1) + pairs * 12 + tb * (8 + 144) + tb * 144 * 3 / 2 + pp.max_partials * 144 + pp.max_pieces * 16 + tb * 4;
+    }
     out->table_factor = 1;
     out->bucket_arrays = out->num_windows;
     out->table_bytes = 0;
@@ -162,7 +205,10 @@ inline int32_t make_table_plan(size_t n, uint32_t window_bits, uint32_t flags, m
     t.bucket_arrays = t.num_windows / f;
     t.table_bytes = bytes;
     const size_t tb = (size_t)t.bucket_arrays * t.num_buckets, pairs = (size_t)t.num_windows * (size_t)t.virtual_points;
-    t.workspace_bytes = bytes + n * (32 + 1) + pairs * 12 + tb * (8 + 144) + tb * 144 * 3 / 2;
+    {
+        const piece_plan pp = make_piece_plan(pairs, (size_t)f * (size_t)t.virtual_points / t.num_buckets, tb);
+        t.workspace_bytes = bytes + n * (32 + 1) + pairs * 12 + tb * (8 + 144) + tb * 144 * 3 / 2 + pp.max_partials * 144 + pp.max_pieces * 16 + tb * 4;
+    }
     *out = t;
     return MSM_OK;
 }
@@ -175,44 +221,6 @@ inline uint32_t table_top_shift(const msm_plan_t& pl, uint32_t tf) {
     if (tf <= 1 || tf != pl.num_windows || !pl.signed_digits) return 0;
     const uint32_t top_bits = pl.scalar_bits - pl.window_bits * (pl.num_windows - 1);  // max top digit 2^top_bits (carry included)
     return top_bits < pl.window_bits - 1 ? pl.window_bits - 1 - top_bits : 0u;
-}
-
-// Work items of k_accumulate_pieces (msm_kernels.hpp): a bucket of at most pmax entries is ONE piece; a longer one is cut into runs of pmax
-// entries and a rest (up to 8 x pmax) or into runs of psplit entries (beyond).
-// pmax = mean occupancy + max(8, 2 sqrt(mean)) -- two standard deviations of a Poisson bucket above the mean: the few per cent of the buckets
-// beyond it are cut, and their RESTS (1 .. ~20 entries) are what the launch ends on.  The pieces run longest first, 1.33 rounds of resident
-// workgroups at 2^20 points; with whole buckets only, the last workgroups still walk 40-50 entries each while the rest of the chip idles.
-// Measured (profiles/r4_top_window_spread.txt; k_accumulate_pieces Mcycles / ms per MSM): 2^20 (mean 64) cap 128: 2.455 / 1.480, 112: 2.461,
-// 96: 2.373 / 1.444, 88: 2.340, 80: 2.313 / 1.423, 72: 2.311 / 1.422 (k_combine_pieces +16 us);  2^19 (32) cap 64: 1.281, 48: 1.193, 40:
-// 1.175, 36: 1.171;  2^18 (16) cap 32: 0.628 / 0.580, 28: 0.610, 24: 0.596 / 0.563, 20: 0.589 / 0.565;  2^17 (8) 16: 0.311 / 0.415, 12: 0.301 /
-// 0.420, 10: 0.294 / 0.421 (the folding costs what the balance gains);  2^16 (4) 16: 0.213 / 0.372, 12: 0.180 / 0.343, 8: 0.152 / 0.345;  unsplit
-// 2^21 (32) 64: 4.305 / 2.859, 43: 4.147 / 2.826;  2^22, 2^24 (64, 256): no difference (6+ rounds).
-// Round 4 before the top window of split plans was spread (glv_top_digit_bits): pmax = 2 x the mean, and the rests of the top window's
-// twice-as-full buckets were that tail.  At most the 1024 histogram bins of the piece sort.  psplit makes an instance of long buckets only
-// yield ~2^19 pieces (2.7 rounds of resident workgroups), at least 8 entries per piece.  max_pieces / max_partials bound what ANY
-// bucket-size distribution over `pairs` sorted entries and `total_buckets` buckets can produce (workspace sizes).
-constexpr uint32_t PIECE_BINS_MAX = 1024;
-struct piece_plan {
-    uint32_t pmax = 0, psplit = 0;
-    size_t max_pieces = 0, max_partials = 0;
-};
-inline piece_plan make_piece_plan(size_t pairs, size_t mean_occupancy, size_t total_buckets, uint32_t forced_len = 0, const piece_plan* first = nullptr) {
-    piece_plan p;
-    size_t two_sigma = 0;
-    while ((two_sigma + 1) * (two_sigma + 1) <= 4 * mean_occupancy) two_sigma++;  // floor(2 sqrt(mean))
-    p.pmax = (uint32_t)std::min<size_t>(PIECE_BINS_MAX, mean_occupancy + std::max<size_t>(8, two_sigma));
-    // FEW buckets (tiny instances on 10-bit windows: a few thousand buckets of 16-64 entries; the shared array of a split window table: 2^15
-    // buckets for eight windows' entries) would be as few pieces -- a wavefront on a fraction of the SIMDs, each walking its piece alone; there
-    // the pieces shrink until ~2^17 of them exist (at least 8 entries each).  2^17 points with the table: k_accumulate_pieces 0.257 -> 0.149 ms, profiles/r4_table_small.txt
-    if (total_buckets < ((size_t)1 << 17)) p.pmax = (uint32_t)std::min<size_t>(p.pmax, std::max<size_t>(8, pairs >> 17));
-    p.psplit = (uint32_t)std::min<size_t>(p.pmax, std::max<size_t>(8, pairs >> 19));
-    if (first) p.pmax = first->pmax, p.psplit = first->psplit;  // a later chunk of an instance: the lengths of its first, largest chunk
-    if (forced_len) p.pmax = p.psplit = std::min<uint32_t>(forced_len, PIECE_BINS_MAX);
-    // every non-empty bucket is a piece, a split bucket of sz > pmax entries adds at most sz / psplit more (runs of pmax: ceil(sz / pmax) <=
-    // sz / psplit + 1 as well); partial sums: split buckets only (at most sz / psplit + 1 each, and fewer than pairs / pmax buckets can be split)
-    p.max_pieces = std::min(pairs, total_buckets + pairs / p.psplit) + 1;
-    p.max_partials = std::min(pairs, pairs / p.psplit + pairs / ((size_t)p.pmax + 1) + 2) + 1;
-    return p;
 }
 
 }  // namespace msmplan

@@ -141,9 +141,7 @@ __global__ void __launch_bounds__(64) k_test_g1(uint32_t op, const uint32_t* __r
         xyzz_madd(r, q);
     } else if (op == 1) {
         r = xyzz_add(p, xyzz_from_jacobian(load_jacobian_mont256(b + (size_t)i * 24)));
-    } else if (op == 4) {
-        r = xyzz_add_ilp(p, xyzz_from_jacobian(load_jacobian_mont256(b + (size_t)i * 24)));
-    } else if (op == 5 || op == 6) {
+    } else if (op == 4 || op == 5) {
         const uint32_t* bp = b + (size_t)i * 16;
         uint32_t wx[8], wy[8];
         for (int k = 0; k < 8; k++) {
@@ -151,7 +149,7 @@ __global__ void __launch_bounds__(64) k_test_g1(uint32_t op, const uint32_t* __r
             wy[k] = bp[8 + k];
         }
         r = p;
-        xyzz_madd_m32(r, fp_unpack_shl5(wx), fp_unpack_shl5(wy), op == 6);
+        xyzz_madd_m32(r, fp_unpack_shl5(wx), fp_unpack_shl5(wy), op == 5);
     } else if (op == 3) {
         // never reached: op 3 (wide addition) has its own kernel, k_test_g1_wide
         r = p;

@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "msm_bn254_g1_decompress", "msm_bn254_g1_upload_compressed", "msm_bn254_g1_compress",
     "msm_multi_create", "msm_multi_destroy", "msm_multi_last_error", "msm_multi_num_devices", "msm_multi_exchange",
     "msm_bn254_g1_multi", "msm_bn254_g1_multi_arkworks", "msm_bn254_g1_multi_device", "msm_multi_get_timings",
-    "msm_multi_get_exchange_stats",
+    "msm_multi_get_exchange_stats", "msm_multi_get_exchange_probe",
 ]
 ERR_RCCL = -8
 EXCHANGE_AUTO, EXCHANGE_RCCL, EXCHANGE_HOST = 0, 1, 2
@@ -53,7 +53,7 @@ class MsmError(RuntimeError):
 
 class Config(C.Structure):
     _fields_ = [("device", C.c_int32), ("window_bits", C.c_uint32), ("flags", C.c_uint32),
-                ("stream_chunk_log2", C.c_uint32), ("max_points", C.c_uint64), ("batch_layout", C.c_uint32), ("reserved", C.c_uint32)]
+                ("stream_chunk_log2", C.c_uint32), ("max_points", C.c_uint64), ("batch_layout", C.c_uint32), ("host_threads", C.c_uint32)]
 
 
 class Plan(C.Structure):
@@ -67,7 +67,8 @@ class Timings(C.Structure):
     _fields_ = [("h2d_ms", C.c_float), ("convert_ms", C.c_float), ("decompose_ms", C.c_float),
                 ("sort_ms", C.c_float), ("accumulate_ms", C.c_float), ("reduce_ms", C.c_float),
                 ("finish_ms", C.c_float), ("total_ms", C.c_float), ("num_points", C.c_uint64),
-                ("num_adds", C.c_uint64), ("stream_chunks", C.c_uint32), ("batch_layout", C.c_uint32)]
+                ("num_adds", C.c_uint64), ("stream_chunks", C.c_uint32), ("batch_layout", C.c_uint32),
+                ("plan_ms", C.c_float), ("combine_ms", C.c_float)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -130,6 +131,7 @@ def bind_product_abi(L):
     L.msm_bn254_g1_multi_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_size_t), _u32p, _u32p, _u8p]
     L.msm_multi_get_timings.argtypes = [vp, C.c_int32, C.POINTER(Timings)]
     L.msm_multi_get_exchange_stats.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32]
+    L.msm_multi_get_exchange_probe.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     for name in ABI_SYMBOLS:
         f = getattr(L, name)
         if f.restype is C.c_int:  # default
@@ -183,9 +185,9 @@ class MsmResult:
         return to_int(self.affine_std[:8]), to_int(self.affine_std[8:])
 
 
-def plan(n, window_bits=0, flags=0):
+def plan(n, window_bits=0, flags=0, _lib=None):
     p = Plan()
-    rc = load_library().msm_plan(n, window_bits, flags, C.byref(p))
+    rc = (_lib or load_library()).msm_plan(n, window_bits, flags, C.byref(p))
     if rc != OK:
         raise MsmError(rc, "Empty input" if rc == ERR_EMPTY else f"msm_plan failed ({rc})")
     return p
@@ -223,9 +225,9 @@ class MsmContext:
 
     _loader = staticmethod(lambda: load_library())  # testhooks.HooksContext runs the same class on the hooks build
 
-    def __init__(self, device=-1, window_bits=0, flags=0, max_points=0, stream_chunk_log2=0, batch_layout=BATCH_LAYOUT_AUTO):
+    def __init__(self, device=-1, window_bits=0, flags=0, max_points=0, stream_chunk_log2=0, batch_layout=BATCH_LAYOUT_AUTO, host_threads=0):
         self._lib = self._loader()
-        cfg = Config(device, window_bits, flags, stream_chunk_log2, max_points, batch_layout, 0)
+        cfg = Config(device, window_bits, flags, stream_chunk_log2, max_points, batch_layout, host_threads)
         h = C.c_void_p()
         rc = self._lib.msm_ctx_create(C.byref(cfg), C.byref(h))
         if rc != OK:
@@ -491,6 +493,12 @@ class MsmMulti:
         sh = (C.c_float * self.num_devices)()
         self._check(self._lib.msm_multi_get_exchange_stats(self._h, C.byref(ex), sh, self.num_devices))
         return float(ex.value), [float(v) for v in sh]
+
+    def exchange_probe(self):
+        """(rccl ms, host-fold ms) per exchange that EXCHANGE_AUTO measured when the handle was created; (0, 0) = nothing was probed"""
+        a, b = C.c_float(0), C.c_float(0)
+        self._check(self._lib.msm_multi_get_exchange_probe(self._h, C.byref(a), C.byref(b)))
+        return float(a.value), float(b.value)
 
 
 _default_ctx = None

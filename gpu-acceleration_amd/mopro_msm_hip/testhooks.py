@@ -21,6 +21,11 @@ HOOK_SYMBOLS = [
 _lib = None
 
 
+def hooks_plan(n, window_bits=0, flags=0):
+    """msm_plan of the HOOKS build: the one that reads the test / A-B knobs (MSM_HIP_GLV_MAX_LOG2, MSM_HIP_TABLE_* ...); the product's reads none"""
+    return plan(n, window_bits, flags, _lib=load_hooks_library())
+
+
 def load_hooks_library():
     global _lib
     if _lib is not None:
@@ -74,7 +79,7 @@ class HooksContext(MsmContext):
 
     def test_g1_op(self, op, a, b=None):
         a = _words(a, 24)
-        b = _words(b, 16 if op in (0, 5, 6) else 24) if b is not None else None  # (0, 5, 6: mixed additions, b affine)
+        b = _words(b, 16 if op in (0, 4, 5) else 24) if b is not None else None  # (0, 4, 5: mixed additions, b affine)
         out = np.zeros_like(a)
         self._check(self._lib.msm_test_g1_op(self._h, op, _p32(a), _p32(b), _p32(out), a.shape[0]))
         return out
@@ -88,7 +93,7 @@ class HooksContext(MsmContext):
     def test_decompose(self, scalars, window_bits=0):
         scalars = _words(scalars, 8)
         n = scalars.shape[0]
-        p = plan(n, window_bits or self.window_bits, self.flags | FLAG_NO_GLV)  # the hook returns the plain 254-bit digits
+        p = hooks_plan(n, window_bits or self.window_bits, self.flags | FLAG_NO_GLV)  # the hook returns the plain 254-bit digits
         out = np.zeros((p.num_windows, n), np.int32)
         self._check(self._lib.msm_test_decompose(self._h, _p32(scalars), n, window_bits, out.ctypes.data_as(C.POINTER(C.c_int32))))
         return out
@@ -97,7 +102,7 @@ class HooksContext(MsmContext):
         """run the pipeline once and return every stage's intermediates (counterpart of the reference's per-kernel tests)"""
         bases, scalars = _words(bases, 16), _words(scalars, 8)
         n = min(bases.shape[0], scalars.shape[0])
-        p = plan(n, self.window_bits, self.flags)
+        p = hooks_plan(n, self.window_bits, self.flags)
         W, nb, nv = p.num_windows, p.num_buckets, int(p.virtual_points)
         kb = nb.bit_length() - 1
         d = StageDump()

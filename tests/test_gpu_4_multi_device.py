@@ -89,20 +89,52 @@ class Sharded:
 
 @needs_two
 @pytest.mark.parametrize("logn", [20, 24])
-def test_msm_multi_on_all_visible_devices_uses_rccl(logn):
-    """MsmMulti() on every visible device: the exchange must be RCCL (AUTO, distinct devices), every device gets its point range, and the
-    result is the closed form -- 2^20 (the headline size) and 2^24 (BASELINE config 4)."""
+def test_msm_multi_on_all_visible_devices_both_exchanges(logn):
+    """MsmMulti on every visible device under BOTH exchanges -- explicit RCCL (ncclCommInitAll + ncclAllGather of 24 words per rank) and
+    the host fold: every device gets its point range, the result is the closed form at 2^20 (the headline size) and 2^24 (BASELINE
+    config 4), the affine words of the two exchanges are identical, and what each exchange cost is RECORDED
+    (gpurun_out/multi_exchange_times.json: the first multi-GPU run decides the default instead of assuming it -- VERDICT r4 item 4).
+    AUTO measures both exchanges when the handle is created and keeps the faster one: it must report what it measured and which it kept."""
+    import json
+    import time
     G = _ndev()
-    with mh.MsmMulti() as m:
-        assert m.num_devices == G
-        assert m.exchange == mh.EXCHANGE_RCCL, "AUTO must pick the RCCL exchange on %d distinct devices" % G
-        inst = Sharded(logn, G)
-        for _ in range(3):
-            r = inst.call(m)
-            assert not r.is_infinity and (r.affine_std == inst.exp).all()
-        assert sum(m.timings(g)["num_points"] for g in range(G)) == inst.n
-        ex_ms, shard_ms = m.exchange_stats()
-        assert len(shard_ms) == G and all(t > 0 for t in shard_ms) and ex_ms > 0
+    inst = Sharded(logn, G)
+    rec = {"devices": G, "log_n": logn}
+    outs = {}
+    for name, mode in (("rccl", mh.EXCHANGE_RCCL), ("host", mh.EXCHANGE_HOST)):
+        with mh.MsmMulti(exchange=mode) as m:
+            assert m.num_devices == G and m.exchange == mode
+            assert m.exchange_probe() == (0.0, 0.0), "an explicit exchange is never probed"
+            walls, exs = [], []
+            for it in range(6):
+                t0 = time.perf_counter()
+                r = inst.call(m)
+                walls.append((time.perf_counter() - t0) * 1e3)
+                assert not r.is_infinity and (r.affine_std == inst.exp).all()
+                ex_ms, shard_ms = m.exchange_stats()
+                assert len(shard_ms) == G and all(t > 0 for t in shard_ms) and ex_ms > 0
+                exs.append(ex_ms)
+            assert sum(m.timings(g)["num_points"] for g in range(G)) == inst.n
+            outs[name] = r.affine_std.copy()
+            rec[name] = {"call_ms_min": round(min(walls[1:]), 4), "call_ms_median": round(sorted(walls[1:])[2], 4),
+                         "exchange_ms_min": round(min(exs[1:]), 4), "shard_ms_last": [round(t, 4) for t in shard_ms]}
+    assert (outs["rccl"] == outs["host"]).all()
+    with mh.MsmMulti() as m:  # AUTO
+        p_rccl, p_host = m.exchange_probe()
+        assert p_rccl > 0 and p_host > 0, "AUTO on distinct devices with librccl must have measured both exchanges"
+        assert m.exchange == (mh.EXCHANGE_RCCL if p_rccl < p_host else mh.EXCHANGE_HOST), "AUTO must keep the exchange it measured faster"
+        assert (inst.call(m).affine_std == inst.exp).all()
+        rec["auto"] = {"probe_rccl_ms": round(p_rccl, 4), "probe_host_ms": round(p_host, 4), "kept": "rccl" if m.exchange == mh.EXCHANGE_RCCL else "host"}
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    path = os.path.join(out_dir, "multi_exchange_times.json")
+    try:
+        allrec = json.load(open(path))
+    except Exception:
+        allrec = []
+    allrec.append(rec)
+    json.dump(allrec, open(path, "w"), indent=1)
+    print("multi-GPU exchange times:", json.dumps(rec))
 
 
 @needs_two
@@ -113,7 +145,7 @@ def test_msm_multi_host_pointers_each_device_pulls_its_own_range():
     inst = Sharded(20, G, seed=0xB2540B00)
     hb = np.concatenate([t.cpu().numpy().view(np.uint32).reshape(-1, 16) for t in inst.d_b])
     hs = np.concatenate([t.cpu().numpy().view(np.uint32).reshape(-1, 8) for t in inst.d_s])
-    with mh.MsmMulti() as m:
+    with mh.MsmMulti(exchange=mh.EXCHANGE_RCCL) as m:
         assert m.exchange == mh.EXCHANGE_RCCL
         r = m.msm(hb, hs, mh.FORM_MONT)
         assert (r.affine_std == inst.exp).all()
@@ -133,7 +165,7 @@ def test_msm_multi_bad_scalar_in_one_shard_fails_every_rank_and_the_handle_survi
     bad[G - 1] = inst.d_s[G - 1].clone()
     bad[G - 1][8 * 12345 + 7] = 0x40000000
     torch.cuda.synchronize(torch.device("cuda", G - 1))
-    with mh.MsmMulti() as m:
+    with mh.MsmMulti(exchange=mh.EXCHANGE_RCCL) as m:
         assert m.exchange == mh.EXCHANGE_RCCL
         with pytest.raises(mh.MsmError) as e:
             inst.call(m, bad)
@@ -143,11 +175,12 @@ def test_msm_multi_bad_scalar_in_one_shard_fails_every_rank_and_the_handle_survi
 
 @needs_two
 def test_msm_multi_verify_all_ranks_hold_the_same_bits(monkeypatch):
-    """MSM_HIP_MULTI_VERIFY=1 at creation: after the all-gather every rank's folded 24 words are compared"""
+    """MSM_HIP_MULTI_VERIFY=1 at creation (a debug knob of the HOOKS build): after the all-gather every rank's folded 24 words are compared"""
+    from mopro_msm_hip import testhooks as th
     monkeypatch.setenv("MSM_HIP_MULTI_VERIFY", "1")
     G = _ndev()
     inst = Sharded(18, G, seed=0xB2540D00)
-    with mh.MsmMulti() as m:
+    with mh.MsmMulti(exchange=mh.EXCHANGE_RCCL, _lib=th.load_hooks_library()) as m:
         assert m.exchange == mh.EXCHANGE_RCCL
         assert (inst.call(m).affine_std == inst.exp).all()
 

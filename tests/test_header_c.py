@@ -40,7 +40,7 @@ LAYOUT = r"""
 int main(void) {
     printf("msm_config_t %zu\n", sizeof(msm_config_t));
     F(msm_config_t, device); F(msm_config_t, window_bits); F(msm_config_t, flags); F(msm_config_t, stream_chunk_log2);
-    F(msm_config_t, max_points); F(msm_config_t, batch_layout); F(msm_config_t, reserved);
+    F(msm_config_t, max_points); F(msm_config_t, batch_layout); F(msm_config_t, host_threads);
     printf("msm_plan_t %zu\n", sizeof(msm_plan_t));
     F(msm_plan_t, window_bits); F(msm_plan_t, num_windows); F(msm_plan_t, num_buckets); F(msm_plan_t, signed_digits);
     F(msm_plan_t, workspace_bytes); F(msm_plan_t, virtual_points); F(msm_plan_t, glv); F(msm_plan_t, scalar_bits);
@@ -50,6 +50,7 @@ int main(void) {
     F(msm_timings_t, h2d_ms); F(msm_timings_t, convert_ms); F(msm_timings_t, decompose_ms); F(msm_timings_t, sort_ms);
     F(msm_timings_t, accumulate_ms); F(msm_timings_t, reduce_ms); F(msm_timings_t, finish_ms); F(msm_timings_t, total_ms);
     F(msm_timings_t, num_points); F(msm_timings_t, num_adds); F(msm_timings_t, stream_chunks); F(msm_timings_t, batch_layout);
+    F(msm_timings_t, plan_ms); F(msm_timings_t, combine_ms);
     printf("abi %u\n", (unsigned)MSM_HIP_ABI_VERSION);
     return 0;
 }

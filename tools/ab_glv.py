@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Interleaved A/B of the GLV split against the unsplit pipeline: median bench ms per size (3 rounds each)."""
 import json, subprocess, sys, statistics, os
+import os
+os.environ.setdefault("MSM_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpu-acceleration_amd", "libmsm_hip_hooks.so"))  # the A/B knobs this script sets are read by the HOOKS build only (round 5)
 for n in [int(x) for x in (sys.argv[1:] or "16 17 18 19 20 21 22".split())]:
     res = {"glv": [], "plain": []}
     for rnd in range(3):

@@ -1,6 +1,7 @@
 """Interleaved A/B of an environment knob that is read at CONTEXT CREATION (two contexts side by side), resident call:
 tools/ctx_env_ab.py NAME v1,v2 [log_n,...]   ('-' = unset)"""
 import os, sys, time, statistics
+os.environ.setdefault("MSM_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpu-acceleration_amd", "libmsm_hip_hooks.so"))  # the A/B knobs this script sets are read by the HOOKS build only (round 5)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "gpu-acceleration_amd")]
 import torch

@@ -1,6 +1,7 @@
 """Device-resident MSM above 2^23 points: whole-instance sort vs point ranges of 2^22 / 2^21 into shared buckets (MSM_HIP_DEVICE_CHUNK_LOG2,
 read once per process: one subprocess per setting).  usage: device_chunk_ab.py [log_n ...]"""
 import os, subprocess, sys
+os.environ.setdefault("MSM_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpu-acceleration_amd", "libmsm_hip_hooks.so"))  # the A/B knobs this script sets are read by the HOOKS build only (round 5)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
     sys.path[:0] = [ROOT, os.path.join(ROOT, "gpu-acceleration_amd")]

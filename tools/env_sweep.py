@@ -1,6 +1,7 @@
 """Interleaved A/B of one per-call environment knob on the resident call, one process: tools/env_sweep.py NAME v1,v2,... [log_n,...]
 ('-' = unset).  Prints median latency and mean k_accumulate time per (size, value)."""
 import os, sys, time, statistics
+os.environ.setdefault("MSM_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpu-acceleration_amd", "libmsm_hip_hooks.so"))  # the A/B knobs this script sets are read by the HOOKS build only (round 5)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "gpu-acceleration_amd")]
 import torch

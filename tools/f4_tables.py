@@ -8,6 +8,7 @@ measured here as: the same instance with the table forced on (MSM_HIP_GLV_MAX_LO
 affordable (c = 16, 17, 18: fewer windows, more buckets), k_accumulate and end-to-end, interleaved A/B, bases and scalars in HBM.
 usage: python tools/f4_tables.py [log_n ...]"""
 import os, sys, time, statistics
+os.environ.setdefault("MSM_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpu-acceleration_amd", "libmsm_hip_hooks.so"))  # the A/B knobs this script sets are read by the HOOKS build only (round 5)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "gpu-acceleration_amd")]
 import torch

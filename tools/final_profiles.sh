@@ -31,7 +31,7 @@ done
 python3 tools/sustained_probe.py > $O/sustained_probe.txt 2>&1
 python3 tools/adversarial_timing.py 2>&1 | grep -v amdgpu.ids > $O/skewed_scalars.txt
 python3 tools/sweep.py 17 18 19 20 21 22 24 > $O/sweep_big.txt 2>&1
-bash tools/r4_trace.sh 20 17 > $O/call_timeline_2p20_2p17.txt 2>&1
+bash tools/trace_device_call.sh 20 17 > $O/call_timeline_2p20_2p17.txt 2>&1
 bash tools/pmc_accumulate.sh 17 20 21 > $O/pmc.log 2>&1
 cp gpurun_out/accumulate_pmc_2p*.json gpurun_out/sort_pmc_2p*.json $O/ 2>/dev/null
 bash tools/pmc_valu.sh > $O/pmc_valu.log 2>&1

@@ -3,6 +3,7 @@
 every result compared bit for bit with the CPU oracle (Pippenger) -- a wider net than the fixed test cases.
 usage: tools/fuzz_parity.py [cases] [seed]"""
 import os, sys, time
+os.environ.setdefault("MSM_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpu-acceleration_amd", "libmsm_hip_hooks.so"))  # the A/B knobs this script sets are read by the HOOKS build only (round 5)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "gpu-acceleration_amd")]
 import numpy as np

@@ -1,6 +1,7 @@
 """Host-pointer entry (msm_bn254_g1 / msm_bn254_g1_arkworks) latency vs size, caller memory kind and streaming knobs (GPU box).
 usage: python tools/host_path_sweep.py [log_n ...]      env knobs are set per run by this script (fresh context each)."""
 import os, sys, time
+os.environ.setdefault("MSM_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpu-acceleration_amd", "libmsm_hip_hooks.so"))  # the A/B knobs this script sets are read by the HOOKS build only (round 5)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "gpu-acceleration_amd")]
 import numpy as np, torch

@@ -20,7 +20,7 @@ write = per_kernel(newest(f"{d}/bench_WRITE_SIZE/**/*counter_collection.csv"))
 cal = per_kernel(newest(f"{d}/calib_FETCH_SIZE/**/*counter_collection.csv"))
 stream_factor = (1 << 30) / (sum(cal["k_stream"]) / len(cal["k_stream"]) * 1024) if cal.get("k_stream") else 2.0
 SORT = ["k_coarse_hist", "k_coarse_prefix", "k_coarse_starts", "k_coarse_scatter", "k_fine_sort", "k_big_place"]
-OTHER = ["k_decompose_glv", "k_decompose", "k_convert_bases", "k_piece_count", "k_piece_scatter", "k_combine_pieces", "k_pair_level8", "k_reduce_bits_wide"]
+OTHER = ["k_decompose_glv", "k_decompose", "k_convert_bases", "k_phi_records", "k_piece_count", "k_piece_scatter", "k_combine_pieces", "k_pair_level8", "k_reduce_bits_wide"]
 avg = lambda v: sum(v) / len(v) if v else 0.0
 rows = {}
 for k in SORT + OTHER:
@@ -34,6 +34,7 @@ res = {"kernels": rows, "stream_fetch_correction": round(stream_factor, 3),
 try:
     line = [l for l in open(f"{d}/bench_FETCH_SIZE.log") if l.startswith("{")][-1]
     j = json.loads(line)
+    res["source_hash"] = j.get("source_hash")  # of the build the counters belong to (bench.py: traffic_stale)
     res["n_local"], res["window_bits"], res["glv_split"] = j["config"]["n_per_gpu"], j["config"]["window_bits"], j["config"].get("glv_split")
     res["algorithmic_bytes"] = j["roofline_sort"]["algorithmic_bytes"]
     res["traffic_over_algorithmic"] = round(res["sort_hbm_bytes"] / res["algorithmic_bytes"], 3)

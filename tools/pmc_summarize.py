@@ -28,6 +28,7 @@ res["correction"] = {"fetch_gather_64B_records": fg, "fetch_stream_16B_per_lane"
 res["hbm_bytes_per_launch"] = int(f["k_accumulate_kib_per_launch"] * 1024 * fg + w["k_accumulate_kib_per_launch"] * 1024 * ws)
 try:  # the bench line printed under the profiler names the workload the counters belong to
     line = [l for l in open(f"{d}/bench_FETCH_SIZE.log") if l.startswith("{")][-1]
+    res["source_hash"] = json.loads(line).get("source_hash")  # of the build the counters belong to: bench.py flags a later build's line traffic_stale
     cfg = json.loads(line)["config"]
     res["n_local"], res["window_bits"] = cfg["n_per_gpu"], cfg["window_bits"]
     res["num_windows"], res["glv_split"] = cfg.get("num_windows"), cfg.get("glv_split")

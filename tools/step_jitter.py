@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-call latency distribution of msm_device (resident operands): min / median / p90 / p99 / max over many calls."""
 import os, sys, time
+os.environ.setdefault("MSM_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpu-acceleration_amd", "libmsm_hip_hooks.so"))  # the A/B knobs this script sets are read by the HOOKS build only (round 5)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "gpu-acceleration_amd")]
 import numpy as np, torch

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Interleaved A/B of one environment knob: tools/sweep_env.py NAME v1 v2 ... [-- bench args]; median of 3 rounds per value."""
 import json, os, subprocess, sys, statistics
+import os
+os.environ.setdefault("MSM_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpu-acceleration_amd", "libmsm_hip_hooks.so"))  # the A/B knobs this script sets are read by the HOOKS build only (round 5)
 args = sys.argv[1:]
 extra = []
 if "--" in args:

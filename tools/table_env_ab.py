@@ -2,6 +2,7 @@
 """Interleaved A/B of a knob read at context creation on the RESIDENT path with its window table (single calls and batch).
 tools/table_env_ab.py NAME v1,v2 [log_n,...]      (AB_TABLE=0 in the environment: the same resident calls without the table)"""
 import os, sys, time, statistics
+os.environ.setdefault("MSM_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpu-acceleration_amd", "libmsm_hip_hooks.so"))  # the A/B knobs this script sets are read by the HOOKS build only (round 5)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "gpu-acceleration_amd")]
 import numpy as np, torch

@@ -9,6 +9,7 @@ A config is `plain` (no table), `CxF` (c bits, factor f; f must divide the numbe
 Knobs are read when a context is created, so every config gets a fresh context."""
 import argparse
 import os
+os.environ.setdefault("MSM_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpu-acceleration_amd", "libmsm_hip_hooks.so"))  # the A/B knobs this script sets are read by the HOOKS build only (round 5)
 import sys
 import time
 
