@@ -477,7 +477,9 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_ms": round(acc_avg_ms, 4), "launches_per_step": launches_per_step,
                          "launches_timed": int(acc_launches),
                          "note": "integer-multiply (VALU) bound kernel; HBM fraction reported because BASELINE.json asks for it; "
-                                 "the multiplier roofline is in roofline_valu"},
+                                 "the multiplier roofline is in roofline_valu.  avg_kernel_ms is k_accumulate_pieces alone: the work-item plan in "
+                                 "front of it (k_piece_count + k_piece_scatter: stage plan_ms) and k_combine_pieces behind it (combine_ms) are "
+                                 "separate launches -- work the round-3 accumulation kernel did itself"},
             # the sort/scatter stages (north_star: "achieved HBM GB/s on the sort/scatter stages"): SURVEY section 8d algorithmic bytes
             # 8*N*W over the hipEvent time of k_coarse_hist .. k_fine_sort in the diagnostic step
             "roofline_sort": ({"bound": "hbm", "kernels": "k_coarse_hist+k_coarse_prefix+k_coarse_starts+k_coarse_scatter+k_fine_sort+k_big_place",

@@ -451,8 +451,9 @@ SortGeom sort_geometry(const msm_ctx* c, const PipeState& ps) {
     return g;
 }
 
+// phi_src / phi_dst (split plans, both or neither): the decomposition also writes the phi records of arkworks-form bases (k_decompose_glv<.., PHI>)
 int32_t enqueue_decompose(msm_ctx* c, const PipeState& ps, const uint8_t* d_inf, const uint32_t* d_scalars, uint32_t scalars_mont,
-                          hipStream_t st, bool first) {
+                          hipStream_t st, bool first, const uint32_t* phi_src = nullptr, uint32_t* phi_dst = nullptr) {
     Range r_("msm:decompose");
     int32_t rc;
     const msm_plan_t& pl = ps.pl;
@@ -476,13 +477,20 @@ int32_t enqueue_decompose(msm_ctx* c, const PipeState& ps, const uint8_t* d_inf,
     const uint32_t nr = (uint32_t)n_real, drow = sg.d16 ? sg.drow : (uint32_t)ps.n;  // row of ONE window (a sort window is tf of them)
     const uint32_t spread_mask = ps.top_bits < ps.kb ? (1u << (ps.kb - ps.top_bits)) - 1u : 0u;  // (plans without a table)
 #define MSM_DECOMP_ARGS d_scalars, d_inf, nr, cbits, W, nb, hist, dg, drow, rk, flags, scalars_mont, ps.top_shift, ps.top_bits, spread_mask, ph, pcu
-#define MSM_DECOMP_GLV_ARGS d_scalars, d_inf, nr, cbits, W, dg, drow, flags, scalars_mont, ps.top_shift, ps.top_bits, spread_mask, ph, pcu
+#define MSM_DECOMP_GLV_ARGS d_scalars, d_inf, nr, cbits, W, dg, drow, flags, scalars_mont, ps.top_shift, ps.top_bits, spread_mask, ph, pcu, phi_src, phi_dst
     if (pl.glv) {
         if (!sg.lds_counts) return fail(c, MSM_ERR_BAD_ARG, "window_bits %u needs the non-GLV path (MSM_FLAG_NO_GLV)", cbits);
-        if (pl.signed_digits && sg.d16) msmk::k_decompose_glv<true, true><<<g, 256, 0, st>>>(MSM_DECOMP_GLV_ARGS);
-        else if (pl.signed_digits) msmk::k_decompose_glv<true, false><<<g, 256, 0, st>>>(MSM_DECOMP_GLV_ARGS);
-        else if (sg.d16) msmk::k_decompose_glv<false, true><<<g, 256, 0, st>>>(MSM_DECOMP_GLV_ARGS);
-        else msmk::k_decompose_glv<false, false><<<g, 256, 0, st>>>(MSM_DECOMP_GLV_ARGS);
+        const bool phi = phi_src != nullptr && phi_dst != nullptr;
+#define MSM_DECOMP_GLV(S, D) \
+    do { \
+        if (phi) msmk::k_decompose_glv<S, D, true><<<g, 256, 0, st>>>(MSM_DECOMP_GLV_ARGS); \
+        else msmk::k_decompose_glv<S, D, false><<<g, 256, 0, st>>>(MSM_DECOMP_GLV_ARGS); \
+    } while (0)
+        if (pl.signed_digits && sg.d16) MSM_DECOMP_GLV(true, true);
+        else if (pl.signed_digits) MSM_DECOMP_GLV(true, false);
+        else if (sg.d16) MSM_DECOMP_GLV(false, true);
+        else MSM_DECOMP_GLV(false, false);
+#undef MSM_DECOMP_GLV
     } else if (pl.signed_digits && sg.d16) msmk::k_decompose<true, false, true><<<g, 256, 0, st>>>(MSM_DECOMP_ARGS);
     else if (pl.signed_digits && sg.lds_counts) msmk::k_decompose<true, false, false><<<g, 256, 0, st>>>(MSM_DECOMP_ARGS);
     else if (pl.signed_digits) msmk::k_decompose<true, true, false><<<g, 256, 0, st>>>(MSM_DECOMP_ARGS);
@@ -603,6 +611,7 @@ struct BaseSrc {
     const uint32_t* phi = nullptr;
     uint32_t nsplit = 0xFFFFFFFFu;
     bool m256 = false;
+    bool phi_pending = false;  // m256, split plan: `phi` is the buffer the DECOMPOSITION will fill (k_decompose_glv<.., PHI>), nothing has been launched for it
     BaseSrc() = default;
     BaseSrc(const uint32_t* internal_records) : rec(internal_records) {}  // NOLINT: the internal-domain form converts implicitly
     BaseSrc shifted(size_t lo) const {  // the point range starting at lo (unsplit plans only)
@@ -832,7 +841,9 @@ int32_t finish_sync(msm_ctx* c, const PipeState& ps, size_t n_total, hipStream_t
 int32_t enqueue_body(msm_ctx* c, const PipeState& ps, const BaseSrc& d_bases, const uint8_t* d_inf, const uint32_t* d_scalars,
                      uint32_t scalars_mont, hipStream_t st, hipEvent_t bases_ready) {
     int32_t rc;
-    if ((rc = enqueue_decompose(c, ps, d_inf, d_scalars, scalars_mont, st, true))) return rc;
+    // (d_bases.phi_pending: the phi records of arkworks-form bases have not been made yet -- the decomposition writes them)
+    const bool fuse = d_bases.m256 && d_bases.phi_pending && ps.pl.glv;
+    if ((rc = enqueue_decompose(c, ps, d_inf, d_scalars, scalars_mont, st, true, fuse ? d_bases.rec : nullptr, fuse ? const_cast<uint32_t*>(d_bases.phi) : nullptr))) return rc;
     if ((rc = enqueue_sort(c, ps, st, false))) return rc;
     return enqueue_accumulate(c, ps, d_bases, st, bases_ready, false);
 }
@@ -1716,6 +1727,17 @@ int32_t msm_bn254_g1_device(msm_ctx* c, const void* d_bases_mont, const void* d_
 #endif
     // Each event record / cross-stream wait costs ~6 us of stream time (measured gaps in the kernel trace), so the
     // conversion only moves to the second stream when it is longer than that (n > 2^18: 32 us at 2^20, 5 us at 2^16).
+#if !defined(MSM_AB_CONVERT) && !defined(MSM_AB_PHI_KERNEL)
+    // Split plans: the phi records are written by the decomposition itself (k_decompose_glv<.., PHI>): no launch, no second stream, no
+    // cross-stream event for the coordinate half of K1 at any size.  (-DMSM_AB_PHI_KERNEL: the separate k_phi_records launch, beside the sort
+    // on the second stream above 2^18 points -- the first round-5 form.)
+    if (glv) {
+        BaseSrc src;
+        src.m256 = true, src.rec = (const uint32_t*)d_bases_mont, src.phi = ib, src.nsplit = (uint32_t)n, src.phi_pending = true;
+        if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_H2D], st));
+        rc = run_pipeline(c, src, (const uint8_t*)d_inf_mask, (const uint32_t*)d_scalars, n, st, out_jac, out_aff, out_inf, 0, nullptr, 0, &ps);
+    } else
+#endif
     if (c->stage_timing || nothing_to_convert || n <= ((size_t)1 << 18)) {  // serialised (also: so that convert_ms means something)
         if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_H2D], st));
         const BaseSrc src = launch_convert(in, d_bases_mont, n, ib, nullptr, glv, st);

@@ -225,16 +225,21 @@ __global__ void k_convert_bases(const uint32_t* __restrict__ in, uint32_t* __res
 // k_accumulate_pieces<.., M256> gathers the caller's records as they are (fp_unpack_shl5: 32 * W is the internal-domain value, unreduced).
 // What is left of K1's coordinate half on that path is the phi half of a split plan: record i = (beta * x_i, y_i) in the SAME word form, one
 // multiplication and 128 bytes per point where k_convert_bases spent three and 192 (unsplit plans: nothing at all).
+// (out of line: inlined into k_decompose_glv the two Montgomery products made the register allocator give that kernel 256 VGPRs -- one
+// wavefront per SIMD, 541 us instead of 45 at 2^20 -- wherever in the kernel the block stood)
+__device__ __noinline__ void phi_record(const uint32_t* __restrict__ in, uint32_t* __restrict__ out) {
+    uint32_t w[8];
+    load_words8(w, in);
+    const fp bx = fp_reduce_lt2p(fp_mul(fp_unpack(w), fp_from_std(glv::BETA_STD)));  // X * beta (mod p), canonical: beta * x in R = 2^256 form
+    fp_pack(w, bx);
+    store_words8(out, w);
+    load_words8(w, in + 8);
+    store_words8(out + 8, w);
+}
 __global__ void k_phi_records(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint32_t w[8];
-    load_words8(w, in + (size_t)i * 16);
-    const fp bx = fp_reduce_lt2p(fp_mul(fp_unpack(w), fp_from_std(glv::BETA_STD)));  // X * beta (mod p), canonical: beta * x in R = 2^256 form
-    fp_pack(w, bx);
-    store_words8(out + (size_t)i * 16, w);
-    load_words8(w, in + (size_t)i * 16 + 8);
-    store_words8(out + (size_t)i * 16 + 8, w);
+    phi_record(in + (size_t)i * 16, out + (size_t)i * 16);
 }
 
 // Zero-copy ingestion of an array of arkworks `G1Affine` structs: the struct array is copied to
@@ -522,11 +527,14 @@ __device__ __forceinline__ uint32_t window128(const uint32_t s[4], uint32_t off,
 // spread_mask != 0 (msmplan::glv_top_digit_bits): the top window's magnitudes are at most 2^top_bits, fewer than the window has buckets;
 // its bucket index is (magnitude - 1) | (i & spread_mask) << top_bits -- the same digit in 2^spread buckets, chosen by the point index, so
 // that the top window's buckets are no fuller than the others'.  The host ignores the bit sums of the index bits above top_bits.
-template <bool SIGNED, bool D16>
-__global__ void k_decompose_glv(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_mask, uint32_t n, uint32_t c,
+// PHI (round 5): the thread also writes the phi record of its point, (beta * x_i, y_i) in the caller's R = 2^256 word form (what k_phi_records
+// does) -- the device call on arkworks-form bases has the base array at hand when the scalars are decomposed, and one launch less (and no
+// second stream, no cross-stream event) is worth more than the 64 + 64 bytes per point cost this kernel.
+template <bool SIGNED, bool D16, bool PHI>
+__global__ void __launch_bounds__(256) k_decompose_glv(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_mask, uint32_t n, uint32_t c,
                                 uint32_t W, void* __restrict__ digits, uint32_t drow, uint32_t* __restrict__ err, uint32_t scalars_mont,
                                 uint32_t top_shift, uint32_t top_bits, uint32_t spread_mask, uint32_t* __restrict__ phist,
-                                uint32_t* __restrict__ pcursor) {
+                                uint32_t* __restrict__ pcursor, const uint32_t* __restrict__ phi_src, uint32_t* __restrict__ phi_dst) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) err[FLAG_LONG] = 0, err[FLAG_MID] = 0, err[FLAG_PIECES] = 0, err[FLAG_PARTIALS] = 0;  // list counters of this (chunk of an) MSM: k_piece_count fills them later in the stream
     if (blockIdx.x == 0) clear_piece_bins(phist, pcursor);
@@ -577,6 +585,7 @@ __global__ void k_decompose_glv(const uint32_t* __restrict__ scalars, const uint
         }
         if (SIGNED && carry) atomicOr(err, 2u);
     }
+    if (PHI) phi_record(phi_src + (size_t)i * 16, phi_dst + (size_t)i * 16);  // (last: nothing of the split is live any more)
 }
 
 // ---------------------------------------------------------------------------------------------

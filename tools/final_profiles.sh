@@ -9,7 +9,7 @@ R="$GRAFT_REPO_ROOT"
 O="$R/gpurun_out/final"
 rm -rf "$O"; mkdir -p "$O"
 cd "$R"
-export BUILD="${BUILD:-round 4 final}"
+export BUILD="${BUILD:-round 5 final}"
 python3 bench.py > $O/bench_line.json 2> $O/bench.err; echo "bench rc $?"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o p -- python3 $R/bench.py --no-host-legs > $O/bench_under_rocprof.json 2>/dev/null  # (no host legs: k_accumulate<false,false> then only has the timed shape)
