@@ -1415,8 +1415,17 @@ __global__ void __launch_bounds__(1024) k_piece_scatter(const uint32_t* __restri
 // M256 (round 5): `bases` are the caller's arkworks words (R = 2^256 Montgomery, x || y) for entries below nsplit and `phi` (biased by -nsplit
 // records, see `record` below) holds the records nsplit + i of a split plan in the same form (k_phi_records); the record is unpacked with the x 2^5 folded into the shifts and the
 // digit's sign goes to S2 (xyzz_madd_m32).  Same instruction count per addition as the internal-domain form, no conversion pass before it.
+// THREE wavefronts per SIMD, pinned (amdgpu_waves_per_eu): the M256 form of the INTO kernel fits 128 VGPRs and the compiler then takes FOUR, which this
+// instruction stream does not like (round 4: +5.6 % cycles with LDS-staged gathers at four; round 5: the streamed host call 2.56 -> 2.42 ms at 2^20 with the
+// INTO kernel back at three, profiles/r5_host_path_waves_ab.txt; the device call is indifferent: 1.368 vs 1.375 ms at 2^20, 4.88 vs 4.74 at 2^22).
+// -DMSM_AB_WAVES_FREE leaves the choice to the register allocator (A/B builds).
+#ifdef MSM_AB_WAVES_FREE
+#define MSM_ACC_WAVES
+#else
+#define MSM_ACC_WAVES __attribute__((amdgpu_waves_per_eu(3, 3)))
+#endif
 template <bool INTO, bool CHUNK, bool M256>
-__global__ void __launch_bounds__(256) k_accumulate_pieces(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ phi, uint32_t nsplit,
+__global__ void __launch_bounds__(256) MSM_ACC_WAVES k_accumulate_pieces(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ phi, uint32_t nsplit,
                                                            const uint32_t* __restrict__ sorted,
                                                            const uint4* __restrict__ plist, const uint32_t* __restrict__ npieces_ptr,
                                                            uint32_t* __restrict__ buckets, uint32_t* __restrict__ partials,

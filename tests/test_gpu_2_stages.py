@@ -167,6 +167,61 @@ def test_stages_global_atomic_fallback():
     assert (aff == g["expected"]).all()
 
 
+def test_stages_glv_tie_digits_leave_the_16_bit_skip_code_free():
+    """Round 5: digits travel as 16-bit codes (bucket 0..14, negate 15, 0xFFFF = zero digit) where a window has <= 2^15 buckets.  The code
+    0xFFFF would also be "bucket 2^15 - 1, negated" = the digit -2^15 = -H.  A window value of exactly H can be written +H or -H (+ carry); the
+    split recode folds the HALF's sign into every digit, so a negative half with a window at H used to give -H (2^-16 per digit).  The tie is
+    now broken by the half's sign: final digits lie in [-(H-1), H] whatever the sign of the half.  Scalars built from halves whose every 16-bit
+    window is H or H + 1 (both signs of both halves) -- k = k1 + lambda k2 mod r, the lattice-reduced split returns the halves it was built
+    from -- through the stage dump at c = 16: digit range, reconstruction, and the MSM result against the oracle."""
+    import json
+    import os
+    lam = int(json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "glv_constants.json")))["lambda"], 16)
+    H = 1 << 15
+    pats = [sum(H << (16 * j) for j in range(7)), sum((H + 1) << (16 * j) for j in range(7)), sum((H if j % 2 else H - 1) << (16 * j) for j in range(7)),
+            H, H << 16, (H << 96) + H]
+    ks = []
+    for a in pats:
+        for b in pats[:3]:
+            for sa in (1, -1):
+                for sb in (1, -1):
+                    ks.append((sa * a + lam * sb * b) % R_ORDER)
+    n = len(ks)
+    scalars = np.stack([orc.int_to_words(k) for k in ks])
+    logs = orc.gen_scalars(0x716, n, nonzero=True)
+    bases = orc.gen_bases_from_logs(logs, orc.FORM_STD)
+    with th.HooksContext(window_bits=16) as c:
+        d = c.stage_dump(bases, scalars, mh.FORM_STD, None)
+    assert d.plan.glv == 1 and d.plan.window_bits == 16 and d.kb == 15
+    W, t = d.W, d.plan.top_digit_bits
+    halves = np.zeros((2, n), object)
+    ties = 0
+    for w in range(W):
+        code = d.digits[w].astype(np.int64)
+        live = code != SKIP
+        idx = code & 0x7FFFFFFF
+        neg = (code & SIGN) != 0
+        if w == W - 1 and t < d.kb:
+            idx = idx & ((1 << t) - 1)
+        mag = np.where(live, idx + 1, 0)
+        assert (mag[neg & live] <= H - 1).all(), ("a negated magnitude of H: the 16-bit skip code", w)
+        assert (mag <= H).all()
+        ties += int((mag == H).sum())
+        dig = np.where(neg, -mag, mag)
+        for h in range(2):
+            for i in range(n):
+                halves[h, i] += int(dig[h * n + i]) << (16 * w)
+    assert ties >= n, "the crafted halves must produce window values of exactly H"
+    for i in range(n):
+        assert (halves[0, i] + lam * halves[1, i] - ks[i]) % R_ORDER == 0, i
+    exp, einf, _ = orc.msm_pippenger(bases, scalars, orc.FORM_STD)
+    aff, inf = orc.g1_to_affine_std(d.jacobian)
+    assert inf == int(einf) and (aff == exp).all()
+    with mh.MsmContext() as c:  # the product library, default plan
+        r = c.msm(bases, scalars, mh.FORM_STD)
+        assert (r.affine_std == exp).all()
+
+
 # ---- row f4: the window table of a resident base set, shared bucket arrays ---------------------------------------------------------
 def check_sort_table(d, digits_signed, inf=None):
     """as check_sort, for V = W / f bucket arrays: array v sorts the f*nv digits of windows v*f .. v*f+f-1 and an entry is the TABLE

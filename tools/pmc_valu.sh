@@ -10,4 +10,4 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_
   --kernel-trace --output-format csv -d $O/sq -- python3 bench.py --steps 3 --warmup 1 --pre-warm-ms 0 --no-cpu-baseline --no-host-legs > $O/sq.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_INST_CYCLES_VMEM_RD \
   --kernel-trace --output-format csv -d $O/grbm -- python3 bench.py --steps 3 --warmup 1 --pre-warm-ms 0 --no-cpu-baseline --no-host-legs > $O/grbm.log 2>&1
-python3 tools/pmc_valu_summarize.py $O "${BUILD:-round 4}"
+python3 tools/pmc_valu_summarize.py $O "${BUILD:-round 5}"

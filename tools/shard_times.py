@@ -28,8 +28,8 @@ def main():
     from mopro_msm_hip import testhooks as th
 
     out = {"build": args.build, "what": "msm_bn254_g1_device, inputs resident in HBM, median ms of %d calls after a 150 ms ramp-up" % args.reps,
-           "device_call_ms_by_log2_points": {}, "exchange_ms_estimate": 0.04,
-           "exchange_note": "96-byte all-gather + two copies + fold, measured with two ranks on one device (tools/exchange_overhead.py, round 2)"}
+           "device_call_ms_by_log2_points": {}, "exchange_ms_estimate": 0.12,
+           "exchange_note": "an ESTIMATE: the largest exchange measured end to end so far (two gloo ranks on one device, profiles/r4_final_bench_torchrun_2x_same_device.json); no multi-GPU run exists"}
     for lg in [int(x) for x in args.logs.split(",")]:
         n = 1 << lg
         d_b = torch.empty(n * 16, dtype=torch.int32, device="cuda:0")
