@@ -66,6 +66,14 @@ def main():
         res = None
         for _ in range(3):
             res = md.distributed_msm_device(ctx, d_b.data_ptr(), d_s.data_ptr(), n, device=xdev)
+    rccl_single = None
+    if nccl and world == 1:
+        # ONE rank over the real RCCL backend (round 5; 1-GPU boxes): all_reduce_msm returns early for world 1, so the exchange itself --
+        # pinned staging, 100 B up, all_gather_into_tensor on the rank's device, 100 B down, stream synchronisation, fold -- is run directly
+        parts, status = md._exchange(xdev, None).run(res.jacobian_mont, mh.OK, None)
+        folded = mh.combine_partials(parts)
+        rccl_single = bool(parts.shape == (1, 24) and int(status[0]) == mh.OK and (parts[0] == res.jacobian_mont).all()
+                           and (folded.affine_std == res.affine_std).all() and md._exchange(xdev, None).last_ms > 0)
     k = th.generate_scalars_host(bs, n, nonzero=True)
     s = th.generate_scalars_host(ss, n)
     to_int = lambda a: [sum(int(w) << (32 * j) for j, w in enumerate(row)) for row in a.tolist()]
@@ -75,9 +83,9 @@ def main():
     g = np.zeros(16, np.uint32)
     g[0], g[8] = 1, 2
     exp, einf = orc.g1_to_affine_std(orc.g1_scalar_mul(g, orc.int_to_words(sum(dots) % orc.R_ORDER)))
-    ok = bool((res.affine_std == exp).all()) and not res.is_infinity
+    ok = bool((res.affine_std == exp).all()) and not res.is_infinity and rccl_single is not False
     sys.stdout.write(json.dumps({"rank": rank, "ok": ok, "affine": res.affine_std.tolist(), "device": dev_index,
-                                 "backend": "nccl" if nccl else "gloo"}) + "\n")  # ONE write: the ranks share a pipe
+                                 "backend": "nccl" if nccl else "gloo", "rccl_exchange_with_one_rank": rccl_single}) + "\n")  # ONE write: the ranks share a pipe
     sys.stdout.flush()
     dist.barrier()
     dist.destroy_process_group()

@@ -1,6 +1,8 @@
 #!/bin/bash
-# round 5: the stage tests touched last, then the judged set (tools/final_profiles.sh)
+# round 5: the whole GPU gate, then the judged set (tools/final_profiles.sh)
 cd "$(dirname "${BASH_SOURCE[0]}")/.."
 export GRAFT_REPO_ROOT=$PWD
-timeout 600 python -m pytest tests/test_gpu_2_stages.py -m gpu -x -q 2>&1 | tail -3
-BUILD="round 5 final" bash tools/final_profiles.sh 2>&1 | tail -30
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/r5_final_pytest.txt 2>&1; echo "pytest rc $?" >> gpurun_out/r5_final_pytest.txt
+tail -6 gpurun_out/r5_final_pytest.txt
+BUILD="round 5 final" bash tools/final_profiles.sh 2>&1 | tail -12
