@@ -144,16 +144,16 @@ struct msm_ctx {
     HostPool* pool = nullptr;        // CPU finish: the caller + one worker
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t copy_stream = nullptr;     // host->HBM uploads and base conversion beside the sort
+    hipStream_t copy_stream = nullptr;     // host->HBM uploads; the coordinate pass of a host call's bases beside the sort (standard form: k_convert_bases; arkworks words: k_phi_records of a split plan)
     uint32_t num_cus = 0;                  // compute units of the device (rounds of k_accumulate workgroups)
     hipEvent_t ev_body = nullptr;          // batch: behind k_combine on the shared stream; the bucket reduction waits for it on another
     uint32_t tuned_layout[2] = {0, 0};     // msm_tune_batch: the measured MSM_BATCH_LAYOUT_* per size class (below / from 2^19 points); 0 = not tuned
     uint32_t last_batch_layout = 0;        // what the last batch call ran under (msm_timings_t.batch_layout)
     bool red_active = false;               // the reduce stream is in use by the batch call that is running
     hipEvent_t ev_copied[STREAM_SLOTS]{}, ev_free[STREAM_SLOTS]{}, ev_scal[STREAM_SLOTS]{};  // streamed host call: slot's bases+scalars there / slot free again / its scalars there
-    hipEvent_t ev_fork = nullptr, ev_bases = nullptr;  // base conversion runs on copy_stream beside the sort kernels
+    hipEvent_t ev_fork = nullptr, ev_bases = nullptr;  // the bases' copy / coordinate pass runs on copy_stream beside the sort kernels
     DevBuf sbases[STREAM_SLOTS], sscalars[STREAM_SLOTS], sinf[STREAM_SLOTS];  // raw inputs of the streamed path, one set per chunk in flight
-    DevBuf sibases;                           // the converted bases of the chunk being accumulated (conversion and accumulation share the compute stream)
+    DevBuf sibases;                           // the chunk being accumulated: its converted bases (standard form, structs) or the phi records of its arkworks words (they share the compute stream with the accumulation)
     msm_config_t cfg{};
     std::string err;
     hipEvent_t ev[EV_COUNT]{};
@@ -1034,7 +1034,8 @@ int32_t run_single(msm_ctx* c, const HostInput& in, size_t n, uint32_t* out_jac,
 // range is cut into chunks; chunk j+1 travels host->HBM and is converted on the copy stream while chunk j is sorted and
 // accumulated on the compute stream.  MSM is linear in the points, so every chunk adds into the SAME bucket array
 // (k_accumulate<INTO>, one plan for the whole instance): ONE bucket reduction, ONE host finish and W*(kb+1) bit sums back,
-// however many chunks.  Raw inputs live in STREAM_SLOTS buffers; the conversion runs on the compute stream right before the chunk's
+// however many chunks.  Raw inputs live in STREAM_SLOTS buffers; the coordinate pass (round 5: none for arkworks words but a split plan's phi records -- the
+// accumulation gathers from the slot itself) runs on the compute stream right before the chunk's
 // accumulation (the copy stream carries copies only).  Transfer (96 B per point at 52-56 GB/s from pinned, ~40 GB/s from pageable memory:
 // 0.48 ms per 2^18 points) and per-chunk work (sort 0.09 + conversion 0.02 + accumulation INTO the buckets 0.29-0.31 + fold 0.02 = 0.43 ms)
 // are about level: the call costs the first transfer, then the slower of the two per chunk, then the last chunk's work, the reduction
@@ -1715,34 +1716,32 @@ int32_t msm_bn254_g1_device(msm_ctx* c, const void* d_bases_mont, const void* d_
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
     auto t0 = std::chrono::steady_clock::now();
     const bool glv = plan_glv(c, n);
+#if defined(MSM_AB_CONVERT)
     if ((rc = ensure(c, c->ibases, (glv ? 2 : 1) * n * 64))) return rc;  // scratch (the resident set has its own buffers)
+#else
+    if ((rc = ensure(c, c->ibases, glv ? n * 64 : 0))) return rc;  // the phi records of a split plan; an unsplit plan needs no copy of the bases at all
+#endif
     PipeState ps;
+    uint32_t* ib = (uint32_t*)c->ibases.p;
+    if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_H2D], st));
+#if !defined(MSM_AB_CONVERT) && !defined(MSM_AB_PHI_KERNEL)
+    // Round 5: nothing is launched for the coordinate half of K1.  The accumulation gathers the caller's arkworks words as they are
+    // (k_accumulate_pieces<.., M256>); the phi records of a split plan are written by the decomposition itself (k_decompose_glv<.., PHI>) --
+    // one stream, no cross-stream event, at every size.
+    BaseSrc src;
+    src.m256 = true, src.rec = (const uint32_t*)d_bases_mont;
+    if (glv) src.phi = ib, src.nsplit = (uint32_t)n, src.phi_pending = true;
+    rc = run_pipeline(c, src, (const uint8_t*)d_inf_mask, (const uint32_t*)d_scalars, n, st, out_jac, out_aff, out_inf, 0, nullptr, 0, &ps);
+#else
+    // A/B builds only (tools/build_variant.sh): the coordinate pass as a launch of its own -- k_convert_bases (-DMSM_AB_CONVERT: rounds 1-4) or
+    // k_phi_records (-DMSM_AB_PHI_KERNEL: the first round-5 form) -- on the second stream beside the sort above 2^18 points (each event
+    // record / cross-stream wait costs ~6 us of stream time, so below that it is serialised)
     HostInput in;  // (only the kind matters here: the records are in HBM already)
     in.kind = KIND_MONT;
-    uint32_t* ib = (uint32_t*)c->ibases.p;
-#ifndef MSM_AB_CONVERT
-    const bool nothing_to_convert = !glv;  // round 5: an unsplit plan gathers the caller's words as they are
-#else
-    const bool nothing_to_convert = false;
-#endif
-    // Each event record / cross-stream wait costs ~6 us of stream time (measured gaps in the kernel trace), so the
-    // conversion only moves to the second stream when it is longer than that (n > 2^18: 32 us at 2^20, 5 us at 2^16).
-#if !defined(MSM_AB_CONVERT) && !defined(MSM_AB_PHI_KERNEL)
-    // Split plans: the phi records are written by the decomposition itself (k_decompose_glv<.., PHI>): no launch, no second stream, no
-    // cross-stream event for the coordinate half of K1 at any size.  (-DMSM_AB_PHI_KERNEL: the separate k_phi_records launch, beside the sort
-    // on the second stream above 2^18 points -- the first round-5 form.)
-    if (glv) {
-        BaseSrc src;
-        src.m256 = true, src.rec = (const uint32_t*)d_bases_mont, src.phi = ib, src.nsplit = (uint32_t)n, src.phi_pending = true;
-        if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_H2D], st));
-        rc = run_pipeline(c, src, (const uint8_t*)d_inf_mask, (const uint32_t*)d_scalars, n, st, out_jac, out_aff, out_inf, 0, nullptr, 0, &ps);
-    } else
-#endif
-    if (c->stage_timing || nothing_to_convert || n <= ((size_t)1 << 18)) {  // serialised (also: so that convert_ms means something)
-        if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_H2D], st));
+    if (c->stage_timing || n <= ((size_t)1 << 18)) {
         const BaseSrc src = launch_convert(in, d_bases_mont, n, ib, nullptr, glv, st);
         rc = run_pipeline(c, src, (const uint8_t*)d_inf_mask, (const uint32_t*)d_scalars, n, st, out_jac, out_aff, out_inf, 0, nullptr, 0, &ps);
-    } else {  // the phi records are not needed before k_accumulate: they are made on the second stream beside the sort
+    } else {
         if (hip_stream) {  // the caller's stream may still be producing the inputs; the context's own stream is idle between calls
             HIPCHK(c, hipEventRecord(c->ev_fork, st));
             HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_fork, 0));
@@ -1751,6 +1750,7 @@ int32_t msm_bn254_g1_device(msm_ctx* c, const void* d_bases_mont, const void* d_
         HIPCHK(c, hipEventRecord(c->ev_bases, c->copy_stream));
         rc = run_pipeline(c, src, (const uint8_t*)d_inf_mask, (const uint32_t*)d_scalars, n, st, out_jac, out_aff, out_inf, 0, c->ev_bases, 0, &ps);
     }
+#endif
     if (rc) return rc;
     c->tm.h2d_ms = 0;
     c->tm.convert_ms = stage_ms(c, EV_H2D, EV_CONVERT);

@@ -1,8 +1,9 @@
 // msm_kernels.hpp -- the gfx950 kernels of the BN254 G1 MSM pipeline.
 //
 // Stage map against the reference (shader/cuzk/*.metal):
-//   K1 convert_point_coords_and_decompose_scalars -> k_convert_bases (one Montgomery product per coordinate instead of two
-//        Barrett multiplications; k_import_ark / k_decompress for the other input forms) + k_decompose
+//   K1 convert_point_coords_and_decompose_scalars -> coordinates: NOTHING for arkworks words (round 5: k_accumulate_pieces<.., M256> gathers them as they
+//        are; a split plan's phi records: k_decompose_glv<.., PHI> / k_phi_records), k_convert_bases for standard-form words (one Montgomery product
+//        per coordinate instead of two Barrett multiplications), k_import_ark / k_decompress for the other input forms; scalars: k_decompose(_glv)
 //   K2 transpose (ONE thread per window, serial 2N+C loop) -> two-level counting sort in LDS: k_coarse_hist, k_coarse_prefix,
 //        k_coarse_starts, k_coarse_scatter, k_fine_sort (fallbacks: k_tile_* for n > 2^24, device-scope atomics in
 //        k_decompose + k_scan_* + k_scatter for windows of more than 2^17 buckets)
@@ -13,10 +14,12 @@
 //   final_reduction (CPU) -> stays on the CPU: host_g1.hpp
 //
 // Data layout in HBM (all little-endian u32 words):
-//   bases    n x 16   affine x||y, INTERNAL Montgomery domain (x*2^261 mod p, canonical, packed 8 x 32-bit
-//                     words per coordinate by k_convert_bases), 64 B per point = half a cache line per gather
+//   bases    n x 16   affine x||y, 64 B per point = half a cache line per gather: the caller's arkworks words (R = 2^256 Montgomery; M256 kernels)
+//                     or the INTERNAL Montgomery domain (x*2^261 mod p, canonical, packed 8 x 32-bit words per coordinate by k_convert_bases:
+//                     standard-form / struct / compressed inputs, resident sets and their window tables)
 //   scalars  n x 8    standard form
-//   digits   W x n    bucket index (bit 31 = negate, 0xFFFFFFFF = digit 0 / base at infinity), window-major
+//   digits   W x n    bucket index (bit 31 = negate, 0xFFFFFFFF = digit 0 / base at infinity), window-major; as 16-bit codes (bit 15, 0xFFFF) where a
+//                     window has <= 2^15 buckets and the two-level sort runs (DIGIT16_* below)
 //   ranks    W x n    arrival rank inside the bucket (fallback path only: more than 2^17 buckets per window)
 //   offsets  W*nb + 1 exclusive prefix sum of bucket sizes == CSC column pointer of the reference
 //   sorted   W x n    point index | sign<<31 grouped by bucket        == val_idxs of the reference

@@ -1,8 +1,9 @@
 """GPU tests that ARM THEMSELVES on a box with two or more visible MI355X (VERDICT r3 "missing" 1-2): on today's 1-GPU boxes every test
 here is skipped; on the first multi-GPU box they exercise what no hardware has run yet --
 
-  * msm_multi on ALL visible devices: ncclCommInitAll over > 1 device, the AUTO -> RCCL selection, one context + host thread per device,
-    ncclAllGather of the 96-byte partials over xGMI, the fold in rank order (csrc/msm_multi.inc);
+  * msm_multi on ALL visible devices under BOTH exchanges: ncclCommInitAll over > 1 device + ncclAllGather of the 96-byte partials over xGMI, and
+    the host fold; one context + host thread per device, the fold in rank order; what each exchange cost is written to
+    gpurun_out/multi_exchange_times.json, and AUTO must report the probe it ran at creation and keep the faster one (csrc/msm_multi.inc);
   * the same with a failing rank (every caller gets MSM_ERR_BAD_ARG, nobody waits in the collective) and with MSM_HIP_MULTI_VERIFY=1;
   * BASELINE config 4 at full size (2^24 points over the visible devices) and the headline size 2^20, by the closed form;
   * the one-process-per-GPU path that bench.py --gpus N runs: torchrun with nproc = device_count on the "nccl" (= RCCL) backend.
@@ -176,7 +177,6 @@ def test_msm_multi_bad_scalar_in_one_shard_fails_every_rank_and_the_handle_survi
 @needs_two
 def test_msm_multi_verify_all_ranks_hold_the_same_bits(monkeypatch):
     """MSM_HIP_MULTI_VERIFY=1 at creation (a debug knob of the HOOKS build): after the all-gather every rank's folded 24 words are compared"""
-    from mopro_msm_hip import testhooks as th
     monkeypatch.setenv("MSM_HIP_MULTI_VERIFY", "1")
     G = _ndev()
     inst = Sharded(18, G, seed=0xB2540D00)
