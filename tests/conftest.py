@@ -51,3 +51,17 @@ def load_zkey_points():
     scalars = np.stack([words(k) for k in d["scalars_hex"]])
     expected = np.concatenate([words(v) for v in d["expected_msm_affine_std_hex"]])
     return bases, inf, scalars, expected, d
+
+
+def load_srs_sets():
+    """tests/golden/srs_kzg_points.json (tools/extract_srs_points.py): the halo2 KZG parameter files the reference ships -- for each, (k, omega,
+    g [2^k,16] u32, g_lagrange [2^k,16] u32), all points as arkworks / MSM_FORM_MONT words exactly as stored.  g[j] = sum_i omega^(i*j) g_lagrange[i]:
+    MSM inputs AND expected outputs held by the reference, written by an implementation this repo shares nothing with."""
+    import json
+    import numpy as np
+    d = json.load(open(os.path.join(GOLDEN, "srs_kzg_points.json")))
+    out = []
+    for st in d["sets"]:
+        pts = lambda hexes: np.stack([np.frombuffer(bytes.fromhex(h), dtype="<u4") for h in hexes]).astype(np.uint32)
+        out.append((st["file"], st["k"], int(st["omega_hex"], 16), pts(st["g_mont_le_hex"]), pts(st["g_lagrange_mont_le_hex"])))
+    return out

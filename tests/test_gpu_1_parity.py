@@ -6,7 +6,7 @@ import pytest
 
 import mopro_msm_hip as mh
 from mopro_msm_hip import testhooks as th
-from conftest import golden_cases, load_golden, load_zkey_points
+from conftest import golden_cases, load_golden, load_srs_sets, load_zkey_points
 from oracle import bn254_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -255,6 +255,28 @@ def test_reference_zkey_points_in_mont_form(hk, wb, flags):
             img = _ark_image(std, inf, 72, 0, 32, 64, np.random.default_rng(5))
             ra = c.msm_arkworks(img, 72, 0, 32, 64, _fr_mont(scalars))
             assert (ra.affine_std == expected).all()
+
+
+@pytest.mark.parametrize("wb,flags", [(0, 0), (0, mh.FLAG_NO_GLV), (16, 0), (13, mh.FLAG_NO_GLV), (0, mh.FLAG_WINDOW_TABLE), (0, mh.FLAG_DETERMINISTIC)])
+def test_reference_srs_known_answer_msms(wb, flags):
+    """The MSM known answers the reference itself ships (tests/golden/srs_kzg_points.json: halo2 KZG parameters, monomial and Lagrange basis of one
+    tau): g[j] = sum_i omega^(i*j) g_lagrange[i] for every j -- inputs AND expected outputs are reference-held R = 2^256 Montgomery words written by
+    halo2curves.  Through the HIP path as they are (MSM_FORM_MONT), every j of both files, host call and resident set; the Jacobian result is
+    compared PROJECTIVELY with the reference-held point as well (what the reference's own gate does, metal_msm.rs:739-760)."""
+    for fname, k, omega, g, gl in load_srs_sets():
+        n = 1 << k
+        with mh.MsmContext(window_bits=wb, flags=flags) as c:
+            c.upload_bases(gl, mh.FORM_MONT)
+            for j in range(n):
+                scalars = np.stack([orc.int_to_words(pow(omega, i * j, R)) for i in range(n)])
+                exp = np.concatenate([orc.fq_from_mont(g[j, :8]), orc.fq_from_mont(g[j, 8:])])
+                r = c.msm(gl, scalars, mh.FORM_MONT)
+                assert not r.is_infinity and (r.affine_std == exp).all(), (fname, j)
+                assert (c.msm_resident(scalars).affine_std == exp).all(), (fname, j, "resident")
+                # X = x Z^2, Y = y Z^3 against the stored (x, y): projective equality with the reference-held point
+                X, Y, Z = (orc.words_to_int(orc.fq_from_mont(r.jacobian_mont[8 * t:8 * t + 8])) for t in range(3))
+                x, y = orc.words_to_int(exp[:8]), orc.words_to_int(exp[8:])
+                assert Z != 0 and (X - x * Z * Z) % P == 0 and (Y - y * Z * Z * Z) % P == 0, (fname, j, "projective")
 
 
 def test_reference_error_and_truncation_semantics(ctx):

@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, golden_cases, load_golden, load_zkey_points
+from conftest import GOLDEN, golden_cases, load_golden, load_srs_sets, load_zkey_points
 from oracle import bn254_oracle as orc
 
 P, R = orc.P, orc.R_ORDER
@@ -174,3 +174,26 @@ def test_reference_zkey_points_pin_the_montgomery_word_format():
     out, is_inf, _ = orc.msm_naive(bases, ones, orc.FORM_MONT, inf)
     exp_sum = np.concatenate([np.frombuffer(int(v, 16).to_bytes(32, "little"), dtype="<u4") for v in d["expected_sum_of_points_affine_std_hex"]])
     assert is_inf == 0 and (out == exp_sum).all()
+
+
+def test_reference_srs_files_hold_msm_known_answers():
+    """The only MSM KNOWN ANSWERS in the reference tree: its halo2 KZG parameter files (example-app/ios/{plonk,gemini}_fibonacci_srs.bin, extracted as
+    data by tools/extract_srs_points.py) hold the monomial basis g[j] = tau^j G AND the Lagrange basis g_lagrange[i] = L_i(tau) G of the same tau, so
+        g[j] = sum_i omega^(i*j) * g_lagrange[i]        for every j < 2^k
+    is an MSM whose inputs and expected output are both reference-held bytes (R = 2^256 Montgomery words), computed by halo2curves -- not by this
+    repo, not by its Python generator.  The oracle must reproduce all 8 + 16 of them in MONT form, through every algorithm it has."""
+    sets = load_srs_sets()
+    assert [(f, k) for f, k, *_ in sets] == [("plonk_fibonacci_srs.bin", 3), ("gemini_fibonacci_srs.bin", 4)]
+    for fname, k, omega, g, gl in sets:
+        n = 1 << k
+        assert pow(omega, n, R) == 1 and pow(omega, n // 2, R) == R - 1 and g.shape == (n, 16) and gl.shape == (n, 16)
+        one = np.stack([orc.int_to_words(1)] * n)
+        out, inf, _ = orc.msm_naive(gl, one, orc.FORM_MONT)
+        gen = np.concatenate([orc.int_to_words(1), orc.int_to_words(2)])
+        assert inf == 0 and (out == gen).all(), "sum of the Lagrange basis is the generator"
+        for j in range(n):
+            scalars = np.stack([orc.int_to_words(pow(omega, i * j, R)) for i in range(n)])
+            exp = np.concatenate([orc.fq_from_mont(g[j, :8]), orc.fq_from_mont(g[j, 8:])])  # the reference-held g[j], leaving the Montgomery domain
+            for label, fn in (("naive", orc.msm_naive), ("pippenger", orc.msm_pippenger), ("cuzk", orc.msm_cuzk)):
+                out, inf, _ = fn(gl, scalars, orc.FORM_MONT)
+                assert inf == 0 and (out == exp).all(), (fname, j, label)
