@@ -1,8 +1,8 @@
 #!/bin/bash
-# round 5: the whole GPU gate, then the judged set (tools/final_profiles.sh)
+# the whole GPU gate, then the judged set of a round (tools/final_profiles.sh): what is run last, on the final tree (BUILD="round N final")
 cd "$(dirname "${BASH_SOURCE[0]}")/.."
 export GRAFT_REPO_ROOT=$PWD
 mkdir -p gpurun_out
 timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/r5_final_pytest.txt 2>&1; echo "pytest rc $?" >> gpurun_out/r5_final_pytest.txt
 tail -6 gpurun_out/r5_final_pytest.txt
-BUILD="round 5 final" bash tools/final_profiles.sh 2>&1 | tail -12
+BUILD="${BUILD:-round 5 final}" bash tools/final_profiles.sh 2>&1 | tail -12
