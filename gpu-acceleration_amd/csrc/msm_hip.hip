@@ -611,7 +611,7 @@ struct BaseSrc {
     const uint32_t* phi = nullptr;
     uint32_t nsplit = 0xFFFFFFFFu;
     bool m256 = false;
-    bool phi_pending = false;  // m256, split plan: `phi` is the buffer the DECOMPOSITION will fill (k_decompose_glv<.., PHI>), nothing has been launched for it
+    uint32_t* phi_fill = nullptr;  // m256, split plan: == phi, and nothing has been launched for it yet -- the DECOMPOSITION fills it (k_decompose_glv<.., PHI>)
     BaseSrc() = default;
     BaseSrc(const uint32_t* internal_records) : rec(internal_records) {}  // NOLINT: the internal-domain form converts implicitly
     BaseSrc shifted(size_t lo) const {  // the point range starting at lo (unsplit plans only)
@@ -841,9 +841,9 @@ int32_t finish_sync(msm_ctx* c, const PipeState& ps, size_t n_total, hipStream_t
 int32_t enqueue_body(msm_ctx* c, const PipeState& ps, const BaseSrc& d_bases, const uint8_t* d_inf, const uint32_t* d_scalars,
                      uint32_t scalars_mont, hipStream_t st, hipEvent_t bases_ready) {
     int32_t rc;
-    // (d_bases.phi_pending: the phi records of arkworks-form bases have not been made yet -- the decomposition writes them)
-    const bool fuse = d_bases.m256 && d_bases.phi_pending && ps.pl.glv;
-    if ((rc = enqueue_decompose(c, ps, d_inf, d_scalars, scalars_mont, st, true, fuse ? d_bases.rec : nullptr, fuse ? const_cast<uint32_t*>(d_bases.phi) : nullptr))) return rc;
+    // (d_bases.phi_fill: the phi records of arkworks-form bases have not been made yet -- the decomposition writes them)
+    const bool fuse = d_bases.m256 && d_bases.phi_fill && ps.pl.glv;
+    if ((rc = enqueue_decompose(c, ps, d_inf, d_scalars, scalars_mont, st, true, fuse ? d_bases.rec : nullptr, fuse ? d_bases.phi_fill : nullptr))) return rc;
     if ((rc = enqueue_sort(c, ps, st, false))) return rc;
     return enqueue_accumulate(c, ps, d_bases, st, bases_ready, false);
 }
@@ -1730,7 +1730,7 @@ int32_t msm_bn254_g1_device(msm_ctx* c, const void* d_bases_mont, const void* d_
     // one stream, no cross-stream event, at every size.
     BaseSrc src;
     src.m256 = true, src.rec = (const uint32_t*)d_bases_mont;
-    if (glv) src.phi = ib, src.nsplit = (uint32_t)n, src.phi_pending = true;
+    if (glv) src.phi = ib, src.phi_fill = ib, src.nsplit = (uint32_t)n;
     rc = run_pipeline(c, src, (const uint8_t*)d_inf_mask, (const uint32_t*)d_scalars, n, st, out_jac, out_aff, out_inf, 0, nullptr, 0, &ps);
 #else
     // A/B builds only (tools/build_variant.sh): the coordinate pass as a launch of its own -- k_convert_bases (-DMSM_AB_CONVERT: rounds 1-4) or

@@ -343,6 +343,11 @@ pub fn hip_variable_base_msm_batch(bases: &[G1Affine], scalar_sets: &[&[BigInt<4
 
 /// `msm_config_t.flags` bit: resident sets carry their window table (include/msm_hip.h MSM_FLAG_WINDOW_TABLE).
 pub const MSM_FLAG_WINDOW_TABLE: u32 = 4;
+/// `msm_config_t.flags` bit (ABI 6): the Jacobian words handed back are the canonical Z = 1 representative -- the same limbs for the same group
+/// element on every call.  Without it `G1Projective` values returned by two identical calls are EQUAL (`==` compares projectively, as the
+/// reference's own `assert_eq!` relies on, T/cuzk/e2e.rs:58-61) but their limbs may differ: the GPU sort places the entries of a bucket with
+/// atomics, and X : Y : Z depends on the order of a bucket's additions (include/msm_hip.h, "Determinism").
+pub const MSM_FLAG_DETERMINISTIC: u32 = 8;
 
 /// A base set that stays in HBM for the lifetime of the value -- a prover's proving key.  The reference has no counterpart (it re-packs
 /// and re-uploads the bases on every `metal_variable_base_msm` call, metal_msm.rs:94, 274-344); `hip_variable_base_msm_batch` above uploads
