@@ -16,7 +16,7 @@ HOOKS_LIB_PATH = os.environ.get("MSM_HIP_HOOKS_LIB") or os.path.join(os.path.dir
 
 HOOK_SYMBOLS = [
     "msm_bn254_g1_generate_device", "msm_bn254_generate_scalars_host", "msm_test_fp_op", "msm_test_g1_op",
-    "msm_test_decompose", "msm_calibrate", "msm_test_stage_dump",
+    "msm_test_decompose", "msm_calibrate", "msm_test_stage_dump", "msm_test_abandon_after_sort",
 ]
 _lib = None
 
@@ -40,6 +40,7 @@ def load_hooks_library():
     L.msm_test_fp_op.argtypes = [vp, C.c_uint32, _u32p, _u32p, _u32p, C.c_size_t]
     L.msm_test_g1_op.argtypes = [vp, C.c_uint32, _u32p, _u32p, _u32p, C.c_size_t]
     L.msm_test_decompose.argtypes = [vp, _u32p, C.c_size_t, C.c_uint32, C.POINTER(C.c_int32)]
+    L.msm_test_abandon_after_sort.argtypes = [vp, _u32p, C.c_size_t]
     L.msm_calibrate.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.msm_test_stage_dump.argtypes = [vp, _u32p, C.c_uint32, _u8p, _u32p, C.c_size_t, _u32p, _u32p, _u32p, _u32p, _u32p,
                                       C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _u32p]
@@ -83,6 +84,12 @@ class HooksContext(MsmContext):
         out = np.zeros_like(a)
         self._check(self._lib.msm_test_g1_op(self._h, op, _p32(a), _p32(b), _p32(out), a.shape[0]))
         return out
+
+    def abandon_after_sort(self, scalars):
+        """decomposition + sort + piece plan of an MSM on `scalars`, then the failure a copy / event wait in front of the accumulation would be:
+        raises MsmError(ERR_HIP); the context is left as that failure leaves it"""
+        scalars = _words(scalars, 8)
+        self._check(self._lib.msm_test_abandon_after_sort(self._h, _p32(scalars), scalars.shape[0]))
 
     def calibrate(self):
         """(v_mad_u64_u32 per second, field multiplications per second) this device sustains -- two ~1 ms micro-kernels."""

@@ -72,6 +72,13 @@ int32_t msm_test_stage_dump(msm_ctx *ctx, const uint32_t *bases_xy, uint32_t bas
                             uint32_t *buckets_jacobian_mont, uint32_t *bit_sums_jacobian_mont, uint32_t *sort_path,
                             uint32_t *big_items, uint32_t out_jacobian_mont[24]);
 
+/* ---- a call that FAILS between its sort and its accumulation (the piece-sort histogram and the bin cursors used to be cleaned by
+ *      the accumulation of the call that used them, so such a failure left them dirty for the next call on the context).  Runs the
+ *      decomposition, the sort and the piece plan of an n-point MSM on `scalars` (host, n x 8 words) and then returns MSM_ERR_HIP as a
+ *      failed copy / event wait in front of the accumulation would: the flag words, the list counters, the piece histogram and its cursors
+ *      are left exactly as that failure leaves them.  The next call on the context must be right. */
+int32_t msm_test_abandon_after_sort(msm_ctx *ctx, const uint32_t *scalars, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -886,3 +886,26 @@ def test_deterministic_flag_gives_one_jacobian_representation(hk):
             r = c.msm(bases, s, mh.FORM_MONT)
             aff, inf = orc.g1_to_affine_std(r.jacobian_mont)
             assert (r.affine_std == exp).all() and inf == 0 and (aff == exp).all()
+
+
+def test_a_call_that_fails_between_sort_and_accumulation_leaves_the_context_usable():
+    """the piece-sort histogram and its bin cursors were cleaned by workgroup 0 of the accumulation of the call that used
+    them; a recoverable error between enqueue_sort and enqueue_accumulate (a failed copy or event wait in the overlap branch of the host call)
+    left them dirty, and the next call's piece list was built from wrong bin starts -- silent corruption.  They are now zeroed at the head of
+    every chain (k_decompose* / k_coarse_hist, msm_kernels.hpp clear_piece_bins).  The hook abandons a call exactly there -- on skewed scalars,
+    whose long buckets fill many bins and both lists -- at several sizes; every following call on the same context must be right, including
+    one of a different shape."""
+    g = load_golden("rand_n4096")
+    n = g["scalars"].shape[0]
+    skew = g["scalars"].copy()
+    skew[: n // 2] = skew[0]
+    with th.HooksContext() as c:
+        for cut in (n, n // 3, 257):
+            for sc in (skew[:cut], g["scalars"][:cut]):
+                with pytest.raises(mh.MsmError) as e:
+                    c.abandon_after_sort(sc)
+                assert e.value.code == mh.ERR_HIP
+                r = c.msm(g["bases"], g["scalars"], mh.FORM_STD, g["inf"])
+                assert r.is_infinity == bool(g["expected_inf"]) and (r.affine_std == g["expected"]).all(), cut
+                small = load_golden("rand_n256")
+                assert (c.msm(small["bases"], small["scalars"], mh.FORM_STD, small["inf"]).affine_std == small["expected"]).all()

@@ -473,6 +473,33 @@ def test_tune_batch_is_explicit_and_reset_by_an_upload(hk):
 
 
 # ---- N > 1 -------------------------------------------------------------------------------------------------------------------
+def test_multi_in_process_deterministic_flag_and_exchange_probe(inst20):
+    """msm_multi with MSM_FLAG_DETERMINISTIC in its configuration: every per-device partial AND the fold are handed out as Z = 1 representatives
+    -- ten calls on three ranks, host pointers and resident shards, give one set of 24 words.  On one physical device AUTO has nothing to measure:
+    the probe reads (0, 0) and the exchange is the host fold; a single device with the exchange forced to RCCL is never probed either."""
+    it = inst20
+    exp, _ = _expected(it.dot())
+    hb = it.d_b.cpu().numpy().view(np.uint32).reshape(it.n, 16)
+    hs = it.d_s.cpu().numpy().view(np.uint32).reshape(it.n, 8)
+    one = orc.fq_to_mont(orc.int_to_words(1))
+    G = 3
+    cuts = [g * it.n // G for g in range(G + 1)]
+    with mh.MsmMulti(devices=[0] * G, flags=mh.FLAG_DETERMINISTIC) as m:
+        assert m.exchange == mh.EXCHANGE_HOST and m.exchange_probe() == (0.0, 0.0)
+        reps = set()
+        for k in range(10):
+            if k % 2:
+                r = m.msm(hb, hs, mh.FORM_MONT)
+            else:
+                r = m.msm_device([it.d_b.data_ptr() + 64 * cuts[g] for g in range(G)], [it.d_s.data_ptr() + 32 * cuts[g] for g in range(G)],
+                                 [cuts[g + 1] - cuts[g] for g in range(G)])
+            assert (r.affine_std == exp).all() and (r.jacobian_mont[16:] == one).all()
+            reps.add(r.jacobian_mont.tobytes())
+        assert len(reps) == 1
+    with mh.MsmMulti(devices=[0], exchange=mh.EXCHANGE_RCCL) as m:
+        assert m.exchange == mh.EXCHANGE_RCCL and m.exchange_probe() == (0.0, 0.0)
+
+
 def test_multi_in_process_on_one_gpu(hk, inst20):
     """msm_multi (include/msm_hip.h "multi-GPU"): one context + host thread per listed device.  On a 1-GPU box the list names
     device 0 several times, which selects the host fold of the partials; a single device with the exchange forced to RCCL runs
