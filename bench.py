@@ -37,16 +37,20 @@ MASK64 = (1 << 64) - 1
 LAYOUT_NAMES = {1: "one stream", 2: "one stream + reduce stream", 3: "two streams"}  # MSM_BATCH_LAYOUT_*
 
 
-def words_to_ints(a):
-    a = np.ascontiguousarray(a, dtype=np.uint32).reshape(-1, 8)
-    out = [0] * a.shape[0]
-    cols = [a[:, j].tolist() for j in range(8)]
-    for i in range(a.shape[0]):
-        v = 0
-        for j in range(7, -1, -1):
-            v = (v << 32) | cols[j][i]
-        out[i] = v
-    return out
+def dot_words(k_words, s_words):
+    """sum_i k_i * s_i as a Python integer for two (n, 8) arrays of little-endian u32 words: 16-bit halves, float64 BLAS in slices of 2^20
+    (every partial sum < 2^32 * 2^20 = 2^52: exact) -- the closed-form check of a 2^26-point instance takes seconds, not minutes"""
+    k = np.ascontiguousarray(k_words, dtype=np.uint32).reshape(-1, 8)
+    s = np.ascontiguousarray(s_words, dtype=np.uint32).reshape(-1, 8)
+    tot = 0
+    for lo in range(0, min(len(k), len(s)), 1 << 20):
+        k16 = k[lo:lo + (1 << 20)].view(np.uint16).reshape(-1, 16).astype(np.float64)
+        s16 = s[lo:lo + (1 << 20)].view(np.uint16).reshape(-1, 16).astype(np.float64)
+        m = k16.T @ s16
+        for a in range(16):
+            for b in range(16):
+                tot += int(m[a, b]) << (16 * (a + b))
+    return tot
 
 
 def kernel_source_hash():
@@ -237,9 +241,15 @@ def main():
         ctx = mh.MsmContext(device=local_rank, window_bits=args.window_bits, flags=ctx_flags, max_points=n_local)
 
     hb_pin = hs_pin = None
-    if args.streamed:  # config 5: the instance lives in (pinned) host memory
-        hb_pin = d_bases[rank if not in_proc else 0].cpu().pin_memory()
-        hs_pin = d_scalars[rank if not in_proc else 0].cpu().pin_memory()
+    if args.streamed:  # config 5: the instance lives in (pinned) host memory; the device copies are dropped (2^26 points: 6.4 GB)
+        g0 = rank if not in_proc else 0
+        hb_pin = torch.empty(d_bases[g0].shape, dtype=torch.int32, pin_memory=True)
+        hs_pin = torch.empty(d_scalars[g0].shape, dtype=torch.int32, pin_memory=True)
+        hb_pin.copy_(d_bases[g0])
+        hs_pin.copy_(d_scalars[g0])
+        torch.cuda.synchronize()
+        d_bases[g0] = d_scalars[g0] = None
+        torch.cuda.empty_cache()
         hbn = hb_pin.numpy().view(np.uint32).reshape(-1, 16)
         hsn = hs_pin.numpy().view(np.uint32).reshape(-1, 8)
 
@@ -345,13 +355,18 @@ def main():
         elapsed = float(t.item())
         per_rank = [None] * world
         dist.all_gather_object(per_rank, {"rank": rank, "device": torch.cuda.current_device(), "shard_points": n_local,
-                                          "shard_ms": shard_ms_acc[0] / max(1, shard_ms_acc[1]), "exchange_ms": exch_ms_sum / max(1, args.steps)})
+                                          "shard_ms": shard_ms_acc[0] / max(1, shard_ms_acc[1]), "exchange_ms": exch_ms_sum / max(1, args.steps),
+                                          "sclk_ghz": round(clk_loop["sclk_ghz"], 4) if clk_loop and clk_loop["samples"] else None,
+                                          "k_accumulate_ms": round(acc_avg_ms, 4)})
         sh = [p["shard_ms"] for p in per_rank]
         exchange = {"backend": "gloo (debug: every rank on cuda:0)" if args.debug_same_device else "rccl (torch.distributed nccl backend)",
                     "world_seen": dist.get_world_size(), "devices_seen": sorted({p["device"] for p in per_rank}),
                     "payload_bytes_per_rank": 4 * md.WORDS, "ms_per_step": round(max(p["exchange_ms"] for p in per_rank), 4),
                     "ms_per_step_min_rank": round(min(p["exchange_ms"] for p in per_rank), 4),
                     "shard_ms_max": round(max(sh), 4), "shard_ms_min": round(min(sh), 4),
+                    # a slow rank is a slow KERNEL or a slow CLOCK: every rank's own shader clock over its timed launches beside its shard time
+                    "per_rank": [{"rank": p["rank"], "device": p["device"], "shard_ms": round(p["shard_ms"], 4), "exchange_ms": round(p["exchange_ms"], 4),
+                                  "sclk_ghz": p["sclk_ghz"], "k_accumulate_ms": p["k_accumulate_ms"]} for p in per_rank],
                     "note": "exchange ms = host wall clock of the 100-byte all-gather incl. its two copies and the wait for the slowest rank"}
     elif in_proc:
         ex_ms, sh = multi.exchange_stats()
@@ -361,16 +376,23 @@ def main():
                     "auto_probe_ms": {"rccl": round(p_rccl, 4), "host": round(p_host, 4)} if (p_rccl or p_host) else None,
                     "world_seen": multi.num_devices, "devices_seen": sorted({devs[g].index for g in my_shards}),
                     "payload_bytes_per_rank": 96, "ms_per_step": round(ex_ms, 4), "shard_ms_max": round(max(sh), 4),
-                    "shard_ms_min": round(min(sh), 4), "note": "last step; shard ms = wall clock of each rank's local MSM on its host thread"}
+                    "shard_ms_min": round(min(sh), 4),
+                    "per_rank": [{"rank": g, "device": devs[g].index, "shard_ms": round(sh[g], 4),
+                                  "sclk_ghz": round(multi.clock_stats(g)["sclk_ghz"], 4), "k_accumulate_ms": round(multi.timings(g)["accumulate_ms"], 4)}
+                                 for g in range(multi.num_devices)],
+                    "note": "last step; shard ms = wall clock of each rank's local MSM on its host thread; sclk_ghz = the shader clock that rank's "
+                            "k_accumulate_pieces measured for itself since the handle was created"}
     ms_per_step = elapsed * 1e3 / args.steps
 
     # ---- correctness gate (outside the timed region): closed form (sum s_i k_i mod r) * G ----------
     dot = 0
     for g in my_shards:
         glo, ghi = shard(g)
-        k_loc = th.generate_scalars_host((BASE_SEED + glo * STREAM_MUL) & MASK64, ghi - glo, nonzero=True)
-        s_loc = th.generate_scalars_host((SCALAR_SEED + glo * STREAM_MUL) & MASK64, ghi - glo)
-        dot += sum(a * b for a, b in zip(words_to_ints(k_loc), words_to_ints(s_loc)))
+        for c0 in range(glo, ghi, 1 << 22):  # in slices: a 2^26-point shard never holds more than 2^22 x 64 bytes of logs
+            cnt = min(1 << 22, ghi - c0)
+            k_loc = th.generate_scalars_host((BASE_SEED + c0 * STREAM_MUL) & MASK64, cnt, nonzero=True)
+            s_loc = th.generate_scalars_host((SCALAR_SEED + c0 * STREAM_MUL) & MASK64, cnt)
+            dot += dot_words(k_loc, s_loc)
     dot %= R_ORDER
     dot_local = dot
     if world > 1:
@@ -457,6 +479,10 @@ def main():
                        "parallelism": "point-range x%d%s" % (nshards, " (one process, msm_multi, exchange=%s)" %
                                                              {1: "rccl", 2: "host-fold"}.get(multi.exchange, "?") if in_proc else ""),
                        "timed_call": "msm_multi_device" if in_proc else "msm_bn254_g1 (host pointers, pinned)" if args.streamed else "msm_bn254_g1_device",
+                       "timed_call_inputs": "pinned HOST memory: the timed call includes the PCIe transfer" if args.streamed else
+                                            "HBM-resident: bases and scalars are in device memory when the timed call starts (no PCIe transfer inside `value`); "
+                                            "the reference's own call shape -- host slices in, benches/e2e.rs:46-60 -- is value_host_pinned_ms / "
+                                            "value_host_pageable_ms / value_host_arkworks_ms beside `value`",
                        "timed_call_returns": "Jacobian Montgomery words (the reference's own result type, metal_msm.rs:228-241); the one field "
                                              "inversion that gives the compared affine words (~10 us on the host) is outside the timed region"},
             "bit_exact": bit_exact,
@@ -517,7 +543,16 @@ def main():
                         lg = args.log_n - g.bit_length() + 1
                         if lg in tms:
                             proj["x%d" % g] = {"ms": round(tms[lg] + ex_est, 4), "speedup": round(tms[args.log_n] / (tms[lg] + ex_est), 2)}
+                    # the sizes the point-range sharding was designed for (BASELINE configs 4 and 5), next to this instance's
+                    designed = {}
+                    for big in (24, 26):
+                        lg8 = big - 3
+                        if lg8 in tms:
+                            one = tms.get(big)
+                            designed["2^%d_x8" % big] = {"ms": round(tms[lg8] + ex_est, 4), "shard_log2": lg8,
+                                                         "speedup_vs_one_gpu": round(one / (tms[lg8] + ex_est), 2) if one else None}
                     out["projected_strong_scaling"] = {"from": "profiles/shard_times.json (single-GPU device calls, %s)" % stj.get("build", "?"),
+                                                       "designed_for": designed,
                                                        "exchange_ms_used": round(ex_est, 4),
                                                        "exchange_ms_is": "measured in this run" if ex_meas else "ESTIMATE (no multi-GPU run: the largest exchange measured on one device)",
                                                        "one_gpu_ms": tms[args.log_n], **proj,
@@ -528,8 +563,6 @@ def main():
         # ---- from here on: UNTIMED extras (host-pointer legs, resident / batch / table legs, the CPU baseline).  The measurement itself is
         #      complete; a watchdog prints the line without whatever is still missing if the extras stall (one run in ~80 on the gpurun pool
         #      sat for 20 minutes on a box that answered again afterwards -- cause unknown, never reproduced: 25 of 25 reruns took 8 s)
-        import threading
-
         import threading
         emit_lock = threading.Lock()  # the line is printed ONCE: by the watchdog (from a snapshot taken before the extras) or by the main thread
         emitted = [False]
@@ -627,6 +660,10 @@ def main():
             legs["note"] = ("host-pointer calls on the same instance (PCIe-inclusive, 96-104 B per point); pageable = numpy arrays, "
                             "pinned = torch pin_memory; median and min of %d calls" % reps)
             out["host_pointer_legs"] = legs
+            # the reference's OWN call shape (host slices in, benches/e2e.rs:46-60) beside `value` (inputs resident in HBM), never instead of it
+            out["value_host_pinned_ms"] = legs["e2e_host_pinned_ms"]
+            out["value_host_pageable_ms"] = legs["e2e_host_pageable_ms"]
+            out["value_host_arkworks_ms"] = legs["e2e_arkworks_zero_copy_ms"]
             bit_exact = bit_exact and ok
 
         if not args.no_cpu_baseline and world == 1 and not in_proc:
@@ -634,8 +671,11 @@ def main():
             # on the SAME bases/scalars (whole instance when it fits ~30 s of CPU work, else a prefix)
             threads = orc.threads_available()
             n_cpu = min(n_local, (1 << 20) if threads >= 8 else (1 << 18))
-            hbc = d_bases[0][: n_cpu * 16].cpu().numpy().view(np.uint32).reshape(n_cpu, 16)
-            hsc = d_scalars[0][: n_cpu * 8].cpu().numpy().view(np.uint32).reshape(n_cpu, 8)
+            if args.streamed:  # (the device copies were dropped: the instance lives in pinned host memory)
+                hbc, hsc = hbn[:n_cpu], hsn[:n_cpu]
+            else:
+                hbc = d_bases[0][: n_cpu * 16].cpu().numpy().view(np.uint32).reshape(n_cpu, 16)
+                hsc = d_scalars[0][: n_cpu * 8].cpu().numpy().view(np.uint32).reshape(n_cpu, 8)
             cpu_runs = []
             for _ in range(5):  # MEDIAN of five, spread in the line (a shared host: single runs moved by 35-43 % in rounds 2 and 3)
                 t0 = time.perf_counter()
@@ -645,7 +685,7 @@ def main():
             if n_cpu == n_local:
                 cpu_ok = bool((cpu_aff == res.affine_std).all())
             else:
-                chk = ctx.msm_device(d_bases[0].data_ptr(), d_scalars[0].data_ptr(), n_cpu)
+                chk = ctx.msm(hbc, hsc, mh.FORM_MONT) if args.streamed else ctx.msm_device(d_bases[0].data_ptr(), d_scalars[0].data_ptr(), n_cpu)
                 cpu_ok = bool((cpu_aff == chk.affine_std).all())
             # arkworks parallelises over windows only (c = ln(n)*0.69 + 2 bits => 17 windows at 2^20): that many threads do work
             lg = int(np.log2(n_cpu))

@@ -85,10 +85,6 @@ FP_HD void xyzz_madd_plain(xyzz& acc, const affine& q) {
 // ripple); three more ripples are saved inside: X3 takes one (fp_sub_b_2c) instead of three, and the two subtractions that only
 // feed Y3's fused multiply-add stay raw.  120 of the ~2250 instructions of a mixed addition.
 FP_HD void xyzz_madd(xyzz& acc, const affine& q) {
-#ifdef FP_PLAIN_MADD  // A/B switch (tools/build_ab.sh)
-    xyzz_madd_plain(acc, affine{q.x, fp_normalize(q.y)});
-    return;
-#endif
     if (xyzz_is_identity(acc)) {
         acc = xyzz{q.x, fp_normalize(q.y), fp_one(), fp_one()};
         return;

@@ -40,34 +40,55 @@ __device__ __forceinline__ fp wide_select(bool c, const fp& a, const fp& b) {
     return r;
 }
 
+// Probe marks (hooks build, k_probe_wide_level: VERDICT r5 item 1a -- where the time of one eight-lane addition goes).  PROBE = false, the
+// only form the product instantiates, compiles to nothing.  A mark waits for every outstanding memory / LDS operation, so that the time
+// between two marks belongs to the instructions between them.
+constexpr int WIDE_MARKS = 16;
+template <bool PROBE>
+__device__ __forceinline__ void wide_mark(long long* ts, int i) {
+    if constexpr (PROBE) {
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_sched_barrier(0);
+        ts[i] = clock64();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // opa, opb: this lane's stage-1 operands (coordinate wide_op?_coord(role) of operand wide_op?_rec(role); roles 6, 7: anything
 // normalised).  operand_is_identity: role 4 passes (ZZ1 == 0 || ZZ2 == 0), other roles false.
 // Returns true (group-uniform) if the pair needs the scalar complete addition; otherwise
 //   role 1: out0 = X3 (< 7p), out1 = Y3 (< 5p)      role 4: out0 = ZZ3 (< 2p)      role 5: out0 = ZZZ3 (< 2p)
-__device__ __forceinline__ bool xyzz_add_wide(const fp& opa, const fp& opb, bool operand_is_identity, fp& out0, fp& out1) {
+template <bool PROBE = false>
+__device__ __forceinline__ bool xyzz_add_wide(const fp& opa, const fp& opb, bool operand_is_identity, fp& out0, fp& out1, long long* ts = nullptr) {
     const int lane = (int)(threadIdx.x & 63u);
     const int base = lane & ~(WIDE_LANES - 1);
     const uint32_t role = (uint32_t)lane & (WIDE_LANES - 1);
 
     // stage 1: r0 U1, r1 U2, r2 S1, r3 S2, r4 Za, r5 Zb                       (operands < 7p, < 2p -> products < 1.09p)
     const fp s1 = fp_mul(opa, opb);
+    wide_mark<PROBE>(ts, 2);
 
     // stage 2: r0 PP = (U2-U1)^2, r1 RR = (S2-S1)^2
     const fp g1 = wide_shfl(s1, base + (role == 0 ? 1 : role == 1 ? 2 : (int)role));  // r0 <- U2, r1 <- S1
     const fp g2 = wide_shfl(s1, base + (role == 1 ? 3 : (int)role));                   // r1 <- S2
     const fp pr = role == 0 ? fp_sub<3>(g1, s1) : fp_sub<3>(g2, g1);  // r0: P = U2-U1, r1: R = S2-S1 (< 4.09p); others: unused
+    wide_mark<PROBE>(ts, 3);
     const fp s2 = fp_sqr(pr);                                           // r0 PP, r1 RR  (< 1.1p)
+    wide_mark<PROBE>(ts, 4);
 
     // P == 0 (same x: doubling or inverse points) or an identity operand -> scalar path for this pair
     const bool mine = (role == 0 && fp_is_zero_lt2p(s2)) || (role == 4 && operand_is_identity);
     const unsigned long long votes = __ballot(mine);
     if ((votes >> base) & 0xFFull) return true;
+    wide_mark<PROBE>(ts, 5);
 
     // stage 3: r0 PPP = P*PP, r2 Q = U1*PP, r4 ZZ3 = Za*PP
     const fp pp = wide_shfl(s2, base);  // PP to everyone
     const fp u1 = wide_shfl(s1, base);  // U1 to everyone (r2 needs it)
     const fp a3 = role == 0 ? pr : role == 2 ? u1 : s1;  // r4: Za = its own stage-1 product
+    wide_mark<PROBE>(ts, 6);
     const fp s3 = fp_mul(a3, pp);                        // r0 PPP (< 1.03p), r2 Q (< 1.01p), r4 ZZ3
+    wide_mark<PROBE>(ts, 7);
 
     // stage 4: r1 T1 = R*(Q - X3), r2 T2 = S1*PPP, r5 ZZZ3 = Zb*PPP
     const fp ppp = wide_shfl(s3, base);      // PPP
@@ -75,11 +96,14 @@ __device__ __forceinline__ bool xyzz_add_wide(const fp& opa, const fp& opb, bool
     const fp x3 = fp_sub<5>(s2, fp_add(ppp, fp_dbl(q)));  // r1: RR - (PPP + 2Q): subtrahend < 3.05p; X3 < 6.1p
     const fp a4 = role == 1 ? pr : s1;                       // r1: R;  r2: S1;  r5: Zb
     const fp b4 = role == 1 ? fp_sub<8>(q, x3) : ppp;        // r1: Q - X3 (< 9.01p)
+    wide_mark<PROBE>(ts, 8);
     const fp s4 = fp_mul(a4, b4);                            // r1 T1 (< 1.22p), r2 T2 (< 1.01p), r5 ZZZ3
+    wide_mark<PROBE>(ts, 9);
 
     const fp t2 = wide_shfl(s4, base + 2);
     out0 = role == 1 ? x3 : role == 4 ? s3 : s4;  // r1 X3, r4 ZZ3, r5 ZZZ3
     out1 = fp_sub<3>(s4, t2);                     // r1: Y3 = T1 - T2 (< 4.3p)
+    wide_mark<PROBE>(ts, 10);
     return false;
 }
 

@@ -387,15 +387,9 @@ int32_t pipe_prepare(msm_ctx* c, size_t n_real, size_t plan_n, uint32_t extra_fl
     if ((rc = ensure(c, c->partials, maxpartials * XB))) return rc;
     if ((rc = ensure(c, c->plist, ps->maxpieces * 16))) return rc;
     if ((rc = ensure(c, c->pbase, tb * 4))) return rc;
-    {
-        const bool fresh = !c->phist.p || !c->pcursor.p;
-        if ((rc = ensure(c, c->phist, (msmk::PIECE_BINS + 1) * 4))) return rc;
-        if ((rc = ensure(c, c->pcursor, (msmk::PIECE_BINS + 1) * 4))) return rc;
-        if (fresh) {  // self-cleaning afterwards (k_accumulate_pieces zeroes them behind the plan kernels)
-            HIPCHK(c, hipMemsetAsync(c->phist.p, 0, c->phist.cap, st));
-            HIPCHK(c, hipMemsetAsync(c->pcursor.p, 0, c->pcursor.cap, st));
-        }
-    }
+    // (no memset: every sort chain zeroes the bins itself, at its head -- msmk::clear_piece_bins in k_decompose* / k_coarse_hist)
+    if ((rc = ensure(c, c->phist, (msmk::PIECE_BINS + 1) * 4))) return rc;
+    if ((rc = ensure(c, c->pcursor, (msmk::PIECE_BINS + 1) * 4))) return rc;
     {   // a long bucket owns >= LONG_SPAN partial sums and gets one (bucket, segment) entry per LONG_SEG of them
         const size_t entries = maxpartials / msmk::LONG_SPAN + maxpartials / msmk::LONG_SEG + 32;
         if ((rc = ensure(c, c->longlist, entries * 8))) return rc;
@@ -442,11 +436,7 @@ SortGeom sort_geometry(const msm_ctx* c, const PipeState& ps) {
     g.two_level = g.fine_bits <= 9 && g.nsuper <= msmk::SUPER_MAX && !c->knobs.direct_scatter;
     g.lds_counts = g.two_level || g.tiled;  // no device-scope histogram / rank atomics in k_decompose
     g.NS = (uint32_t)((sn + msmk::SUBTILE - 1) / msmk::SUBTILE);
-#ifdef MSM_AB_DIGITS32  // A/B builds only (tools/build_variant.sh): the 32-bit codes of rounds 1-4 everywhere
-    g.d16 = false;
-#else
     g.d16 = g.two_level && ps.tf == 1 && kb <= 15;
-#endif
     g.drow = (uint32_t)(g.d16 ? (sn + 1) & ~(size_t)1 : sn);  // (d16: tf == 1, a sort window is a decomposition window)
     return g;
 }
@@ -942,7 +932,6 @@ BaseSrc launch_convert(const HostInput& in, const void* d_raw, size_t cnt, uint3
                                                              d_out, d_inf, glv ? 1u : 0u);
         return BaseSrc(d_out);
     }
-#ifndef MSM_AB_CONVERT  // (A/B builds only, tools/build_variant.sh: the conversion pass of rounds 1-4)
     if (in.kind == KIND_MONT) {
         BaseSrc src;
         src.m256 = true;
@@ -954,9 +943,7 @@ BaseSrc launch_convert(const HostInput& in, const void* d_raw, size_t cnt, uint3
         }
         return src;
     }
-#endif
-    msmk::k_convert_bases<<<grid1(2 * cnt, 256), 256, 0, st>>>((const uint32_t*)d_raw, d_out, (uint32_t)cnt,
-                                                            in.kind == KIND_MONT ? 1u : 0u, glv ? 1u : 0u);
+    msmk::k_convert_bases<<<grid1(2 * cnt, 256), 256, 0, st>>>((const uint32_t*)d_raw, d_out, (uint32_t)cnt, 0u, glv ? 1u : 0u);  // standard form
     return BaseSrc(d_out);
 }
 
@@ -1716,15 +1703,10 @@ int32_t msm_bn254_g1_device(msm_ctx* c, const void* d_bases_mont, const void* d_
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
     auto t0 = std::chrono::steady_clock::now();
     const bool glv = plan_glv(c, n);
-#if defined(MSM_AB_CONVERT)
-    if ((rc = ensure(c, c->ibases, (glv ? 2 : 1) * n * 64))) return rc;  // scratch (the resident set has its own buffers)
-#else
     if ((rc = ensure(c, c->ibases, glv ? n * 64 : 0))) return rc;  // the phi records of a split plan; an unsplit plan needs no copy of the bases at all
-#endif
     PipeState ps;
     uint32_t* ib = (uint32_t*)c->ibases.p;
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_H2D], st));
-#if !defined(MSM_AB_CONVERT) && !defined(MSM_AB_PHI_KERNEL)
     // Round 5: nothing is launched for the coordinate half of K1.  The accumulation gathers the caller's arkworks words as they are
     // (k_accumulate_pieces<.., M256>); the phi records of a split plan are written by the decomposition itself (k_decompose_glv<.., PHI>) --
     // one stream, no cross-stream event, at every size.
@@ -1732,25 +1714,6 @@ int32_t msm_bn254_g1_device(msm_ctx* c, const void* d_bases_mont, const void* d_
     src.m256 = true, src.rec = (const uint32_t*)d_bases_mont;
     if (glv) src.phi = ib, src.phi_fill = ib, src.nsplit = (uint32_t)n;
     rc = run_pipeline(c, src, (const uint8_t*)d_inf_mask, (const uint32_t*)d_scalars, n, st, out_jac, out_aff, out_inf, 0, nullptr, 0, &ps);
-#else
-    // A/B builds only (tools/build_variant.sh): the coordinate pass as a launch of its own -- k_convert_bases (-DMSM_AB_CONVERT: rounds 1-4) or
-    // k_phi_records (-DMSM_AB_PHI_KERNEL: the first round-5 form) -- on the second stream beside the sort above 2^18 points (each event
-    // record / cross-stream wait costs ~6 us of stream time, so below that it is serialised)
-    HostInput in;  // (only the kind matters here: the records are in HBM already)
-    in.kind = KIND_MONT;
-    if (c->stage_timing || n <= ((size_t)1 << 18)) {
-        const BaseSrc src = launch_convert(in, d_bases_mont, n, ib, nullptr, glv, st);
-        rc = run_pipeline(c, src, (const uint8_t*)d_inf_mask, (const uint32_t*)d_scalars, n, st, out_jac, out_aff, out_inf, 0, nullptr, 0, &ps);
-    } else {
-        if (hip_stream) {  // the caller's stream may still be producing the inputs; the context's own stream is idle between calls
-            HIPCHK(c, hipEventRecord(c->ev_fork, st));
-            HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_fork, 0));
-        }
-        const BaseSrc src = launch_convert(in, d_bases_mont, n, ib, nullptr, glv, c->copy_stream);
-        HIPCHK(c, hipEventRecord(c->ev_bases, c->copy_stream));
-        rc = run_pipeline(c, src, (const uint8_t*)d_inf_mask, (const uint32_t*)d_scalars, n, st, out_jac, out_aff, out_inf, 0, c->ev_bases, 0, &ps);
-    }
-#endif
     if (rc) return rc;
     c->tm.h2d_ms = 0;
     c->tm.convert_ms = stage_ms(c, EV_H2D, EV_CONVERT);
@@ -1764,6 +1727,12 @@ int32_t msm_bn254_g1_combine(const uint32_t* partials, size_t k, uint32_t out_ja
     return combine_partials(partials, k, out_jac, out_aff, out_inf, false);
 }
 
+int32_t msm_bn254_g1_combine_flags(const uint32_t* partials, size_t k, uint32_t flags, uint32_t out_jac[24], uint32_t out_aff[16],
+                                   uint8_t* out_inf) {
+    if (flags & ~(uint32_t)MSM_FLAG_DETERMINISTIC) return MSM_ERR_BAD_ARG;
+    return combine_partials(partials, k, out_jac, out_aff, out_inf, (flags & MSM_FLAG_DETERMINISTIC) != 0);
+}
+
 int32_t msm_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_plan_t* out) {
     if (!out) return MSM_ERR_BAD_ARG;
     if (n == 0) return MSM_ERR_EMPTY;
@@ -1775,6 +1744,11 @@ int32_t msm_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_plan_t* out
 int32_t msm_get_timings(const msm_ctx* c, msm_timings_t* out) {
     if (!c || !out) return MSM_ERR_BAD_ARG;
     *out = c->tm;
+    return MSM_OK;
+}
+int32_t msm_get_timings_sized(const msm_ctx* c, void* out, size_t out_size) {
+    if (!c || !out || out_size == 0) return MSM_ERR_BAD_ARG;
+    std::memcpy(out, &c->tm, std::min(out_size, sizeof(msm_timings_t)));
     return MSM_OK;
 }
 int32_t msm_get_accumulate_kernel_stats(const msm_ctx* c, double* avg_ms, uint64_t* launches) {

@@ -147,13 +147,16 @@ __device__ __forceinline__ void store_coord(uint32_t* rec, uint32_t coord, const
 __device__ __forceinline__ void add_records_complete(const uint32_t* a_rec, const uint32_t* b_rec, uint32_t* out_rec) {
     store_xyzz(out_rec, xyzz_add(load_xyzz(a_rec), load_xyzz(b_rec)));
 }
-__device__ __forceinline__ void wide_add_records(const uint32_t* a_rec, const uint32_t* b_rec, uint32_t* out_rec) {
+template <bool PROBE = false>
+__device__ __forceinline__ void wide_add_records(const uint32_t* a_rec, const uint32_t* b_rec, uint32_t* out_rec, long long* ts = nullptr) {
     const uint32_t role = threadIdx.x & (WIDE_LANES - 1);
+    wide_mark<PROBE>(ts, 0);
     const fp opa = load_coord(wide_opa_rec(role) ? b_rec : a_rec, wide_opa_coord(role));
     const fp opb = load_coord(wide_opb_rec(role) ? b_rec : a_rec, wide_opb_coord(role));
     const bool ident = role == 4 && (fp_is_zero_exact(opa) || fp_is_zero_exact(opb));  // role 4 holds ZZ1 and ZZ2
+    wide_mark<PROBE>(ts, 1);
     fp o0, o1;
-    if (xyzz_add_wide(opa, opb, ident, o0, o1)) {
+    if (xyzz_add_wide<PROBE>(opa, opb, ident, o0, o1, ts)) {
         if (role == 0) add_records_complete(a_rec, b_rec, out_rec);
         return;
     }
@@ -165,6 +168,7 @@ __device__ __forceinline__ void wide_add_records(const uint32_t* a_rec, const ui
     } else if (role == 5) {
         store_coord(out_rec, 3, o0);
     }
+    wide_mark<PROBE>(ts, 11);
 }
 constexpr uint32_t WIDE_TREE_MAX = 256;  // records one workgroup's LDS tree holds (36 KB)
 // pairwise tree over m XYZZ records in LDS, wide additions, result in e[0].  Whole workgroup; blockDim multiple of 64.
@@ -1106,37 +1110,6 @@ __global__ void __launch_bounds__(FINE_BLOCK) k_fine_sort(const uint32_t* __rest
             s_out[pos] = ((e[k] & idx_mask) + sort_hi_of(hi, s_bnd, threadIdx.x + k * FINE_BLOCK, idx_bits)) | (e[k] & SIGN_BIT);
         }
         __syncthreads();
-#ifdef MSM_AB_SORTED_BUCKETS
-        // EXPERIMENT (round 5; A/B builds only): a deterministic PLACEMENT.  Every staged bucket's run is put in ascending
-        // point-index order: an element's slot = bucket start + the number of entries of its bucket with a smaller index (a bucket holds ~64
-        // entries: ~64 LDS reads per element, lanes of a wavefront mostly on the same address).  With it the XYZZ bucket sums, and the 24
-        // Jacobian words of the result, repeat between identical calls on uniform scalars (regions that fit the staging area).  Cost: see
-        // profiles/NOTES_r5.md -- the product gives the same guarantee with MSM_FLAG_DETERMINISTIC for one host inversion instead.
-        {
-            uint32_t val[FINE_PER_THREAD], dst[FINE_PER_THREAD];
-#pragma unroll 1
-            for (int k = 0; k < FINE_PER_THREAD; k++) {
-                const uint32_t p = threadIdx.x + k * FINE_BLOCK;
-                dst[k] = 0xFFFFFFFFu;
-                if (p >= S) continue;
-                uint32_t lo = 0, hi_f = nfine;  // the bucket of slot p: the first f with s_cur[f] (= its end) > p
-                while (lo < hi_f) {
-                    const uint32_t mid = (lo + hi_f) >> 1;
-                    if (s_cur[mid] > p) hi_f = mid; else lo = mid + 1;
-                }
-                const uint32_t b0 = lo ? s_cur[lo - 1] : 0u, b1 = s_cur[lo];
-                const uint32_t v = s_out[p], key = v & ~SIGN_BIT;
-                uint32_t below = 0;
-                for (uint32_t j = b0; j < b1; j++) below += (s_out[j] & ~SIGN_BIT) < key ? 1u : 0u;
-                val[k] = v, dst[k] = b0 + below;
-            }
-            __syncthreads();
-#pragma unroll 1
-            for (int k = 0; k < FINE_PER_THREAD; k++)
-                if (dst[k] != 0xFFFFFFFFu) s_out[dst[k]] = val[k];
-            __syncthreads();
-        }
-#endif
         for (uint32_t k = threadIdx.x; k < S; k += FINE_BLOCK) sorted[rs + k] = s_out[k];
     } else {  // skewed data: the region does not fit LDS, place directly (aggregated cursors hand consecutive lanes
               // consecutive slots, so the stores of a hot bucket are still coalesced)
@@ -1421,12 +1394,7 @@ __global__ void __launch_bounds__(1024) k_piece_scatter(const uint32_t* __restri
 // THREE wavefronts per SIMD, pinned (amdgpu_waves_per_eu): the M256 form of the INTO kernel fits 128 VGPRs and the compiler then takes FOUR, which this
 // instruction stream does not like (round 4: +5.6 % cycles with LDS-staged gathers at four; round 5: the streamed host call 2.56 -> 2.42 ms at 2^20 with the
 // INTO kernel back at three, profiles/r5_host_path_waves_ab.txt; the device call is indifferent: 1.368 vs 1.375 ms at 2^20, 4.88 vs 4.74 at 2^22).
-// -DMSM_AB_WAVES_FREE leaves the choice to the register allocator (A/B builds).
-#ifdef MSM_AB_WAVES_FREE
-#define MSM_ACC_WAVES
-#else
 #define MSM_ACC_WAVES __attribute__((amdgpu_waves_per_eu(3, 3)))
-#endif
 template <bool INTO, bool CHUNK, bool M256>
 __global__ void __launch_bounds__(256) MSM_ACC_WAVES k_accumulate_pieces(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ phi, uint32_t nsplit,
                                                            const uint32_t* __restrict__ sorted,

@@ -202,6 +202,60 @@ __global__ void __launch_bounds__(64) k_test_g1_wide(const uint32_t* __restrict_
     if (i < n && role == 0) store_jacobian_mont256(out + (size_t)i * 24, xyzz_to_jacobian(load_xyzz(e + (size_t)(2 * g) * XW)));
 }
 
+// Probe: ONE workgroup runs `iters` pairwise levels of the same size over m records in LDS -- the body of
+// lds_tree_wide: e[i] += e[i + m/2] by eight lanes per addition, a barrier per level.  PROBE: wavefront 0 brackets the parts of its
+// addition with the shader-cycle counter (ec_wide.hpp wide_mark; each mark drains the memory counters) and sums the intervals; without
+// it only the whole loop is bracketed, so the two totals show what the marks themselves cost.
+//   out[0] shader cycles of the loop, out[1] constant-rate ticks of the loop, out[2 + k] cycles between mark k - 1 and mark k summed over the levels
+//   marks: 0 entry, 1 operands loaded, 2 stage-1 product, 3 exchange + P / R, 4 squares, 5 special-case vote, 6 exchange + stage-3 operands,
+//          7 stage-3 product, 8 exchange + X3 + stage-4 operands, 9 stage-4 product, 10 exchange + Y3, 11 result stored, 12 loop left, 13 barrier passed
+template <bool PROBE>
+__global__ void __launch_bounds__(512) k_probe_wide_level(const uint32_t* __restrict__ src, uint32_t m, uint32_t iters, long long* __restrict__ out) {
+    __shared__ uint32_t e[WIDE_TREE_MAX * XW];
+    for (uint32_t i = threadIdx.x; i < m * XW; i += blockDim.x) e[i] = src[i];
+    __syncthreads();
+    const uint32_t g = threadIdx.x / WIDE_LANES, ng = blockDim.x / WIDE_LANES, h = m >> 1;
+    long long acc[WIDE_MARKS], ts[WIDE_MARKS];
+#pragma unroll
+    for (int k = 0; k < WIDE_MARKS; k++) acc[k] = 0, ts[k] = 0;
+    const long long c0 = clock64(), w0 = wall_clock64();
+#pragma unroll 1
+    for (uint32_t it = 0; it < iters; it++) {
+        for (uint32_t i = g; i < h; i += ng) wide_add_records<PROBE>(e + (size_t)i * XW, e + (size_t)(i + h) * XW, e + (size_t)i * XW, ts);
+        wide_mark<PROBE>(ts, 12);
+        __syncthreads();
+        wide_mark<PROBE>(ts, 13);
+        if (PROBE) {
+#pragma unroll
+            for (int k = 1; k <= 13; k++) acc[k] += ts[k] - ts[k - 1];
+        }
+    }
+    const long long c1 = clock64(), w1 = wall_clock64();
+    if (threadIdx.x == 0) {
+        out[0] = c1 - c0;
+        out[1] = w1 - w0;
+#pragma unroll
+        for (int k = 0; k < WIDE_MARKS; k++) out[2 + k] = acc[k];
+    }
+}
+// the same m / 2 additions by ONE lane each (the form of k_pair_level / the serial folds of k_pair_level8), for the lone-wavefront price of xyzz_add
+__global__ void __launch_bounds__(512) k_probe_scalar_level(const uint32_t* __restrict__ src, uint32_t m, uint32_t iters, long long* __restrict__ out) {
+    __shared__ uint32_t e[WIDE_TREE_MAX * XW];
+    for (uint32_t i = threadIdx.x; i < m * XW; i += blockDim.x) e[i] = src[i];
+    __syncthreads();
+    const uint32_t h = m >> 1;
+    const long long c0 = clock64(), w0 = wall_clock64();
+#pragma unroll 1
+    for (uint32_t it = 0; it < iters; it++) {
+        if (threadIdx.x < h) add_records_complete(e + (size_t)threadIdx.x * XW, e + (size_t)(threadIdx.x + h) * XW, e + (size_t)threadIdx.x * XW);
+        __syncthreads();
+    }
+    const long long c1 = clock64(), w1 = wall_clock64();
+    if (threadIdx.x == 0) out[0] = c1 - c0, out[1] = w1 - w0;
+}
+__global__ void k_probe_empty(uint32_t* sink) {
+    if (sink && threadIdx.x == 12345u) sink[0] = 1;
+}
 
 // stage tests: XYZZ records (bucket sums) -> Jacobian R = 2^256 Montgomery words, the C-ABI point format
 __global__ void k_dump_xyzz_as_jacobian(const uint32_t* __restrict__ recs, uint32_t n, uint32_t* __restrict__ out) {

@@ -30,13 +30,14 @@ OK, ERR_EMPTY, ERR_BAD_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_STATE, ERR_INVA
 ABI_SYMBOLS = [
     "msm_abi_version", "msm_ctx_create", "msm_ctx_destroy", "msm_last_error", "msm_bn254_g1",
     "msm_bn254_g1_arkworks", "msm_bn254_g1_upload_bases", "msm_bn254_g1_resident", "msm_bn254_g1_resident_batch", "msm_tune_batch", "msm_bn254_g1_resident_device", "msm_bn254_g1_device",
-    "msm_bn254_g1_combine",
+    "msm_bn254_g1_combine", "msm_bn254_g1_combine_flags", "msm_get_timings_sized", "msm_multi_get_timings_sized", "msm_multi_get_clock_stats",
     "msm_plan", "msm_get_timings", "msm_set_stage_timing", "msm_get_accumulate_kernel_stats", "msm_reset_kernel_stats", "msm_get_clock_stats",
     "msm_bn254_g1_decompress", "msm_bn254_g1_upload_compressed", "msm_bn254_g1_compress",
     "msm_multi_create", "msm_multi_destroy", "msm_multi_last_error", "msm_multi_num_devices", "msm_multi_exchange",
     "msm_bn254_g1_multi", "msm_bn254_g1_multi_arkworks", "msm_bn254_g1_multi_device", "msm_multi_get_timings",
     "msm_multi_get_exchange_stats", "msm_multi_get_exchange_probe",
 ]
+ABI_VERSION = 7  # == MSM_HIP_ABI_VERSION of include/msm_hip.h this binding was written against (checked when a library is loaded)
 ERR_RCCL = -8
 EXCHANGE_AUTO, EXCHANGE_RCCL, EXCHANGE_HOST = 0, 1, 2
 # msm_config_t.batch_layout (include/msm_hip.h MSM_BATCH_LAYOUT_*)
@@ -108,6 +109,10 @@ def bind_product_abi(L):
     L.msm_bn254_g1_device.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, _u32p, _u32p, _u8p]
     L.msm_bn254_g1_resident_device.argtypes = [vp, vp, C.c_size_t, vp, _u32p, _u32p, _u8p]
     L.msm_bn254_g1_combine.argtypes = [_u32p, C.c_size_t, _u32p, _u32p, _u8p]
+    L.msm_bn254_g1_combine_flags.argtypes = [_u32p, C.c_size_t, C.c_uint32, _u32p, _u32p, _u8p]
+    L.msm_get_timings_sized.argtypes = [vp, vp, C.c_size_t]
+    L.msm_multi_get_timings_sized.argtypes = [vp, C.c_int32, vp, C.c_size_t]
+    L.msm_multi_get_clock_stats.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.msm_plan.argtypes = [C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(Plan)]
     L.msm_get_timings.argtypes = [vp, C.POINTER(Timings)]
     L.msm_set_stage_timing.argtypes = [vp, C.c_int32]
@@ -136,6 +141,10 @@ def bind_product_abi(L):
         f = getattr(L, name)
         if f.restype is C.c_int:  # default
             f.restype = C.c_int32
+    # the structs above (Config, Plan, Timings) are those of ONE ABI: a library of another would be read / written past their ends
+    have = int(L.msm_abi_version())
+    if have != ABI_VERSION:
+        raise MsmError(ERR_STATE, "library ABI %d, this binding is written against ABI %d (rebuild: make -C gpu-acceleration_amd/csrc)" % (have, ABI_VERSION))
     return L
 
 
@@ -193,12 +202,14 @@ def plan(n, window_bits=0, flags=0, _lib=None):
     return p
 
 
-def combine_partials(partials_jacobian_mont, want_affine=True):
+def combine_partials(partials_jacobian_mont, want_affine=True, flags=0):
     """Fold per-rank partial sums in fixed rank order (host arithmetic inside the library).
-    want_affine=False skips the field inversion; MsmResult.affine_std then computes it on first use."""
+    want_affine=False skips the field inversion; MsmResult.affine_std then computes it on first use.
+    flags=FLAG_DETERMINISTIC: the Jacobian words are the canonical Z = 1 representative (msm_bn254_g1_combine_flags) -- what the ranks of a
+    one-process-per-GPU job fold with when their contexts carry the flag."""
     p = _words(partials_jacobian_mont, 24)
     jac, aff, inf = np.zeros(24, np.uint32), (np.zeros(16, np.uint32) if want_affine else None), C.c_uint8(0)
-    rc = load_library().msm_bn254_g1_combine(_p32(p), p.shape[0], _p32(jac), _p32(aff), C.byref(inf))
+    rc = load_library().msm_bn254_g1_combine_flags(_p32(p), p.shape[0], flags, _p32(jac), _p32(aff), C.byref(inf))
     if rc != OK:
         raise MsmError(rc, "Empty input" if rc == ERR_EMPTY else f"combine failed ({rc})")
     return MsmResult(jac, aff, inf.value)
@@ -413,9 +424,9 @@ class MsmMulti:
     and one host thread per device, partials exchanged with RCCL (all-gather of 24 words + fold in rank order) or folded on
     the host.  Same call signatures as MsmContext."""
 
-    def __init__(self, devices=None, window_bits=0, flags=0, stream_chunk_log2=0, exchange=EXCHANGE_AUTO, _lib=None):
+    def __init__(self, devices=None, window_bits=0, flags=0, stream_chunk_log2=0, exchange=EXCHANGE_AUTO, host_threads=0, _lib=None):
         self._lib = _lib or load_library()
-        cfg = Config(-1, window_bits, flags, stream_chunk_log2, 0, 0, 0)
+        cfg = Config(-1, window_bits, flags, stream_chunk_log2, 0, 0, host_threads)
         h = C.c_void_p()
         if devices is None:
             rc = self._lib.msm_multi_create(None, 0, C.byref(cfg), exchange, C.byref(h))
@@ -493,6 +504,12 @@ class MsmMulti:
         sh = (C.c_float * self.num_devices)()
         self._check(self._lib.msm_multi_get_exchange_stats(self._h, C.byref(ex), sh, self.num_devices))
         return float(ex.value), [float(v) for v in sh]
+
+    def clock_stats(self, g=0):
+        """msm_get_clock_stats of rank g's context: {"sclk_ghz", "cycles_per_addition", "samples"}"""
+        a, b, n = C.c_double(0), C.c_double(0), C.c_uint64(0)
+        self._check(self._lib.msm_multi_get_clock_stats(self._h, g, C.byref(a), C.byref(b), C.byref(n)))
+        return {"sclk_ghz": a.value, "cycles_per_addition": b.value, "samples": n.value}
 
     def exchange_probe(self):
         """(rccl ms, host-fold ms) per exchange that EXCHANGE_AUTO measured when the handle was created; (0, 0) = nothing was probed"""

@@ -7,7 +7,7 @@ in rank order -- identical bits on every rank.  The reference has no multi-devic
 """
 import numpy as np
 
-from . import ERR_HIP, OK, MsmError, MsmResult, combine_partials
+from . import ERR_HIP, FLAG_DETERMINISTIC, OK, MsmError, MsmResult, combine_partials
 
 WORDS = 25  # what a rank sends: 24 words of its partial (Jacobian, Montgomery) + 1 status word (C-ABI code, 0 = ok)
 
@@ -84,8 +84,11 @@ def all_gather_partials(partial_jacobian_mont, device=None, group=None):
     return _exchange(device, group).run(partial_jacobian_mont, OK, group)[0]
 
 
-def all_reduce_msm(local_result, device=None, group=None) -> MsmResult:
+def all_reduce_msm(local_result, device=None, group=None, flags=0) -> MsmResult:
     """exchange + fold: every rank ends with the full MSM result.
+
+    flags: the contexts' MSM_FLAG_DETERMINISTIC, if they carry it -- the fold then hands out the canonical Z = 1 Jacobian words, the same 24
+    words a single GPU or msm_multi returns for this group element (msm_bn254_g1_combine_flags).
 
     `local_result` is this rank's MsmResult -- or the MsmError its local MSM raised.  NO RANK MAY HANG: a rank whose local MSM
     failed (one scalar >= 2^254 in its shard is enough) still joins the all-gather, with the identity as its partial and its
@@ -105,10 +108,10 @@ def all_reduce_msm(local_result, device=None, group=None) -> MsmResult:
         r = int(bad[0])
         own = " (this rank: %s)" % local_result if failed else ""
         raise MsmError(int(status[r]), "rank %d of %d failed with status %d%s" % (r, len(status), int(status[r]), own))
-    return combine_partials(parts, want_affine=False)
+    return combine_partials(parts, want_affine=False, flags=flags & FLAG_DETERMINISTIC)
 
 
-def guarded(local_call, device=None, group=None) -> MsmResult:
+def guarded(local_call, device=None, group=None, flags=0) -> MsmResult:
     """run this rank's local MSM (`local_call()` -> MsmResult) and all-reduce it; an MsmError raised by the local call travels
     through the exchange instead of keeping this rank out of the collective -- and so does ANY other exception (status ERR_HIP on
     the peers; this rank re-raises the original exception after the exchange)"""
@@ -121,7 +124,7 @@ def guarded(local_call, device=None, group=None) -> MsmResult:
         pending = e         # their way into the all-gather, so this rank joins it too, with a generic status, and re-raises afterwards
         local = MsmError(ERR_HIP, "%s: %s" % (type(e).__name__, e))
     try:
-        return all_reduce_msm(local, device, group)
+        return all_reduce_msm(local, device, group, flags)
     except MsmError:
         if pending is not None:
             raise pending
@@ -130,4 +133,4 @@ def guarded(local_call, device=None, group=None) -> MsmResult:
 
 def distributed_msm_device(ctx, d_bases_ptr, d_scalars_ptr, n_local, device=None, group=None, d_inf_ptr=None) -> MsmResult:
     """this rank's shard is already in its HBM: run the HIP pipeline on it, then all-reduce the partials"""
-    return guarded(lambda: ctx.msm_device(d_bases_ptr, d_scalars_ptr, n_local, d_inf_ptr), device, group)
+    return guarded(lambda: ctx.msm_device(d_bases_ptr, d_scalars_ptr, n_local, d_inf_ptr), device, group, getattr(ctx, "flags", 0))

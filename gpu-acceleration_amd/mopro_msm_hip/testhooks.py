@@ -17,6 +17,7 @@ HOOKS_LIB_PATH = os.environ.get("MSM_HIP_HOOKS_LIB") or os.path.join(os.path.dir
 HOOK_SYMBOLS = [
     "msm_bn254_g1_generate_device", "msm_bn254_generate_scalars_host", "msm_test_fp_op", "msm_test_g1_op",
     "msm_test_decompose", "msm_calibrate", "msm_test_stage_dump", "msm_test_abandon_after_sort",
+    "msm_probe_wide_level", "msm_probe_launch_chain",
 ]
 _lib = None
 
@@ -42,6 +43,8 @@ def load_hooks_library():
     L.msm_test_decompose.argtypes = [vp, _u32p, C.c_size_t, C.c_uint32, C.POINTER(C.c_int32)]
     L.msm_test_abandon_after_sort.argtypes = [vp, _u32p, C.c_size_t]
     L.msm_calibrate.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.msm_probe_wide_level.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_longlong)]
+    L.msm_probe_launch_chain.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]
     L.msm_test_stage_dump.argtypes = [vp, _u32p, C.c_uint32, _u8p, _u32p, C.c_size_t, _u32p, _u32p, _u32p, _u32p, _u32p,
                                       C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _u32p]
     for name in HOOK_SYMBOLS:
@@ -96,6 +99,18 @@ class HooksContext(MsmContext):
         a, b = C.c_double(0), C.c_double(0)
         self._check(self._lib.msm_calibrate(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def probe_wide_level(self, threads, m, iters, mode):
+        """one workgroup, `iters` pairwise levels over m records in LDS (msm_probe_wide_level): 18 counters, see include/msm_hip_testhooks.h"""
+        out = (C.c_longlong * 18)()
+        self._check(self._lib.msm_probe_wide_level(self._h, threads, m, iters, mode, out))
+        return [int(v) for v in out]
+
+    def probe_launch_chain(self, n_adds, launches):
+        """microseconds per dependent launch of k_pair_level_wide over n_adds additions (0: an empty kernel)"""
+        us = C.c_double(0)
+        self._check(self._lib.msm_probe_launch_chain(self._h, n_adds, launches, C.byref(us)))
+        return us.value
 
     def test_decompose(self, scalars, window_bits=0):
         scalars = _words(scalars, 8)

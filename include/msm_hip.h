@@ -44,7 +44,10 @@
 extern "C" {
 #endif
 
-#define MSM_HIP_ABI_VERSION 6u
+/* A consumer must be built against the header of the library it loads: check msm_abi_version() == MSM_HIP_ABI_VERSION once after loading
+ * (the Rust shim and the Python binding do) -- msm_timings_t and msm_config_t have grown with the ABI number, and the plain getters write the
+ * whole struct of THEIR build.  ABI 7: msm_bn254_g1_combine_flags, msm_get_timings_sized / msm_multi_get_timings_sized, msm_multi_get_clock_stats. */
+#define MSM_HIP_ABI_VERSION 7u
 
 /* status codes */
 #define MSM_OK 0
@@ -144,7 +147,7 @@ typedef struct {
     float decompose_ms;  /* scalar windowing + signed digits + bucket histogram */
     float sort_ms;       /* bucket offsets (scan) + scatter of point indices    */
     float accumulate_ms; /* per-bucket point accumulation -- the graded kernel  */
-    float reduce_ms;     /* running-sum bucket reduction + per-window sums      */
+    float reduce_ms;     /* bucket reduction (row / column sums, bit sums).  Until ABI 5 this field also held what is now combine_ms */
     float finish_ms;     /* host Horner over the bit sums (+ normalisation if asked) */
     float total_ms;      /* wall clock of the whole call                        */
     uint64_t num_points;
@@ -248,6 +251,12 @@ int32_t msm_bn254_g1_device(msm_ctx *ctx, const void *d_bases_mont, const void *
  *      metal_msm.rs:204-261 runs on the CPU).  partials: k x 24 words Jacobian Montgomery. -------- */
 int32_t msm_bn254_g1_combine(const uint32_t *partials_jacobian_mont, size_t k, uint32_t out_jacobian_mont[24],
                              uint32_t out_affine_std[16], uint8_t *out_is_inf);
+/* the same with the representative chosen by the caller (ABI 7): flags = 0 behaves as msm_bn254_g1_combine; MSM_FLAG_DETERMINISTIC hands out the
+ * Z = 1 representative, i.e. the words a single context or msm_multi with that flag returns for the same group element -- what a
+ * one-process-per-GPU job folds its ranks' partials with when its contexts carry the flag (mopro_msm_hip.distributed.all_reduce_msm).
+ * Any other flag bit: MSM_ERR_BAD_ARG. */
+int32_t msm_bn254_g1_combine_flags(const uint32_t *partials_jacobian_mont, size_t k, uint32_t flags, uint32_t out_jacobian_mont[24],
+                                   uint32_t out_affine_std[16], uint8_t *out_is_inf);
 
 /* ---- multi-GPU inside ONE process (the reference has no multi-device code: host/gpu.rs:3-5 opens the
  *      system default device).  The caller-facing signature is the same as the single-GPU calls; the point range is cut
@@ -298,12 +307,18 @@ int32_t msm_multi_get_timings(const msm_multi *m, int32_t g, msm_timings_t *out)
  * rendezvous on the host first and ALL skip the exchange; the call returns the first failing rank's status, and
  * msm_multi_last_error() names the device and rank (metal_msm.rs:647-656: errors are returned, nothing hangs). */
 int32_t msm_multi_get_exchange_stats(const msm_multi *m, float *exchange_ms, float *shard_ms, int32_t nshard);
+int32_t msm_multi_get_timings_sized(const msm_multi *m, int32_t rank, void *out, size_t out_size); /* ABI 7, see msm_get_timings_sized */
+/* msm_get_clock_stats of rank `rank`'s context (ABI 7): a slow rank of a multi-GPU call can be told from a slow CLOCK on its device */
+int32_t msm_multi_get_clock_stats(msm_multi *m, int32_t rank, double *sclk_ghz, double *cycles_per_addition, uint64_t *samples);
 
 /* ---- introspection --------------------------------------------------------------------------- */
 /* the plan of a call on n points under (window_bits, flags); with MSM_FLAG_WINDOW_TABLE in flags: the plan of a RESIDENT call on a
  * set of n bases uploaded under those flags (window width, table factor, table memory) */
 int32_t msm_plan(size_t n, uint32_t window_bits, uint32_t flags, msm_plan_t *out);
 int32_t msm_get_timings(const msm_ctx *ctx, msm_timings_t *out);
+/* size-checked forms (ABI 7): at most out_size bytes are written -- a consumer built against an older, shorter msm_timings_t passes ITS
+ * sizeof and is not overrun; fields beyond the library's struct are left untouched.  out_size == 0: MSM_ERR_BAD_ARG. */
+int32_t msm_get_timings_sized(const msm_ctx *ctx, void *out, size_t out_size);
 /* per-stage hipEvents are OFF by default (every record costs ~6 us of stream time); when off, the stage fields of
  * msm_timings_t other than accumulate_ms / finish_ms / total_ms read 0 */
 int32_t msm_set_stage_timing(msm_ctx *ctx, int32_t enabled);

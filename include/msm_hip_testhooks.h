@@ -79,6 +79,20 @@ int32_t msm_test_stage_dump(msm_ctx *ctx, const uint32_t *bases_xy, uint32_t bas
  *      are left exactly as that failure leaves them.  The next call on the context must be right. */
 int32_t msm_test_abandon_after_sort(msm_ctx *ctx, const uint32_t *scalars, size_t n);
 
+/* ---- probes of the bucket reduction's dependent chain (tools/wide_level_probe.py -> profiles/r6_wide_level_breakdown.txt).
+ *      msm_probe_wide_level: ONE workgroup of `threads` threads runs `iters` pairwise levels e[i] += e[i + m/2] over m XYZZ records in LDS.
+ *        mode 0: eight lanes per addition (the body of lds_tree_wide), loop bracketed only
+ *        mode 1: the same with shader-cycle marks inside the addition of wavefront 0 (needs m/2 <= threads/8)
+ *        mode 2: one lane per addition (xyzz_add, the form of k_pair_level)
+ *      out[0] shader cycles of the loop, out[1] constant-rate (100 MHz) ticks of the loop, out[2 + k] (mode 1) cycles between mark k - 1 and
+ *      mark k summed over the levels: 1 operands loaded, 2 stage-1 product, 3 exchange + P / R, 4 squares, 5 special-case vote,
+ *      6 exchange + stage-3 operands, 7 stage-3 product, 8 exchange + X3 + stage-4 operands, 9 stage-4 product, 10 exchange + Y3,
+ *      11 result stored, 12 loop left, 13 barrier passed.
+ *      msm_probe_launch_chain: `launches` dependent launches back to back on the context's stream -- k_pair_level_wide over n_adds additions
+ *      each, or an empty kernel (n_adds = 0) -- microseconds per launch by hipEvents. */
+int32_t msm_probe_wide_level(msm_ctx *ctx, uint32_t threads, uint32_t m, uint32_t iters, uint32_t mode, long long out[18]);
+int32_t msm_probe_launch_chain(msm_ctx *ctx, uint32_t n_adds, uint32_t launches, double *us_per_launch);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,6 +72,10 @@ extern "C" {
         ctx: *mut MsmCtx, d_scalars: *const core::ffi::c_void, n: usize, hip_stream: *mut core::ffi::c_void, out_jacobian_mont: *mut u32,
         out_affine_std: *mut u32, out_is_inf: *mut u8,
     ) -> i32;
+    fn msm_abi_version() -> u32;
+    fn msm_bn254_g1_combine_flags(
+        partials_jacobian_mont: *const u32, k: usize, flags: u32, out_jacobian_mont: *mut u32, out_affine_std: *mut u32, out_is_inf: *mut u8,
+    ) -> i32;
 }
 
 struct Ctx(*mut MsmCtx);
@@ -79,8 +83,27 @@ unsafe impl Send for Ctx {}
 
 /// Process-global context: the reference rebuilds its whole Metal pipeline on every call
 /// (metal_msm.rs:693); here device, stream and HBM workspace persist.
+/// The header this file's `#[repr(C)]` structs and externs were written against (include/msm_hip.h MSM_HIP_ABI_VERSION): a library of
+/// another ABI would read `MsmConfig` past its end, so every handle creation checks it first.
+const MSM_HIP_ABI_VERSION: u32 = 7;
+fn abi_check() -> Result<(), String> {
+    let have = unsafe { msm_abi_version() };
+    if have == MSM_HIP_ABI_VERSION { Ok(()) } else { Err(format!("libmsm_hip.so has ABI {have}, mopro-msm-hip is built against ABI {MSM_HIP_ABI_VERSION}")) }
+}
+/// `msm_config_t.flags` of the process-global handles: `MSM_HIP_DETERMINISTIC=1` in the environment asks for the canonical Z = 1
+/// Jacobian limbs (MSM_FLAG_DETERMINISTIC) from `metal_variable_base_msm` -- the opt-in for callers that hash or `memcmp` a
+/// `G1Projective` instead of comparing it with `==` (include/msm_hip.h, "Determinism").
+fn global_flags() -> u32 {
+    match std::env::var("MSM_HIP_DETERMINISTIC") {
+        Ok(v) if !v.is_empty() && v != "0" => MSM_FLAG_DETERMINISTIC,
+        _ => 0,
+    }
+}
 static CTX: Lazy<Mutex<Result<Ctx, String>>> = Lazy::new(|| {
-    let cfg = MsmConfig { device: -1, window_bits: 0, flags: 0, stream_chunk_log2: 0, max_points: 0, batch_layout: 0, host_threads: 0 };
+    if let Err(e) = abi_check() {
+        return Mutex::new(Err(e));
+    }
+    let cfg = MsmConfig { device: -1, window_bits: 0, flags: global_flags(), stream_chunk_log2: 0, max_points: 0, batch_layout: 0, host_threads: 0 };
     let mut p: *mut MsmCtx = std::ptr::null_mut();
     let rc = unsafe { msm_ctx_create(&cfg, &mut p) };
     Mutex::new(if rc == 0 { Ok(Ctx(p)) } else { Err(last_error(std::ptr::null())) })
@@ -141,10 +164,10 @@ static LAYOUT: Lazy<Option<Layout>> = Lazy::new(|| {
 struct Multi(*mut MsmMulti);
 unsafe impl Send for Multi {}
 static MULTI: Lazy<Mutex<Option<Multi>>> = Lazy::new(|| {
-    if std::env::var_os("MSM_HIP_DEVICES").is_none() {
+    if std::env::var_os("MSM_HIP_DEVICES").is_none() || abi_check().is_err() {
         return Mutex::new(None);
     }
-    let cfg = MsmConfig { device: -1, window_bits: 0, flags: 0, stream_chunk_log2: 0, max_points: 0, batch_layout: 0, host_threads: 0 };
+    let cfg = MsmConfig { device: -1, window_bits: 0, flags: global_flags(), stream_chunk_log2: 0, max_points: 0, batch_layout: 0, host_threads: 0 };
     let mut p: *mut MsmMulti = std::ptr::null_mut();
     let rc = unsafe { msm_multi_create(std::ptr::null(), 0, &cfg, 0 /* MSM_MULTI_EXCHANGE_AUTO */, &mut p) };
     if rc == 0 && unsafe { msm_multi_num_devices(p) } > 1 {
@@ -341,6 +364,30 @@ pub fn hip_variable_base_msm_batch(bases: &[G1Affine], scalar_sets: &[&[BigInt<4
     Ok(jac.iter().map(to_projective).collect())
 }
 
+/// Fold the partial results of several GPUs / processes in the order given (host arithmetic inside the library; the "all-reduce" of a
+/// one-process-per-GPU job after its all-gather).  `deterministic`: hand out the canonical Z = 1 limbs -- the same limbs a single GPU with
+/// MSM_FLAG_DETERMINISTIC returns for this group element (msm_bn254_g1_combine_flags, ABI 7).
+pub fn hip_combine_partials(partials: &[G1Projective], deterministic: bool) -> Result<G1Projective, Box<dyn Error>> {
+    if partials.is_empty() {
+        return Err("Empty input".into());
+    }
+    abi_check()?;
+    let mut words = vec![0u64; partials.len() * 12];
+    for (i, p) in partials.iter().enumerate() {
+        words[i * 12..i * 12 + 4].copy_from_slice(&p.x.0 .0);
+        words[i * 12 + 4..i * 12 + 8].copy_from_slice(&p.y.0 .0);
+        words[i * 12 + 8..i * 12 + 12].copy_from_slice(&p.z.0 .0);
+    }
+    let mut jac = [0u64; 12];
+    let rc = unsafe {
+        msm_bn254_g1_combine_flags(
+            words.as_ptr() as *const u32, partials.len(), if deterministic { MSM_FLAG_DETERMINISTIC } else { 0 }, jac.as_mut_ptr() as *mut u32,
+            std::ptr::null_mut(), std::ptr::null_mut(),
+        )
+    };
+    if rc == 0 { Ok(to_projective(&jac)) } else { Err(format!("msm_bn254_g1_combine_flags failed ({rc})").into()) }
+}
+
 /// `msm_config_t.flags` bit: resident sets carry their window table (include/msm_hip.h MSM_FLAG_WINDOW_TABLE).
 pub const MSM_FLAG_WINDOW_TABLE: u32 = 4;
 /// `msm_config_t.flags` bit (ABI 6): the Jacobian words handed back are the canonical Z = 1 representative -- the same limbs for the same group
@@ -363,12 +410,15 @@ unsafe impl Send for HipResidentBases {}
 
 impl HipResidentBases {
     pub fn new(bases: &[G1Affine], window_table: bool) -> Result<Self, Box<dyn Error>> {
+        Self::with_flags(bases, if window_table { MSM_FLAG_WINDOW_TABLE } else { 0 })
+    }
+    /// `flags`: any of MSM_FLAG_WINDOW_TABLE | MSM_FLAG_DETERMINISTIC (canonical Z = 1 limbs from every MSM on this set)
+    pub fn with_flags(bases: &[G1Affine], flags: u32) -> Result<Self, Box<dyn Error>> {
         if bases.is_empty() {
             return Err("Empty input".into());
         }
-        let cfg = MsmConfig {
-            device: -1, window_bits: 0, flags: if window_table { MSM_FLAG_WINDOW_TABLE } else { 0 }, stream_chunk_log2: 0, max_points: 0, batch_layout: 0, host_threads: 0,
-        };
+        abi_check()?;
+        let cfg = MsmConfig { device: -1, window_bits: 0, flags, stream_chunk_log2: 0, max_points: 0, batch_layout: 0, host_threads: 0 };
         let mut p: *mut MsmCtx = std::ptr::null_mut();
         if unsafe { msm_ctx_create(&cfg, &mut p) } != 0 {
             return Err(last_error(std::ptr::null()).into());

@@ -62,10 +62,15 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         sys.exit(0 if good else 1)
-    with mh.MsmContext(device=dev_index) as ctx:
+    # MSM_TEST_DETERMINISTIC=1: the contexts carry MSM_FLAG_DETERMINISTIC, so the fold of the ranks' partials must hand out the
+    # canonical Z = 1 Jacobian words -- identical on every rank and on every repetition, Z == R mod p (Montgomery one)
+    det = os.environ.get("MSM_TEST_DETERMINISTIC", "0") == "1"
+    jac_seen = set()
+    with mh.MsmContext(device=dev_index, flags=mh.FLAG_DETERMINISTIC if det else 0) as ctx:
         res = None
         for _ in range(3):
             res = md.distributed_msm_device(ctx, d_b.data_ptr(), d_s.data_ptr(), n, device=xdev)
+            jac_seen.add(bytes(res.jacobian_mont.tobytes()))
     rccl_single = None
     if nccl and world == 1:
         # ONE rank over the real RCCL backend (round 5; 1-GPU boxes): all_reduce_msm returns early for world 1, so the exchange itself --
@@ -84,7 +89,11 @@ def main():
     g[0], g[8] = 1, 2
     exp, einf = orc.g1_to_affine_std(orc.g1_scalar_mul(g, orc.int_to_words(sum(dots) % orc.R_ORDER)))
     ok = bool((res.affine_std == exp).all()) and not res.is_infinity and rccl_single is not False
+    if det:
+        one = orc.fq_to_mont(orc.int_to_words(1))
+        ok = ok and len(jac_seen) == 1 and bool((res.jacobian_mont[16:24] == one).all())
     sys.stdout.write(json.dumps({"rank": rank, "ok": ok, "affine": res.affine_std.tolist(), "device": dev_index,
+                                 "jacobian": res.jacobian_mont.tolist(), "jacobian_representations": len(jac_seen),
                                  "backend": "nccl" if nccl else "gloo", "rccl_exchange_with_one_rank": rccl_single}) + "\n")  # ONE write: the ranks share a pipe
     sys.stdout.flush()
     dist.barrier()

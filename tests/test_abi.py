@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/msm_hip.h but not exported"
     assert sorted(mh.ABI_SYMBOLS) == syms
-    assert lib.msm_abi_version() == 6
+    assert lib.msm_abi_version() == mh.ABI_VERSION == 7
 
 
 def test_hooks_live_in_their_own_library():

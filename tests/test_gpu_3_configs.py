@@ -565,6 +565,50 @@ def test_two_ranks_on_one_gpu():
     assert len(lines) == 2 and all(l["ok"] for l in lines) and lines[0]["affine"] == lines[1]["affine"]
 
 
+def test_two_ranks_deterministic_flag_gives_the_canonical_jacobian_on_every_rank():
+    """with MSM_FLAG_DETERMINISTIC on every rank's context the one-process-per-GPU fold (distributed.all_reduce_msm ->
+    msm_bn254_g1_combine_flags) must return the Z = 1 representative -- the same 24 words on both ranks, on every repetition, and the
+    words a single context with the flag returns for the whole instance."""
+    p, lines = _torchrun_two_ranks({"MSM_TEST_DETERMINISTIC": "1"})
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert len(lines) == 2 and all(l["ok"] for l in lines), lines
+    assert lines[0]["jacobian"] == lines[1]["jacobian"] and all(l["jacobian_representations"] == 1 for l in lines)
+    # one context, whole instance (the worker's generator streams: seeds 0xB2540091 / 92, 2^18 points)
+    import torch
+    n = 1 << 18
+    d_b = torch.empty(n * 16, dtype=torch.int32, device="cuda:0")
+    d_s = torch.empty(n * 8, dtype=torch.int32, device="cuda:0")
+    with th.HooksContext() as gen:
+        gen.generate_device(0xB2540091, 0xB2540092, n, d_b.data_ptr(), d_s.data_ptr())
+    with mh.MsmContext(flags=mh.FLAG_DETERMINISTIC) as c:
+        r = c.msm_device(d_b.data_ptr(), d_s.data_ptr(), n)
+    assert r.jacobian_mont.tolist() == lines[0]["jacobian"]
+    # and the plain fold keeps handing out whatever representative the addition chain gives (flags = 0), the flagged one the canonical words
+    parts = np.stack([r.jacobian_mont, np.zeros(24, np.uint32)])
+    assert (mh.combine_partials(parts, flags=mh.FLAG_DETERMINISTIC).jacobian_mont == r.jacobian_mont).all()
+    with pytest.raises(mh.MsmError):
+        mh.combine_partials(parts, flags=mh.FLAG_WINDOW_TABLE)  # only the representative may be chosen here
+
+
+@pytest.mark.parametrize("threads", [1, 2, 4])
+def test_host_threads_of_the_configuration(hk, threads):
+    """msm_config_t.host_threads (ABI 6, was `reserved`): 1 = no pool, the caller finishes alone; 2 = default; 4; 65 -> BAD_ARG.
+    Same bits whatever the thread count, through a context and through msm_multi."""
+    it = Instance(hk, 16, seed=0xB2540A51)
+    exp, _ = _expected(it.dot())
+    with mh.MsmContext(host_threads=threads) as c:
+        for _ in range(3):
+            assert (c.msm_device(it.d_b.data_ptr(), it.d_s.data_ptr(), it.n).affine_std == exp).all()
+    hb = it.d_b.cpu().numpy().view(np.uint32).reshape(it.n, 16)
+    hs = it.d_s.cpu().numpy().view(np.uint32).reshape(it.n, 8)
+    with mh.MsmMulti(devices=[0, 0], host_threads=threads) as m:
+        assert (m.msm(hb, hs, mh.FORM_MONT).affine_std == exp).all()
+    if threads == 1:
+        with pytest.raises(mh.MsmError) as e:
+            mh.MsmContext(host_threads=65)
+        assert e.value.code == mh.ERR_BAD_ARG
+
+
 def test_one_rank_over_the_rccl_backend():
     """torch.distributed's `nccl` backend (= RCCL) had run on no hardware (VERDICT r4 missing 1: no box with two devices).  One torchrun rank on
     the one device there is: init_process_group("nccl", device_id), the 100-byte all_gather_into_tensor of mopro_msm_hip.distributed on the
