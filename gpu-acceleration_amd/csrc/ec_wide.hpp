@@ -56,10 +56,14 @@ __device__ __forceinline__ void wide_mark(long long* ts, int i) {
 
 // opa, opb: this lane's stage-1 operands (coordinate wide_op?_coord(role) of operand wide_op?_rec(role); roles 6, 7: anything
 // normalised).  operand_is_identity: role 4 passes (ZZ1 == 0 || ZZ2 == 0), other roles false.
-// Returns true (group-uniform) if the pair needs the scalar complete addition; otherwise
-//   role 1: out0 = X3 (< 7p), out1 = Y3 (< 5p)      role 4: out0 = ZZ3 (< 2p)      role 5: out0 = ZZZ3 (< 2p)
+// Returns true (group-uniform) if the pair needs the scalar complete addition; otherwise ONE output coordinate per role:
+//   role 1: out = X3 (< 7p)      role 2: out = Y3 (< 5p)      role 4: out = ZZ3 (< 2p)      role 5: out = ZZZ3 (< 2p)
+// (wide_out_coord(role) names the coordinate; round 6: one coordinate per lane -- the result goes out in one predicated store instead of three
+// divergent ones -- one subtraction per stage instead of both candidates, X3 with one carry ripple: 6861 -> see profiles/r6_wide_level_breakdown.txt)
+__device__ __forceinline__ bool wide_has_out(uint32_t role) { return (0x36u >> role) & 1u; }                // roles 1, 2, 4, 5
+__device__ __forceinline__ uint32_t wide_out_coord(uint32_t role) { return (0x0E10u >> (2 * role)) & 3u; }  // -,0,1,-,2,3,-,-
 template <bool PROBE = false>
-__device__ __forceinline__ bool xyzz_add_wide(const fp& opa, const fp& opb, bool operand_is_identity, fp& out0, fp& out1, long long* ts = nullptr) {
+__device__ __forceinline__ bool xyzz_add_wide(const fp& opa, const fp& opb, bool operand_is_identity, fp& out, long long* ts = nullptr) {
     const int lane = (int)(threadIdx.x & 63u);
     const int base = lane & ~(WIDE_LANES - 1);
     const uint32_t role = (uint32_t)lane & (WIDE_LANES - 1);
@@ -71,7 +75,8 @@ __device__ __forceinline__ bool xyzz_add_wide(const fp& opa, const fp& opb, bool
     // stage 2: r0 PP = (U2-U1)^2, r1 RR = (S2-S1)^2
     const fp g1 = wide_shfl(s1, base + (role == 0 ? 1 : role == 1 ? 2 : (int)role));  // r0 <- U2, r1 <- S1
     const fp g2 = wide_shfl(s1, base + (role == 1 ? 3 : (int)role));                   // r1 <- S2
-    const fp pr = role == 0 ? fp_sub<3>(g1, s1) : fp_sub<3>(g2, g1);  // r0: P = U2-U1, r1: R = S2-S1 (< 4.09p); others: unused
+    // r0: P = U2 - U1 = g1 - s1;  r1: R = S2 - S1 = g2 - g1 (< 4.09p); others: unused.  Minuend and subtrahend are SELECTED, then subtracted once
+    const fp pr = fp_sub<3>(wide_select(role == 0, g1, g2), wide_select(role == 0, s1, g1));
     wide_mark<PROBE>(ts, 3);
     const fp s2 = fp_sqr(pr);                                           // r0 PP, r1 RR  (< 1.1p)
     wide_mark<PROBE>(ts, 4);
@@ -93,16 +98,17 @@ __device__ __forceinline__ bool xyzz_add_wide(const fp& opa, const fp& opb, bool
     // stage 4: r1 T1 = R*(Q - X3), r2 T2 = S1*PPP, r5 ZZZ3 = Zb*PPP
     const fp ppp = wide_shfl(s3, base);      // PPP
     const fp q = wide_shfl(s3, base + 2);    // Q
-    const fp x3 = fp_sub<5>(s2, fp_add(ppp, fp_dbl(q)));  // r1: RR - (PPP + 2Q): subtrahend < 3.05p; X3 < 6.1p
+    const fp x3 = fp_sub_b_2c(s2, ppp, q);   // r1: RR + 5p - PPP - 2Q, one carry ripple (PPP + 2Q < 3.05p < 4p); X3 < 6.1p
     const fp a4 = role == 1 ? pr : s1;                       // r1: R;  r2: S1;  r5: Zb
     const fp b4 = role == 1 ? fp_sub<8>(q, x3) : ppp;        // r1: Q - X3 (< 9.01p)
     wide_mark<PROBE>(ts, 8);
     const fp s4 = fp_mul(a4, b4);                            // r1 T1 (< 1.22p), r2 T2 (< 1.01p), r5 ZZZ3
     wide_mark<PROBE>(ts, 9);
 
-    const fp t2 = wide_shfl(s4, base + 2);
-    out0 = role == 1 ? x3 : role == 4 ? s3 : s4;  // r1 X3, r4 ZZ3, r5 ZZZ3
-    out1 = fp_sub<3>(s4, t2);                     // r1: Y3 = T1 - T2 (< 4.3p)
+    // Y3 = T1 - T2 on role 2 (it holds T2 and fetches T1), so that roles 1, 2, 4, 5 hand out one coordinate each
+    const fp t1 = wide_shfl(s4, base + 1);
+    const fp y3 = fp_sub<3>(t1, s4);                         // r2: (< 4.3p); others: unused
+    out = role == 1 ? x3 : role == 2 ? y3 : role == 4 ? s3 : s4;
     wide_mark<PROBE>(ts, 10);
     return false;
 }

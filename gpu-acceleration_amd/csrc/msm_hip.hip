@@ -108,6 +108,7 @@ struct Knobs {
     uint32_t device_chunk_log2 = 22;           // MSM_HIP_DEVICE_CHUNK_LOG2: point ranges of device-resident instances; 0 = never cut
     uint32_t stream_min_log2 = 19;             // MSM_HIP_STREAM_MIN_LOG2: host calls are streamed from this size on (tools/host_path_sweep.py)
     uint32_t stream_chunk_log2 = 0;            // MSM_HIP_STREAM_CHUNK_LOG2: 0 = by size (product: msm_config_t.stream_chunk_log2)
+    std::vector<uint32_t> stream_schedule;     // MSM_HIP_STREAM_SCHEDULE="17,18,18,18,17": the chunks of a streamed host call as log2 sizes, used when they sum to n (tools/host_schedule_sweep.py)
     int host_threads = -1;                     // MSM_HIP_HOST_THREADS: CPU finish threads incl. the caller; -1 = msm_config_t.host_threads
     msmplan::table_knobs table;                // MSM_HIP_TABLE_C / MSM_HIP_TABLE_F / MSM_HIP_TABLE_MAX_GB / MSM_HIP_TABLE_GLV_MAX_LOG2 (window table of a resident set)
     static Knobs from_env() {
@@ -124,6 +125,15 @@ struct Knobs {
         k.device_chunk_log2 = (uint32_t)num("MSM_HIP_DEVICE_CHUNK_LOG2", 0, 30, 22);
         k.stream_min_log2 = (uint32_t)num("MSM_HIP_STREAM_MIN_LOG2", 9, 31, 19);
         k.stream_chunk_log2 = std::getenv("MSM_HIP_STREAM_CHUNK_LOG2") ? (uint32_t)num("MSM_HIP_STREAM_CHUNK_LOG2", 8, 28, 0) : 0u;
+        if (const char* e = std::getenv("MSM_HIP_STREAM_SCHEDULE")) {
+            for (const char* p = e; *p;) {
+                char* end = nullptr;
+                const long v = std::strtol(p, &end, 10);
+                if (end == p) break;
+                if (v >= 8 && v <= 28) k.stream_schedule.push_back((uint32_t)v);
+                p = *end ? end + 1 : end;
+            }
+        }
         if (std::getenv("MSM_HIP_HOST_THREADS")) k.host_threads = (int)num("MSM_HIP_HOST_THREADS", 0, 64, 2);
         k.table.c = (uint32_t)num("MSM_HIP_TABLE_C", 0, 20, 0);
         k.table.f = (uint32_t)num("MSM_HIP_TABLE_F", 0, 128, 0);
@@ -538,19 +548,24 @@ int32_t enqueue_sort(msm_ctx* c, const PipeState& ps, hipStream_t st, bool into)
         // workgroup size by mean region size (a workgroup stages up to 16 elements per thread); grid.x = the window's regions +
         // BIG_WORKERS_X worker blocks for the batches of oversized regions, which k_big_place then places
         const uint32_t wx = std::max(msmk::BIG_WORKERS_X, (msmk::BIG_WORKERS_MIN + sW - 1) / sW);  // worker blocks per sort window
-        const dim3 gf(ncoarse + wx, sW), gp(wx, sW);
+        const dim3 gf(ncoarse + wx, sW);
         uint32_t* srt = (uint32_t*)c->sorted.p;
         const msmk::sort_hi hi{counts, NS, sg.nsuper, (uint32_t)(((size_t)1 << idx_bits) / msmk::SUBTILE)};
-        if (fine_block == 256) {
-            msmk::k_fine_sort<256><<<gf, 256, 0, st>>>(tmp, rstart, offsets, srt, nb, fine_bits, idx_bits, ncoarse, bigslot, big, hi);
-            msmk::k_big_place<256><<<gp, 256, 0, st>>>(tmp, rstart, offsets, srt, nb, fine_bits, idx_bits, ncoarse, bigslot, big, hi);
-        } else if (fine_block == 512) {  // (up to a mean of 2048: at 4096 the 512-thread variant is 1.5 us faster on uniform scalars only)
-            msmk::k_fine_sort<512><<<gf, 512, 0, st>>>(tmp, rstart, offsets, srt, nb, fine_bits, idx_bits, ncoarse, bigslot, big, hi);
-            msmk::k_big_place<512><<<gp, 512, 0, st>>>(tmp, rstart, offsets, srt, nb, fine_bits, idx_bits, ncoarse, bigslot, big, hi);
-        } else {
-            msmk::k_fine_sort<1024><<<gf, 1024, 0, st>>>(tmp, rstart, offsets, srt, nb, fine_bits, idx_bits, ncoarse, bigslot, big, hi);
-            msmk::k_big_place<1024><<<gp, 1024, 0, st>>>(tmp, rstart, offsets, srt, nb, fine_bits, idx_bits, ncoarse, bigslot, big, hi);
-        }
+        // ... in the SAME launch that tallies the accumulation's pieces (k_place_count, round 6: k_big_place was an empty launch on uniform scalars,
+        // 4.5 us of the dependent chain at every size).  The sort stage ends with the fine sort (EV_SORT); the merged launch belongs to plan_ms.
+        const uint32_t count_blocks = (uint32_t)((tb + msmk::PLACE_COUNT_SPAN - 1) / msmk::PLACE_COUNT_SPAN);
+#define MSM_FINE_AND_PLACE(FB) \
+    do { \
+        msmk::k_fine_sort<FB><<<gf, FB, 0, st>>>(tmp, rstart, offsets, srt, nb, fine_bits, idx_bits, ncoarse, bigslot, big, hi); \
+        if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_SORT], st)); \
+        msmk::k_place_count<FB><<<count_blocks + wx * sW, FB, 0, st>>>(tmp, rstart, offsets, srt, nb, fine_bits, idx_bits, ncoarse, bigslot, big, hi, count_blocks, wx, sW, \
+                                                                  (uint32_t)tb, ps.pmax, ps.psplit, (uint32_t*)c->phist.p, flags, (uint32_t*)c->longlist.p, \
+                                                                  (uint32_t*)c->midlist.p, (uint32_t*)c->pbase.p, (uint32_t*)c->buckets.p, into ? 1u : 0u); \
+    } while (0)
+        if (fine_block == 256) MSM_FINE_AND_PLACE(256);
+        else if (fine_block == 512) MSM_FINE_AND_PLACE(512);  // (up to a mean of 2048: at 4096 the 512-thread variant is 1.5 us faster on uniform scalars only)
+        else MSM_FINE_AND_PLACE(1024);
+#undef MSM_FINE_AND_PLACE
     } else {
         // K2/1: per-tile LDS histograms, then per-bucket prefix over tiles
         if (sg.tiled) {
@@ -574,10 +589,12 @@ int32_t enqueue_sort(msm_ctx* c, const PipeState& ps, hipStream_t st, bool into)
             msmk::k_scatter<<<g, 256, 0, st>>>(digits, (uint32_t*)c->ranks.p, offsets, (uint32_t*)c->sorted.p, (uint32_t)sn, nb);
         }
     }
-    if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_SORT], st));
     // the piece list, longest first (its histogram and bin cursors were zeroed at the head of this chain: msmk::clear_piece_bins)
-    msmk::k_piece_count<<<grid1(tb, 1024), 1024, 0, st>>>(offsets, (uint32_t)tb, ps.pmax, ps.psplit, (uint32_t*)c->phist.p, flags, (uint32_t*)c->longlist.p,
-                                                        (uint32_t*)c->midlist.p, (uint32_t*)c->pbase.p, (uint32_t*)c->buckets.p, into ? 1u : 0u);
+    if (!sg.two_level) {  // (the two-level sort tallied the pieces in its last launch, k_place_count)
+        if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_SORT], st));
+        msmk::k_piece_count<<<grid1(tb, 1024), 1024, 0, st>>>(offsets, (uint32_t)tb, ps.pmax, ps.psplit, (uint32_t*)c->phist.p, flags, (uint32_t*)c->longlist.p,
+                                                            (uint32_t*)c->midlist.p, (uint32_t*)c->pbase.p, (uint32_t*)c->buckets.p, into ? 1u : 0u);
+    }
     msmk::k_piece_scatter<<<grid1(tb, 1024), 1024, 0, st>>>(offsets, (uint32_t)tb, ps.pmax, ps.psplit, (const uint32_t*)c->phist.p, (uint32_t*)c->pcursor.p,
                                                           (const uint32_t*)c->pbase.p, (uint4*)c->plist.p, flags);
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_PLAN], st));  // msm_timings_t.plan_ms
@@ -709,7 +726,7 @@ int32_t enqueue_reduce(msm_ctx* c, const PipeState& ps, hipStream_t st, uint32_t
     HIPCHK(c, hipHostGetDevicePointer((void**)&q_dev, h_qsums_dst, 0));
     HIPCHK(c, hipHostGetDevicePointer((void**)&f_dev, h_flags_dst, 0));
     if (n_hi / 2 <= msmk::WIDE_TREE_MAX && n_lo <= msmk::WIDE_TREE_MAX)
-        msmk::k_reduce_bits_wide<<<W * (kb + 1), 512, 0, st>>>(rin, cin, q_dev, n_hi, n_lo, kb_lo, kb, flags, f_dev);
+        msmk::k_reduce_bits_wide<7><<<W * (kb + 1), 512, 0, st>>>(rin, cin, q_dev, n_hi, n_lo, kb_lo, kb, flags, f_dev);
     else
         msmk::k_reduce_bits<<<W * (kb + 1), 64, 0, st>>>(rin, cin, q_dev, n_hi, n_lo, kb_lo, kb, flags, f_dev);
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_REDUCE], st));
@@ -1101,6 +1118,14 @@ std::vector<size_t> stream_schedule(const msm_ctx* c, size_t n) {
     // kernels and three slots: halved once / twice / three times +0.08 / +0.2 / +0.3 ms -- a 2^17-point chunk still costs 0.30 ms of
     // sort + accumulation INTO 2^18 buckets, two of them 0.17 ms more than the chunk they replace, and the compute stream has no slack
     // left to hide it).  A remainder below half a chunk joins the last chunk.
+    if (!c->knobs.stream_schedule.empty()) {  // (hooks build: an explicit schedule, taken when it covers exactly n points)
+        size_t tot = 0;
+        for (uint32_t lg2 : c->knobs.stream_schedule) tot += (size_t)1 << lg2;
+        if (tot == n) {
+            for (uint32_t lg2 : c->knobs.stream_schedule) sizes.push_back((size_t)1 << lg2);
+            return sizes;
+        }
+    }
     const uint32_t min_log2 = c->knobs.stream_min_log2;
     uint32_t lg = n < ((size_t)1 << 21) ? 18u : n < ((size_t)1 << 23) ? 19u : 20u;
     if (c->knobs.stream_chunk_log2) lg = c->knobs.stream_chunk_log2;

@@ -155,19 +155,12 @@ __device__ __forceinline__ void wide_add_records(const uint32_t* a_rec, const ui
     const fp opb = load_coord(wide_opb_rec(role) ? b_rec : a_rec, wide_opb_coord(role));
     const bool ident = role == 4 && (fp_is_zero_exact(opa) || fp_is_zero_exact(opb));  // role 4 holds ZZ1 and ZZ2
     wide_mark<PROBE>(ts, 1);
-    fp o0, o1;
-    if (xyzz_add_wide<PROBE>(opa, opb, ident, o0, o1, ts)) {
+    fp o;
+    if (xyzz_add_wide<PROBE>(opa, opb, ident, o, ts)) {
         if (role == 0) add_records_complete(a_rec, b_rec, out_rec);
         return;
     }
-    if (role == 1) {
-        store_coord(out_rec, 0, o0);
-        store_coord(out_rec, 1, o1);
-    } else if (role == 4) {
-        store_coord(out_rec, 2, o0);
-    } else if (role == 5) {
-        store_coord(out_rec, 3, o0);
-    }
+    if (wide_has_out(role)) store_coord(out_rec, wide_out_coord(role), o);
     wide_mark<PROBE>(ts, 11);
 }
 constexpr uint32_t WIDE_TREE_MAX = 256;  // records one workgroup's LDS tree holds (36 KB)
@@ -191,6 +184,33 @@ __device__ __forceinline__ void store_jacobian_mont256(uint32_t* o, const jacobi
     store_words8(o + 8, w);
     fp_to_mont256(w, j.z);
     store_words8(o + 16, w);
+}
+// The same for the XYZZ record `rec` (LDS), by the first THREE lanes of the calling wavefront (round 6).  The conversion is three independent chains --
+//   X' = X * (ZZ^2)^2 * c     Y' = Y * (ZZZ^2)^2 * c     Z' = ZZ * ZZZ * c          (c = 2^256 / 2^261: internal -> arkworks' Montgomery domain)
+// -- of 4, 4 and 2 multiplications: lane 0, 1, 2 run one each through ONE fp_mul call site (a loop of four trips), 4 multiplications in series and
+// 1.4 KB of code instead of the 10 in series and ~14 KB, executed once and cold, of store_jacobian_mont256(xyzz_to_jacobian()) on one lane: that tail
+// was 14 of k_reduce_bits_wide's 40 us (profiles/r6_wide_level_breakdown.txt).  The identity (ZZ == 0) goes out as (R, R, 0), as there.
+// Call with threadIdx.x < 64 (whole first wavefront, any lanes beyond 2 idle along); o = 24 words, HBM or pinned host memory.
+__device__ __forceinline__ void store_jacobian_mont256_lanes(uint32_t* o, const uint32_t* rec) {
+    const uint32_t lane = threadIdx.x;
+    if (lane >= 3) return;
+    const fp zz = load_coord(rec, 2), zzz = load_coord(rec, 3);
+    const bool ident = fp_is_zero_exact(zz);
+    const fp xy = load_coord(rec, lane == 1 ? 1u : 0u);  // lane 0: X, lane 1: Y (lane 2: unused)
+    const fp cm = fp_const(FP29_OUT_MONT);
+    fp a = lane == 1 ? zzz : zz, b = lane == 0 ? zz : zzz, r = a;  // trip 0: ZZ^2 | ZZZ^2 | ZZ * ZZZ
+#pragma unroll 1
+    for (int t = 0; t < 4; t++) {
+        const fp m = fp_mul(a, b);
+        if (lane < 2 || t < 2) r = m;  // lane 2 is done after two trips (its later products are discarded)
+        // next trip:  1: square again | square again | * c      2: * X | * Y | -      3: * c | * c | -
+        a = r;
+        b = t == 0 ? (lane == 2 ? cm : r) : t == 1 ? xy : cm;
+        if (t == 1 && ident && lane < 2) a = fp_one(), b = fp_one();  // identity: X = Y = 1 (internal domain: one * one = one), then * c like any value
+    }
+    uint32_t w[8];
+    fp_pack(w, fp_reduce_lt2p(r));
+    store_words8(o + 8 * lane, w);
 }
 __device__ __forceinline__ jacobian load_jacobian_mont256(const uint32_t* p) {
     uint32_t w[8];
@@ -1129,59 +1149,6 @@ __global__ void __launch_bounds__(FINE_BLOCK) k_fine_sort(const uint32_t* __rest
     }
 }
 
-// second half of the oversized-region path: bucket offsets from the region's global fine histogram, then every batch is placed;
-// a batch reserves its share of each bucket with ONE global cursor add per bucket.  grid = (BIG_WORKERS_X, W).
-template <int FINE_BLOCK>
-__global__ void __launch_bounds__(FINE_BLOCK) k_big_place(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ region_start,
-                                                          uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted, uint32_t nb,
-                                                          uint32_t fine_bits, uint32_t idx_bits, uint32_t ncoarse,
-                                                          const uint32_t* __restrict__ bigslot, uint32_t* __restrict__ big, sort_hi hi) {
-    constexpr uint32_t CAP = (uint32_t)FINE_BLOCK * FINE_PER_THREAD;
-    __shared__ uint32_t s_ex[FINE_BINS_MAX], s_cnt[FINE_BINS_MAX], s_base[FINE_BINS_MAX], s_wtot[FINE_BINS_MAX / 64], s_bnd[SUPER_MAX];
-    const uint32_t nitems = min(big[0], BIG_MAX_ITEMS);
-    const uint32_t nfine = 1u << fine_bits, fmask = nfine - 1u, idx_mask = (1u << idx_bits) - 1u;
-    for (uint32_t it = blockIdx.x + gridDim.x * blockIdx.y; it < nitems; it += gridDim.x * gridDim.y) {
-        const uint32_t rr = big[BIG_ITEMS_OFF + 2 * it], z = big[BIG_ITEMS_OFF + 2 * it + 1];
-        if (rr == BIG_NONE) continue;  // uniform
-        uint32_t* tab = big + BIG_TAB_OFF + (size_t)bigslot[rr] * BIG_SLOT_WORDS;
-        const uint32_t r0 = region_start[rr], b0 = r0 + z * CAP, b1 = min(region_start[rr + 1], b0 + CAP);
-        __syncthreads();
-        sort_hi_load(hi, rr / ncoarse, rr % ncoarse, ncoarse, s_bnd);
-        // exclusive prefix of the region's bucket counts
-        const uint32_t ex = fine_scan(threadIdx.x < nfine ? tab[threadIdx.x] : 0u, s_wtot);
-        if (threadIdx.x < nfine) {
-            s_ex[threadIdx.x] = ex;
-            s_cnt[threadIdx.x] = 0;
-        }
-        __syncthreads();
-        if (z == 0 && threadIdx.x < nfine)  // the first batch publishes the buckets' CSC column pointers
-            offsets[(size_t)(rr / ncoarse) * nb + ((size_t)(rr % ncoarse) << fine_bits) + threadIdx.x] = r0 + s_ex[threadIdx.x];
-        uint32_t eb[FINE_PER_THREAD];
-#pragma unroll
-        for (int k = 0; k < FINE_PER_THREAD; k++) {
-            uint32_t j = b0 + threadIdx.x + k * FINE_BLOCK;
-            eb[k] = j < b1 ? tmp[j] : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < FINE_PER_THREAD; k++)
-            if (b0 + threadIdx.x + k * FINE_BLOCK < b1) lds_inc(s_cnt, (eb[k] >> idx_bits) & fmask);
-        __syncthreads();
-        if (threadIdx.x < nfine) {
-            const uint32_t cn = s_cnt[threadIdx.x];
-            s_base[threadIdx.x] = cn ? atomicAdd(&tab[FINE_BINS_MAX + threadIdx.x], cn) : 0u;  // this batch's slice of every bucket
-            s_cnt[threadIdx.x] = 0;                                                             // becomes the local cursor
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < FINE_PER_THREAD; k++) {
-            if (b0 + threadIdx.x + k * FINE_BLOCK >= b1) continue;
-            const uint32_t f = (eb[k] >> idx_bits) & fmask;
-            const uint32_t pos = r0 + s_ex[f] + s_base[f] + lds_inc(s_cnt, f);
-            sorted[pos] = ((eb[k] & idx_mask) + sort_hi_of(hi, s_bnd, b0 - r0 + threadIdx.x + k * FINE_BLOCK, idx_bits)) | (eb[k] & SIGN_BIT);
-        }
-    }
-}
-
 // K2 phase 3 (fallback path): place every (point, sign) at offsets[bucket] + rank
 __global__ void k_scatter(const uint32_t* __restrict__ digits, const uint32_t* __restrict__ ranks,
                           const uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted, uint32_t n, uint32_t nb) {
@@ -1220,7 +1187,7 @@ __global__ void k_scatter(const uint32_t* __restrict__ digits, const uint32_t* _
 // 2^22 5.32 -> 5.00.
 constexpr uint32_t LONG_SPAN = 8;     // split buckets of this many pieces or more are folded by whole workgroups (k_combine_pieces)
 constexpr uint32_t LONG_SEG = 2048;   // pieces of a long bucket folded by one workgroup
-constexpr uint32_t LONG_BLOCKS = 1024, MID_BLOCKS = 128;  // k_combine_pieces' grid: (bucket, segment) items grid-stride over the first, listed buckets over the rest
+constexpr uint32_t LONG_BLOCKS = 1024, MID_BLOCKS = 1024;  // k_combine_pieces' grid: (bucket, segment) items grid-stride over the first, listed buckets over the rest
 // (PIECE_BINS, at the top of this file: pmax <= PIECE_BINS, one histogram bin per piece length)
 constexpr uint32_t PF_WHOLE = 0x80000000u;            // piece.z: the bucket is this one piece -> the sum goes to buckets[k]
 constexpr uint32_t PF_FIRST = 0x40000000u;            // piece.z: first piece of a split bucket (INTO: starts from the bucket's old value)
@@ -1262,44 +1229,45 @@ __device__ __forceinline__ uint32_t block1024_exclusive_scan(uint32_t v, uint32_
 }
 
 // pass 1: histogram of the piece lengths (LDS per workgroup, one global add per non-empty bin), the identity for empty buckets, a run of
-// partial-sum slots and a list entry for every split bucket.  One thread per bucket.
-__global__ void __launch_bounds__(1024) k_piece_count(const uint32_t* __restrict__ offsets, uint32_t total_buckets, uint32_t pmax, uint32_t psplit,
-                                                     uint32_t* __restrict__ hist, uint32_t* __restrict__ flags, uint32_t* __restrict__ long_list,
-                                                     uint32_t* __restrict__ mid_list, uint32_t* __restrict__ pbase, uint32_t* __restrict__ buckets,
-                                                     uint32_t into) {
-    __shared__ uint32_t s_hist[PIECE_BINS + 1];
-    __shared__ uint32_t s_n[3], s_base[3];  // [0] mid list, [1] long list, [2] partial-sum slots: reserved once per workgroup
+// partial-sum slots and a list entry for every split bucket.  One thread per bucket.  The steps are functions because two kernels run them:
+// k_piece_count (every sort path) and k_place_count (the two-level sort: the same launch also places the batches of oversized regions).
+struct piece_tally {
+    uint32_t kindl, slot, nseg, m, pslot;  // kindl: 0 = mid list, 1 = long list, 2 = none
+};
+__device__ __forceinline__ void piece_tally_begin(uint32_t* s_hist, uint32_t* s_n, uint32_t pmax) {  // whole workgroup
     for (uint32_t i = threadIdx.x; i <= pmax; i += blockDim.x) s_hist[i] = 0;
     if (threadIdx.x < 3) s_n[threadIdx.x] = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0)  // mixed additions executed so far (msm_timings_t.num_adds), all chunks of a streamed MSM
-        *reinterpret_cast<unsigned long long*>(flags + FLAG_ADDS64) += (unsigned long long)flags[FLAG_PAIRS];
     __syncthreads();
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t kindl = 2, slot = 0, nseg = 1, m = 0, pslot = 0;  // 0 = mid list, 1 = long list, 2 = none
-    if (k < total_buckets) {
-        const uint32_t beg = offsets[k], sz = offsets[k + 1] - beg;
-        if (sz == 0) {
-            if (!into) store_xyzz(buckets + (size_t)k * XW, xyzz_identity());  // (into: the bucket keeps the earlier chunks' sum)
+}
+__device__ __forceinline__ piece_tally piece_tally_bucket(uint32_t k, uint32_t sz, uint32_t pmax, uint32_t psplit, uint32_t* s_hist, uint32_t* s_n,
+                                                          uint32_t* __restrict__ buckets, uint32_t into) {
+    piece_tally t{2u, 0u, 1u, 0u, 0u};
+    if (sz == 0) {
+        if (!into) store_xyzz(buckets + (size_t)k * XW, xyzz_identity());  // (into: the bucket keeps the earlier chunks' sum)
+    } else {
+        uint32_t q;
+        t.m = piece_split(sz, pmax, psplit, &q);
+        if (t.m == 1) {
+            atomicAdd(&s_hist[sz], 1u);
         } else {
-            uint32_t q;
-            m = piece_split(sz, pmax, psplit, &q);
-            if (m == 1) {
-                atomicAdd(&s_hist[sz], 1u);
-            } else {
-                atomicAdd(&s_hist[q], m - 1);
-                atomicAdd(&s_hist[sz - (m - 1) * q], 1u);
-                pslot = atomicAdd(&s_n[2], m);  // (LDS; the short top window of a small instance splits ~8000 buckets: one device-scope
+            atomicAdd(&s_hist[q], t.m - 1);
+            atomicAdd(&s_hist[sz - (t.m - 1) * q], 1u);
+            t.pslot = atomicAdd(&s_n[2], t.m);  // (LDS; the short top window of a small instance splits ~8000 buckets: one device-scope
                                                 // add each on ONE word took k_piece_count 19 us at 2^17 where 2^20 takes 8)
-                if (m >= LONG_SPAN) {
-                    kindl = 1;
-                    nseg = (m + LONG_SEG - 1) / LONG_SEG;
-                } else {
-                    kindl = 0;
-                }
+            if (t.m >= LONG_SPAN) {
+                t.kindl = 1;
+                t.nseg = (t.m + LONG_SEG - 1) / LONG_SEG;
+            } else {
+                t.kindl = 0;
             }
         }
     }
-    if (kindl < 2) slot = atomicAdd(&s_n[kindl], nseg);
+    if (t.kindl < 2) t.slot = atomicAdd(&s_n[t.kindl], t.nseg);
+    return t;
+}
+// the workgroup's share of the lists, the partial-sum slots and every histogram bin: one device-scope add each (whole workgroup)
+__device__ __forceinline__ void piece_tally_reserve(const uint32_t* s_hist, const uint32_t* s_n, uint32_t* s_base, uint32_t* __restrict__ hist,
+                                                    uint32_t* __restrict__ flags, uint32_t pmax) {
     __syncthreads();
     if (threadIdx.x == 0 && s_n[0]) s_base[0] = atomicAdd(flags + FLAG_MID, s_n[0]);
     if (threadIdx.x == 1 && s_n[1]) s_base[1] = atomicAdd(flags + FLAG_LONG, s_n[1]);
@@ -1307,13 +1275,132 @@ __global__ void __launch_bounds__(1024) k_piece_count(const uint32_t* __restrict
     for (uint32_t i = threadIdx.x; i <= pmax; i += blockDim.x)
         if (s_hist[i]) atomicAdd(&hist[i], s_hist[i]);
     __syncthreads();
-    if (m > 1) pbase[k] = s_base[2] + pslot;
-    if (kindl == 0) {
-        mid_list[s_base[0] + slot] = k;
-    } else if (kindl == 1) {  // one entry per LONG_SEG pieces: (bucket, segment)
-        for (uint32_t j = 0; j < nseg; j++) {
-            long_list[2 * (size_t)(s_base[1] + slot + j)] = k;
-            long_list[2 * (size_t)(s_base[1] + slot + j) + 1] = j;
+}
+__device__ __forceinline__ void piece_tally_publish(uint32_t k, const piece_tally& t, const uint32_t* s_base, uint32_t* __restrict__ pbase,
+                                                    uint32_t* __restrict__ mid_list, uint32_t* __restrict__ long_list) {
+    if (t.m > 1) pbase[k] = s_base[2] + t.pslot;
+    if (t.kindl == 0) {
+        mid_list[s_base[0] + t.slot] = k;
+    } else if (t.kindl == 1) {  // one entry per LONG_SEG pieces: (bucket, segment)
+        for (uint32_t j = 0; j < t.nseg; j++) {
+            long_list[2 * (size_t)(s_base[1] + t.slot + j)] = k;
+            long_list[2 * (size_t)(s_base[1] + t.slot + j) + 1] = j;
+        }
+    }
+}
+__global__ void __launch_bounds__(1024) k_piece_count(const uint32_t* __restrict__ offsets, uint32_t total_buckets, uint32_t pmax, uint32_t psplit,
+                                                     uint32_t* __restrict__ hist, uint32_t* __restrict__ flags, uint32_t* __restrict__ long_list,
+                                                     uint32_t* __restrict__ mid_list, uint32_t* __restrict__ pbase, uint32_t* __restrict__ buckets,
+                                                     uint32_t into) {
+    __shared__ uint32_t s_hist[PIECE_BINS + 1];
+    __shared__ uint32_t s_n[3], s_base[3];  // [0] mid list, [1] long list, [2] partial-sum slots: reserved once per workgroup
+    if (blockIdx.x == 0 && threadIdx.x == 0)  // mixed additions executed so far (msm_timings_t.num_adds), all chunks of a streamed MSM
+        *reinterpret_cast<unsigned long long*>(flags + FLAG_ADDS64) += (unsigned long long)flags[FLAG_PAIRS];
+    piece_tally_begin(s_hist, s_n, pmax);
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    piece_tally t{2u, 0u, 1u, 0u, 0u};
+    if (k < total_buckets) t = piece_tally_bucket(k, offsets[k + 1] - offsets[k], pmax, psplit, s_hist, s_n, buckets, into);
+    piece_tally_reserve(s_hist, s_n, s_base, hist, flags, pmax);
+    if (k < total_buckets) piece_tally_publish(k, t, s_base, pbase, mid_list, long_list);
+}
+
+// The two-level sort's LAST launch (round 6): k_big_place and k_piece_count in one.  On uniform scalars no region is oversized and k_big_place was
+// an empty launch in the middle of the dependent chain -- 4.5 us at every size.  Workgroups [0, count_blocks) tally 1024
+// buckets each, as k_piece_count does, leaving out the buckets of oversized regions (their column pointers are not written yet); the other
+// wx * sW workgroups place the batches of those regions as k_big_place did, and the workgroup that publishes a region's column pointers (batch 0)
+// tallies its buckets from the counts it holds.  A bucket's END is its successor's column pointer -- which for the last bucket of a region
+// belongs to the next region and may be written by this very launch: the region table has it.
+constexpr uint32_t PLACE_COUNT_SPAN = 1024;  // buckets per tallying workgroup (one histogram flush per workgroup, as with k_piece_count's 1024 threads)
+template <int FINE_BLOCK>
+__global__ void __launch_bounds__(FINE_BLOCK) k_place_count(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ region_start,
+                                                            uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted, uint32_t nb,
+                                                            uint32_t fine_bits, uint32_t idx_bits, uint32_t ncoarse,
+                                                            const uint32_t* __restrict__ bigslot, uint32_t* __restrict__ big, sort_hi hi,
+                                                            uint32_t count_blocks, uint32_t wx, uint32_t sW, uint32_t total_buckets, uint32_t pmax,
+                                                            uint32_t psplit, uint32_t* __restrict__ hist, uint32_t* __restrict__ flags,
+                                                            uint32_t* __restrict__ long_list, uint32_t* __restrict__ mid_list,
+                                                            uint32_t* __restrict__ pbase, uint32_t* __restrict__ buckets, uint32_t into) {
+    __shared__ uint32_t s_hist[PIECE_BINS + 1];
+    __shared__ uint32_t s_n[3], s_pbase[3];
+    const uint32_t nfine = 1u << fine_bits, fmask = nfine - 1u;
+    if (blockIdx.x < count_blocks) {
+        if (blockIdx.x == 0 && threadIdx.x == 0)  // mixed additions executed so far (msm_timings_t.num_adds), all chunks of a streamed MSM
+            *reinterpret_cast<unsigned long long*>(flags + FLAG_ADDS64) += (unsigned long long)flags[FLAG_PAIRS];
+        piece_tally_begin(s_hist, s_n, pmax);
+        constexpr int ITER = PLACE_COUNT_SPAN / FINE_BLOCK;
+        piece_tally t[ITER];
+#pragma unroll
+        for (int it = 0; it < ITER; it++) {
+            t[it] = piece_tally{2u, 0u, 1u, 0u, 0u};
+            const uint32_t k = blockIdx.x * PLACE_COUNT_SPAN + it * FINE_BLOCK + threadIdx.x;
+            if (k < total_buckets) {
+                const uint32_t w = k / nb, b = k - w * nb, r = w * ncoarse + (b >> fine_bits);
+                if (bigslot[r] == BIG_NONE) {
+                    const uint32_t end = (b & fmask) == fmask ? region_start[r + 1] : offsets[k + 1];
+                    t[it] = piece_tally_bucket(k, end - offsets[k], pmax, psplit, s_hist, s_n, buckets, into);
+                }
+            }
+        }
+        piece_tally_reserve(s_hist, s_n, s_pbase, hist, flags, pmax);
+#pragma unroll
+        for (int it = 0; it < ITER; it++) {
+            const uint32_t k = blockIdx.x * PLACE_COUNT_SPAN + it * FINE_BLOCK + threadIdx.x;
+            if (k < total_buckets) piece_tally_publish(k, t[it], s_pbase, pbase, mid_list, long_list);
+        }
+        return;
+    }
+    // second half of the oversized-region path: bucket offsets from the region's global fine histogram, then every batch is placed;
+    // a batch reserves its share of each bucket with ONE global cursor add per bucket.
+    constexpr uint32_t CAP = (uint32_t)FINE_BLOCK * FINE_PER_THREAD;
+    __shared__ uint32_t s_ex[FINE_BINS_MAX], s_cnt[FINE_BINS_MAX], s_base[FINE_BINS_MAX], s_wtot[FINE_BINS_MAX / 64], s_bnd[SUPER_MAX];
+    const uint32_t nitems = min(big[0], BIG_MAX_ITEMS);
+    const uint32_t idx_mask = (1u << idx_bits) - 1u;
+    for (uint32_t it = blockIdx.x - count_blocks; it < nitems; it += wx * sW) {
+        const uint32_t rr = big[BIG_ITEMS_OFF + 2 * it], z = big[BIG_ITEMS_OFF + 2 * it + 1];
+        if (rr == BIG_NONE) continue;  // uniform
+        uint32_t* tab = big + BIG_TAB_OFF + (size_t)bigslot[rr] * BIG_SLOT_WORDS;
+        const uint32_t r0 = region_start[rr], b0 = r0 + z * CAP, b1 = min(region_start[rr + 1], b0 + CAP);
+        __syncthreads();
+        sort_hi_load(hi, rr / ncoarse, rr % ncoarse, ncoarse, s_bnd);
+        // exclusive prefix of the region's bucket counts
+        const uint32_t mycnt = threadIdx.x < nfine ? tab[threadIdx.x] : 0u;
+        const uint32_t ex = fine_scan(mycnt, s_wtot);
+        if (threadIdx.x < nfine) {
+            s_ex[threadIdx.x] = ex;
+            s_cnt[threadIdx.x] = 0;
+        }
+        __syncthreads();
+        if (z == 0) {  // the first batch publishes the buckets' CSC column pointers and tallies the region's buckets (uniform)
+            const uint32_t kb0 = (rr / ncoarse) * nb + ((rr % ncoarse) << fine_bits);
+            if (threadIdx.x < nfine) offsets[(size_t)kb0 + threadIdx.x] = r0 + s_ex[threadIdx.x];
+            piece_tally_begin(s_hist, s_n, pmax);
+            piece_tally t{2u, 0u, 1u, 0u, 0u};
+            if (threadIdx.x < nfine) t = piece_tally_bucket(kb0 + threadIdx.x, mycnt, pmax, psplit, s_hist, s_n, buckets, into);
+            piece_tally_reserve(s_hist, s_n, s_pbase, hist, flags, pmax);
+            if (threadIdx.x < nfine) piece_tally_publish(kb0 + threadIdx.x, t, s_pbase, pbase, mid_list, long_list);
+        }
+        uint32_t eb[FINE_PER_THREAD];
+#pragma unroll
+        for (int k = 0; k < FINE_PER_THREAD; k++) {
+            uint32_t j = b0 + threadIdx.x + k * FINE_BLOCK;
+            eb[k] = j < b1 ? tmp[j] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < FINE_PER_THREAD; k++)
+            if (b0 + threadIdx.x + k * FINE_BLOCK < b1) lds_inc(s_cnt, (eb[k] >> idx_bits) & fmask);
+        __syncthreads();
+        if (threadIdx.x < nfine) {
+            const uint32_t cn = s_cnt[threadIdx.x];
+            s_base[threadIdx.x] = cn ? atomicAdd(&tab[FINE_BINS_MAX + threadIdx.x], cn) : 0u;  // this batch's slice of every bucket
+            s_cnt[threadIdx.x] = 0;                                                             // becomes the local cursor
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < FINE_PER_THREAD; k++) {
+            if (b0 + threadIdx.x + k * FINE_BLOCK >= b1) continue;
+            const uint32_t f = (eb[k] >> idx_bits) & fmask;
+            const uint32_t pos = r0 + s_ex[f] + s_base[f] + lds_inc(s_cnt, f);
+            sorted[pos] = ((eb[k] & idx_mask) + sort_hi_of(hi, s_bnd, b0 - r0 + threadIdx.x + k * FINE_BLOCK, idx_bits)) | (eb[k] & SIGN_BIT);
         }
     }
 }
@@ -1465,49 +1552,63 @@ __global__ void __launch_bounds__(256) MSM_ACC_WAVES k_accumulate_pieces(const u
 // Split buckets (longer than pmax entries: skewed scalars, tiny top windows): partial sums partials[pbase[k] .. + m).  ONE launch, two kinds of workgroups: the leading LONG_BLOCKS workgroups take the long list -- (bucket, segment) items of buckets with
 // LONG_SPAN or more pieces: LDS trees of eight-lane additions per 2048-piece segment, the last-arriving workgroup of a bucket folds the
 // segment sums -- the others one bucket of 2..LONG_SPAN-1 pieces per thread.  On uniform scalars both lists are empty.
+// `pre` (64 or WIDE_TREE_MAX): how many records the eight-lane tree starts from; longer runs are first folded down to `pre` by `pre` lanes with
+// one-lane additions.  With FEW items in flight (a handful of huge buckets) the item's latency is what the launch waits for: 256 lanes fold, the tree takes
+// 256 records.  With THOUSANDS of items (hundreds of distinct scalars: 4096 buckets of 256 pieces at 2^20) the chip is full and work counts: an
+// eight-lane addition costs 3.4x the instructions of a one-lane one, so a 256-record tree (34 wavefront passes) is replaced by 3 one-lane additions on one
+// wavefront + a 64-record tree (10 passes): half the instructions (round 6; k_combine_pieces 0.45 ms at 256 distinct scalars before).
 __device__ __forceinline__ void fold_partials(uint32_t* e, const uint32_t* partials, uint32_t base, uint32_t first, uint32_t stride,
-                                              uint32_t count) {
-    constexpr uint32_t CAP = WIDE_TREE_MAX;
+                                              uint32_t count, uint32_t pre) {
     __syncthreads();  // e is reused
-    if (count <= CAP) {
+    if (count <= pre) {
         for (uint32_t i = threadIdx.x >> 2; i < count; i += blockDim.x >> 2) {
             const uint32_t co = threadIdx.x & 3u;
             store_coord(e + (size_t)i * XW, co, load_coord(partials + (size_t)(base + first + i * stride) * XW, co));
         }
-    } else if (threadIdx.x < CAP) {
+    } else if (threadIdx.x < pre) {
         xyzz acc = xyzz_identity();
 #pragma unroll 1
-        for (uint32_t i = threadIdx.x; i < count; i += CAP) acc = xyzz_add(acc, load_xyzz(partials + (size_t)(base + first + i * stride) * XW));
+        for (uint32_t i = threadIdx.x; i < count; i += pre) acc = xyzz_add(acc, load_xyzz(partials + (size_t)(base + first + i * stride) * XW));
         store_xyzz(e + (size_t)threadIdx.x * XW, acc);
     }
-    lds_tree_wide(e, count < CAP ? count : CAP);
+    lds_tree_wide(e, count < pre ? count : pre);
 }
 __global__ void __launch_bounds__(512) k_combine_pieces(const uint32_t* __restrict__ offsets, uint32_t* __restrict__ partials,
                                                         uint32_t* __restrict__ buckets, uint32_t pmax, uint32_t psplit, const uint32_t* __restrict__ pbase,
                                                         const uint32_t* __restrict__ mid_count, const uint32_t* __restrict__ mid_list,
                                                         const uint32_t* __restrict__ long_count, const uint32_t* __restrict__ long_list,
                                                         uint32_t* __restrict__ long_done) {
+    __shared__ uint32_t e[WIDE_TREE_MAX * XW];
     if (blockIdx.x >= LONG_BLOCKS) {
-        const uint32_t nmid = *mid_count;
-        for (uint32_t i = (blockIdx.x - LONG_BLOCKS) * blockDim.x + threadIdx.x; i < nmid; i += MID_BLOCKS * blockDim.x) {
+        // mid list: EIGHT lanes per listed bucket (round 6; one lane folding its 2..7 pieces with complete additions took this launch 19 us on uniform
+        // scalars -- a lone wavefront's xyzz_add is 6.6 us warm and its ~40 KB of code arrive cold -- and up to 0.45 ms on skewed ones).  Two pieces: one
+        // eight-lane addition straight from the partial sums into the bucket; more: the running sum lives in the group's LDS record (in-order LDS traffic of one wavefront).
+        const uint32_t nmid = *mid_count, g = threadIdx.x / WIDE_LANES, ng = blockDim.x / WIDE_LANES;
+        uint32_t* acc = e + (size_t)g * XW;
+        for (uint32_t i = (blockIdx.x - LONG_BLOCKS) * ng + g; i < nmid; i += MID_BLOCKS * ng) {  // (whole groups share i)
             const uint32_t k = mid_list[i];
             uint32_t q;
             const uint32_t m = piece_split(offsets[k + 1] - offsets[k], pmax, psplit, &q), base = pbase[k];
-            xyzz acc = load_xyzz(partials + (size_t)base * XW);
-            for (uint32_t p = 1; p < m; p++) acc = xyzz_add(acc, load_xyzz(partials + (size_t)(base + p) * XW));
-            store_xyzz(buckets + (size_t)k * XW, acc);
+            const uint32_t* p0 = partials + (size_t)base * XW;
+            uint32_t* out = buckets + (size_t)k * XW;
+            const uint32_t* a = p0;
+#pragma unroll 1
+            for (uint32_t p = 1; p < m; p++) {  // ONE call site (an eight-lane addition carries the ~40 KB scalar fallback for the special pairs)
+                wide_add_records(a, p0 + (size_t)p * XW, p + 1 == m ? out : acc);
+                a = acc;
+            }
         }
         return;
     }
-    __shared__ uint32_t e[WIDE_TREE_MAX * XW];
     __shared__ uint32_t s_last;
     const uint32_t nlong = *long_count;
+    const uint32_t pre = nlong > 2 * LONG_BLOCKS ? 64u : WIDE_TREE_MAX;  // (fold_partials: work-bound with many items, latency-bound with few)
     for (uint32_t item = blockIdx.x; item < nlong; item += LONG_BLOCKS) {
         const uint32_t k = long_list[2 * (size_t)item], seg = long_list[2 * (size_t)item + 1];
         uint32_t q;
         const uint32_t cnt = piece_split(offsets[k + 1] - offsets[k], pmax, psplit, &q), nseg = (cnt + LONG_SEG - 1) / LONG_SEG, base = pbase[k];
         const uint32_t first = seg * LONG_SEG, count = min(LONG_SEG, cnt - first);
-        fold_partials(e, partials, base, first, 1, count);
+        fold_partials(e, partials, base, first, 1, count, pre);
         if (nseg == 1) {
             if (threadIdx.x < 4) store_coord(buckets + (size_t)k * XW, threadIdx.x, load_coord(e, threadIdx.x));
             continue;
@@ -1521,7 +1622,7 @@ __global__ void __launch_bounds__(512) k_combine_pieces(const uint32_t* __restri
         __syncthreads();
         if (!s_last) continue;  // uniform
         __threadfence();        // see the other segments' sums
-        fold_partials(e, partials, base, 0, LONG_SEG, nseg);
+        fold_partials(e, partials, base, 0, LONG_SEG, nseg, pre);
         if (threadIdx.x < 4) store_coord(buckets + (size_t)k * XW, threadIdx.x, load_coord(e, threadIdx.x));
         if (threadIdx.x == 0) long_done[item - seg] = 0;  // ready for the next call
     }
@@ -1635,6 +1736,9 @@ __global__ void __launch_bounds__(256) k_pair_level8(const uint32_t* __restrict_
 
 // k_reduce_bits with wide additions: one 512-thread workgroup per (window, bit); the selected elements are staged in LDS
 // and folded by a pairwise tree (log2(nsel) levels of 4 multiplications each).  Needs nsel <= WIDE_TREE_MAX.
+// PARTS (hooks build's probe, tools/wide_level_probe.py): 7 = the kernel; bit 0 clear: nothing staged (the tree runs on whatever LDS holds); bit 1 clear: no tree;
+// bit 2 clear: no XYZZ -> Jacobian -> R = 2^256 conversion (the raw record's first 24 words go out).  The product instantiates 7 only.
+template <int PARTS = 7>
 __global__ void __launch_bounds__(512) k_reduce_bits_wide(const uint32_t* __restrict__ R, const uint32_t* __restrict__ C,
                                                           uint32_t* __restrict__ q, uint32_t n_hi, uint32_t n_lo, uint32_t kb_lo,
                                                           uint32_t kb, uint32_t* __restrict__ flags, uint32_t* __restrict__ flags_out) {
@@ -1661,14 +1765,21 @@ __global__ void __launch_bounds__(512) k_reduce_bits_wide(const uint32_t* __rest
     }
     const uint32_t nsel = bit == 0xFFFFFFFFu ? cnt : cnt >> 1;
     // thread t stages coordinate t&3 of the (t>>2)-th SELECTED element (index = m with a 1 inserted at position `bit`)
-    for (uint32_t m = threadIdx.x >> 2; m < nsel; m += blockDim.x >> 2) {
-        const uint32_t j = bit == 0xFFFFFFFFu ? m : (((m >> bit) << (bit + 1)) | (1u << bit) | (m & ((1u << bit) - 1u)));
-        const uint32_t co = threadIdx.x & 3u;
-        store_coord(e + (size_t)m * XW, co, load_coord(src + (size_t)j * XW, co));
+    if (PARTS & 1) {
+        for (uint32_t m = threadIdx.x >> 2; m < nsel; m += blockDim.x >> 2) {
+            const uint32_t j = bit == 0xFFFFFFFFu ? m : (((m >> bit) << (bit + 1)) | (1u << bit) | (m & ((1u << bit) - 1u)));
+            const uint32_t co = threadIdx.x & 3u;
+            store_coord(e + (size_t)m * XW, co, load_coord(src + (size_t)j * XW, co));
+        }
+        if (nsel == 0 && threadIdx.x == 0) store_xyzz(e, xyzz_identity());
     }
-    if (nsel == 0 && threadIdx.x == 0) store_xyzz(e, xyzz_identity());
-    lds_tree_wide(e, nsel);
-    if (threadIdx.x == 0) store_jacobian_mont256(q + (size_t)blockIdx.x * 24, xyzz_to_jacobian(load_xyzz(e)));
+    if (PARTS & 2) lds_tree_wide(e, nsel);
+    else __syncthreads();
+    if (PARTS & 4) {
+        if (threadIdx.x < 64) store_jacobian_mont256_lanes(q + (size_t)blockIdx.x * 24, e);
+    } else if (threadIdx.x == 0) {
+        for (int i = 0; i < 24; i++) q[(size_t)blockIdx.x * 24 + i] = e[i];
+    }
 }
 
 // one wavefront per (window, bit): R[w][0..n_hi), C[w][0..n_lo);  q[w][u] Jacobian

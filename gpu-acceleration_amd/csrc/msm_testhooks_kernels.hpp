@@ -256,6 +256,16 @@ __global__ void __launch_bounds__(512) k_probe_scalar_level(const uint32_t* __re
 __global__ void k_probe_empty(uint32_t* sink) {
     if (sink && threadIdx.x == 12345u) sink[0] = 1;
 }
+// an empty kernel that OWNS resources: LDS_WORDS of static LDS per workgroup (launched with any grid / block): what does dispatching
+// k_combine_pieces' 1152 workgroups of 512 threads and 36 KB cost when its lists are empty?
+template <int LDS_WORDS>
+__global__ void __launch_bounds__(1024) k_probe_empty_lds(uint32_t* sink) {
+    __shared__ uint32_t e[LDS_WORDS];
+    if (sink && threadIdx.x == 12345u) {
+        e[threadIdx.x % LDS_WORDS] = 1;
+        sink[0] = e[0];
+    }
+}
 
 // stage tests: XYZZ records (bucket sums) -> Jacobian R = 2^256 Montgomery words, the C-ABI point format
 __global__ void k_dump_xyzz_as_jacobian(const uint32_t* __restrict__ recs, uint32_t n, uint32_t* __restrict__ out) {

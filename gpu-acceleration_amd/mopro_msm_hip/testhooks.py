@@ -17,7 +17,7 @@ HOOKS_LIB_PATH = os.environ.get("MSM_HIP_HOOKS_LIB") or os.path.join(os.path.dir
 HOOK_SYMBOLS = [
     "msm_bn254_g1_generate_device", "msm_bn254_generate_scalars_host", "msm_test_fp_op", "msm_test_g1_op",
     "msm_test_decompose", "msm_calibrate", "msm_test_stage_dump", "msm_test_abandon_after_sort",
-    "msm_probe_wide_level", "msm_probe_launch_chain",
+    "msm_probe_wide_level", "msm_probe_launch_chain", "msm_probe_empty_launch", "msm_test_get_list_counts", "msm_probe_reduce_bits",
 ]
 _lib = None
 
@@ -45,6 +45,9 @@ def load_hooks_library():
     L.msm_calibrate.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.msm_probe_wide_level.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_longlong)]
     L.msm_probe_launch_chain.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]
+    L.msm_probe_empty_launch.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]
+    L.msm_test_get_list_counts.argtypes = [vp, _u32p]
+    L.msm_probe_reduce_bits.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]
     L.msm_test_stage_dump.argtypes = [vp, _u32p, C.c_uint32, _u8p, _u32p, C.c_size_t, _u32p, _u32p, _u32p, _u32p, _u32p,
                                       C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _u32p]
     for name in HOOK_SYMBOLS:
@@ -105,6 +108,24 @@ class HooksContext(MsmContext):
         out = (C.c_longlong * 18)()
         self._check(self._lib.msm_probe_wide_level(self._h, threads, m, iters, mode, out))
         return [int(v) for v in out]
+
+    def probe_empty_launch(self, blocks, threads, lds_kb, launches=200):
+        """microseconds per dependent launch of an empty kernel of blocks x threads with lds_kb of static LDS per workgroup"""
+        us = C.c_double(0)
+        self._check(self._lib.msm_probe_empty_launch(self._h, blocks, threads, lds_kb, launches, C.byref(us)))
+        return us.value
+
+    def probe_reduce_bits(self, parts, launches=100):
+        """microseconds per launch of k_reduce_bits_wide<parts> on the 2^20 shape (bit 0 staging, 1 tree, 2 final conversion)"""
+        us = C.c_double(0)
+        self._check(self._lib.msm_probe_reduce_bits(self._h, parts, launches, C.byref(us)))
+        return us.value
+
+    def list_counts(self):
+        """{"long", "mid", "pieces", "partials"}: the list counters the last sort chain / accumulation left on the device"""
+        out = np.zeros(4, np.uint32)
+        self._check(self._lib.msm_test_get_list_counts(self._h, _p32(out)))
+        return dict(zip(("long", "mid", "pieces", "partials"), (int(v) for v in out)))
 
     def probe_launch_chain(self, n_adds, launches):
         """microseconds per dependent launch of k_pair_level_wide over n_adds additions (0: an empty kernel)"""

@@ -92,6 +92,15 @@ int32_t msm_test_abandon_after_sort(msm_ctx *ctx, const uint32_t *scalars, size_
  *      each, or an empty kernel (n_adds = 0) -- microseconds per launch by hipEvents. */
 int32_t msm_probe_wide_level(msm_ctx *ctx, uint32_t threads, uint32_t m, uint32_t iters, uint32_t mode, long long out[18]);
 int32_t msm_probe_launch_chain(msm_ctx *ctx, uint32_t n_adds, uint32_t launches, double *us_per_launch);
+/* `launches` dependent launches of an EMPTY kernel of blocks x threads with lds_kb of static LDS per workgroup (0, 1 or 36): what the
+ * dispatch of a large grid costs when every workgroup leaves at once (k_combine_pieces on uniform scalars) */
+int32_t msm_probe_empty_launch(msm_ctx *ctx, uint32_t blocks, uint32_t threads, uint32_t lds_kb, uint32_t launches, double *us_per_launch);
+/* k_reduce_bits_wide of the 2^20 shape (8 windows x 16 bit sums = 128 workgroups) on synthetic row / column sums with parts switched off:
+ * parts bit 0 = staging (HBM -> LDS), bit 1 = the LDS tree, bit 2 = the XYZZ -> Jacobian -> R = 2^256 conversion; 7 = the kernel as the product runs it */
+int32_t msm_probe_reduce_bits(msm_ctx *ctx, uint32_t parts, uint32_t launches, double *us_per_launch);
+/* the list counters the last sort chain / accumulation left on the device: out[0] long-list entries, out[1] mid-list entries (the buckets
+ * k_combine_pieces folds), out[2] pieces, out[3] partial-sum slots */
+int32_t msm_test_get_list_counts(msm_ctx *ctx, uint32_t out[4]);
 
 #ifdef __cplusplus
 }

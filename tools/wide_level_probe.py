@@ -51,6 +51,16 @@ def main():
             us = ctx.probe_launch_chain(n_adds, 200)
             what = "empty kernel" if n_adds == 0 else f"k_pair_level_wide, {n_adds} additions ({n_adds * 8 // 64} wavefronts)"
             print(f"   {what:60s} {us:7.2f} us per launch")
+        print("\n# dependent launches of an EMPTY kernel whose workgroups leave at once: blocks x threads, static LDS per workgroup")
+        for blocks, threads, lds in ((1, 64, 0), (256, 256, 0), (1152, 512, 0), (1152, 512, 1), (1152, 512, 36), (288, 512, 36), (136, 512, 36), (1152, 64, 0), (8, 512, 36)):
+            ctx.calibrate()
+            us = ctx.probe_empty_launch(blocks, threads, lds)
+            print(f"   {blocks:5d} x {threads:4d} threads ({blocks * threads // 64:5d} wavefronts), {lds:2d} KB LDS {us:7.2f} us per launch")
+        print("\n# k_reduce_bits_wide, 2^20 shape (128 workgroups of 512 threads), parts switched off; dependent launches back to back")
+        for parts, what in ((7, "whole kernel"), (3, "without the final XYZZ -> Jacobian -> R = 2^256 conversion"), (5, "without the LDS tree"),
+                            (6, "without the staging (HBM -> LDS)"), (1, "staging only"), (2, "tree only"), (4, "final conversion only"), (0, "nothing (launch + flag copy)")):
+            ctx.calibrate()
+            print(f"   {what:70s} {ctx.probe_reduce_bits(parts):7.2f} us per launch")
 
 
 if __name__ == "__main__":
