@@ -147,6 +147,9 @@ def main():
     ap.add_argument("--pre-warm-ms", type=float, default=150.0,
                     help="untimed steps run for this long BEFORE the warm-up steps: after ~50 ms without work the GPU clock drops and takes "
                          "~20 MSMs (35 ms) to come back (tools/clock_ramp.py: steps 1-5 after an idle gap 2.0-2.4 ms, steady state 1.67)")
+    ap.add_argument("--kernel-timing-every", type=int, default=4,
+                    help="every n-th launch of k_accumulate_pieces in the timed loop carries its pair of hipEvents (the roofline's live kernel time); a "
+                         "timed dispatch does not overlap its neighbours' launch latency (~11 us per MSM), the library's default is none (msm_set_kernel_timing)")
     ap.add_argument("--log-n", type=int, default=LOG_N, help="total instance size (default 2^20, the BASELINE metric; 24 = config 4, 26 --streamed = config 5)")
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -292,7 +295,10 @@ def main():
     for _ in range(args.warmup):
         res = step()
     if ctx is not None:
+        ctx.set_kernel_timing(max(1, args.kernel_timing_every))
         ctx.reset_kernel_stats()
+    else:
+        multi.set_kernel_timing(1)  # (per-rank kernel times of the last step are read from msm_multi_get_timings)
     shard_ms_acc[0], shard_ms_acc[1] = 0.0, 0
     exch_ms_sum = 0.0
     step_jac = []  # the Jacobian words every timed step returned (96 bytes each): all checked after the loop
@@ -501,8 +507,9 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_over_algorithmic": round(traffic / alg_bytes, 3) if traffic else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_ms": round(acc_avg_ms, 4), "launches_per_step": launches_per_step,
-                         "launches_timed": int(acc_launches),
-                         "note": "integer-multiply (VALU) bound kernel; HBM fraction reported because BASELINE.json asks for it; "
+                         "launches_timed": int(acc_launches), "kernel_timing_every": max(1, args.kernel_timing_every),
+                         "note": "avg_kernel_ms = hipEvents on the dispatch of every kernel_timing_every-th launch of the timed loop (the library's default times "
+                                 "none: a timed dispatch costs the call ~11 us of launch overlap).  Integer-multiply (VALU) bound kernel; HBM fraction reported because BASELINE.json asks for it; "
                                  "the multiplier roofline is in roofline_valu.  avg_kernel_ms is k_accumulate_pieces alone: the work-item plan in "
                                  "front of it (k_piece_count + k_piece_scatter: stage plan_ms) and k_combine_pieces behind it (combine_ms) are "
                                  "separate launches -- work the round-3 accumulation kernel did itself"},

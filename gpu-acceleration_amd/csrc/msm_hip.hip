@@ -105,6 +105,7 @@ struct Knobs {
     size_t glv_max = msmplan::GLV_MAX_POINTS;  // MSM_HIP_GLV_MAX_LOG2
     uint32_t piece_len = 0;                    // MSM_HIP_PIECE_LEN: longest whole bucket = split length of k_accumulate_pieces' work items; 0 = by size (tests force 1, 7, 26, 35)
     bool direct_scatter = false;               // MSM_HIP_DIRECT_SCATTER: skip the two-level LDS sort
+    bool no_poll = false;                      // MSM_HIP_NO_POLL: wait for the stream instead of polling the last kernel's sequence words (A/B: tools/ab_env.py)
     uint32_t device_chunk_log2 = 22;           // MSM_HIP_DEVICE_CHUNK_LOG2: point ranges of device-resident instances; 0 = never cut
     uint32_t stream_min_log2 = 19;             // MSM_HIP_STREAM_MIN_LOG2: host calls are streamed from this size on (tools/host_path_sweep.py)
     uint32_t stream_chunk_log2 = 0;            // MSM_HIP_STREAM_CHUNK_LOG2: 0 = by size (product: msm_config_t.stream_chunk_log2)
@@ -122,6 +123,7 @@ struct Knobs {
         k.glv_max = msmplan::glv_max_from_env();
         k.piece_len = (uint32_t)num("MSM_HIP_PIECE_LEN", 0, msmk::PIECE_BINS, 0);
         k.direct_scatter = std::getenv("MSM_HIP_DIRECT_SCATTER") != nullptr;  // (tests: the one-level LDS / global-atomic sort fallbacks)
+        k.no_poll = std::getenv("MSM_HIP_NO_POLL") != nullptr;
         k.device_chunk_log2 = (uint32_t)num("MSM_HIP_DEVICE_CHUNK_LOG2", 0, 30, 22);
         k.stream_min_log2 = (uint32_t)num("MSM_HIP_STREAM_MIN_LOG2", 9, 31, 19);
         k.stream_chunk_log2 = std::getenv("MSM_HIP_STREAM_CHUNK_LOG2") ? (uint32_t)num("MSM_HIP_STREAM_CHUNK_LOG2", 8, 28, 0) : 0u;
@@ -181,7 +183,8 @@ struct msm_ctx {
     uint32_t wall_clock_khz = 0;  // rate of the constant counter (hipDeviceAttributeWallClockRate)
     DevBuf rbases, rinf;  // the RESIDENT base set (msm_bn254_g1_upload_bases / _upload_compressed): never used as scratch
     bool pow2_ready = false;
-    uint32_t* h_qsums = nullptr;  // pinned: W x (kb+1) Jacobian bit sums
+    uint32_t* h_qsums = nullptr;  // pinned: W x (kb+1) Jacobian bit sums, and behind them (word MAX_QSUM_POINTS * 24 on) one SEQUENCE word per bit sum
+    uint32_t done_seq = 0;        // sequence number of the latest bucket reduction queued on this context (the last kernel publishes it per workgroup)
     uint32_t* h_flags = nullptr;    // pinned
     // resident bases
     size_t resident_n = 0;
@@ -193,6 +196,8 @@ struct msm_ctx {
     bool stage_timing = false;  // record the per-stage hipEvents (each costs ~6 us of stream time); k_accumulate's pair is always on
     double acc_ms_sum = 0;
     uint64_t acc_launches = 0;
+    uint32_t ktime_every = 0, ktime_count = 0;  // msm_set_kernel_timing: every n-th launch of k_accumulate_pieces carries its pair of events (0 = none)
+    bool acc_last_timed = false;                // ... and whether the latest launch did
     std::chrono::steady_clock::time_point t_prepare{};  // trace: when the call started preparing / enqueueing
     float enqueue_ms = 0;         // trace: host time from there until everything was queued (what a hipGraph could shorten)
     bool flags_clean = false;     // the device flag words are known to be zero (set when an MSM completes)
@@ -646,8 +651,15 @@ int32_t enqueue_accumulate(msm_ctx* c, const PipeState& ps, const BaseSrc& src, 
     uint32_t *bk = (uint32_t*)c->buckets.p, *pt = (uint32_t*)c->partials.p;
     unsigned long long* clk = (unsigned long long*)c->clk.p;  // clock probe of the launch's first workgroup (msm_get_clock_stats)
     const hipEvent_t e0 = c->ev[EV_ACC0], e1 = c->ev[EV_ACC1];
+    // every ktime_every-th launch carries the pair of events (msm_set_kernel_timing): they ride on the dispatch, but a dispatch that is timed does not
+    // overlap its neighbours' launch latency -- ~6.6 us in front of the kernel and ~4.6 behind it (profiles/r5_final_call_timeline_2p20_2p17.txt)
+    const bool timed = c->stage_timing || (c->ktime_every && (c->ktime_count++ % c->ktime_every) == 0);
+    c->acc_last_timed = timed;
 #define MSM_ACC_LAUNCH(INTO, CHUNK, M256) \
-    hipExtLaunchKernelGGL((msmk::k_accumulate_pieces<INTO, CHUNK, M256>), gp, dim3(256), 0, st, e0, e1, 0, src.rec, phi_biased, src.nsplit, srt, pl, np, bk, pt, clk)
+    do { \
+        if (timed) hipExtLaunchKernelGGL((msmk::k_accumulate_pieces<INTO, CHUNK, M256>), gp, dim3(256), 0, st, e0, e1, 0, src.rec, phi_biased, src.nsplit, srt, pl, np, bk, pt, clk); \
+        else hipLaunchKernelGGL((msmk::k_accumulate_pieces<INTO, CHUNK, M256>), gp, dim3(256), 0, st, src.rec, phi_biased, src.nsplit, srt, pl, np, bk, pt, clk); \
+    } while (0)
     // the kernel indexes the phi records by the ENTRY (nsplit + i): hand it the array biased by -nsplit records (never dereferenced below nsplit)
     const uint32_t* phi_biased = src.phi ? (const uint32_t*)((uintptr_t)src.phi - (uintptr_t)src.nsplit * 64u) : src.rec;
     if (src.m256) {
@@ -704,6 +716,23 @@ int32_t enqueue_reduce(msm_ctx* c, const PipeState& ps, hipStream_t st, uint32_t
         l = 3;
     }
     for (; l < levels; l++) {
+        // Round 6: once a level is small enough for eight lanes per addition, ALL the levels that are left run in ONE launch, inside the workgroups'
+        // LDS (k_pair_tail: 2.7 us per level instead of 5.2 per dependent launch) -- when at least two are left and the partial sums per output fit a tree
+        {
+            const size_t nadds_now = (l < kb_lo ? rn / 2 : 0) + (l < kb_hi ? cn / 2 : 0);
+            const uint32_t np_r = l < kb_lo ? 1u << (kb_lo - l) : 1u, np_c = l < kb_hi ? 1u << (kb_hi - l) : 1u;
+            if (nadds_now <= WIDE_MAX_ADDS && levels - l >= 2 && np_r <= msmk::WIDE_TREE_MAX && np_c <= msmk::WIDE_TREE_MAX) {
+                const uint32_t n_rout = (uint32_t)(rn / np_r), n_cout = (uint32_t)(cn / np_c);
+                const uint32_t rblocks = np_r > 1 ? (n_rout + msmk::WIDE_TREE_MAX / np_r - 1) / (msmk::WIDE_TREE_MAX / np_r) : 0u;
+                const uint32_t cblocks = np_c > 1 ? (n_cout + msmk::WIDE_TREE_MAX / np_c - 1) / (msmk::WIDE_TREE_MAX / np_c) : 0u;
+                // (outputs go to the ping-pong halves this level would have written -- they hold nothing that is still read and are large enough:
+                // a level writes half its input, this launch at most that)
+                msmk::k_pair_tail<<<rblocks + cblocks, 512, 0, st>>>(rin, rbuf[l & 1], n_rout, np_r > 1 ? np_r : 2u, cin, cbuf[l & 1], n_cout, np_c > 1 ? np_c : 2u, n_lo, rblocks);
+                if (np_r > 1) rin = rbuf[l & 1], rn = n_rout;
+                if (np_c > 1) cin = cbuf[l & 1], cn = n_cout;
+                break;
+            }
+        }
         msmk::pair_job ja{nullptr, nullptr, 0, 1}, jb{nullptr, nullptr, 0, 1};
         if (l < kb_lo) {
             rn /= 2;
@@ -725,10 +754,13 @@ int32_t enqueue_reduce(msm_ctx* c, const PipeState& ps, hipStream_t st, uint32_t
     uint32_t *q_dev = nullptr, *f_dev = nullptr;
     HIPCHK(c, hipHostGetDevicePointer((void**)&q_dev, h_qsums_dst, 0));
     HIPCHK(c, hipHostGetDevicePointer((void**)&f_dev, h_flags_dst, 0));
+    // (the sequence words live behind the bit sums of the same pinned buffer: h_qsums_dst + MAX_QSUM_POINTS * 24)
+    uint32_t* done_dev = q_dev + MAX_QSUM_POINTS * 24;
+    if (++c->done_seq == 0) c->done_seq = 1;  // (0 is what fresh words hold)
     if (n_hi / 2 <= msmk::WIDE_TREE_MAX && n_lo <= msmk::WIDE_TREE_MAX)
-        msmk::k_reduce_bits_wide<7><<<W * (kb + 1), 512, 0, st>>>(rin, cin, q_dev, n_hi, n_lo, kb_lo, kb, flags, f_dev);
+        msmk::k_reduce_bits_wide<7><<<W * (kb + 1), 512, 0, st>>>(rin, cin, q_dev, n_hi, n_lo, kb_lo, kb, flags, f_dev, done_dev, c->done_seq);
     else
-        msmk::k_reduce_bits<<<W * (kb + 1), 64, 0, st>>>(rin, cin, q_dev, n_hi, n_lo, kb_lo, kb, flags, f_dev);
+        msmk::k_reduce_bits<<<W * (kb + 1), 64, 0, st>>>(rin, cin, q_dev, n_hi, n_lo, kb_lo, kb, flags, f_dev, done_dev, c->done_seq);
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_REDUCE], st));
     return MSM_OK;
 }
@@ -812,8 +844,36 @@ int32_t finish_sync(msm_ctx* c, const PipeState& ps, size_t n_total, hipStream_t
                     hipEvent_t done = nullptr /* recorded after the last kernel when `st` carries other work too */) {
     if (trace_enabled()) c->enqueue_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - c->t_prepare).count();
     if (c->pool && n_total >= 256) c->pool->arm();  // workers wake up while the GPU works
-    if (done) HIPCHK(c, hipEventSynchronize(done));
-    else HIPCHK(c, hipStreamSynchronize(st));
+    // Round 6: the host polls the sequence words the last kernel's workgroups publish behind their bit sums (pinned memory) instead of waiting
+    // for the stream: the results are there a few microseconds before the kernel has retired and the runtime has woken the waiting thread.
+    // Every ~1000 polls the stream is queried, so that a failed launch or a lost device ends the wait with an error instead of a hang.
+    // (Stage timing reads events recorded behind the kernel: it waits for the stream as before.)
+    if (c->stage_timing || c->knobs.no_poll) {
+        if (done) HIPCHK(c, hipEventSynchronize(done));
+        else HIPCHK(c, hipStreamSynchronize(st));
+    } else {
+        const uint32_t nblk = ps.rW * (ps.rkb + 1), seq = c->done_seq;
+        const volatile uint32_t* d = c->h_qsums + MAX_QSUM_POINTS * 24;
+        for (uint32_t spins = 1;; spins++) {
+            uint32_t i = 0;
+            while (i < nblk && d[i] == seq) i++;
+            if (i == nblk) break;
+            if ((spins & 0x3FFu) == 0) {
+                const hipError_t q = done ? hipEventQuery(done) : hipStreamQuery(st);
+                if (q == hipSuccess) {  // retired: the words must be there now
+                    i = 0;
+                    while (i < nblk && d[i] == seq) i++;
+                    if (i == nblk) break;
+                    return fail(c, MSM_ERR_HIP, "internal: the bucket reduction finished without publishing bit sum %u of %u", i, nblk);
+                }
+                if (q != hipErrorNotReady) HIPCHK(c, q);
+            }
+#if defined(__x86_64__) || defined(__i386__)
+            __builtin_ia32_pause();
+#endif
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
     HIPCHK(c, hipGetLastError());
     c->flags_clean = true;  // the last kernel zeroed the flag words after copying them out
     auto t_fin0 = std::chrono::steady_clock::now();
@@ -827,10 +887,12 @@ int32_t finish_sync(msm_ctx* c, const PipeState& ps, size_t n_total, hipStream_t
     tm = msm_timings_t{};
     tm.decompose_ms = stage_ms(c, EV_CONVERT, EV_DECOMP);
     tm.sort_ms = stage_ms(c, EV_DECOMP, EV_SORT);
-    (void)hipEventElapsedTime(&ms, c->ev[EV_ACC0], c->ev[EV_ACC1]);  // of the last chunk, when the MSM was streamed
+    if (c->acc_last_timed) {  // (msm_set_kernel_timing: every n-th launch carries events; 0 otherwise)
+        (void)hipEventElapsedTime(&ms, c->ev[EV_ACC0], c->ev[EV_ACC1]);  // of the last chunk, when the MSM was streamed
+        c->acc_ms_sum += ms;
+        c->acc_launches += 1;
+    }
     tm.accumulate_ms = ms;
-    c->acc_ms_sum += ms;
-    c->acc_launches += 1;
     tm.plan_ms = stage_ms(c, EV_SORT, EV_PLAN);
     tm.combine_ms = stage_ms(c, EV_ACC1, EV_COMBINE);
     tm.reduce_ms = stage_ms(c, EV_COMBINE, EV_REDUCE);
@@ -1256,7 +1318,8 @@ static int32_t ctx_create_impl(const msm_config_t* cfg, msm_ctx** out, int main_
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_free[i], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_scal[i], hipEventDisableTiming);
     }
-    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_qsums, MAX_QSUM_POINTS * 96, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_qsums, MAX_QSUM_POINTS * 100, hipHostMallocDefault);
+    if (e == hipSuccess) std::memset(c->h_qsums, 0, MAX_QSUM_POINTS * 100);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_flags, 64, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc(&c->clk.p, 32);
     if (e == hipSuccess) {
@@ -1774,6 +1837,14 @@ int32_t msm_get_timings(const msm_ctx* c, msm_timings_t* out) {
 int32_t msm_get_timings_sized(const msm_ctx* c, void* out, size_t out_size) {
     if (!c || !out || out_size == 0) return MSM_ERR_BAD_ARG;
     std::memcpy(out, &c->tm, std::min(out_size, sizeof(msm_timings_t)));
+    return MSM_OK;
+}
+int32_t msm_set_kernel_timing(msm_ctx* c, uint32_t every_n) {
+    if (!c) return MSM_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->ktime_every = every_n;
+    c->ktime_count = 0;
+    if (c->lane1) msm_set_kernel_timing(c->lane1, every_n);
     return MSM_OK;
 }
 int32_t msm_get_accumulate_kernel_stats(const msm_ctx* c, double* avg_ms, uint64_t* launches) {

@@ -175,6 +175,19 @@ __device__ __forceinline__ void lds_tree_wide(uint32_t* e, uint32_t m) {
     }
     __syncthreads();
 }
+// the same tree stopped at `stop` records (both powers of two, m >= stop): e[i] += e[i + m/2] level by level; records whose index modulo `stop` is
+// >= valid are left alone (a workgroup that owns fewer than `stop` outputs: their slots hold nothing)
+__device__ __forceinline__ void lds_tree_wide_until(uint32_t* e, uint32_t m, uint32_t stop, uint32_t valid) {
+    const uint32_t g = threadIdx.x / WIDE_LANES, ng = blockDim.x / WIDE_LANES;
+    while (m > stop) {  // uniform
+        const uint32_t h = m >> 1;
+        __syncthreads();
+        for (uint32_t i = g; i < h; i += ng)
+            if ((i & (stop - 1u)) < valid) wide_add_records(e + (size_t)i * XW, e + (size_t)(i + h) * XW, e + (size_t)i * XW);
+        m = h;
+    }
+    __syncthreads();
+}
 // Jacobian in the C-ABI format: 24 words, canonical R = 2^256 Montgomery
 __device__ __forceinline__ void store_jacobian_mont256(uint32_t* o, const jacobian& j) {
     uint32_t w[8];
@@ -1689,6 +1702,36 @@ __global__ void __launch_bounds__(256) k_pair_level_wide(pair_job ja, pair_job j
     wide_add_records(j.in + i0 * XW, j.in + (i0 + j.B) * XW, j.out + (size_t)t * XW);
 }
 
+// ALL the remaining pairwise levels of both families in ONE launch (round 6): a dependent launch of k_pair_level_wide costs 5.2 us of which 2.5 are the
+// eight-lane addition, the same level inside a workgroup's LDS 2.7 (profiles/r6_wide_level_breakdown.txt) -- the five launches behind k_pair_level8 at
+// 2^20 (12.1 + 7.2 + 3 x 5.2 us) become one.  Rows: output o = sum of the np_r CONSECUTIVE partial sums in[o * np_r ..); columns: output (w, b) = sum
+// over a < np_c of in[(w * np_c + a) * n_lo + b].  A workgroup owns opw = WIDE_TREE_MAX / np outputs: their WIDE_TREE_MAX partial sums are staged
+// partial-major (record j * opw + oo = partial j of output oo), so that every level is e[i] += e[i + m/2] and the tree simply stops at opw records.
+// np_r, np_c: powers of two in [2, WIDE_TREE_MAX] (a family with one partial per output is already done: zero workgroups for it).
+__global__ void __launch_bounds__(512) k_pair_tail(const uint32_t* __restrict__ rin, uint32_t* __restrict__ rout, uint32_t n_rout, uint32_t np_r,
+                                                   const uint32_t* __restrict__ cin, uint32_t* __restrict__ cout, uint32_t n_cout, uint32_t np_c,
+                                                   uint32_t n_lo, uint32_t rblocks) {
+    __shared__ uint32_t e[WIDE_TREE_MAX * XW];
+    const bool rows = blockIdx.x < rblocks;
+    const uint32_t np = rows ? np_r : np_c, opw = WIDE_TREE_MAX / np, n_out = rows ? n_rout : n_cout;
+    const uint32_t o0 = (rows ? blockIdx.x : blockIdx.x - rblocks) * opw, valid = min(opw, n_out - o0);
+    const uint32_t* in = rows ? rin : cin;
+    // staging: thread t takes coordinate t & 3 of record t >> 2 (+ 128 per trip)
+    for (uint32_t rec = threadIdx.x >> 2; rec < WIDE_TREE_MAX; rec += blockDim.x >> 2) {
+        const uint32_t j = rec / opw, oo = rec - j * opw, co = threadIdx.x & 3u;
+        if (oo >= valid) continue;
+        const uint32_t o = o0 + oo;
+        const size_t src = rows ? (size_t)o * np + j : ((size_t)(o / n_lo) * np + j) * n_lo + (o % n_lo);
+        store_coord(e + (size_t)rec * XW, co, load_coord(in + src * XW, co));
+    }
+    lds_tree_wide_until(e, WIDE_TREE_MAX, opw, valid);
+    uint32_t* out = rows ? rout : cout;
+    for (uint32_t rec = threadIdx.x >> 2; rec < valid; rec += blockDim.x >> 2) {
+        const uint32_t co = threadIdx.x & 3u;
+        store_coord(out + (size_t)(o0 + rec) * XW, co, load_coord(e + (size_t)rec * XW, co));
+    }
+}
+
 // THREE pairwise levels of both families in one launch: out_r[o] = in[8o] + ... + in[8o+7] (rows: the lo dimension shrinks by 8),
 // out_c[w][a][b] = in[w][8a][b] + ... + in[w][8a+7][b] (cols: the hi dimension shrinks by 8).  One thread per output, seven dependent
 // additions; every bucket is read twice (once per family) and the two intermediate levels are never written: three launches and
@@ -1741,8 +1784,9 @@ __global__ void __launch_bounds__(256) k_pair_level8(const uint32_t* __restrict_
 template <int PARTS = 7>
 __global__ void __launch_bounds__(512) k_reduce_bits_wide(const uint32_t* __restrict__ R, const uint32_t* __restrict__ C,
                                                           uint32_t* __restrict__ q, uint32_t n_hi, uint32_t n_lo, uint32_t kb_lo,
-                                                          uint32_t kb, uint32_t* __restrict__ flags, uint32_t* __restrict__ flags_out) {
-    if (blockIdx.x == 0 && threadIdx.x < 8) {  // q, flags_out: pinned HOST memory
+                                                          uint32_t kb, uint32_t* __restrict__ flags, uint32_t* __restrict__ flags_out,
+                                                          uint32_t* __restrict__ done, uint32_t seq) {
+    if (blockIdx.x == 0 && threadIdx.x < 8) {  // q, flags_out, done: pinned HOST memory
         flags_out[threadIdx.x] = flags[threadIdx.x];
         flags[threadIdx.x] = 0;  // this kernel ends the MSM: the next one starts from clean error / count words
     }
@@ -1780,13 +1824,20 @@ __global__ void __launch_bounds__(512) k_reduce_bits_wide(const uint32_t* __rest
     } else if (threadIdx.x == 0) {
         for (int i = 0; i < 24; i++) q[(size_t)blockIdx.x * 24 + i] = e[i];
     }
+    // The host does not wait for the kernel to RETIRE (end-of-kernel cache maintenance, completion signal, the runtime's wake-up): every workgroup
+    // ends by publishing the call's sequence number behind its bit sum, after a system-scope fence, and the host polls those words (finish_sync).
+    if (threadIdx.x < 64) {
+        __threadfence_system();
+        if (threadIdx.x == 0) done[blockIdx.x] = seq;
+    }
 }
 
 // one wavefront per (window, bit): R[w][0..n_hi), C[w][0..n_lo);  q[w][u] Jacobian
 __global__ void __launch_bounds__(64) k_reduce_bits(const uint32_t* __restrict__ R, const uint32_t* __restrict__ C,
                                                     uint32_t* __restrict__ q, uint32_t n_hi, uint32_t n_lo, uint32_t kb_lo,
-                                                    uint32_t kb, uint32_t* __restrict__ flags, uint32_t* __restrict__ flags_out) {
-    if (blockIdx.x == 0 && threadIdx.x < 8) {  // q, flags_out: pinned HOST memory
+                                                    uint32_t kb, uint32_t* __restrict__ flags, uint32_t* __restrict__ flags_out,
+                                                    uint32_t* __restrict__ done, uint32_t seq) {
+    if (blockIdx.x == 0 && threadIdx.x < 8) {  // q, flags_out, done: pinned HOST memory
         flags_out[threadIdx.x] = flags[threadIdx.x];
         flags[threadIdx.x] = 0;  // this kernel ends the MSM: the next one starts from clean error / count words
     }
@@ -1838,6 +1889,8 @@ __global__ void __launch_bounds__(64) k_reduce_bits(const uint32_t* __restrict__
     if (threadIdx.x == 0) {
         store_jacobian_mont256(q + (size_t)blockIdx.x * 24, xyzz_to_jacobian(acc));
     }
+    __threadfence_system();  // (see k_reduce_bits_wide: the host polls the sequence words)
+    if (threadIdx.x == 0) done[blockIdx.x] = seq;
 }
 
 }  // namespace msmk

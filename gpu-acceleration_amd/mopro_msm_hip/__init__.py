@@ -30,8 +30,8 @@ OK, ERR_EMPTY, ERR_BAD_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_STATE, ERR_INVA
 ABI_SYMBOLS = [
     "msm_abi_version", "msm_ctx_create", "msm_ctx_destroy", "msm_last_error", "msm_bn254_g1",
     "msm_bn254_g1_arkworks", "msm_bn254_g1_upload_bases", "msm_bn254_g1_resident", "msm_bn254_g1_resident_batch", "msm_tune_batch", "msm_bn254_g1_resident_device", "msm_bn254_g1_device",
-    "msm_bn254_g1_combine", "msm_bn254_g1_combine_flags", "msm_get_timings_sized", "msm_multi_get_timings_sized", "msm_multi_get_clock_stats",
-    "msm_plan", "msm_get_timings", "msm_set_stage_timing", "msm_get_accumulate_kernel_stats", "msm_reset_kernel_stats", "msm_get_clock_stats",
+    "msm_bn254_g1_combine", "msm_bn254_g1_combine_flags", "msm_get_timings_sized", "msm_multi_get_timings_sized", "msm_multi_get_clock_stats", "msm_multi_set_kernel_timing",
+    "msm_plan", "msm_get_timings", "msm_set_stage_timing", "msm_set_kernel_timing", "msm_get_accumulate_kernel_stats", "msm_reset_kernel_stats", "msm_get_clock_stats",
     "msm_bn254_g1_decompress", "msm_bn254_g1_upload_compressed", "msm_bn254_g1_compress",
     "msm_multi_create", "msm_multi_destroy", "msm_multi_last_error", "msm_multi_num_devices", "msm_multi_exchange",
     "msm_bn254_g1_multi", "msm_bn254_g1_multi_arkworks", "msm_bn254_g1_multi_device", "msm_multi_get_timings",
@@ -112,10 +112,12 @@ def bind_product_abi(L):
     L.msm_bn254_g1_combine_flags.argtypes = [_u32p, C.c_size_t, C.c_uint32, _u32p, _u32p, _u8p]
     L.msm_get_timings_sized.argtypes = [vp, vp, C.c_size_t]
     L.msm_multi_get_timings_sized.argtypes = [vp, C.c_int32, vp, C.c_size_t]
+    L.msm_multi_set_kernel_timing.argtypes = [vp, C.c_uint32]
     L.msm_multi_get_clock_stats.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.msm_plan.argtypes = [C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(Plan)]
     L.msm_get_timings.argtypes = [vp, C.POINTER(Timings)]
     L.msm_set_stage_timing.argtypes = [vp, C.c_int32]
+    L.msm_set_kernel_timing.argtypes = [vp, C.c_uint32]
     L.msm_get_accumulate_kernel_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.msm_reset_kernel_stats.argtypes = [vp]
     L.msm_reset_kernel_stats.restype = None
@@ -403,6 +405,10 @@ class MsmContext:
         self._check(self._lib.msm_get_timings(self._h, C.byref(t)))
         return t.as_dict()
 
+    def set_kernel_timing(self, every_n):
+        """every `every_n`-th launch of the accumulate kernel carries its pair of hipEvents (0 = none: the default; 1 = all: ~11 us more per MSM); accumulate_kernel_stats() and timings()["accumulate_ms"] see the timed launches only"""
+        self._check(self._lib.msm_set_kernel_timing(self._h, every_n))
+
     def accumulate_kernel_stats(self):
         avg, cnt = C.c_double(0), C.c_uint64(0)
         self._check(self._lib.msm_get_accumulate_kernel_stats(self._h, C.byref(avg), C.byref(cnt)))
@@ -504,6 +510,9 @@ class MsmMulti:
         sh = (C.c_float * self.num_devices)()
         self._check(self._lib.msm_multi_get_exchange_stats(self._h, C.byref(ex), sh, self.num_devices))
         return float(ex.value), [float(v) for v in sh]
+
+    def set_kernel_timing(self, every_n):
+        self._check(self._lib.msm_multi_set_kernel_timing(self._h, every_n))
 
     def clock_stats(self, g=0):
         """msm_get_clock_stats of rank g's context: {"sclk_ghz", "cycles_per_addition", "samples"}"""

@@ -46,7 +46,7 @@ extern "C" {
 
 /* A consumer must be built against the header of the library it loads: check msm_abi_version() == MSM_HIP_ABI_VERSION once after loading
  * (the Rust shim and the Python binding do) -- msm_timings_t and msm_config_t have grown with the ABI number, and the plain getters write the
- * whole struct of THEIR build.  ABI 7: msm_bn254_g1_combine_flags, msm_get_timings_sized / msm_multi_get_timings_sized, msm_multi_get_clock_stats. */
+ * whole struct of THEIR build.  ABI 7: msm_bn254_g1_combine_flags, msm_get_timings_sized / msm_multi_get_timings_sized, msm_multi_get_clock_stats, msm_set_kernel_timing. */
 #define MSM_HIP_ABI_VERSION 7u
 
 /* status codes */
@@ -308,6 +308,7 @@ int32_t msm_multi_get_timings(const msm_multi *m, int32_t g, msm_timings_t *out)
  * msm_multi_last_error() names the device and rank (metal_msm.rs:647-656: errors are returned, nothing hangs). */
 int32_t msm_multi_get_exchange_stats(const msm_multi *m, float *exchange_ms, float *shard_ms, int32_t nshard);
 int32_t msm_multi_get_timings_sized(const msm_multi *m, int32_t rank, void *out, size_t out_size); /* ABI 7, see msm_get_timings_sized */
+int32_t msm_multi_set_kernel_timing(msm_multi *m, uint32_t every_n); /* ABI 7: msm_set_kernel_timing on every rank's context */
 /* msm_get_clock_stats of rank `rank`'s context (ABI 7): a slow rank of a multi-GPU call can be told from a slow CLOCK on its device */
 int32_t msm_multi_get_clock_stats(msm_multi *m, int32_t rank, double *sclk_ghz, double *cycles_per_addition, uint64_t *samples);
 
@@ -322,8 +323,13 @@ int32_t msm_get_timings_sized(const msm_ctx *ctx, void *out, size_t out_size);
 /* per-stage hipEvents are OFF by default (every record costs ~6 us of stream time); when off, the stage fields of
  * msm_timings_t other than accumulate_ms / finish_ms / total_ms read 0 */
 int32_t msm_set_stage_timing(msm_ctx *ctx, int32_t enabled);
-/* average duration (ms) of the accumulate kernel launches since the last reset, measured with
- * hipEvents on the stream the kernel runs on; *launches receives the count */
+/* Which launches of the accumulate kernel carry their pair of hipEvents (ABI 7): every `every_n`-th one; 0 = none (the DEFAULT since ABI 7), 1 = all of them (what ABI <= 6 did).
+ * The events ride on the kernel's dispatch, but a timed dispatch does not overlap its neighbours' launch latency: ~11 us per MSM at every size.  A caller
+ * that reads msm_get_accumulate_kernel_stats / msm_timings_t.accumulate_ms turns them on; bench.py samples every 4th launch of its timed loop.
+ * Stage timing (msm_set_stage_timing) times every launch whatever this says.  msm_timings_t.accumulate_ms reads 0 after an untimed launch. */
+int32_t msm_set_kernel_timing(msm_ctx *ctx, uint32_t every_n);
+/* average duration (ms) of the TIMED accumulate kernel launches since the last reset, measured with
+ * hipEvents on the stream the kernel runs on; *launches receives their count */
 int32_t msm_get_accumulate_kernel_stats(const msm_ctx *ctx, double *avg_ms, uint64_t *launches);
 void msm_reset_kernel_stats(msm_ctx *ctx);
 /* Clock probe of the accumulate kernel since the last reset (ABI 5): the first workgroup of every launch brackets its chunk with the

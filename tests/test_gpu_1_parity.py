@@ -467,7 +467,10 @@ def test_full_size_closed_form_and_linearity(ctx, hk, logn):
     # point-range sharding (the multi-GPU decomposition) gives the same group element
     h = n // 2
     p0 = ctx.msm_device(d_bases.data_ptr(), d_s.data_ptr(), h)
+    assert ctx.timings()["accumulate_ms"] == 0  # no launch carries events unless asked for (msm_set_kernel_timing, ABI 7)
+    ctx.set_kernel_timing(1)
     p1 = ctx.msm_device(d_bases.data_ptr() + h * 64, d_s.data_ptr() + h * 32, n - h)
+    ctx.set_kernel_timing(0)
     comb = mh.combine_partials(np.stack([p0.jacobian_mont, p1.jacobian_mont]))
     assert (comb.affine_std == exp).all()
     tm = ctx.timings()

@@ -12,6 +12,7 @@ for lg in [int(a) for a in sys.argv[1:]] or [20, 21, 22, 23, 24]:
     gen.generate_device(1, 2, n, d_b.data_ptr(), d_s.data_ptr()); torch.cuda.synchronize()
     rows = {16: [], 17: []}
     with mh.MsmContext(window_bits=16) as c16, mh.MsmContext(window_bits=17) as c17:
+        c16.set_kernel_timing(1); c17.set_kernel_timing(1)
         for rnd in range(3):
             for c, ctx in ((16, c16), (17, c17)):
                 for _ in range(2): ctx.msm_device(d_b.data_ptr(), d_s.data_ptr(), n)

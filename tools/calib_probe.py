@@ -27,6 +27,7 @@ def msm(ctx, tag):
 msm(hk, "hooks context msm")
 cal("after hooks msm")
 c = mh.MsmContext()
+c.set_kernel_timing(1)
 cal("+ product context created")
 msm(c, "product context msm")
 cal("after product msm")

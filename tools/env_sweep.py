@@ -16,6 +16,7 @@ for lg in sizes:
     d_b = torch.empty(n * 16, dtype=torch.int32, device="cuda:0"); d_s = torch.empty(n * 8, dtype=torch.int32, device="cuda:0")
     gen.generate_device(1, 2, n, d_b.data_ptr(), d_s.data_ptr()); torch.cuda.synchronize()
     with mh.MsmContext() as c:
+        c.set_kernel_timing(1)
         ref = None
         rows = {v: [] for v in vals}
         for rnd in range(3):

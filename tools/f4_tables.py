@@ -29,6 +29,7 @@ for lg in sizes:
             label, table, c = cfg
             os.environ["MSM_HIP_GLV_MAX_LOG2"] = "23" if table else "0"
             with mh.MsmContext(window_bits=c) as ctx:
+                ctx.set_kernel_timing(1)
                 for _ in range(3): r = ctx.msm_device(d_b.data_ptr(), d_s.data_ptr(), n)
                 ctx.reset_kernel_stats()
                 ts = []

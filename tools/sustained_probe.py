@@ -16,6 +16,7 @@ with th.HooksContext() as gen:
 torch.cuda.synchronize()
 hb = d_b.cpu().numpy().view(np.uint32).reshape(n, 16)
 with mh.MsmContext() as c:
+    c.set_kernel_timing(1)
     c.upload_bases(hb, mh.FORM_MONT)
     def block(kind, reps=200):
         c.set_stage_timing(kind == "one stream")

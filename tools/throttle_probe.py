@@ -23,6 +23,7 @@ def main():
     d_b = torch.empty(n * 16, dtype=torch.int32, device="cuda:0")
     d_s = torch.empty(n * 8, dtype=torch.int32, device="cuda:0")
     with th.HooksContext() as hk, mh.MsmContext(max_points=n) as ctx:
+        ctx.set_kernel_timing(1)
         hk.generate_device(11, 12, n, d_b.data_ptr(), d_s.data_ptr())
         torch.cuda.synchronize()
         for gap_ms in (0.0, 0.2, 0.5, 1.0, 2.0, 5.0, 0.0):
