@@ -147,7 +147,7 @@ def main():
     ap.add_argument("--pre-warm-ms", type=float, default=150.0,
                     help="untimed steps run for this long BEFORE the warm-up steps: after ~50 ms without work the GPU clock drops and takes "
                          "~20 MSMs (35 ms) to come back (tools/clock_ramp.py: steps 1-5 after an idle gap 2.0-2.4 ms, steady state 1.67)")
-    ap.add_argument("--kernel-timing-every", type=int, default=4,
+    ap.add_argument("--kernel-timing-every", type=int, default=1,
                     help="every n-th launch of k_accumulate_pieces in the timed loop carries its pair of hipEvents (the roofline's live kernel time); a "
                          "timed dispatch does not overlap its neighbours' launch latency (~11 us per MSM), the library's default is none (msm_set_kernel_timing)")
     ap.add_argument("--log-n", type=int, default=LOG_N, help="total instance size (default 2^20, the BASELINE metric; 24 = config 4, 26 --streamed = config 5)")
@@ -511,18 +511,18 @@ def main():
                          "note": "avg_kernel_ms = hipEvents on the dispatch of every kernel_timing_every-th launch of the timed loop (the library's default times "
                                  "none: a timed dispatch costs the call ~11 us of launch overlap).  Integer-multiply (VALU) bound kernel; HBM fraction reported because BASELINE.json asks for it; "
                                  "the multiplier roofline is in roofline_valu.  avg_kernel_ms is k_accumulate_pieces alone: the work-item plan in "
-                                 "front of it (k_piece_count + k_piece_scatter: stage plan_ms) and k_combine_pieces behind it (combine_ms) are "
+                                 "front of it (k_place_count + k_piece_scatter: stage plan_ms) and k_combine_pieces behind it (combine_ms) are "
                                  "separate launches -- work the round-3 accumulation kernel did itself"},
             # the sort/scatter stages (north_star: "achieved HBM GB/s on the sort/scatter stages"): SURVEY section 8d algorithmic bytes
             # 8*N*W over the hipEvent time of k_coarse_hist .. k_fine_sort in the diagnostic step
-            "roofline_sort": ({"bound": "hbm", "kernels": "k_coarse_hist+k_coarse_prefix+k_coarse_starts+k_coarse_scatter+k_fine_sort+k_big_place",
+            "roofline_sort": ({"bound": "hbm", "kernels": "k_coarse_hist+k_coarse_prefix+k_coarse_starts+k_coarse_scatter+k_fine_sort",
                                "algorithmic_bytes": sort_bytes, "ms": round(sort_ms, 4), "achieved": round(sort_bytes / (sort_ms * 1e-3) / 1e9, 1),
                                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(sort_bytes / (sort_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
                                "traffic": sort_traffic, "traffic_source": sort_traffic_src,
                                "traffic_GBps": round(sort_traffic / (sort_ms * 1e-3) / 1e9, 1) if sort_traffic else None,
-                               "note": "achieved = SURVEY's algorithmic bytes (one read + one write of the pairs) over the hipEvent time of the six launches; a "
-                                       "counting sort reads the digits three times and writes them twice (traffic: what the counters saw), and four of the "
-                                       "six launches are launch-bound (~5 us each)"} if sort_ms > 0 else None),
+                               "note": "achieved = SURVEY's algorithmic bytes (one read + one write of the pairs) over the hipEvent time of the five launches; a "
+                                       "counting sort reads the digits three times and writes them twice (traffic: what the counters saw), and three of the "
+                                       "five launches are launch-bound (~5 us each); the placement of oversized regions (skewed scalars) runs in k_place_count, the plan stage"} if sort_ms > 0 else None),
             # the bound that actually holds: multiplier work of the launch against what two calibration
             # micro-kernels sustain on THIS device (dependent chains, 4 wavefronts per SIMD, like k_accumulate)
             "roofline_valu": valu_roofline(int(tm.get("num_adds", 0)), acc_avg_ms, mad_peak, fpmul_peak) if not args.streamed else None,

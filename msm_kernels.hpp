@@ -1586,7 +1586,7 @@ __device__ __forceinline__ void fold_partials(uint32_t* e, const uint32_t* parti
     }
     lds_tree_wide(e, count < CAP ? count : CAP);
 }
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) k_combine_pieces(const uint32_t* __restrict__ offsets, uint32_t* __restrict__ partials,
+__global__ void __launch_bounds__(512) k_combine_pieces(const uint32_t* __restrict__ offsets, uint32_t* __restrict__ partials,
                                                         uint32_t* __restrict__ buckets, uint32_t pmax, uint32_t psplit, const uint32_t* __restrict__ pbase,
                                                         const uint32_t* __restrict__ mid_count, const uint32_t* __restrict__ mid_list,
                                                         const uint32_t* __restrict__ long_count, const uint32_t* __restrict__ long_list,

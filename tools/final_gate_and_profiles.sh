@@ -3,6 +3,6 @@
 cd "$(dirname "${BASH_SOURCE[0]}")/.."
 export GRAFT_REPO_ROOT=$PWD
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/r5_final_pytest.txt 2>&1; echo "pytest rc $?" >> gpurun_out/r5_final_pytest.txt
-tail -6 gpurun_out/r5_final_pytest.txt
-BUILD="${BUILD:-round 5 final}" bash tools/final_profiles.sh 2>&1 | tail -12
+timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/r6_final_pytest.txt 2>&1; echo "pytest rc $?" >> gpurun_out/r6_final_pytest.txt
+tail -6 gpurun_out/r6_final_pytest.txt
+BUILD="${BUILD:-round 6 final}" bash tools/final_profiles.sh 2>&1 | tail -12

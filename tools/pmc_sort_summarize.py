@@ -19,8 +19,8 @@ fetch = per_kernel(newest(f"{d}/bench_FETCH_SIZE/**/*counter_collection.csv"))
 write = per_kernel(newest(f"{d}/bench_WRITE_SIZE/**/*counter_collection.csv"))
 cal = per_kernel(newest(f"{d}/calib_FETCH_SIZE/**/*counter_collection.csv"))
 stream_factor = (1 << 30) / (sum(cal["k_stream"]) / len(cal["k_stream"]) * 1024) if cal.get("k_stream") else 2.0
-SORT = ["k_coarse_hist", "k_coarse_prefix", "k_coarse_starts", "k_coarse_scatter", "k_fine_sort", "k_big_place"]
-OTHER = ["k_decompose_glv", "k_decompose", "k_convert_bases", "k_phi_records", "k_piece_count", "k_piece_scatter", "k_combine_pieces", "k_pair_level8", "k_reduce_bits_wide"]
+SORT = ["k_coarse_hist", "k_coarse_prefix", "k_coarse_starts", "k_coarse_scatter", "k_fine_sort"]  # (round 6: k_big_place became part of k_place_count, the plan stage)
+OTHER = ["k_decompose_glv", "k_decompose", "k_convert_bases", "k_phi_records", "k_place_count", "k_piece_count", "k_piece_scatter", "k_combine_pieces", "k_pair_level8", "k_pair_tail", "k_reduce_bits_wide"]
 avg = lambda v: sum(v) / len(v) if v else 0.0
 rows = {}
 for k in SORT + OTHER:
