@@ -1796,12 +1796,16 @@ __global__ void __launch_bounds__(256) k_pair_level8(const uint32_t* __restrict_
     constexpr uint32_t PER = 8 / G, SERIAL = PER - 1, LEVELS = G == 1 ? 0 : G == 2 ? 1 : 2;
     const size_t first = i0 + (size_t)sub * PER * stride;
     xyzz acc = load_xyzz(in + first * XW);
-    // ONE call site for the serial folds and the shuffle levels (an inlined complete addition is ~40 KB of code)
+    // ONE call site for the serial folds and the shuffle levels (an inlined complete addition is ~40 KB of code).
+    // The NEXT record is in flight while the current one is added (round 6): the chain is a lone wavefront per SIMD, so every record's load latency
+    // used to sit in series with the seven additions.
+    xyzz nxt = load_xyzz(in + (first + stride) * XW);
 #pragma unroll 1
     for (uint32_t step = 0; step < SERIAL + LEVELS; step++) {
         xyzz other;
         if (step < SERIAL) {
-            other = load_xyzz(in + (first + (size_t)(step + 1) * stride) * XW);
+            other = nxt;
+            if (step + 1 < SERIAL) nxt = load_xyzz(in + (first + (size_t)(step + 2) * stride) * XW);
         } else {
             const uint32_t d = (G / 2) >> (step - SERIAL);
             other = shfl_down_xyzz(acc, (int)d, G);
