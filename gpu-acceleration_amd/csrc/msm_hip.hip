@@ -672,7 +672,7 @@ int32_t enqueue_accumulate(msm_ctx* c, const PipeState& ps, const BaseSrc& src, 
         else MSM_ACC_LAUNCH(false, false, false);
     }
 #undef MSM_ACC_LAUNCH
-    msmk::k_combine_pieces<<<dim3(msmk::LONG_BLOCKS + msmk::MID_BLOCKS), 512, 0, st>>>(
+    msmk::k_combine_pieces<<<dim3(msmk::LONG_BLOCKS + msmk::MID_BLOCKS), msmk::COMBINE_BLOCK, 0, st>>>(
         offsets, pt, bk, ps.pmax, ps.psplit, (const uint32_t*)c->pbase.p, flags + msmk::FLAG_MID, (const uint32_t*)c->midlist.p, flags + msmk::FLAG_LONG,
         (const uint32_t*)c->longlist.p, (uint32_t*)c->longdone.p);
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_COMBINE], st));  // msm_timings_t.combine_ms

@@ -888,7 +888,7 @@ __global__ void __launch_bounds__(1024) k_coarse_prefix(uint32_t* __restrict__ c
 constexpr uint32_t BIG_NONE = 0xFFFFFFFFu;
 constexpr uint32_t BIG_MAX_ITEMS = 4096;
 constexpr uint32_t BIG_WORKERS_X = 16;  // worker blocks per window row (grid.y = sort windows), at least BIG_WORKERS_MIN in all
-constexpr uint32_t BIG_WORKERS_MIN = 128;
+constexpr uint32_t BIG_WORKERS_MIN = 512;
 constexpr uint32_t BIG_ITEMS_OFF = 16, BIG_TAB_OFF = BIG_ITEMS_OFF + 2 * BIG_MAX_ITEMS;
 constexpr uint32_t BIG_SLOT_WORDS = 1024;  // == 2 * FINE_BINS_MAX: counts, then cursors, of up to 512 fine bins
 constexpr size_t BIG_WORDS = (size_t)BIG_TAB_OFF + (size_t)BIG_MAX_ITEMS * BIG_SLOT_WORDS;
@@ -1199,9 +1199,10 @@ __global__ void k_scatter(const uint32_t* __restrict__ digits, const uint32_t* _
 // Measured against the chunk form, same build, one box (profiles/r4_pieces_vs_chunks.txt): 2^20 1.557 -> 1.488 ms, 2^17 0.470 -> 0.440,
 // 2^22 5.32 -> 5.00.
 constexpr uint32_t LONG_SPAN = 8;     // split buckets of this many pieces or more are folded by whole workgroups (k_combine_pieces)
-constexpr uint32_t LONG_SEG = 2048;   // pieces of a long bucket folded by one workgroup
+constexpr uint32_t LONG_SEG = 1024;   // pieces of a long bucket folded by one workgroup (round 6: was 2048 -- with 256-thread workgroups four serial one-lane additions per lane instead of eight)
 constexpr uint32_t WAVE_ITEM_MAX = 512;      // long buckets of at most this many pieces are folded by one wavefront (k_combine_pieces pass A) ...
-constexpr uint32_t WAVE_ITEM_RECORDS = 32;   // ... in a 32-record region of the workgroup's LDS (8 wavefronts x 32 = WIDE_TREE_MAX records)
+constexpr uint32_t COMBINE_BLOCK = 256;      // threads of a k_combine_pieces workgroup: at three wavefronts per SIMD three of them share a CU (512 threads at the kernel's 175 VGPRs: ONE)
+constexpr uint32_t WAVE_ITEM_RECORDS = 64;   // ... in a 64-record region of the workgroup's LDS (4 wavefronts x 64 = WIDE_TREE_MAX records)
 constexpr uint32_t LONG_BLOCKS = 1024, MID_BLOCKS = 1024;  // k_combine_pieces' grid: (bucket, segment) items grid-stride over the first, listed buckets over the rest
 // (PIECE_BINS, at the top of this file: pmax <= PIECE_BINS, one histogram bin per piece length)
 constexpr uint32_t PF_WHOLE = 0x80000000u;            // piece.z: the bucket is this one piece -> the sum goes to buckets[k]
@@ -1586,7 +1587,7 @@ __device__ __forceinline__ void fold_partials(uint32_t* e, const uint32_t* parti
     }
     lds_tree_wide(e, count < CAP ? count : CAP);
 }
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) k_combine_pieces(const uint32_t* __restrict__ offsets, uint32_t* __restrict__ partials,
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3))) k_combine_pieces(const uint32_t* __restrict__ offsets, uint32_t* __restrict__ partials,
                                                         uint32_t* __restrict__ buckets, uint32_t pmax, uint32_t psplit, const uint32_t* __restrict__ pbase,
                                                         const uint32_t* __restrict__ mid_count, const uint32_t* __restrict__ mid_list,
                                                         const uint32_t* __restrict__ long_count, const uint32_t* __restrict__ long_list,
