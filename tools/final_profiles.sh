@@ -18,13 +18,14 @@ cp gpurun_out/accumulate_pmc_2p*.json gpurun_out/sort_pmc_2p*.json profiles/ 2>/
 bash tools/pmc_valu.sh > $O/pmc_valu.log 2>&1
 cp gpurun_out/pmc_valu/summary.json $O/accumulate_valu_pmc.json 2>/dev/null
 cp gpurun_out/pmc_valu/summary.json profiles/accumulate_valu_pmc.json 2>/dev/null
+python3 tools/shard_times.py --build "$BUILD" > $O/shard_times.txt 2>&1   # (the line's projected_strong_scaling reads profiles/shard_times.json)
+cp gpurun_out/shard_times.json $O/shard_times.json
+cp gpurun_out/shard_times.json profiles/shard_times.json
 python3 bench.py > $O/bench_line.json 2> $O/bench.err; echo "bench rc $?"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o p -- python3 $R/bench.py --no-host-legs > $O/bench_under_rocprof.json 2>/dev/null  # (no host legs: k_accumulate<false,false> then only has the timed shape)
 cp $O/stats/p_kernel_stats.csv $O/kernel_stats.csv
 cd "$R"
-python3 tools/shard_times.py --build "$BUILD" > $O/shard_times.txt 2>&1
-cp gpurun_out/shard_times.json $O/shard_times.json
 python3 tools/sweep.py 10 12 13 14 15 16 > $O/sweep_small.txt 2>&1
 python3 tools/host_path_sweep.py 16 18 19 20 22 > $O/host_sweep.txt 2>&1
 TOPK=18 bash tools/prof_kernels.sh 17 19 21 > $O/kernel_stats_2p17_2p19_2p21.txt 2>&1
