@@ -105,6 +105,7 @@ struct Knobs {
     size_t glv_max = msmplan::GLV_MAX_POINTS;  // MSM_HIP_GLV_MAX_LOG2
     uint32_t piece_len = 0;                    // MSM_HIP_PIECE_LEN: longest whole bucket = split length of k_accumulate_pieces' work items; 0 = by size (tests force 1, 7, 26, 35)
     bool direct_scatter = false;               // MSM_HIP_DIRECT_SCATTER: skip the two-level LDS sort
+    uint32_t pair8_max_mb = 200;               // MSM_HIP_PAIR8_MAX_MB: bucket arrays up to this size take k_pair_level8 (three levels in one launch)
     bool no_poll = false;                      // MSM_HIP_NO_POLL: wait for the stream instead of polling the last kernel's sequence words (A/B: tools/ab_env.py)
     uint32_t device_chunk_log2 = 22;           // MSM_HIP_DEVICE_CHUNK_LOG2: point ranges of device-resident instances; 0 = never cut
     uint32_t stream_min_log2 = 19;             // MSM_HIP_STREAM_MIN_LOG2: host calls are streamed from this size on (tools/host_path_sweep.py)
@@ -124,6 +125,7 @@ struct Knobs {
         k.piece_len = (uint32_t)num("MSM_HIP_PIECE_LEN", 0, msmk::PIECE_BINS, 0);
         k.direct_scatter = std::getenv("MSM_HIP_DIRECT_SCATTER") != nullptr;  // (tests: the one-level LDS / global-atomic sort fallbacks)
         k.no_poll = std::getenv("MSM_HIP_NO_POLL") != nullptr;
+        k.pair8_max_mb = (uint32_t)num("MSM_HIP_PAIR8_MAX_MB", 0, 4096, 200);
         k.device_chunk_log2 = (uint32_t)num("MSM_HIP_DEVICE_CHUNK_LOG2", 0, 30, 22);
         k.stream_min_log2 = (uint32_t)num("MSM_HIP_STREAM_MIN_LOG2", 9, 31, 19);
         k.stream_chunk_log2 = std::getenv("MSM_HIP_STREAM_CHUNK_LOG2") ? (uint32_t)num("MSM_HIP_STREAM_CHUNK_LOG2", 8, 28, 0) : 0u;
@@ -696,12 +698,13 @@ int32_t enqueue_reduce(msm_ctx* c, const PipeState& ps, hipStream_t st, uint32_t
     size_t rn = tb, cn = tb;  // current element counts
     const uint32_t levels = kb_hi > kb_lo ? kb_hi : kb_lo;
     // Round 2: the first three levels (ALU-bound, most of the adds) run as ONE launch that reads every bucket once per family and never
-    // writes the two intermediate levels (-14..-16 us of kernel time at every size up to 2^20).  Not above ~100 MB of buckets (c = 17,
-    // 15 x 65536 buckets: there its strided record reads lose 20-35 us to the pairwise levels).  A matching single launch for the
+    // writes the two intermediate levels (-14..-16 us of kernel time at every size up to 2^20).  Round 2 kept it below ~100 MB of buckets (c = 17,
+    // 15 x 65536 buckets = 141 MB: its strided record reads lost 20-35 us to the pairwise levels there); with the next record in flight during an addition
+    // (round 6) it wins there too: reduce 0.308 -> 0.298 ms at 2^21, 0.324 -> 0.307 at 2^22 (MSM_HIP_PAIR8_MAX_MB of the hooks build) => up to 200 MB.  A matching single launch for the
     // LAST levels (one LDS tree of eight-lane additions per output) was slower than the launch-bound k_pair_level_wide levels it
     // replaced (2^20: 52 vs 37 us: a tree's upper levels leave most lanes of its wavefront idle): profiles/NOTES_r2.md.
     uint32_t l = 0;
-    if (levels >= 3 && kb_lo >= 3 && tb * XB <= ((size_t)100 << 20)) {
+    if (levels >= 3 && kb_lo >= 3 && tb * XB <= ((size_t)c->knobs.pair8_max_mb << 20)) {
         rn = tb / 8, cn = tb / 8;
         // lanes per output: one lane while every SIMD has a wavefront of outputs (the kernel is multiplier bound then: 8 x 32768 buckets,
         // 2^14 .. 2^20 points: 1 / 2 / 4 lanes 0.471 / 0.470 / 0.487 ms at 2^17); below that the seven dependent additions of an output are
