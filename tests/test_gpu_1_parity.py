@@ -475,6 +475,13 @@ def test_full_size_closed_form_and_linearity(ctx, hk, logn):
     assert (comb.affine_std == exp).all()
     tm = ctx.timings()
     assert tm["num_points"] == n - h and tm["accumulate_ms"] > 0 and tm["sort_ms"] == 0
+    # ABI 7: the size-checked getter writes at most the caller's sizeof (a consumer built against an older, shorter msm_timings_t is not overrun)
+    import ctypes as C
+    buf = (C.c_uint8 * 96)(*([0xAB] * 96))
+    assert ctx._lib.msm_get_timings_sized(ctx._h, C.cast(buf, C.c_void_p), 40) == mh.OK  # 40 bytes: h2d_ms .. total_ms + num_points
+    assert bytes(buf[40:]) == b"\xab" * 56 and C.cast(buf, C.POINTER(C.c_float))[4] == pytest.approx(tm["accumulate_ms"])
+    assert C.cast(C.byref(buf, 32), C.POINTER(C.c_uint64))[0] == n - h
+    assert ctx._lib.msm_get_timings_sized(ctx._h, C.cast(buf, C.c_void_p), 0) == mh.ERR_BAD_ARG
     ctx.set_stage_timing(True)
     ctx.msm_device(d_bases.data_ptr(), d_s.data_ptr(), n)
     tm = ctx.timings()
