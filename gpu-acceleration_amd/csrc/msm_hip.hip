@@ -105,6 +105,7 @@ struct Knobs {
     size_t glv_max = msmplan::GLV_MAX_POINTS;  // MSM_HIP_GLV_MAX_LOG2
     uint32_t piece_len = 0;                    // MSM_HIP_PIECE_LEN: longest whole bucket = split length of k_accumulate_pieces' work items; 0 = by size (tests force 1, 7, 26, 35)
     bool direct_scatter = false;               // MSM_HIP_DIRECT_SCATTER: skip the two-level LDS sort
+    bool ark_slow = false;                     // MSM_HIP_ARK_SLOW: struct arrays always through k_import_ark (A/B and tests of the path a set infinity flag falls back to)
     uint32_t pair8_max_mb = 200;               // MSM_HIP_PAIR8_MAX_MB: bucket arrays up to this size take k_pair_level8 (three levels in one launch)
     bool no_poll = false;                      // MSM_HIP_NO_POLL: wait for the stream instead of polling the last kernel's sequence words (A/B: tools/ab_env.py)
     uint32_t device_chunk_log2 = 22;           // MSM_HIP_DEVICE_CHUNK_LOG2: point ranges of device-resident instances; 0 = never cut
@@ -124,6 +125,7 @@ struct Knobs {
         k.glv_max = msmplan::glv_max_from_env();
         k.piece_len = (uint32_t)num("MSM_HIP_PIECE_LEN", 0, msmk::PIECE_BINS, 0);
         k.direct_scatter = std::getenv("MSM_HIP_DIRECT_SCATTER") != nullptr;  // (tests: the one-level LDS / global-atomic sort fallbacks)
+        k.ark_slow = std::getenv("MSM_HIP_ARK_SLOW") != nullptr;
         k.no_poll = std::getenv("MSM_HIP_NO_POLL") != nullptr;
         k.pair8_max_mb = (uint32_t)num("MSM_HIP_PAIR8_MAX_MB", 0, 4096, 200);
         k.device_chunk_log2 = (uint32_t)num("MSM_HIP_DEVICE_CHUNK_LOG2", 0, 30, 22);
@@ -475,7 +477,10 @@ int32_t enqueue_decompose(msm_ctx* c, const PipeState& ps, const uint8_t* d_inf,
     // The flag words clean themselves (a hipMemsetAsync is its own dispatch: ~5 us + a ~12 us bubble in front of it, per call and per
     // streamed chunk): k_decompose zeroes the list counters of the chunk, the kernel that ends an MSM zeroes the error and count
     // words after copying them out.  Only a context whose last call did not complete (error paths) is cleaned from the host.
-    if (first && !c->flags_clean) HIPCHK(c, hipMemsetAsync(flags, 0, 64, st));
+    if (first && !c->flags_clean) {  // (error recovery only; waited for, so that no kernel of this call on the OTHER stream -- k_ark_repack raises an error bit -- can be overtaken by it)
+        HIPCHK(c, hipMemsetAsync(flags, 0, 64, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+    }
     if (first) c->flags_clean = false;
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_CONVERT], st));
     void* dg = c->digits.p;
@@ -823,11 +828,13 @@ hostg1::Jac host_finish(msm_ctx* c, const uint32_t* h_qsums, const PipeState& g)
     return total;
 }
 
+constexpr int32_t ARK_RETRY_SLOW = 1;  // (internal, never handed out: see KIND_ARKFAST)
 int32_t check_flags(msm_ctx* c, const uint32_t* h_flags) {
     if (h_flags[0] & 1u) return fail(c, MSM_ERR_BAD_ARG, "a scalar is >= 2^254 (not a canonical Fr element)");
     if (h_flags[0] & 2u) return fail(c, MSM_ERR_HIP, "internal: signed-digit carry out of the top window");
     if (h_flags[0] & 4u) return fail(c, MSM_ERR_HIP, "internal: a GLV half exceeds its bound (7 * 2^123)");
     if (h_flags[0] & 8u) return fail(c, MSM_ERR_HIP, "internal: a digit collides with the 16-bit skip code");
+    if (h_flags[0] & 16u) return ARK_RETRY_SLOW;  // a struct of the optimistic struct-array path had its infinity flag set (run_host_input repeats the call)
     return MSM_OK;
 }
 
@@ -981,7 +988,9 @@ int32_t check_common(msm_ctx* c, const void* a, const void* b, size_t n) {
 // What the two host-pointer entries hand over: packed x||y words (standard or Montgomery form) with an optional byte mask of
 // points at infinity, or an array of arkworks G1Affine structs read through (stride, offsets); scalars in standard form or as
 // arkworks Fr Montgomery words.
-enum : uint32_t { KIND_STD = 0, KIND_MONT = 1, KIND_ARK = 2 };
+// KIND_ARKFAST: a struct array taken OPTIMISTICALLY as free of points at infinity (k_ark_repack); a flag that is set makes the call return ARK_RETRY_SLOW
+// internally and run_host_input repeats it as KIND_ARK
+enum : uint32_t { KIND_STD = 0, KIND_MONT = 1, KIND_ARK = 2, KIND_ARKFAST = 3 };
 struct HostInput {
     const uint8_t* bases = nullptr;
     size_t stride = 64;  // bytes per base record
@@ -1007,7 +1016,18 @@ int32_t h2d(msm_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t cs
 // from.  arkworks-form words (R = 2^256 Montgomery): the records stay where they are -- nothing to do for an unsplit plan, the phi records of a
 // split one go to d_out (k_phi_records, round 5).  Standard-form words and struct arrays: internal-domain records in d_out (+ infinity bytes
 // for the struct form).
-BaseSrc launch_convert(const HostInput& in, const void* d_raw, size_t cnt, uint32_t* d_out, uint8_t* d_inf, bool glv, hipStream_t st) {
+BaseSrc launch_convert(const HostInput& in, const void* d_raw, size_t cnt, uint32_t* d_out, uint8_t* d_inf, bool glv, hipStream_t st,
+                       uint32_t* err_flags = nullptr) {
+    if (in.kind == KIND_ARKFAST) {  // repacked to x || y words in d_out (+ the phi records behind them): gathered like the packed-words call's
+        msmk::k_ark_repack<<<grid1(cnt, 256), 256, 0, st>>>((const uint8_t*)d_raw, (uint64_t)in.stride, in.x_off, in.y_off,
+                                                          in.has_inf_field ? in.inf_off : 0u, in.has_inf_field ? 1u : 0u, (uint32_t)cnt, d_out, err_flags,
+                                                          glv ? 1u : 0u);
+        BaseSrc src;
+        src.m256 = true;
+        src.rec = d_out;
+        if (glv) src.phi = d_out + cnt * 16, src.nsplit = (uint32_t)cnt;
+        return src;
+    }
     if (in.kind == KIND_ARK) {
         msmk::k_import_ark<<<grid1(2 * cnt, 256), 256, 0, st>>>((const uint8_t*)d_raw, (uint64_t)in.stride, in.x_off, in.y_off,
                                                              in.has_inf_field ? in.inf_off : 0u, in.has_inf_field ? 1u : 0u, (uint32_t)cnt,
@@ -1042,7 +1062,7 @@ int32_t feed_bases(msm_ctx* c, const HostInput& in, size_t lo, size_t cnt, void*
                    hipStream_t s, BaseSrc* src) {
     int32_t rc = h2d(c, d_raw, in.bases + lo * in.stride, cnt * in.stride, s);
     if (rc) return rc;
-    *src = launch_convert(in, d_raw, cnt, d_ibases, d_inf, glv, s);
+    *src = launch_convert(in, d_raw, cnt, d_ibases, d_inf, glv, s, (uint32_t*)c->flags.p);
     return MSM_OK;
 }
 
@@ -1151,7 +1171,7 @@ int32_t run_streamed(msm_ctx* c, const HostInput& in, size_t n, const std::vecto
             if ((rc = enqueue_digits_sort(c, ps, d_inf, (const uint32_t*)c->sscalars[s].p, in.scalars_mont, st, j == 0))) return rc;
         }
         HIPCHK(c, hipStreamWaitEvent(st, c->ev_copied[s], 0));
-        const BaseSrc src = launch_convert(in, c->sbases[s].p, cnt, (uint32_t*)c->sibases.p, d_inf, glv, st);  // (arkworks words: gathered from the slot itself)
+        const BaseSrc src = launch_convert(in, c->sbases[s].p, cnt, (uint32_t*)c->sibases.p, d_inf, glv, st, (uint32_t*)c->flags.p);  // (arkworks words: gathered from the slot itself)
         if (!early_sort && (rc = enqueue_digits_sort(c, ps, d_inf, (const uint32_t*)c->sscalars[s].p, in.scalars_mont, st, j == 0))) return rc;
         if ((rc = enqueue_accumulate(c, ps, src, st, nullptr, j > 0, true))) return rc;
         HIPCHK(c, hipEventRecord(c->ev_free[s], st));
@@ -1209,10 +1229,18 @@ std::vector<size_t> stream_schedule(const msm_ctx* c, size_t n) {
     return sizes;
 }
 
-int32_t run_host_input(msm_ctx* c, const HostInput& in, size_t n, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf) {
+int32_t run_host_input(msm_ctx* c, const HostInput& in0, size_t n, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf) {
     auto t0 = std::chrono::steady_clock::now();
     const std::vector<size_t> sizes = stream_schedule(c, n);
+    // Struct arrays (round 6): first as if no point were at infinity -- the words are repacked and the call runs like the packed-words call, its sort
+    // overlapped with the transfer of the bases; a set flag (error bit 16, seen when the call has finished) repeats the call with the flags as a mask.
+    HostInput in = in0;
+    if (in.kind == KIND_ARK && !c->knobs.ark_slow) in.kind = KIND_ARKFAST;
     int32_t rc = sizes.empty() ? run_single(c, in, n, out_jac, out_aff, out_inf) : run_streamed(c, in, n, sizes, out_jac, out_aff, out_inf);
+    if (rc == ARK_RETRY_SLOW) {
+        in.kind = KIND_ARK;
+        rc = sizes.empty() ? run_single(c, in, n, out_jac, out_aff, out_inf) : run_streamed(c, in, n, sizes, out_jac, out_aff, out_inf);
+    }
     if (rc) return rc;
     c->tm.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return MSM_OK;

@@ -300,6 +300,29 @@ __global__ void k_import_ark(const uint8_t* __restrict__ raw, uint64_t stride, u
     if (which == 0 && inf_out) inf_out[pt] = has_inf ? (rec[inf_off] != 0) : 0;
 }
 
+// The FAST form of the same ingestion (round 6), for struct arrays WITHOUT points at infinity -- every proving key, every SRS: the Fq words are already what
+// k_accumulate_pieces<.., M256> gathers (arkworks' own Montgomery words), so the structs are only REPACKED to 64-byte x || y records (no field
+// multiplication; with glv the phi record (beta * x, y) of every point behind them, at record n + i) and the call runs like the packed-words call: the sort
+// starts when the scalars are there, not when the bases are.  A set `infinity` flag is not handled here: it raises error bit 16 and the host runs the call again
+// through k_import_ark (the flags then travel to the decomposition as an infinity mask).
+__global__ void __launch_bounds__(256) k_ark_repack(const uint8_t* __restrict__ raw, uint64_t stride, uint32_t x_off, uint32_t y_off, uint32_t inf_off, uint32_t has_inf,
+                                                    uint32_t n, uint32_t* __restrict__ out, uint32_t* __restrict__ err, uint32_t glv) {
+    const uint32_t pt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pt >= n) return;
+    const uint8_t* rec = raw + (size_t)pt * stride;
+    const uint32_t* sx = reinterpret_cast<const uint32_t*>(rec + x_off);  // 4-byte aligned (checked on the host)
+    const uint32_t* sy = reinterpret_cast<const uint32_t*>(rec + y_off);
+    uint32_t w[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) w[k] = sx[k];
+    store_words8(out + (size_t)pt * 16, w);
+#pragma unroll
+    for (int k = 0; k < 8; k++) w[k] = sy[k];
+    store_words8(out + (size_t)pt * 16 + 8, w);
+    if (has_inf && rec[inf_off] != 0) atomicOr(err + FLAG_ERR, 16u);
+    if (glv) phi_record(out + (size_t)pt * 16, out + (size_t)(n + pt) * 16);  // (reads back what this thread just wrote)
+}
+
 // Row f3: arkworks `serialize_compressed` images of G1Affine (reference utils/preprocess.rs:193-223) -> bases.
 // One thread per point: x (standard form, flags in bits 254/255) -> y = (x^3+3)^((p+1)/4)  (p = 3 mod 4), the root
 // is checked (y^2 == x^3+3, else the image is invalid) and the sign picked as ark-ec 0.4 does: flag bit 255 set <=> y is

@@ -183,7 +183,10 @@ int32_t msm_bn254_g1(msm_ctx *ctx, const uint32_t *bases_xy, uint32_t base_form,
  * x, y and the `infinity` bool; inf_off = (size_t)-1 if there is none) -- the Rust shim measures these with
  * size_of / addr_of!, the struct is not repr(C).  Coordinates and scalars are arkworks' internal Montgomery words
  * (Fq.0 / Fr.0, R = 2^256): no CPU-side `into_bigint()`, no repacking (replaces pack_affine_and_scalars,
- * utils/limbs_conversion.rs:311-378: 3 Montgomery reductions + 3 heap allocations per point). */
+ * utils/limbs_conversion.rs:311-378: 3 Montgomery reductions + 3 heap allocations per point).
+ * Round 6: the call first runs as if no struct had its `infinity` flag set (the words are repacked on the device and gathered as they are, the sort
+ * overlaps the transfer of the bases); if one does, the call is repeated internally with the flags as an infinity mask -- same result, about twice
+ * the time for such inputs (proving keys and SRS points are never at infinity). */
 int32_t msm_bn254_g1_arkworks(msm_ctx *ctx, const void *bases, size_t stride, size_t x_off, size_t y_off, size_t inf_off,
                               const uint32_t *scalars_mont, size_t n, uint32_t out_jacobian_mont[24],
                               uint32_t out_affine_std[16], uint8_t *out_is_inf);

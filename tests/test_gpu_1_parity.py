@@ -829,6 +829,45 @@ def test_arkworks_struct_ingestion(ctx, layout):
         assert (r.affine_std == g["expected"]).all(), (name, layout)
 
 
+@pytest.mark.parametrize("slow", [False, True])
+def test_arkworks_structs_optimistic_path_and_its_fallback(monkeypatch, slow):
+    """round 6: a struct array is first taken as free of points at infinity (k_ark_repack: the words are repacked and gathered as they are, the sort starts with
+    the scalars); a set `infinity` flag raises error bit 16 and the call is repeated through k_import_ark with the flags as a mask.  Same bits either way, with
+    and without flags, single shot and streamed (2^19 points), and forced through the slow path from the start (MSM_HIP_ARK_SLOW of the hooks build)."""
+    if slow:
+        monkeypatch.setenv("MSM_HIP_ARK_SLOW", "1")
+    n = 1 << 19
+    k = th.generate_scalars_host(0xB2540D01, n, nonzero=True)
+    s = th.generate_scalars_host(0xB2540D02, n)
+    bases = orc.gen_bases_from_logs(k, orc.FORM_MONT)
+    rinv = pow(1 << 256, -1, orc.R_ORDER)
+    g = np.zeros(16, np.uint32)
+    g[0], g[8] = 1, 2
+    expect = lambda d: orc.g1_to_affine_std(orc.g1_scalar_mul(g, orc.int_to_words(d % orc.R_ORDER)))[0]
+    img = np.zeros((n, 72), np.uint8)
+    img[:, :64] = bases.view(np.uint8).reshape(n, 64)
+    e_all = expect(orc.dot_words(k, s) * rinv)
+    inf = np.zeros(n, np.uint8)
+    inf[[0, 3, 77777, (1 << 18) - 1, 1 << 18, n - 1]] = 1
+    img_inf = img.copy()
+    img_inf[:, 64] = inf
+    img_inf[inf != 0, :64] = 0  # arkworks' identity: x = y = 0, infinity = true
+    s_masked = s.copy()
+    s_masked[inf != 0] = 0
+    e_inf = expect(orc.dot_words(k, s_masked) * rinv)
+    with th.HooksContext() as c:
+        for m in (n, 1 << 16, 4097):  # streamed (>= 2^19 points), single shot with the bases on the copy stream, and just above the overlap threshold
+            e1 = e_all if m == n else expect(orc.dot_words(k[:m], s[:m]) * rinv)
+            assert (c.msm_arkworks(img[:m], 72, 0, 32, 64, s[:m]).affine_std == e1).all(), (m, slow)
+        assert c.timings()["stream_chunks"] == 0
+        r = c.msm_arkworks(img_inf, 72, 0, 32, 64, s)  # flags set: the optimistic pass notices, the call is repeated
+        assert (r.affine_std == e_inf).all() and c.timings()["stream_chunks"] >= 2
+        assert (c.msm_arkworks(img, 72, 0, 32, 64, s).affine_std == e_all).all()  # and the context is as good as new
+    with th.HooksContext(flags=mh.FLAG_NO_GLV, window_bits=13) as c:  # an unsplit plan: no phi records behind the repacked words
+        assert (c.msm_arkworks(img_inf, 72, 0, 32, 64, s).affine_std == e_inf).all()
+        assert (c.msm_arkworks(img, 72, 0, 32, 64, s).affine_std == e_all).all()
+
+
 def test_arkworks_ingestion_rejects_bad_layout(ctx):
     g = load_golden("rand_n3")
     img = _ark_image(g["bases"], None, 72, 0, 32, 64, np.random.default_rng(1))
