@@ -29,6 +29,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -206,6 +207,7 @@ struct msm_ctx {
     float enqueue_ms = 0;         // trace: host time from there until everything was queued (what a hipGraph could shorten)
     bool flags_clean = false;     // the device flag words are known to be zero (set when an MSM completes)
     uint32_t last_sort_path = 0;  // 2 = two-level LDS sort, 1 = tiled LDS histogram, 0 = global atomics (stage tests, trace)
+    bool no_host_pin = false;     // a context of an msm_multi handle: the handle pins the caller's arrays once for all its ranks (HostPin)
 };
 
 namespace {
@@ -1229,8 +1231,76 @@ std::vector<size_t> stream_schedule(const msm_ctx* c, size_t n) {
     return sizes;
 }
 
+// Pageable caller memory, pinned IN PLACE for the duration of the call (round 6).  hipMemcpyAsync from pageable memory is staged by the runtime at ~40 GB/s and blocks
+// the calling thread; from registered memory it is a DMA at the link's 53-55 GB/s -- and on this platform hipHostRegister / hipHostUnregister of 96 MB take ~3 us
+// each (tools/host_register_probe.py): 2^20 points from plain heap memory 2.55 -> 2.42 ms, what torch-pinned memory gives.  Memory the runtime already knows
+// (pinned by the caller, or registered by an msm_multi handle for all its ranks) is left alone; a range that cannot be registered (read-only mappings) simply
+// travels as before.  Unregistered when the call has consumed it (every copy is ordered in front of the kernel whose results the call waited for).
+// Registrations are shared process-wide: two contexts handed the SAME array at the same time (two threads of a prover, the ranks of an msm_multi handle) must not
+// unregister it under each other's copies -- a range this library registered is reference-counted, and a pointer inside such a range takes a reference on it.
+struct HostPinRegistry {
+    struct Entry {
+        uintptr_t lo, hi;
+        int refs;
+    };
+    std::mutex mu;
+    std::vector<Entry> live;
+    static HostPinRegistry& get() {
+        static HostPinRegistry r;
+        return r;
+    }
+};
+struct HostPin {
+    uintptr_t key = 0;  // start of the registered range this pin holds a reference on (0: none)
+    void pin(const void* ptr, size_t bytes, bool all_devices = false) {
+        if (!ptr || bytes < ((size_t)1 << 20) || key) return;
+        HostPinRegistry& R = HostPinRegistry::get();
+        std::lock_guard<std::mutex> lk(R.mu);
+        const uintptr_t a = (uintptr_t)ptr;
+        for (auto& e : R.live)
+            if (a >= e.lo && a < e.hi) {  // ours already (possibly a larger range: the whole arrays of an msm_multi call)
+                e.refs++;
+                key = e.lo;
+                return;
+            }
+        hipPointerAttribute_t at{};
+        const hipError_t q = hipPointerGetAttributes(&at, ptr);
+        (void)hipGetLastError();
+        if (q == hipSuccess && at.type != hipMemoryTypeUnregistered) return;  // pinned / registered by the caller: left alone
+        if (hipHostRegister(const_cast<void*>(ptr), bytes, all_devices ? hipHostRegisterPortable : hipHostRegisterDefault) == hipSuccess) {
+            R.live.push_back({a, a + bytes, 1});
+            key = a;
+        } else {
+            (void)hipGetLastError();  // (read-only mappings, exotic memory: the data travels as pageable memory does)
+        }
+    }
+    ~HostPin() {
+        if (!key) return;
+        HostPinRegistry& R = HostPinRegistry::get();
+        std::lock_guard<std::mutex> lk(R.mu);
+        for (size_t i = 0; i < R.live.size(); i++)
+            if (R.live[i].lo == key) {
+                if (--R.live[i].refs == 0) {
+                    (void)hipHostUnregister((void*)key);
+                    (void)hipGetLastError();
+                    R.live.erase(R.live.begin() + (long)i);
+                }
+                break;
+            }
+    }
+    HostPin() = default;
+    HostPin(const HostPin&) = delete;
+    HostPin& operator=(const HostPin&) = delete;
+};
+
 int32_t run_host_input(msm_ctx* c, const HostInput& in0, size_t n, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf) {
     auto t0 = std::chrono::steady_clock::now();
+    HostPin pin_b, pin_s, pin_i;
+    if (!c->no_host_pin) {
+        pin_b.pin(in0.bases, n * in0.stride);
+        pin_s.pin(in0.scalars, n * 32);
+        pin_i.pin(in0.inf_mask, n);
+    }
     const std::vector<size_t> sizes = stream_schedule(c, n);
     // Struct arrays (round 6): first as if no point were at infinity -- the words are repacked and the call runs like the packed-words call, its sort
     // overlapped with the transfer of the bases; a set flag (error bit 16, seen when the call has finished) repeats the call with the flags as a mask.
@@ -1490,6 +1560,8 @@ int32_t msm_bn254_g1_upload_bases(msm_ctx* c, const uint32_t* bases_xy, uint32_t
     DeviceGuard g(c->device);
     c->resident_n = 0;
     c->tuned_layout[0] = c->tuned_layout[1] = 0;  // a measured batch layout belongs to the base set it was measured on
+    HostPin pin_b;
+    pin_b.pin(bases_xy, n * 64);
     if ((rc = upload_resident_locked(c, bases_xy, base_form, inf_mask, n))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
@@ -1687,6 +1759,8 @@ int32_t msm_bn254_g1_resident(msm_ctx* c, const uint32_t* scalars, size_t n, uin
     std::lock_guard<std::mutex> lk(c->mu);
     if (c->resident_n == 0) return fail(c, MSM_ERR_STATE, "no resident bases: call msm_bn254_g1_upload_bases first");
     DeviceGuard g(c->device);
+    HostPin pin_s;  // (pageable scalars travel at the pinned rate: 32 MB at 2^20)
+    pin_s.pin(scalars, std::min(n, c->resident_n) * 32);
     return resident_on_lane(c, c, scalars, n, out_jac, out_aff, out_inf);
 }
 
@@ -1770,6 +1844,9 @@ int32_t msm_bn254_g1_resident_batch(msm_ctx* c, const uint32_t* const* scalars, 
     std::lock_guard<std::mutex> lk(c->mu);
     if (c->resident_n == 0) return fail(c, MSM_ERR_STATE, "no resident bases: call msm_bn254_g1_upload_bases first");
     DeviceGuard g(c->device);
+    std::unique_ptr<HostPin[]> pins(new (std::nothrow) HostPin[count]);  // (a vector listed twice is registered once: the second look finds it known)
+    if (pins)
+        for (size_t i = 0; i < count; i++) pins[i].pin(scalars[i], std::min(n, c->resident_n) * 32);
     return resident_batch_locked(c, scalars, n, count, out_jac, out_aff, out_inf, 0);
 }
 

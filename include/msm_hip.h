@@ -167,7 +167,11 @@ void msm_ctx_destroy(msm_ctx *ctx);
 const char *msm_last_error(const msm_ctx *ctx);
 uint32_t msm_abi_version(void);
 
-/* ---- the drop-in call: host pointers in, host results out ---------------------------------- */
+/* ---- the drop-in call: host pointers in, host results out ----------------------------------
+ * Round 6: pageable caller memory is PINNED IN PLACE for the duration of a host-pointer call (hipHostRegister; msm_bn254_g1, _arkworks, _resident(_batch),
+ * _upload_bases, the msm_multi forms) and unregistered when the call has consumed it: the copies run at the link rate (53-55 GB/s instead of the ~40 of
+ * staged pageable copies -- 2^20 points 2.55 -> 2.45 ms) and registration costs microseconds on this platform.  Memory the caller pinned itself is left alone;
+ * a range that cannot be registered travels as before; registrations are reference-counted across contexts and threads of the process. */
 /* replaces metal_variable_base_msm (metal_msm.rs:642-695).  bases: n x 16 words; inf_mask: n bytes
  * (non-zero = point at infinity, arkworks G1Affine.infinity) or NULL; scalars: n x 8 words.
  * Any of the three outputs may be NULL.  out_jacobian_mont is the reference's own result type (G::new(x, y, z),

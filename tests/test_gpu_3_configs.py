@@ -254,6 +254,49 @@ def test_automatic_streaming_pinned_and_pageable_at_2_pow_22(hk):
             assert (r.affine_std == e3).all() and c.timings()["stream_chunks"] == 0
 
 
+def test_pageable_caller_memory_is_pinned_in_place_for_the_call(hk, tmp_path):
+    """round 6: a host-pointer call registers the caller's pageable arrays for its duration (hipHostRegister: the copies then run at the pinned rate) and
+    unregisters them afterwards.  The registrations are reference-counted process-wide: TWO contexts handed the SAME arrays at the same time (two host threads)
+    must both be right and leave the arrays usable; a read-only file mapping (a proving key mmap'ed from disk) must work whether or not it can be registered; the
+    arrays are ordinary memory again afterwards (torch can pin a copy, numpy can write)."""
+    import threading
+    it = Instance(hk, 20, seed=0xB2540B01)
+    exp, _ = _expected(it.dot())
+    hb = it.d_b.cpu().numpy().view(np.uint32).reshape(it.n, 16).copy()
+    hs = it.d_s.cpu().numpy().view(np.uint32).reshape(it.n, 8).copy()
+    out, errs = {}, []
+
+    def worker(tag):
+        try:
+            with mh.MsmContext() as c:
+                for _ in range(4):
+                    out.setdefault(tag, []).append(c.msm(hb, hs, mh.FORM_MONT).affine_std.copy())
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    assert all((r == exp).all() for k in out for r in out[k]) and sum(len(v) for v in out.values()) == 8
+    hb[0, 0] ^= 0  # still writable, ordinary memory
+    # a read-only mapping of the same bytes
+    fb, fs = tmp_path / "bases.bin", tmp_path / "scalars.bin"
+    hb.tofile(fb)
+    hs.tofile(fs)
+    mb = np.memmap(fb, dtype=np.uint32, mode="r").reshape(it.n, 16)
+    ms = np.memmap(fs, dtype=np.uint32, mode="r").reshape(it.n, 8)
+    with mh.MsmContext() as c:
+        assert (c.msm(mb, ms, mh.FORM_MONT).affine_std == exp).all()
+        assert (c.msm(mb[: 1 << 18], ms[: 1 << 18], mh.FORM_MONT).affine_std == _expected(it.dot(0, 1 << 18))[0]).all()
+        c.upload_bases(mb, mh.FORM_MONT)
+        assert (c.msm_resident(ms).affine_std == exp).all()
+        assert all((r.affine_std == exp).all() for r in c.msm_resident_batch([ms, hs, ms], want_affine=True))
+    with mh.MsmMulti(devices=[0, 0]) as m:  # the handle registers the arrays once for both ranks
+        assert (m.msm(hb, hs, mh.FORM_MONT).affine_std == exp).all()
+        assert (m.msm(mb, ms, mh.FORM_MONT).affine_std == exp).all()
+
+
 def test_streamed_shared_buckets_small_chunks(hk):
     """forced tiny chunks: GLV plan of the whole instance shared by all chunks, infinity masks, a scalar error in a
     late chunk"""
