@@ -107,6 +107,8 @@ struct Knobs {
     uint32_t piece_len = 0;                    // MSM_HIP_PIECE_LEN: longest whole bucket = split length of k_accumulate_pieces' work items; 0 = by size (tests force 1, 7, 26, 35)
     bool direct_scatter = false;               // MSM_HIP_DIRECT_SCATTER: skip the two-level LDS sort
     bool ark_slow = false;                     // MSM_HIP_ARK_SLOW: struct arrays always through k_import_ark (A/B and tests of the path a set infinity flag falls back to)
+    uint32_t mid_lane_min = msmk::MID_LANE_MIN;  // MSM_HIP_MID_LANE_MIN: k_combine_pieces folds mid lists longer than this one lane per bucket
+    size_t split_target = msmplan::SPLIT_PIECES_TARGET;  // MSM_HIP_SPLIT_TARGET: pieces the runs of very long buckets are sized for (make_piece_plan)
     uint32_t pair8_max_mb = 200;               // MSM_HIP_PAIR8_MAX_MB: bucket arrays up to this size take k_pair_level8 (three levels in one launch)
     bool no_poll = false;                      // MSM_HIP_NO_POLL: wait for the stream instead of polling the last kernel's sequence words (A/B: tools/ab_env.py)
     uint32_t device_chunk_log2 = 22;           // MSM_HIP_DEVICE_CHUNK_LOG2: point ranges of device-resident instances; 0 = never cut
@@ -129,6 +131,8 @@ struct Knobs {
         k.ark_slow = std::getenv("MSM_HIP_ARK_SLOW") != nullptr;
         k.no_poll = std::getenv("MSM_HIP_NO_POLL") != nullptr;
         k.pair8_max_mb = (uint32_t)num("MSM_HIP_PAIR8_MAX_MB", 0, 4096, 200);
+        k.split_target = (size_t)num("MSM_HIP_SPLIT_TARGET", 1024, 1 << 30, (long)msmplan::SPLIT_PIECES_TARGET);
+        k.mid_lane_min = (uint32_t)num("MSM_HIP_MID_LANE_MIN", 0, 0x7FFFFFFF, msmk::MID_LANE_MIN);
         k.device_chunk_log2 = (uint32_t)num("MSM_HIP_DEVICE_CHUNK_LOG2", 0, 30, 22);
         k.stream_min_log2 = (uint32_t)num("MSM_HIP_STREAM_MIN_LOG2", 9, 31, 19);
         k.stream_chunk_log2 = std::getenv("MSM_HIP_STREAM_CHUNK_LOG2") ? (uint32_t)num("MSM_HIP_STREAM_CHUNK_LOG2", 8, 28, 0) : 0u;
@@ -394,7 +398,7 @@ int32_t pipe_prepare(msm_ctx* c, size_t n_real, size_t plan_n, uint32_t extra_fl
     {
         msmplan::piece_plan fp;
         if (first) fp.pmax = first->pmax, fp.psplit = first->psplit;
-        const msmplan::piece_plan pp = msmplan::make_piece_plan(pairs, ps->sn / nb, tb, c->knobs.piece_len, first ? &fp : nullptr);
+        const msmplan::piece_plan pp = msmplan::make_piece_plan(pairs, ps->sn / nb, tb, c->knobs.piece_len, first ? &fp : nullptr, c->knobs.split_target);
         ps->pmax = pp.pmax, ps->psplit = pp.psplit, ps->maxpieces = pp.max_pieces, ps->maxpartials = pp.max_partials;
     }
     const size_t maxpartials = ps->maxpartials;
@@ -418,7 +422,8 @@ int32_t pipe_prepare(msm_ctx* c, size_t n_real, size_t plan_n, uint32_t extra_fl
         if ((rc = ensure(c, c->longdone, entries * 4))) return rc;
         if (c->longdone.cap != had) HIPCHK(c, hipMemsetAsync(c->longdone.p, 0, c->longdone.cap, st));  // self-cleaning afterwards
     }
-    if ((rc = ensure(c, c->midlist, (maxpartials / 2 + 16) * 4))) return rc;  // a listed bucket owns >= 2 partial sums
+    // two lists: the two-piece buckets from entry 0 (at most tb of them), those of 3 .. LONG_SPAN-1 pieces from entry tb (piece_tally_publish)
+    if ((rc = ensure(c, c->midlist, (tb + std::min(tb, maxpartials / 3) + 16) * 4))) return rc;
     if ((rc = ensure(c, c->rc, (tb + tb / 2 + 4) * XB))) return rc;  // two families x (1/2 + 1/4) ping-pong levels
     if ((rc = ensure(c, c->flags, 64))) return rc;
     return MSM_OK;
@@ -681,9 +686,10 @@ int32_t enqueue_accumulate(msm_ctx* c, const PipeState& ps, const BaseSrc& src, 
         else MSM_ACC_LAUNCH(false, false, false);
     }
 #undef MSM_ACC_LAUNCH
-    msmk::k_combine_pieces<<<dim3(msmk::LONG_BLOCKS + msmk::MID_BLOCKS), msmk::COMBINE_BLOCK, 0, st>>>(
-        offsets, pt, bk, ps.pmax, ps.psplit, (const uint32_t*)c->pbase.p, flags + msmk::FLAG_MID, (const uint32_t*)c->midlist.p, flags + msmk::FLAG_LONG,
-        (const uint32_t*)c->longlist.p, (uint32_t*)c->longdone.p);
+    msmk::k_combine_pieces<<<dim3(msmk::LONG_BLOCKS + msmk::MID_BLOCKS + msmk::MID2_BLOCKS), msmk::COMBINE_BLOCK, 0, st>>>(
+        offsets, pt, bk, ps.pmax, ps.psplit, (const uint32_t*)c->pbase.p, flags + msmk::FLAG_MID, flags + msmk::FLAG_MID2, (const uint32_t*)c->midlist.p, (uint32_t)ps.tb,
+        flags + msmk::FLAG_LONG,
+        (const uint32_t*)c->longlist.p, (uint32_t*)c->longdone.p, c->knobs.mid_lane_min);
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_COMBINE], st));  // msm_timings_t.combine_ms
     return MSM_OK;
 }

@@ -41,7 +41,7 @@ constexpr int SCALAR_BITS = 254;
 constexpr int XW = 36;  // words per XYZZ record in HBM: 4 coordinates x 9 limbs
 // flags (u32 words, one set per context): [0] error bits  [4] sorted entries of this (chunk of an) MSM  [6,7] running 64-bit total of
 // sorted entries over the chunks of a streamed MSM  [8] long-list entries  [9] mid-list entries  [10] pieces  [11] partial-sum slots
-constexpr uint32_t FLAG_ERR = 0, FLAG_PAIRS = 4, FLAG_ADDS64 = 6, FLAG_LONG = 8, FLAG_MID = 9, FLAG_PIECES = 10, FLAG_PARTIALS = 11;
+constexpr uint32_t FLAG_ERR = 0, FLAG_PAIRS = 4, FLAG_ADDS64 = 6, FLAG_LONG = 8, FLAG_MID = 9, FLAG_PIECES = 10, FLAG_PARTIALS = 11, FLAG_MID2 = 12;
 
 // 16-BIT DIGIT CODES (round 5).  Where a window has at most 2^15 buckets and the two-level LDS sort runs (every default plan without a
 // window table: c <= 16 signed), a digit travels from k_decompose to the two sort kernels that read it as 16 bits: bucket index in bits
@@ -533,7 +533,7 @@ __global__ void k_decompose(const uint32_t* __restrict__ scalars, const uint8_t*
                             uint32_t* __restrict__ phist, uint32_t* __restrict__ pcursor) {
     static_assert(!(HIST && D16), "the global-atomic fallback keeps 32-bit digits");
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) err[FLAG_LONG] = 0, err[FLAG_MID] = 0, err[FLAG_PIECES] = 0, err[FLAG_PARTIALS] = 0;  // list counters of this (chunk of an) MSM: k_piece_count fills them later in the stream
+    if (i == 0) err[FLAG_LONG] = 0, err[FLAG_MID] = 0, err[FLAG_MID2] = 0, err[FLAG_PIECES] = 0, err[FLAG_PARTIALS] = 0;  // list counters of this (chunk of an) MSM: k_piece_count fills them later in the stream
     if (blockIdx.x == 0) clear_piece_bins(phist, pcursor);
     if (i >= n) return;
     const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
@@ -599,7 +599,7 @@ __global__ void __launch_bounds__(256) k_decompose_glv(const uint32_t* __restric
                                 uint32_t top_shift, uint32_t top_bits, uint32_t spread_mask, uint32_t* __restrict__ phist,
                                 uint32_t* __restrict__ pcursor, const uint32_t* __restrict__ phi_src, uint32_t* __restrict__ phi_dst) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) err[FLAG_LONG] = 0, err[FLAG_MID] = 0, err[FLAG_PIECES] = 0, err[FLAG_PARTIALS] = 0;  // list counters of this (chunk of an) MSM: k_piece_count fills them later in the stream
+    if (i == 0) err[FLAG_LONG] = 0, err[FLAG_MID] = 0, err[FLAG_MID2] = 0, err[FLAG_PIECES] = 0, err[FLAG_PARTIALS] = 0;  // list counters of this (chunk of an) MSM: k_piece_count fills them later in the stream
     if (blockIdx.x == 0) clear_piece_bins(phist, pcursor);
     if (i >= n) return;
     const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
@@ -850,7 +850,7 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_coarse_hist(const void* __restri
     // list counters and piece bins of THIS sort call (k_piece_count fills them later in the stream; k_decompose zeroes them too -- kept
     // here so that a sort never depends on which kernel ran before it)
     if (st == 0 && w == 0) {
-        if (threadIdx.x == 0) flags[FLAG_LONG] = 0, flags[FLAG_MID] = 0, flags[FLAG_PIECES] = 0, flags[FLAG_PARTIALS] = 0;
+        if (threadIdx.x == 0) flags[FLAG_LONG] = 0, flags[FLAG_MID] = 0, flags[FLAG_MID2] = 0, flags[FLAG_PIECES] = 0, flags[FLAG_PARTIALS] = 0;
         clear_piece_bins(phist, pcursor);
     }
     if (threadIdx.x < COARSE_BINS_MAX) s_h[threadIdx.x] = 0;
@@ -1227,6 +1227,8 @@ constexpr uint32_t WAVE_ITEM_MAX = 512;      // long buckets of at most this man
 constexpr uint32_t COMBINE_BLOCK = 256;      // threads of a k_combine_pieces workgroup: at three wavefronts per SIMD three of them share a CU (512 threads at the kernel's 175 VGPRs: ONE)
 constexpr uint32_t WAVE_ITEM_RECORDS = 64;   // ... in a 64-record region of the workgroup's LDS (4 wavefronts x 64 = WIDE_TREE_MAX records)
 constexpr uint32_t LONG_BLOCKS = 1024, MID_BLOCKS = 1024;  // k_combine_pieces' grid: (bucket, segment) items grid-stride over the first, listed buckets over the rest
+constexpr uint32_t MID2_BLOCKS = 1024;       // ... and the workgroups that fold the two-piece buckets one LANE per bucket when there are more than MID_LANE_MIN of them
+constexpr uint32_t MID_LANE_MIN = 32768;     // (more than ~1.3 rounds of resident eight-lane groups)
 // (PIECE_BINS, at the top of this file: pmax <= PIECE_BINS, one histogram bin per piece length)
 constexpr uint32_t PF_WHOLE = 0x80000000u;            // piece.z: the bucket is this one piece -> the sum goes to buckets[k]
 constexpr uint32_t PF_FIRST = 0x40000000u;            // piece.z: first piece of a split bucket (INTO: starts from the bucket's old value)
@@ -1271,11 +1273,11 @@ __device__ __forceinline__ uint32_t block1024_exclusive_scan(uint32_t v, uint32_
 // partial-sum slots and a list entry for every split bucket.  One thread per bucket.  The steps are functions because two kernels run them:
 // k_piece_count (every sort path) and k_place_count (the two-level sort: the same launch also places the batches of oversized regions).
 struct piece_tally {
-    uint32_t kindl, slot, nseg, m, pslot;  // kindl: 0 = mid list, 1 = long list, 2 = none
+    uint32_t kindl, slot, nseg, m, pslot;  // kindl: 0 = mid list (3 .. LONG_SPAN-1 pieces), 1 = long list, 2 = none, 3 = list of the two-piece buckets
 };
 __device__ __forceinline__ void piece_tally_begin(uint32_t* s_hist, uint32_t* s_n, uint32_t pmax) {  // whole workgroup
     for (uint32_t i = threadIdx.x; i <= pmax; i += blockDim.x) s_hist[i] = 0;
-    if (threadIdx.x < 3) s_n[threadIdx.x] = 0;
+    if (threadIdx.x < 4) s_n[threadIdx.x] = 0;
     __syncthreads();
 }
 __device__ __forceinline__ piece_tally piece_tally_bucket(uint32_t k, uint32_t sz, uint32_t pmax, uint32_t psplit, uint32_t* s_hist, uint32_t* s_n,
@@ -1297,11 +1299,11 @@ __device__ __forceinline__ piece_tally piece_tally_bucket(uint32_t k, uint32_t s
                 t.kindl = 1;
                 t.nseg = (t.m + LONG_SEG - 1) / LONG_SEG;
             } else {
-                t.kindl = 0;
+                t.kindl = t.m == 2 ? 3u : 0u;
             }
         }
     }
-    if (t.kindl < 2) t.slot = atomicAdd(&s_n[t.kindl], t.nseg);
+    if (t.kindl != 2) t.slot = atomicAdd(&s_n[t.kindl], t.nseg);
     return t;
 }
 // the workgroup's share of the lists, the partial-sum slots and every histogram bin: one device-scope add each (whole workgroup)
@@ -1311,15 +1313,20 @@ __device__ __forceinline__ void piece_tally_reserve(const uint32_t* s_hist, cons
     if (threadIdx.x == 0 && s_n[0]) s_base[0] = atomicAdd(flags + FLAG_MID, s_n[0]);
     if (threadIdx.x == 1 && s_n[1]) s_base[1] = atomicAdd(flags + FLAG_LONG, s_n[1]);
     if (threadIdx.x == 2 && s_n[2]) s_base[2] = atomicAdd(flags + FLAG_PARTIALS, s_n[2]);
+    if (threadIdx.x == 3 && s_n[3]) s_base[3] = atomicAdd(flags + FLAG_MID2, s_n[3]);
     for (uint32_t i = threadIdx.x; i <= pmax; i += blockDim.x)
         if (s_hist[i]) atomicAdd(&hist[i], s_hist[i]);
     __syncthreads();
 }
 __device__ __forceinline__ void piece_tally_publish(uint32_t k, const piece_tally& t, const uint32_t* s_base, uint32_t* __restrict__ pbase,
-                                                    uint32_t* __restrict__ mid_list, uint32_t* __restrict__ long_list) {
+                                                    uint32_t* __restrict__ mid_list, uint32_t* __restrict__ long_list, uint32_t total_buckets) {
+    // mid_list holds TWO lists: the buckets of exactly two pieces from entry 0 (one addition each: k_combine_pieces folds them one LANE per bucket when
+    // there are many), those of 3 .. LONG_SPAN-1 pieces (a dependent chain per bucket: always eight lanes) from entry total_buckets
     if (t.m > 1) pbase[k] = s_base[2] + t.pslot;
-    if (t.kindl == 0) {
-        mid_list[s_base[0] + t.slot] = k;
+    if (t.kindl == 3) {
+        mid_list[s_base[3] + t.slot] = k;
+    } else if (t.kindl == 0) {
+        mid_list[total_buckets + s_base[0] + t.slot] = k;
     } else if (t.kindl == 1) {  // one entry per LONG_SEG pieces: (bucket, segment)
         for (uint32_t j = 0; j < t.nseg; j++) {
             long_list[2 * (size_t)(s_base[1] + t.slot + j)] = k;
@@ -1332,7 +1339,7 @@ __global__ void __launch_bounds__(1024) k_piece_count(const uint32_t* __restrict
                                                      uint32_t* __restrict__ mid_list, uint32_t* __restrict__ pbase, uint32_t* __restrict__ buckets,
                                                      uint32_t into) {
     __shared__ uint32_t s_hist[PIECE_BINS + 1];
-    __shared__ uint32_t s_n[3], s_base[3];  // [0] mid list, [1] long list, [2] partial-sum slots: reserved once per workgroup
+    __shared__ uint32_t s_n[4], s_base[4];  // [0] mid list, [1] long list, [2] partial-sum slots, [3] two-piece list: reserved once per workgroup
     if (blockIdx.x == 0 && threadIdx.x == 0)  // mixed additions executed so far (msm_timings_t.num_adds), all chunks of a streamed MSM
         *reinterpret_cast<unsigned long long*>(flags + FLAG_ADDS64) += (unsigned long long)flags[FLAG_PAIRS];
     piece_tally_begin(s_hist, s_n, pmax);
@@ -1340,7 +1347,7 @@ __global__ void __launch_bounds__(1024) k_piece_count(const uint32_t* __restrict
     piece_tally t{2u, 0u, 1u, 0u, 0u};
     if (k < total_buckets) t = piece_tally_bucket(k, offsets[k + 1] - offsets[k], pmax, psplit, s_hist, s_n, buckets, into);
     piece_tally_reserve(s_hist, s_n, s_base, hist, flags, pmax);
-    if (k < total_buckets) piece_tally_publish(k, t, s_base, pbase, mid_list, long_list);
+    if (k < total_buckets) piece_tally_publish(k, t, s_base, pbase, mid_list, long_list, total_buckets);
 }
 
 // The two-level sort's LAST launch (round 6): k_big_place and k_piece_count in one.  On uniform scalars no region is oversized and k_big_place was
@@ -1360,7 +1367,7 @@ __global__ void __launch_bounds__(FINE_BLOCK) k_place_count(const uint32_t* __re
                                                             uint32_t* __restrict__ long_list, uint32_t* __restrict__ mid_list,
                                                             uint32_t* __restrict__ pbase, uint32_t* __restrict__ buckets, uint32_t into) {
     __shared__ uint32_t s_hist[PIECE_BINS + 1];
-    __shared__ uint32_t s_n[3], s_pbase[3];
+    __shared__ uint32_t s_n[4], s_pbase[4];
     const uint32_t nfine = 1u << fine_bits, fmask = nfine - 1u;
     if (blockIdx.x < count_blocks) {
         if (blockIdx.x == 0 && threadIdx.x == 0)  // mixed additions executed so far (msm_timings_t.num_adds), all chunks of a streamed MSM
@@ -1384,7 +1391,7 @@ __global__ void __launch_bounds__(FINE_BLOCK) k_place_count(const uint32_t* __re
 #pragma unroll
         for (int it = 0; it < ITER; it++) {
             const uint32_t k = blockIdx.x * PLACE_COUNT_SPAN + it * FINE_BLOCK + threadIdx.x;
-            if (k < total_buckets) piece_tally_publish(k, t[it], s_pbase, pbase, mid_list, long_list);
+            if (k < total_buckets) piece_tally_publish(k, t[it], s_pbase, pbase, mid_list, long_list, total_buckets);
         }
         return;
     }
@@ -1416,7 +1423,7 @@ __global__ void __launch_bounds__(FINE_BLOCK) k_place_count(const uint32_t* __re
             piece_tally t{2u, 0u, 1u, 0u, 0u};
             if (threadIdx.x < nfine) t = piece_tally_bucket(kb0 + threadIdx.x, mycnt, pmax, psplit, s_hist, s_n, buckets, into);
             piece_tally_reserve(s_hist, s_n, s_pbase, hist, flags, pmax);
-            if (threadIdx.x < nfine) piece_tally_publish(kb0 + threadIdx.x, t, s_pbase, pbase, mid_list, long_list);
+            if (threadIdx.x < nfine) piece_tally_publish(kb0 + threadIdx.x, t, s_pbase, pbase, mid_list, long_list, total_buckets);
         }
         uint32_t eb[FINE_PER_THREAD];
 #pragma unroll
@@ -1612,18 +1619,35 @@ __device__ __forceinline__ void fold_partials(uint32_t* e, const uint32_t* parti
 }
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3))) k_combine_pieces(const uint32_t* __restrict__ offsets, uint32_t* __restrict__ partials,
                                                         uint32_t* __restrict__ buckets, uint32_t pmax, uint32_t psplit, const uint32_t* __restrict__ pbase,
-                                                        const uint32_t* __restrict__ mid_count, const uint32_t* __restrict__ mid_list,
+                                                        const uint32_t* __restrict__ mid_count, const uint32_t* __restrict__ mid2_count,
+                                                        const uint32_t* __restrict__ mid_list, uint32_t mid3_off,
                                                         const uint32_t* __restrict__ long_count, const uint32_t* __restrict__ long_list,
-                                                        uint32_t* __restrict__ long_done) {
+                                                        uint32_t* __restrict__ long_done, uint32_t mid_lane_min) {
     __shared__ uint32_t e[WIDE_TREE_MAX * XW];
     if (blockIdx.x >= LONG_BLOCKS) {
         // mid list: EIGHT lanes per listed bucket (round 6; one lane folding its 2..7 pieces with complete additions took this launch 19 us on uniform
         // scalars -- a lone wavefront's xyzz_add is 6.6 us warm and its ~40 KB of code arrive cold -- and up to 0.45 ms on skewed ones).  Two pieces: one
         // eight-lane addition straight from the partial sums into the bucket; more: the running sum lives in the group's LDS record (in-order LDS traffic of one wavefront).
-        const uint32_t nmid = *mid_count, g = threadIdx.x / WIDE_LANES, ng = blockDim.x / WIDE_LANES;
+        // The buckets of exactly TWO pieces are listed apart (mid_list[0 .. n2), one addition each) from those of 3 .. LONG_SPAN-1 pieces (mid_list[mid3_off ..), a
+        // dependent chain each).  Many two-piece buckets -- thousands of distinct scalars repeated: the reference's fixture shape at T = 128 lists 80 000 of them
+        // and 23 000 longer ones -- are the THROUGHPUT regime: the groups of eight would take several rounds of resident workgroups, each a dependent eight-lane
+        // addition that keeps the multiplier half busy; the trailing MID2_BLOCKS workgroups fold them one LANE per bucket in one round of complete additions
+        // (one list for both and the lanes walking 1 .. 6 additions: a wavefront runs its longest chain, 0.125 ms at T = 128 where the eight-lane groups took 0.175).
+        const uint32_t n3 = *mid_count, n2 = *mid2_count, g = threadIdx.x / WIDE_LANES, ng = blockDim.x / WIDE_LANES;
+        const bool lanes2 = n2 > mid_lane_min;
+        if (blockIdx.x >= LONG_BLOCKS + MID_BLOCKS) {
+            if (!lanes2) return;
+            for (uint32_t i = (blockIdx.x - LONG_BLOCKS - MID_BLOCKS) * blockDim.x + threadIdx.x; i < n2; i += MID2_BLOCKS * blockDim.x) {
+                const uint32_t k = mid_list[i];
+                const uint32_t* p0 = partials + (size_t)pbase[k] * XW;
+                store_xyzz(buckets + (size_t)k * XW, xyzz_add(load_xyzz(p0), load_xyzz(p0 + XW)));
+            }
+            return;
+        }
+        const uint32_t nmid = n3 + (lanes2 ? 0u : n2);
         uint32_t* acc = e + (size_t)g * XW;
-        for (uint32_t i = (blockIdx.x - LONG_BLOCKS) * ng + g; i < nmid; i += MID_BLOCKS * ng) {  // (whole groups share i)
-            const uint32_t k = mid_list[i];
+        for (uint32_t i = (blockIdx.x - LONG_BLOCKS) * ng + g; i < nmid; i += MID_BLOCKS * ng) {  // (whole groups share i; the chains first)
+            const uint32_t k = i < n3 ? mid_list[mid3_off + i] : mid_list[i - n3];
             uint32_t q;
             const uint32_t m = piece_split(offsets[k + 1] - offsets[k], pmax, psplit, &q), base = pbase[k];
             const uint32_t* p0 = partials + (size_t)base * XW;

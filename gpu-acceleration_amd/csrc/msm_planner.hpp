@@ -90,11 +90,13 @@ inline uint32_t plan_window_bits_glv(size_t n, bool is_signed) {
 // yield ~2^19 pieces (2.7 rounds of resident workgroups), at least 8 entries per piece.  max_pieces / max_partials bound what ANY
 // bucket-size distribution over `pairs` sorted entries and `total_buckets` buckets can produce (workspace sizes).
 constexpr uint32_t PIECE_BINS_MAX = 1024;
+constexpr size_t SPLIT_PIECES_TARGET = (size_t)1 << 18;  // pieces an instance of very long buckets is cut into, about (make_piece_plan: psplit)
 struct piece_plan {
     uint32_t pmax = 0, psplit = 0;
     size_t max_pieces = 0, max_partials = 0;
 };
-inline piece_plan make_piece_plan(size_t pairs, size_t mean_occupancy, size_t total_buckets, uint32_t forced_len = 0, const piece_plan* first = nullptr) {
+inline piece_plan make_piece_plan(size_t pairs, size_t mean_occupancy, size_t total_buckets, uint32_t forced_len = 0, const piece_plan* first = nullptr,
+                                  size_t split_target = SPLIT_PIECES_TARGET) {
     piece_plan p;
     size_t two_sigma = 0;
     while ((two_sigma + 1) * (two_sigma + 1) <= 4 * mean_occupancy) two_sigma++;  // floor(2 sqrt(mean))
@@ -103,7 +105,16 @@ inline piece_plan make_piece_plan(size_t pairs, size_t mean_occupancy, size_t to
     // buckets for eight windows' entries) would be as few pieces -- a wavefront on a fraction of the SIMDs, each walking its piece alone; there
     // the pieces shrink until ~2^17 of them exist (at least 8 entries each).  2^17 points with the table: k_accumulate_pieces 0.257 -> 0.149 ms, profiles/r4_table_small.txt
     if (total_buckets < ((size_t)1 << 17)) p.pmax = (uint32_t)std::min<size_t>(p.pmax, std::max<size_t>(8, pairs >> 17));
-    p.psplit = (uint32_t)std::min<size_t>(p.pmax, std::max<size_t>(8, pairs >> 19));
+    // Runs of a bucket too long for the pmax rule (a handful of distinct scalars): a POWER OF TWO of entries, about pairs / 2^18 of them (64 at 2^20 points: 2^18
+    // pieces, 1.33 rounds of the 196 608 resident lanes, what uniform scalars give).  Round 4's pairs >> 19 (32 entries, 2^19 pieces) left k_combine_pieces twice the
+    // partial sums for the same accumulation time; lengths that are not a power of two cost the accumulation 5-8 % whatever the number of rounds they make
+    // (MSM_HIP_SPLIT_TARGET of the hooks build, whole calls at 2^20 on one box, ms: all-equal 32: 1.42, 36: 1.53, 40: 1.50, 44: 1.45, 48: 1.54, 64: 1.41;
+    // 3-distinct 32: 1.55, 44: 1.47-1.52, 64: 1.49; 256-distinct 32: 1.44, 44: 1.47, 64: 1.425 -- profiles/NOTES_r6.md section 14).
+    {
+        const size_t want = std::min<size_t>(p.pmax, std::max<size_t>(8, (pairs + split_target - 1) / split_target));
+        p.psplit = 8;
+        while ((size_t)p.psplit * 2 <= want) p.psplit *= 2;
+    }
     if (first) p.pmax = first->pmax, p.psplit = first->psplit;  // a later chunk of an instance: the lengths of its first, largest chunk
     if (forced_len) p.pmax = p.psplit = std::min<uint32_t>(forced_len, PIECE_BINS_MAX);
     // every non-empty bucket is a piece, a split bucket of sz > pmax entries adds at most sz / psplit more (runs of pmax: ceil(sz / pmax) <=

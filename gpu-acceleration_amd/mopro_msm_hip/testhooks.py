@@ -122,10 +122,10 @@ class HooksContext(MsmContext):
         return us.value
 
     def list_counts(self):
-        """{"long", "mid", "pieces", "partials"}: the list counters the last sort chain / accumulation left on the device"""
-        out = np.zeros(4, np.uint32)
+        """{"long", "mid", "pieces", "partials", "mid2"}: the list counters the last sort chain / accumulation left on the device"""
+        out = np.zeros(5, np.uint32)
         self._check(self._lib.msm_test_get_list_counts(self._h, _p32(out)))
-        return dict(zip(("long", "mid", "pieces", "partials"), (int(v) for v in out)))
+        return dict(zip(("long", "mid", "pieces", "partials", "mid2"), (int(v) for v in out)))
 
     def probe_launch_chain(self, n_adds, launches):
         """microseconds per dependent launch of k_pair_level_wide over n_adds additions (0: an empty kernel)"""

@@ -98,9 +98,9 @@ int32_t msm_probe_empty_launch(msm_ctx *ctx, uint32_t blocks, uint32_t threads, 
 /* k_reduce_bits_wide of the 2^20 shape (8 windows x 16 bit sums = 128 workgroups) on synthetic row / column sums with parts switched off:
  * parts bit 0 = staging (HBM -> LDS), bit 1 = the LDS tree, bit 2 = the XYZZ -> Jacobian -> R = 2^256 conversion; 7 = the kernel as the product runs it */
 int32_t msm_probe_reduce_bits(msm_ctx *ctx, uint32_t parts, uint32_t launches, double *us_per_launch);
-/* the list counters the last sort chain / accumulation left on the device: out[0] long-list entries, out[1] mid-list entries (the buckets
- * k_combine_pieces folds), out[2] pieces, out[3] partial-sum slots */
-int32_t msm_test_get_list_counts(msm_ctx *ctx, uint32_t out[4]);
+/* the list counters the last sort chain / accumulation left on the device: out[0] long-list entries, out[1] mid-list entries (buckets of 3 .. 7
+ * pieces k_combine_pieces folds), out[2] pieces, out[3] partial-sum slots, out[4] buckets of exactly two pieces (listed apart) */
+int32_t msm_test_get_list_counts(msm_ctx *ctx, uint32_t out[5]);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,7 @@ from mopro_msm_hip import testhooks as th
 
 GEN = th.HooksContext()  # the synthetic-instance generator lives in the hooks build
 n = 1 << int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
+ONLY = sys.argv[2] if len(sys.argv) > 2 else None  # substring of a row's label: that row alone (to profile one case: rocprofv3 ... -- python3 tools/adversarial_timing.py 20 T=128)
 
 
 def dev(a):
@@ -70,6 +71,8 @@ with mh.MsmContext() as c:
         print("reference-held points not available:", e)
     base = None
     for label, bb, ss in cases:
+        if ONLY and ONLY not in label:
+            continue
         tb, ts_ = dev(bb), dev(ss)
         c.set_stage_timing(False)
         ms = timed(c, tb, ts_)

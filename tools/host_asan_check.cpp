@@ -212,10 +212,10 @@ static int check_partitions() {
 }
 
 static int check_piece_plan() {
-    // the BASELINE shape: 8 windows x 2^21 entries over 8 x 32768 buckets (mean 64): whole buckets up to 128 entries, runs of 32
+    // the BASELINE shape: 8 windows x 2^21 entries over 8 x 32768 buckets (mean 64): whole buckets up to 80 entries, runs of 64 (a power of two, ~2^18 pieces)
     {
         const msmplan::piece_plan p = msmplan::make_piece_plan((size_t)8 << 21, 64, (size_t)8 << 15);
-        REQUIRE(p.pmax == 80 && p.psplit == 32);
+        REQUIRE(p.pmax == 80 && p.psplit == 64);
     }
     // tiny instance, forced lengths, a later chunk keeps its first chunk's lengths
     REQUIRE(msmplan::make_piece_plan(1000, 0, 512).pmax == 8 && msmplan::make_piece_plan(1000, 0, 512).psplit == 8);
