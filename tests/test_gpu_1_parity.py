@@ -272,7 +272,10 @@ def test_reference_srs_known_answer_msms(wb, flags):
                 exp = np.concatenate([orc.fq_from_mont(g[j, :8]), orc.fq_from_mont(g[j, 8:])])
                 r = c.msm(gl, scalars, mh.FORM_MONT)
                 assert not r.is_infinity and (r.affine_std == exp).all(), (fname, j)
-                assert (c.msm_resident(scalars).affine_std == exp).all(), (fname, j, "resident")
+                rr = c.msm_resident(scalars)
+                if not (rr.affine_std == exp).all():  # (seen ONCE in ~20 runs of the suite in round 6: say whether the same call repeated gives the point)
+                    again = [bool((c.msm_resident(scalars).affine_std == exp).all()) for _ in range(3)]
+                    raise AssertionError((fname, j, "resident", "the same call repeated equals the expected point:", again, c.timings()))
                 # X = x Z^2, Y = y Z^3 against the stored (x, y): projective equality with the reference-held point
                 X, Y, Z = (orc.words_to_int(orc.fq_from_mont(r.jacobian_mont[8 * t:8 * t + 8])) for t in range(3))
                 x, y = orc.words_to_int(exp[:8]), orc.words_to_int(exp[8:])
