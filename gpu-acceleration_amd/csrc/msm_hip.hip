@@ -192,9 +192,11 @@ struct msm_ctx {
     uint32_t wall_clock_khz = 0;  // rate of the constant counter (hipDeviceAttributeWallClockRate)
     DevBuf rbases, rinf;  // the RESIDENT base set (msm_bn254_g1_upload_bases / _upload_compressed): never used as scratch
     bool pow2_ready = false;
-    uint32_t* h_qsums = nullptr;  // pinned: W x (kb+1) Jacobian bit sums, and behind them (word MAX_QSUM_POINTS * 24 on) one SEQUENCE word per bit sum
-    uint32_t done_seq = 0;        // sequence number of the latest bucket reduction queued on this context (the last kernel publishes it per workgroup)
-    uint32_t* h_flags = nullptr;    // pinned
+    uint32_t* h_qsums = nullptr;  // pinned: W x (kb+1) Jacobian bit sums as the last kernel writes them: 24 (word, sequence number) PAIRS each (msmk::store_words8_tagged)
+    uint32_t done_seq = 0;        // sequence number of the latest bucket reduction queued on this context (the tag of its pairs)
+    uint32_t* h_flags = nullptr;  // pinned: the 8 flag words, as pairs as well
+    std::vector<uint32_t> qsums;  // the bit sums of the call being finished, 24 words each, taken out of the pairs once every tag is the call's (gather_results)
+    uint32_t flagw[8] = {};       // ... and its flag words
     // resident bases
     size_t resident_n = 0;
     bool resident_has_inf = false;
@@ -770,13 +772,11 @@ int32_t enqueue_reduce(msm_ctx* c, const PipeState& ps, hipStream_t st, uint32_t
     uint32_t *q_dev = nullptr, *f_dev = nullptr;
     HIPCHK(c, hipHostGetDevicePointer((void**)&q_dev, h_qsums_dst, 0));
     HIPCHK(c, hipHostGetDevicePointer((void**)&f_dev, h_flags_dst, 0));
-    // (the sequence words live behind the bit sums of the same pinned buffer: h_qsums_dst + MAX_QSUM_POINTS * 24)
-    uint32_t* done_dev = q_dev + MAX_QSUM_POINTS * 24;
-    if (++c->done_seq == 0) c->done_seq = 1;  // (0 is what fresh words hold)
+    if (++c->done_seq == 0) c->done_seq = 1;  // (0 is what fresh pairs hold)
     if (n_hi / 2 <= msmk::WIDE_TREE_MAX && n_lo <= msmk::WIDE_TREE_MAX)
-        msmk::k_reduce_bits_wide<7><<<W * (kb + 1), 512, 0, st>>>(rin, cin, q_dev, n_hi, n_lo, kb_lo, kb, flags, f_dev, done_dev, c->done_seq);
+        msmk::k_reduce_bits_wide<7><<<W * (kb + 1), 512, 0, st>>>(rin, cin, q_dev, n_hi, n_lo, kb_lo, kb, flags, f_dev, c->done_seq);
     else
-        msmk::k_reduce_bits<<<W * (kb + 1), 64, 0, st>>>(rin, cin, q_dev, n_hi, n_lo, kb_lo, kb, flags, f_dev, done_dev, c->done_seq);
+        msmk::k_reduce_bits<<<W * (kb + 1), 64, 0, st>>>(rin, cin, q_dev, n_hi, n_lo, kb_lo, kb, flags, f_dev, c->done_seq);
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_REDUCE], st));
     return MSM_OK;
 }
@@ -857,6 +857,28 @@ void trace_line(const msm_ctx* c, const char* entry, const PipeState& ps) {
                  c->enqueue_ms, (unsigned long long)t.num_adds);
 }
 
+// The last kernel's results out of pinned memory: every word arrives as an aligned 8-byte (word, sequence number) pair written by ONE device store and read
+// here by ONE load, so a word is taken only with the tag of THIS call (msm_kernels.hpp, store_words8_tagged: why a sequence word behind a fence was not enough).
+// false: some pair is not there yet (nothing is half-taken: the caller polls on, or reports an error when the kernel has retired).
+bool gather_results(msm_ctx* c, uint32_t nblk, uint32_t seq) {
+    const volatile uint64_t* q64 = reinterpret_cast<const volatile uint64_t*>(c->h_qsums);
+    const volatile uint64_t* f64 = reinterpret_cast<const volatile uint64_t*>(c->h_flags);
+    uint32_t* out = c->qsums.data();
+    const size_t npairs = (size_t)nblk * 24;
+    for (size_t k = 0; k < npairs; k++) {
+        const uint64_t v = q64[k];
+        if ((uint32_t)(v >> 32) != seq) return false;
+        out[k] = (uint32_t)v;
+    }
+    for (int k = 0; k < 8; k++) {
+        const uint64_t v = f64[k];
+        if ((uint32_t)(v >> 32) != seq) return false;
+        c->flagw[k] = (uint32_t)v;
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return true;
+}
+
 // wait for the queued pipeline, finish on the CPU, fill outputs and timings
 int32_t finish_sync(msm_ctx* c, const PipeState& ps, size_t n_total, hipStream_t st, uint32_t* out_jac, uint32_t* out_aff, uint8_t* out_inf,
                     hipEvent_t done = nullptr /* recorded after the last kernel when `st` carries other work too */) {
@@ -866,23 +888,23 @@ int32_t finish_sync(msm_ctx* c, const PipeState& ps, size_t n_total, hipStream_t
     // for the stream: the results are there a few microseconds before the kernel has retired and the runtime has woken the waiting thread.
     // Every ~1000 polls the stream is queried, so that a failed launch or a lost device ends the wait with an error instead of a hang.
     // (Stage timing reads events recorded behind the kernel: it waits for the stream as before.)
+    const uint32_t nblk = ps.rW * (ps.rkb + 1), seq = c->done_seq;
     if (c->stage_timing || c->knobs.no_poll) {
         if (done) HIPCHK(c, hipEventSynchronize(done));
         else HIPCHK(c, hipStreamSynchronize(st));
+        if (!gather_results(c, nblk, seq)) return fail(c, MSM_ERR_HIP, "internal: the bucket reduction finished without publishing its %u bit sums", nblk);
     } else {
-        const uint32_t nblk = ps.rW * (ps.rkb + 1), seq = c->done_seq;
-        const volatile uint32_t* d = c->h_qsums + MAX_QSUM_POINTS * 24;
+        // cheap test first: the LAST pair of every bit sum; then every pair (a pair that is not there yet: keep polling)
+        const volatile uint64_t* q64 = reinterpret_cast<const volatile uint64_t*>(c->h_qsums);
         for (uint32_t spins = 1;; spins++) {
             uint32_t i = 0;
-            while (i < nblk && d[i] == seq) i++;
-            if (i == nblk) break;
+            while (i < nblk && (uint32_t)(q64[(size_t)i * 24 + 23] >> 32) == seq) i++;
+            if (i == nblk && gather_results(c, nblk, seq)) break;
             if ((spins & 0x3FFu) == 0) {
                 const hipError_t q = done ? hipEventQuery(done) : hipStreamQuery(st);
-                if (q == hipSuccess) {  // retired: the words must be there now
-                    i = 0;
-                    while (i < nblk && d[i] == seq) i++;
-                    if (i == nblk) break;
-                    return fail(c, MSM_ERR_HIP, "internal: the bucket reduction finished without publishing bit sum %u of %u", i, nblk);
+                if (q == hipSuccess) {  // retired: the pairs must be there now
+                    if (gather_results(c, nblk, seq)) break;
+                    return fail(c, MSM_ERR_HIP, "internal: the bucket reduction finished without publishing its %u bit sums", nblk);
                 }
                 if (q != hipErrorNotReady) HIPCHK(c, q);
             }
@@ -890,14 +912,29 @@ int32_t finish_sync(msm_ctx* c, const PipeState& ps, size_t n_total, hipStream_t
             __builtin_ia32_pause();
 #endif
         }
-        std::atomic_thread_fence(std::memory_order_acquire);
+#ifdef MSM_HIP_TEST_HOOKS
+        if (std::getenv("MSM_HIP_POLL_VERIFY")) {  // diagnosis (tools/race_hunt.py): is what the host accepted what the RETIRED kernel left?
+            const std::vector<uint32_t> snap(c->qsums.begin(), c->qsums.begin() + (size_t)nblk * 24);
+            uint32_t fl[8];
+            std::memcpy(fl, c->flagw, sizeof fl);
+            if (done) HIPCHK(c, hipEventSynchronize(done));
+            else HIPCHK(c, hipStreamSynchronize(st));
+            if (!gather_results(c, nblk, seq)) return fail(c, MSM_ERR_HIP, "internal: POLL_VERIFY: pairs missing after the kernel retired");
+            for (uint32_t k = 0; k < nblk * 24; k++)
+                if (snap[k] != c->qsums[k]) {
+                    std::fprintf(stderr, "[msm_hip] POLL_VERIFY: bit sum %u word %u accepted as %08x, is %08x (seq %u, %u sums)\n", k / 24, k % 24, snap[k], c->qsums[k], seq, nblk);
+                    break;
+                }
+            if (std::memcmp(fl, c->flagw, sizeof fl)) std::fprintf(stderr, "[msm_hip] POLL_VERIFY: flag words accepted early differ\n");
+        }
+#endif
     }
     HIPCHK(c, hipGetLastError());
     c->flags_clean = true;  // the last kernel zeroed the flag words after copying them out
     auto t_fin0 = std::chrono::steady_clock::now();
     int32_t rc;
-    if ((rc = check_flags(c, c->h_flags))) return rc;
-    hostg1::Jac total = host_finish(c, c->h_qsums, ps);
+    if ((rc = check_flags(c, c->flagw))) return rc;
+    hostg1::Jac total = host_finish(c, c->qsums.data(), ps);
     finish_outputs(total, out_jac, out_aff, out_inf, (c->cfg.flags & MSM_FLAG_DETERMINISTIC) != 0);
     auto t_fin1 = std::chrono::steady_clock::now();
     float ms = 0;
@@ -917,7 +954,7 @@ int32_t finish_sync(msm_ctx* c, const PipeState& ps, size_t n_total, hipStream_t
     tm.batch_layout = c->last_batch_layout;  // (of the last BATCH call: a single call in between does not reset it -- ADVICE r4)
     tm.finish_ms = std::chrono::duration<float, std::milli>(t_fin1 - t_fin0).count();
     tm.num_points = n_total;
-    tm.num_adds = (uint64_t)c->h_flags[msmk::FLAG_ADDS64] | ((uint64_t)c->h_flags[msmk::FLAG_ADDS64 + 1] << 32);
+    tm.num_adds = (uint64_t)c->flagw[msmk::FLAG_ADDS64] | ((uint64_t)c->flagw[msmk::FLAG_ADDS64 + 1] << 32);
     return MSM_OK;
 }
 
@@ -1425,9 +1462,11 @@ static int32_t ctx_create_impl(const msm_config_t* cfg, msm_ctx** out, int main_
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_free[i], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_scal[i], hipEventDisableTiming);
     }
-    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_qsums, MAX_QSUM_POINTS * 100, hipHostMallocDefault);
-    if (e == hipSuccess) std::memset(c->h_qsums, 0, MAX_QSUM_POINTS * 100);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_flags, 64, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_qsums, MAX_QSUM_POINTS * 192, hipHostMallocDefault);  // 24 (word, seq) pairs per bit sum
+    if (e == hipSuccess) std::memset(c->h_qsums, 0, MAX_QSUM_POINTS * 192);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_flags, 64, hipHostMallocDefault);  // 8 pairs
+    if (e == hipSuccess) std::memset(c->h_flags, 0, 64);
+    if (e == hipSuccess) c->qsums.assign(MAX_QSUM_POINTS * 24, 0u);
     if (e == hipSuccess) e = hipMalloc(&c->clk.p, 32);
     if (e == hipSuccess) {
         c->clk.cap = 32;

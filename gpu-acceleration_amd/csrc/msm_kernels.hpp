@@ -198,13 +198,35 @@ __device__ __forceinline__ void store_jacobian_mont256(uint32_t* o, const jacobi
     fp_to_mont256(w, j.z);
     store_words8(o + 16, w);
 }
+// RESULTS IN PINNED HOST MEMORY, self-validating (round 6).  The host does not wait for the last kernel to retire: it polls what the kernel writes.  A first
+// form -- the 24 words of a bit sum, a system-scope fence, then a sequence word per workgroup -- was WRONG about once in 50 000 calls: the host saw every
+// sequence word of the call and still read a 32-byte chunk of the previous call's sum (tools/race_hunt.py; the chunk arrived after the word that was stored
+// behind the fence -- device stores to host memory are posted writes, and nothing the shader can do orders two of them at their destination).  Now every
+// result word travels as an aligned 8-byte PAIR (word, sequence number of the call): a pair is written by one store and read by one load, so a word whose
+// tag is the call's number IS this call's word, whatever order the pairs arrive in.  48 words per bit sum instead of 24 + 1; no fence.
+__device__ __forceinline__ void store_words8_tagged(uint32_t* p, const uint32_t w[8], uint32_t seq) {  // p: 16 words, 16-byte aligned
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(w[0], seq, w[1], seq);
+    q[1] = make_uint4(w[2], seq, w[3], seq);
+    q[2] = make_uint4(w[4], seq, w[5], seq);
+    q[3] = make_uint4(w[6], seq, w[7], seq);
+}
+__device__ __forceinline__ void store_jacobian_mont256_tagged(uint32_t* o, const jacobian& j, uint32_t seq) {  // o: 48 words
+    uint32_t w[8];
+    fp_to_mont256(w, j.x);
+    store_words8_tagged(o, w, seq);
+    fp_to_mont256(w, j.y);
+    store_words8_tagged(o + 16, w, seq);
+    fp_to_mont256(w, j.z);
+    store_words8_tagged(o + 32, w, seq);
+}
 // The same for the XYZZ record `rec` (LDS), by the first THREE lanes of the calling wavefront (round 6).  The conversion is three independent chains --
 //   X' = X * (ZZ^2)^2 * c     Y' = Y * (ZZZ^2)^2 * c     Z' = ZZ * ZZZ * c          (c = 2^256 / 2^261: internal -> arkworks' Montgomery domain)
 // -- of 4, 4 and 2 multiplications: lane 0, 1, 2 run one each through ONE fp_mul call site (a loop of four trips), 4 multiplications in series and
 // 1.4 KB of code instead of the 10 in series and ~14 KB, executed once and cold, of store_jacobian_mont256(xyzz_to_jacobian()) on one lane: that tail
 // was 14 of k_reduce_bits_wide's 40 us (profiles/r6_wide_level_breakdown.txt).  The identity (ZZ == 0) goes out as (R, R, 0), as there.
-// Call with threadIdx.x < 64 (whole first wavefront, any lanes beyond 2 idle along); o = 24 words, HBM or pinned host memory.
-__device__ __forceinline__ void store_jacobian_mont256_lanes(uint32_t* o, const uint32_t* rec) {
+// Call with threadIdx.x < 64 (whole first wavefront, any lanes beyond 2 idle along); o = 48 words of pinned host memory ((word, seq) pairs, see above).
+__device__ __forceinline__ void store_jacobian_mont256_lanes(uint32_t* o, const uint32_t* rec, uint32_t seq) {
     const uint32_t lane = threadIdx.x;
     if (lane >= 3) return;
     const fp zz = load_coord(rec, 2), zzz = load_coord(rec, 3);
@@ -223,7 +245,7 @@ __device__ __forceinline__ void store_jacobian_mont256_lanes(uint32_t* o, const 
     }
     uint32_t w[8];
     fp_pack(w, fp_reduce_lt2p(r));
-    store_words8(o + 8 * lane, w);
+    store_words8_tagged(o + 16 * lane, w, seq);
 }
 __device__ __forceinline__ jacobian load_jacobian_mont256(const uint32_t* p) {
     uint32_t w[8];
@@ -1872,9 +1894,9 @@ template <int PARTS = 7>
 __global__ void __launch_bounds__(512) k_reduce_bits_wide(const uint32_t* __restrict__ R, const uint32_t* __restrict__ C,
                                                           uint32_t* __restrict__ q, uint32_t n_hi, uint32_t n_lo, uint32_t kb_lo,
                                                           uint32_t kb, uint32_t* __restrict__ flags, uint32_t* __restrict__ flags_out,
-                                                          uint32_t* __restrict__ done, uint32_t seq) {
-    if (blockIdx.x == 0 && threadIdx.x < 8) {  // q, flags_out, done: pinned HOST memory
-        flags_out[threadIdx.x] = flags[threadIdx.x];
+                                                          uint32_t seq) {
+    if (blockIdx.x == 0 && threadIdx.x < 8) {  // q, flags_out: pinned HOST memory, (word, seq) pairs (store_words8_tagged)
+        reinterpret_cast<uint2*>(flags_out)[threadIdx.x] = make_uint2(flags[threadIdx.x], seq);
         flags[threadIdx.x] = 0;  // this kernel ends the MSM: the next one starts from clean error / count words
     }
     __shared__ uint32_t e[WIDE_TREE_MAX * XW];
@@ -1907,15 +1929,11 @@ __global__ void __launch_bounds__(512) k_reduce_bits_wide(const uint32_t* __rest
     if (PARTS & 2) lds_tree_wide(e, nsel);
     else __syncthreads();
     if (PARTS & 4) {
-        if (threadIdx.x < 64) store_jacobian_mont256_lanes(q + (size_t)blockIdx.x * 24, e);
+        // The host does not wait for the kernel to RETIRE (end-of-kernel cache maintenance, completion signal, the runtime's wake-up): it polls the
+        // (word, seq) pairs themselves (finish_sync)
+        if (threadIdx.x < 64) store_jacobian_mont256_lanes(q + (size_t)blockIdx.x * 48, e, seq);
     } else if (threadIdx.x == 0) {
-        for (int i = 0; i < 24; i++) q[(size_t)blockIdx.x * 24 + i] = e[i];
-    }
-    // The host does not wait for the kernel to RETIRE (end-of-kernel cache maintenance, completion signal, the runtime's wake-up): every workgroup
-    // ends by publishing the call's sequence number behind its bit sum, after a system-scope fence, and the host polls those words (finish_sync).
-    if (threadIdx.x < 64) {
-        __threadfence_system();
-        if (threadIdx.x == 0) done[blockIdx.x] = seq;
+        for (int i = 0; i < 24; i++) reinterpret_cast<uint2*>(q)[(size_t)blockIdx.x * 24 + i] = make_uint2(e[i], seq);
     }
 }
 
@@ -1923,9 +1941,9 @@ __global__ void __launch_bounds__(512) k_reduce_bits_wide(const uint32_t* __rest
 __global__ void __launch_bounds__(64) k_reduce_bits(const uint32_t* __restrict__ R, const uint32_t* __restrict__ C,
                                                     uint32_t* __restrict__ q, uint32_t n_hi, uint32_t n_lo, uint32_t kb_lo,
                                                     uint32_t kb, uint32_t* __restrict__ flags, uint32_t* __restrict__ flags_out,
-                                                    uint32_t* __restrict__ done, uint32_t seq) {
-    if (blockIdx.x == 0 && threadIdx.x < 8) {  // q, flags_out, done: pinned HOST memory
-        flags_out[threadIdx.x] = flags[threadIdx.x];
+                                                    uint32_t seq) {
+    if (blockIdx.x == 0 && threadIdx.x < 8) {  // q, flags_out: pinned HOST memory, (word, seq) pairs
+        reinterpret_cast<uint2*>(flags_out)[threadIdx.x] = make_uint2(flags[threadIdx.x], seq);
         flags[threadIdx.x] = 0;  // this kernel ends the MSM: the next one starts from clean error / count words
     }
     uint32_t w = blockIdx.x / (kb + 1), u = blockIdx.x % (kb + 1);
@@ -1974,10 +1992,8 @@ __global__ void __launch_bounds__(64) k_reduce_bits(const uint32_t* __restrict__
         acc = xyzz_add(acc, other);
     }
     if (threadIdx.x == 0) {
-        store_jacobian_mont256(q + (size_t)blockIdx.x * 24, xyzz_to_jacobian(acc));
+        store_jacobian_mont256_tagged(q + (size_t)blockIdx.x * 48, xyzz_to_jacobian(acc), seq);  // (see k_reduce_bits_wide: the host polls the pairs)
     }
-    __threadfence_system();  // (see k_reduce_bits_wide: the host polls the sequence words)
-    if (threadIdx.x == 0) done[blockIdx.x] = seq;
 }
 
 }  // namespace msmk

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity run on the GPU box: random sizes, window sizes, digit modes, infinity masks and scalar skews,
 every result compared bit for bit with the CPU oracle (Pippenger) -- a wider net than the fixed test cases.
-usage: tools/fuzz_parity.py [cases] [seed]"""
+usage: tools/fuzz_parity.py [cases] [seed] [only_case [repeats]]   (only_case: replay the random draws, run THAT case `repeats` times and say which check fails)"""
 import os, sys, time
 os.environ.setdefault("MSM_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpu-acceleration_amd", "libmsm_hip_hooks.so"))  # the A/B knobs this script sets are read by the HOOKS build only (round 5)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,6 +12,8 @@ from oracle import bn254_oracle as orc
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20261002)
+ONLY = int(sys.argv[3]) if len(sys.argv) > 3 else None
+REPEATS = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 NMAX = 60000
 k_all = orc.gen_scalars(4242, NMAX, nonzero=True)
 bases_all = orc.gen_bases_from_logs(k_all, orc.FORM_MONT)
@@ -48,18 +50,23 @@ for it in range(cases):
         divs = [f for f in range(2, pl.num_windows + 1) if pl.num_windows % f == 0]
         if divs and rng.random() < 0.5:
             os.environ["MSM_HIP_TABLE_F"] = str(int(rng.choice(divs)))
-    with mh.MsmContext(window_bits=wb, flags=flags) as ctx:
-        if table:
-            ctx.upload_bases(bases, mh.FORM_MONT, inf)
-            r = ctx.msm_resident(s)
-            r2 = ctx.msm_resident_batch([s, s])[1]
-        else:
-            r = ctx.msm(bases, s, mh.FORM_MONT, inf)
-            r2 = ctx.msm(bases, s, mh.FORM_MONT, inf)
-    exp, einf, _ = orc.msm_pippenger(bases, s, orc.FORM_MONT, inf)
-    ok = r.is_infinity == bool(einf) and (r.affine_std == exp).all() and (r2.affine_std == r.affine_std).all()
-    if not ok:
-        bad += 1
-        print("MISMATCH case", it, dict(n=n, off=off, mode=mode, wb=wb, flags=flags, table_f=os.environ.get('MSM_HIP_TABLE_F'), inf=None if inf is None else int(inf.sum())), flush=True)
+    if ONLY is not None and it != ONLY:
+        continue
+    for rep in range(REPEATS if ONLY is not None else 1):
+        with mh.MsmContext(window_bits=wb, flags=flags) as ctx:
+            if table:
+                ctx.upload_bases(bases, mh.FORM_MONT, inf)
+                r = ctx.msm_resident(s)
+                r2 = ctx.msm_resident_batch([s, s])[1]
+            else:
+                r = ctx.msm(bases, s, mh.FORM_MONT, inf)
+                r2 = ctx.msm(bases, s, mh.FORM_MONT, inf)
+        exp, einf, _ = orc.msm_pippenger(bases, s, orc.FORM_MONT, inf)
+        ok1 = r.is_infinity == bool(einf) and (r.affine_std == exp).all()
+        ok2 = r2.is_infinity == bool(einf) and (r2.affine_std == exp).all()
+        if not (ok1 and ok2):
+            bad += 1
+            print("MISMATCH case", it, "rep", rep, "first call ok", bool(ok1), "second call ok", bool(ok2),
+                  dict(n=n, off=off, mode=mode, wb=wb, flags=flags, table_f=os.environ.get('MSM_HIP_TABLE_F'), inf=None if inf is None else int(inf.sum())), flush=True)
 print(f"fuzz_parity: {cases} cases, {bad} mismatches, {time.time() - t0:.1f} s")
 sys.exit(1 if bad else 0)
