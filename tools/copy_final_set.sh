@@ -13,3 +13,4 @@ for f in sweep_small sweep_big host_sweep skewed_scalars call_timeline_2p20_2p17
 for f in bench_in_process_2x_same_device bench_streamed_2p22 bench_torchrun_2x_same_device bench_torchrun_4x_same_device; do cp $F/$f.json profiles/${P}_$f.json; done
 cp $F/wide_level_breakdown.txt profiles/r6_wide_level_breakdown.txt
 cp gpurun_out/r6_final_pytest.txt profiles/${P}_pytest.txt
+cp gpurun_out/r6_final_race_hunt.txt profiles/${P}_race_hunt.txt
