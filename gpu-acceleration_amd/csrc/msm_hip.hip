@@ -1127,6 +1127,13 @@ int32_t run_single(msm_ctx* c, const HostInput& in, size_t n, uint32_t* out_jac,
     const bool overlap = n >= 4096 && !c->stage_timing;  // below that two cross-stream waits cost more than the copy
     hipStream_t bs = overlap ? cs : st;                  // stream the bases travel and are converted on
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_START], st));
+    if (overlap && in.kind == KIND_ARKFAST) {
+        // k_ark_repack raises its error bit in the flag words from the COPY stream.  The previous call returned when its results were in host memory, possibly
+        // before its last kernel -- which zeroes those words -- had retired and written its lines back: the copy stream waits for everything queued on the
+        // compute stream so far (nothing of this call yet), so that the bit cannot be lost under that write-back.
+        HIPCHK(c, hipEventRecord(c->ev_free[0], st));  // (an event of the streamed path: unused by a single-shot call)
+        HIPCHK(c, hipStreamWaitEvent(cs, c->ev_free[0], 0));
+    }
     const uint8_t* d_inf = in.carries_inf() ? (const uint8_t*)c->inf.p : nullptr;
     uint32_t* ib = (uint32_t*)c->ibases.p;
     BaseSrc src;
