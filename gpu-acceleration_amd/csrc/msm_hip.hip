@@ -109,6 +109,7 @@ struct Knobs {
     bool ark_slow = false;                     // MSM_HIP_ARK_SLOW: struct arrays always through k_import_ark (A/B and tests of the path a set infinity flag falls back to)
     uint32_t mid_lane_min = msmk::MID_LANE_MIN;  // MSM_HIP_MID_LANE_MIN: k_combine_pieces folds mid lists longer than this one lane per bucket
     size_t split_target = msmplan::SPLIT_PIECES_TARGET;  // MSM_HIP_SPLIT_TARGET: pieces the runs of very long buckets are sized for (make_piece_plan)
+    uint32_t split_shift = msmplan::SPLIT_ENTRIES_SHIFT;  // MSM_HIP_SPLIT_SHIFT: the kernels shorten the runs of very long buckets to entries >> this (msmk::effective_psplit); 0 = never
     uint32_t pair8_max_mb = 200;               // MSM_HIP_PAIR8_MAX_MB: bucket arrays up to this size take k_pair_level8 (three levels in one launch)
     bool no_poll = false;                      // MSM_HIP_NO_POLL: wait for the stream instead of polling the last kernel's sequence words (A/B: tools/ab_env.py)
     uint32_t device_chunk_log2 = 22;           // MSM_HIP_DEVICE_CHUNK_LOG2: point ranges of device-resident instances; 0 = never cut
@@ -132,6 +133,7 @@ struct Knobs {
         k.no_poll = std::getenv("MSM_HIP_NO_POLL") != nullptr;
         k.pair8_max_mb = (uint32_t)num("MSM_HIP_PAIR8_MAX_MB", 0, 4096, 200);
         k.split_target = (size_t)num("MSM_HIP_SPLIT_TARGET", 1024, 1 << 30, (long)msmplan::SPLIT_PIECES_TARGET);
+        k.split_shift = (uint32_t)num("MSM_HIP_SPLIT_SHIFT", 0, 24, msmplan::SPLIT_ENTRIES_SHIFT);
         k.mid_lane_min = (uint32_t)num("MSM_HIP_MID_LANE_MIN", 0, 0x7FFFFFFF, msmk::MID_LANE_MIN);
         k.device_chunk_log2 = (uint32_t)num("MSM_HIP_DEVICE_CHUNK_LOG2", 0, 30, 22);
         k.stream_min_log2 = (uint32_t)num("MSM_HIP_STREAM_MIN_LOG2", 9, 31, 19);
@@ -400,7 +402,7 @@ int32_t pipe_prepare(msm_ctx* c, size_t n_real, size_t plan_n, uint32_t extra_fl
     {
         msmplan::piece_plan fp;
         if (first) fp.pmax = first->pmax, fp.psplit = first->psplit;
-        const msmplan::piece_plan pp = msmplan::make_piece_plan(pairs, ps->sn / nb, tb, c->knobs.piece_len, first ? &fp : nullptr, c->knobs.split_target);
+        const msmplan::piece_plan pp = msmplan::make_piece_plan(pairs, ps->sn / nb, tb, c->knobs.piece_len, first ? &fp : nullptr, c->knobs.split_target, c->knobs.split_shift);
         ps->pmax = pp.pmax, ps->psplit = pp.psplit, ps->maxpieces = pp.max_pieces, ps->maxpartials = pp.max_partials;
     }
     const size_t maxpartials = ps->maxpartials;
@@ -430,6 +432,10 @@ int32_t pipe_prepare(msm_ctx* c, size_t n_real, size_t plan_n, uint32_t extra_fl
     if ((rc = ensure(c, c->flags, 64))) return rc;
     return MSM_OK;
 }
+
+// the run length of very long buckets as the kernels take it (msmk::effective_psplit): the plan's psplit, the shift that shortens it for instances with few
+// entries, and "fixed" when a test forces the lengths
+inline uint32_t split_arg(const msm_ctx* c, const PipeState& ps) { return msmk::psplit_arg(ps.psplit, c->knobs.split_shift, c->knobs.piece_len != 0); }
 
 // K1b: digits + signed recode of one (chunk of an) MSM on stream st (with the GLV split: two halves below 7 * 2^123 per scalar, 2*n_real digit
 // columns).  Needs the scalars (and the infinity mask), NOT the bases.  first = false: a later chunk of a streamed MSM (error bits and
@@ -580,7 +586,7 @@ int32_t enqueue_sort(msm_ctx* c, const PipeState& ps, hipStream_t st, bool into)
         msmk::k_fine_sort<FB><<<gf, FB, 0, st>>>(tmp, rstart, offsets, srt, nb, fine_bits, idx_bits, ncoarse, bigslot, big, hi); \
         if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_SORT], st)); \
         msmk::k_place_count<FB><<<count_blocks + wx * sW, FB, 0, st>>>(tmp, rstart, offsets, srt, nb, fine_bits, idx_bits, ncoarse, bigslot, big, hi, count_blocks, wx, sW, \
-                                                                  (uint32_t)tb, ps.pmax, ps.psplit, (uint32_t*)c->phist.p, flags, (uint32_t*)c->longlist.p, \
+                                                                  (uint32_t)tb, ps.pmax, split_arg(c, ps), (uint32_t*)c->phist.p, flags, (uint32_t*)c->longlist.p, \
                                                                   (uint32_t*)c->midlist.p, (uint32_t*)c->pbase.p, (uint32_t*)c->buckets.p, into ? 1u : 0u); \
     } while (0)
         if (fine_block == 256) MSM_FINE_AND_PLACE(256);
@@ -613,10 +619,10 @@ int32_t enqueue_sort(msm_ctx* c, const PipeState& ps, hipStream_t st, bool into)
     // the piece list, longest first (its histogram and bin cursors were zeroed at the head of this chain: msmk::clear_piece_bins)
     if (!sg.two_level) {  // (the two-level sort tallied the pieces in its last launch, k_place_count)
         if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_SORT], st));
-        msmk::k_piece_count<<<grid1(tb, 1024), 1024, 0, st>>>(offsets, (uint32_t)tb, ps.pmax, ps.psplit, (uint32_t*)c->phist.p, flags, (uint32_t*)c->longlist.p,
+        msmk::k_piece_count<<<grid1(tb, 1024), 1024, 0, st>>>(offsets, (uint32_t)tb, ps.pmax, split_arg(c, ps), (uint32_t*)c->phist.p, flags, (uint32_t*)c->longlist.p,
                                                             (uint32_t*)c->midlist.p, (uint32_t*)c->pbase.p, (uint32_t*)c->buckets.p, into ? 1u : 0u);
     }
-    msmk::k_piece_scatter<<<grid1(tb, 1024), 1024, 0, st>>>(offsets, (uint32_t)tb, ps.pmax, ps.psplit, (const uint32_t*)c->phist.p, (uint32_t*)c->pcursor.p,
+    msmk::k_piece_scatter<<<grid1(tb, 1024), 1024, 0, st>>>(offsets, (uint32_t)tb, ps.pmax, split_arg(c, ps), (const uint32_t*)c->phist.p, (uint32_t*)c->pcursor.p,
                                                           (const uint32_t*)c->pbase.p, (uint4*)c->plist.p, flags);
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_PLAN], st));  // msm_timings_t.plan_ms
     return MSM_OK;
@@ -689,9 +695,9 @@ int32_t enqueue_accumulate(msm_ctx* c, const PipeState& ps, const BaseSrc& src, 
     }
 #undef MSM_ACC_LAUNCH
     msmk::k_combine_pieces<<<dim3(msmk::LONG_BLOCKS + msmk::MID_BLOCKS + msmk::MID2_BLOCKS), msmk::COMBINE_BLOCK, 0, st>>>(
-        offsets, pt, bk, ps.pmax, ps.psplit, (const uint32_t*)c->pbase.p, flags + msmk::FLAG_MID, flags + msmk::FLAG_MID2, (const uint32_t*)c->midlist.p, (uint32_t)ps.tb,
+        offsets, pt, bk, ps.pmax, split_arg(c, ps), (const uint32_t*)c->pbase.p, flags + msmk::FLAG_MID, flags + msmk::FLAG_MID2, (const uint32_t*)c->midlist.p, (uint32_t)ps.tb,
         flags + msmk::FLAG_LONG,
-        (const uint32_t*)c->longlist.p, (uint32_t*)c->longdone.p, c->knobs.mid_lane_min);
+        (const uint32_t*)c->longlist.p, (uint32_t*)c->longdone.p, c->knobs.mid_lane_min, flags + msmk::FLAG_PAIRS);
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_COMBINE], st));  // msm_timings_t.combine_ms
     return MSM_OK;
 }

@@ -27,6 +27,7 @@
 //   plist    pieces x 4     (bucket, first sorted entry, length | flags, partial slot), longest pieces first
 //   partials  x 36          partial sums of the pieces of buckets longer than the cap (mean + 2 sigma: msmplan::make_piece_plan)
 #pragma once
+#include "msm_planner.hpp"
 #include "ec_bn254.hpp"
 #include "ec_wide.hpp"
 #include "glv_bn254.hpp"
@@ -1256,6 +1257,22 @@ constexpr uint32_t PF_WHOLE = 0x80000000u;            // piece.z: the bucket is 
 constexpr uint32_t PF_FIRST = 0x40000000u;            // piece.z: first piece of a split bucket (INTO: starts from the bucket's old value)
 constexpr uint32_t PF_LEN_MASK = 0x00FFFFFFu;
 
+// The run length of very long buckets as the DEVICE sees the instance (round 6).  The host plans `psplit` for the most entries the instance can have (W * n_v); an
+// instance whose scalars are mostly zero or tiny sorts far fewer, and its one or two hot buckets, cut into runs planned for a full instance, are what the
+// launch then waits for: a witness-like mix at 2^20 (40 % zeros, 30 % ones: 3.8 M entries instead of 16.8 M, one bucket of 314 000) accumulated in 0.25 ms with
+// runs of 32 and in 0.35 with the 64 a full instance wants.  The kernels that cut buckets shorten the runs to the largest power of two <= entries >> shift
+// (never below 8, never above the host's plan -- the workspace is sized for that).  The argument packs: bits 0-15 the host's psplit, 16-23 the shift,
+// bit 31 = fixed (a forced length of the tests: taken as it is).
+constexpr uint32_t PSPLIT_FIXED = 0x80000000u;
+__host__ __device__ __forceinline__ uint32_t psplit_arg(uint32_t psplit, uint32_t shift, bool fixed) {
+    return (psplit & 0xFFFFu) | ((shift & 0xFFu) << 16) | (fixed ? PSPLIT_FIXED : 0u);
+}
+__device__ __forceinline__ uint32_t effective_psplit(uint32_t arg, uint32_t entries) {
+    const uint32_t psplit = arg & 0xFFFFu;
+    if (arg & PSPLIT_FIXED) return psplit;
+    return msmplan::effective_psplit(psplit, (arg >> 16) & 0xFFu, entries);
+}
+
 // how a bucket of sz entries is cut: 1 piece up to pmax entries; up to LONG_SPAN * pmax entries into runs of pmax and a remainder (one
 // addition to fold them; the short rests are what the launch ends on: cut into EQUAL halves instead, buckets of twice the mean cost
 // k_accumulate_pieces 2.63 instead of 2.40 Mcycles at 2^20, the smallest items then being ~35 entries long); beyond that into runs of psplit.
@@ -1364,6 +1381,7 @@ __global__ void __launch_bounds__(1024) k_piece_count(const uint32_t* __restrict
     __shared__ uint32_t s_n[4], s_base[4];  // [0] mid list, [1] long list, [2] partial-sum slots, [3] two-piece list: reserved once per workgroup
     if (blockIdx.x == 0 && threadIdx.x == 0)  // mixed additions executed so far (msm_timings_t.num_adds), all chunks of a streamed MSM
         *reinterpret_cast<unsigned long long*>(flags + FLAG_ADDS64) += (unsigned long long)flags[FLAG_PAIRS];
+    psplit = effective_psplit(psplit, flags[FLAG_PAIRS]);  // (the packed argument -> the run length for THIS instance's entries)
     piece_tally_begin(s_hist, s_n, pmax);
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     piece_tally t{2u, 0u, 1u, 0u, 0u};
@@ -1390,6 +1408,7 @@ __global__ void __launch_bounds__(FINE_BLOCK) k_place_count(const uint32_t* __re
                                                             uint32_t* __restrict__ pbase, uint32_t* __restrict__ buckets, uint32_t into) {
     __shared__ uint32_t s_hist[PIECE_BINS + 1];
     __shared__ uint32_t s_n[4], s_pbase[4];
+    psplit = effective_psplit(psplit, flags[FLAG_PAIRS]);
     const uint32_t nfine = 1u << fine_bits, fmask = nfine - 1u;
     if (blockIdx.x < count_blocks) {
         if (blockIdx.x == 0 && threadIdx.x == 0)  // mixed additions executed so far (msm_timings_t.num_adds), all chunks of a streamed MSM
@@ -1481,6 +1500,7 @@ __global__ void __launch_bounds__(1024) k_piece_scatter(const uint32_t* __restri
                                                        const uint32_t* __restrict__ pbase, uint4* __restrict__ plist, uint32_t* __restrict__ flags) {
     __shared__ uint32_t s_start[PIECE_BINS + 1], s_cnt[PIECE_BINS + 1], s_cur[PIECE_BINS + 1];
     __shared__ uint32_t s_wsum[16];
+    psplit = effective_psplit(psplit, flags[FLAG_PAIRS]);
     {   // thread r owns the bin of length pmax - r (r < pmax); lengths above pmax do not exist, length 0 is never a piece
         const uint32_t len = threadIdx.x < pmax ? pmax - threadIdx.x : 0u;
         const uint32_t h = len ? hist[len] : 0u;
@@ -1644,8 +1664,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3))) k
                                                         const uint32_t* __restrict__ mid_count, const uint32_t* __restrict__ mid2_count,
                                                         const uint32_t* __restrict__ mid_list, uint32_t mid3_off,
                                                         const uint32_t* __restrict__ long_count, const uint32_t* __restrict__ long_list,
-                                                        uint32_t* __restrict__ long_done, uint32_t mid_lane_min) {
+                                                        uint32_t* __restrict__ long_done, uint32_t mid_lane_min, const uint32_t* __restrict__ entries) {
     __shared__ uint32_t e[WIDE_TREE_MAX * XW];
+    psplit = effective_psplit(psplit, *entries);  // (flags + FLAG_PAIRS: what the sort chain of this accumulation counted)
     if (blockIdx.x >= LONG_BLOCKS) {
         // mid list: EIGHT lanes per listed bucket (round 6; one lane folding its 2..7 pieces with complete additions took this launch 19 us on uniform
         // scalars -- a lone wavefront's xyzz_add is 6.6 us warm and its ~40 KB of code arrive cold -- and up to 0.45 ms on skewed ones).  Two pieces: one

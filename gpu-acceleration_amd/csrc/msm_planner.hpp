@@ -95,8 +95,25 @@ struct piece_plan {
     uint32_t pmax = 0, psplit = 0;
     size_t max_pieces = 0, max_partials = 0;
 };
+// The kernels shorten psplit for instances that sort FEW entries (msmk::effective_psplit: the largest power of two <= entries >> SPLIT_ENTRIES_SHIFT, at least 8, at
+// most psplit): such an instance is cut into fewer than 2^(shift + 1) runs (entries < (want + 1) * 2^shift <= 2 p * 2^shift), which max_pieces / max_partials allow for.
+// Measured (tools/split_length_ab.py MSM_HIP_SPLIT_SHIFT=..., 2^20 points, ms): witness-like mix (40 % zeros, 30 % ones) shift 0 (never): 0.759, 15: 0.761, 16: 0.657, 17: 0.662,
+// 18: 0.668; all scalars < 2^32: 0.667 / 0.672 / 0.663 / 0.622 / 0.622; every full-size row (uniform, all-equal, 3-distinct, 256-distinct, fixture shapes) unchanged.
+constexpr uint32_t SPLIT_ENTRIES_SHIFT = 17;
+#ifdef __HIPCC__
+#define MSMPLAN_HD __host__ __device__
+#else
+#define MSMPLAN_HD
+#endif
+// the rule itself (the kernels call it through msmk::effective_psplit; tools/host_asan_check.cpp holds make_piece_plan's bounds against it)
+MSMPLAN_HD inline uint32_t effective_psplit(uint32_t psplit, uint32_t shift, uint32_t entries) {
+    const uint32_t want = entries >> shift;  // (shift 0: never shortened)
+    uint32_t p = 8;
+    while (p * 2 <= want && p * 2 <= psplit) p *= 2;
+    return p < psplit ? p : psplit;
+}
 inline piece_plan make_piece_plan(size_t pairs, size_t mean_occupancy, size_t total_buckets, uint32_t forced_len = 0, const piece_plan* first = nullptr,
-                                  size_t split_target = SPLIT_PIECES_TARGET) {
+                                  size_t split_target = SPLIT_PIECES_TARGET, uint32_t entries_shift = SPLIT_ENTRIES_SHIFT) {
     piece_plan p;
     size_t two_sigma = 0;
     while ((two_sigma + 1) * (two_sigma + 1) <= 4 * mean_occupancy) two_sigma++;  // floor(2 sqrt(mean))
@@ -119,8 +136,10 @@ inline piece_plan make_piece_plan(size_t pairs, size_t mean_occupancy, size_t to
     if (forced_len) p.pmax = p.psplit = std::min<uint32_t>(forced_len, PIECE_BINS_MAX);
     // every non-empty bucket is a piece, a split bucket of sz > pmax entries adds at most sz / psplit more (runs of pmax: ceil(sz / pmax) <=
     // sz / psplit + 1 as well); partial sums: split buckets only (at most sz / psplit + 1 each, and fewer than pairs / pmax buckets can be split)
-    p.max_pieces = std::min(pairs, total_buckets + pairs / p.psplit) + 1;
-    p.max_partials = std::min(pairs, pairs / p.psplit + pairs / ((size_t)p.pmax + 1) + 2) + 1;
+    // (runs of psplit -- or of the shorter length the kernels pick for an instance of few entries: fewer than 2^(entries_shift + 1) of those)
+    const size_t runs = forced_len || entries_shift == 0 ? pairs / p.psplit : std::max<size_t>(pairs / p.psplit, (size_t)1 << std::min<uint32_t>(entries_shift + 1, 40));
+    p.max_pieces = std::min(pairs, total_buckets + runs) + 1;
+    p.max_partials = std::min(pairs, runs + pairs / ((size_t)p.pmax + 1) + 2) + 1;
     return p;
 }
 

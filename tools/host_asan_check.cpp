@@ -261,6 +261,27 @@ static int check_piece_plan() {
         }
         REQUIRE(q.psplit >= 1 && q.psplit <= q.pmax && q.pmax <= msmplan::PIECE_BINS_MAX);
         REQUIRE(pieces <= q.max_pieces && partials <= q.max_partials);
+        // the same buckets inside an instance planned for up to 64 x as many entries (mostly-zero scalars): the kernels shorten the runs
+        // (msmplan::effective_psplit) and the plan's bounds must still hold
+        if (!forced) {
+            const size_t pairs_max = pairs * (1 + rnd() % 64);
+            const msmplan::piece_plan w = msmplan::make_piece_plan(pairs_max, pairs_max / tb, tb);
+            const uint32_t run_eff = msmplan::effective_psplit(w.psplit, msmplan::SPLIT_ENTRIES_SHIFT, (uint32_t)pairs);
+            REQUIRE(run_eff >= 8 || run_eff == w.psplit);
+            REQUIRE(run_eff <= w.psplit);
+            size_t pc = 0, pt = 0;
+            for (size_t k = 0; k < tb; k++) {
+                if (!sz[k]) continue;
+                size_t m = 1;
+                if (sz[k] > w.pmax) {
+                    const size_t run = sz[k] <= (size_t)8 * w.pmax ? w.pmax : run_eff;
+                    m = (sz[k] + run - 1) / run;
+                }
+                pc += m;
+                if (m > 1) pt += m;
+            }
+            REQUIRE(pc <= w.max_pieces && pt <= w.max_partials);
+        }
     }
     return 0;
 }
