@@ -1479,7 +1479,13 @@ static int32_t ctx_create_impl(const msm_config_t* cfg, msm_ctx** out, int main_
     if (e == hipSuccess) std::memset(c->h_qsums, 0, MAX_QSUM_POINTS * 192);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_flags, 64, hipHostMallocDefault);  // 8 pairs
     if (e == hipSuccess) std::memset(c->h_flags, 0, 64);
-    if (e == hipSuccess) c->qsums.assign(MAX_QSUM_POINTS * 24, 0u);
+    if (e == hipSuccess) {
+        try {
+            c->qsums.assign(MAX_QSUM_POINTS * 24, 0u);
+        } catch (const std::bad_alloc&) {  // (no exception crosses the C ABI)
+            e = hipErrorOutOfMemory;
+        }
+    }
     if (e == hipSuccess) e = hipMalloc(&c->clk.p, 32);
     if (e == hipSuccess) {
         c->clk.cap = 32;
