@@ -111,7 +111,7 @@ struct Knobs {
     size_t split_target = msmplan::SPLIT_PIECES_TARGET;  // MSM_HIP_SPLIT_TARGET: pieces the runs of very long buckets are sized for (make_piece_plan)
     uint32_t split_shift = msmplan::SPLIT_ENTRIES_SHIFT;  // MSM_HIP_SPLIT_SHIFT: the kernels shorten the runs of very long buckets to entries >> this (msmk::effective_psplit); 0 = never
     uint32_t pair8_max_mb = 200;               // MSM_HIP_PAIR8_MAX_MB: bucket arrays up to this size take k_pair_level8 (three levels in one launch)
-    bool no_poll = false;                      // MSM_HIP_NO_POLL: wait for the stream instead of polling the last kernel's sequence words (A/B: tools/ab_env.py)
+    bool no_poll = false;                      // MSM_HIP_NO_POLL: wait for the stream instead of polling the last kernel's result pairs (A/B: tools/ab_env.py)
     uint32_t device_chunk_log2 = 22;           // MSM_HIP_DEVICE_CHUNK_LOG2: point ranges of device-resident instances; 0 = never cut
     uint32_t stream_min_log2 = 19;             // MSM_HIP_STREAM_MIN_LOG2: host calls are streamed from this size on (tools/host_path_sweep.py)
     uint32_t stream_chunk_log2 = 0;            // MSM_HIP_STREAM_CHUNK_LOG2: 0 = by size (product: msm_config_t.stream_chunk_log2)
@@ -890,8 +890,8 @@ int32_t finish_sync(msm_ctx* c, const PipeState& ps, size_t n_total, hipStream_t
                     hipEvent_t done = nullptr /* recorded after the last kernel when `st` carries other work too */) {
     if (trace_enabled()) c->enqueue_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - c->t_prepare).count();
     if (c->pool && n_total >= 256) c->pool->arm();  // workers wake up while the GPU works
-    // Round 6: the host polls the sequence words the last kernel's workgroups publish behind their bit sums (pinned memory) instead of waiting
-    // for the stream: the results are there a few microseconds before the kernel has retired and the runtime has woken the waiting thread.
+    // Round 6: the host polls the results themselves -- (word, call number) pairs the last kernel's workgroups write into pinned memory (gather_results) -- instead of
+    // waiting for the stream: they are there a few microseconds before the kernel has retired and the runtime has woken the waiting thread.
     // Every ~1000 polls the stream is queried, so that a failed launch or a lost device ends the wait with an error instead of a hang.
     // (Stage timing reads events recorded behind the kernel: it waits for the stream as before.)
     const uint32_t nblk = ps.rW * (ps.rkb + 1), seq = c->done_seq;

@@ -1241,7 +1241,8 @@ __global__ void k_scatter(const uint32_t* __restrict__ digits, const uint32_t* _
 // start first and the launch ends on its shortest ones (LPT order: the rests of the cut buckets), and a bucket that is one piece is
 // written straight to its slot.  (First form: the top window of a plan was not spread yet and its twice-as-full buckets, cut at 2 x the mean,
 // supplied the rests; now the decomposition spreads it -- k_decompose(_glv) -- and the cap itself does.)  Split buckets leave partial sums in `partials` and are listed for k_combine_pieces
-// (2..7 pieces: one thread per bucket; 8 or more: LDS trees of eight-lane additions per 2048-piece segment).
+// (two pieces: one addition -- eight lanes, or one lane per bucket when tens of thousands are listed; 3..7 pieces: a chain of eight-lane additions; 8 or more: a wavefront per bucket up to
+// 512 pieces, LDS trees of eight-lane additions per 1024-piece segment beyond).
 // Measured against the chunk form, same build, one box (profiles/r4_pieces_vs_chunks.txt): 2^20 1.557 -> 1.488 ms, 2^17 0.470 -> 0.440,
 // 2^22 5.32 -> 5.00.
 constexpr uint32_t LONG_SPAN = 8;     // split buckets of this many pieces or more are folded by whole workgroups (k_combine_pieces)
@@ -1637,9 +1638,10 @@ __global__ void __launch_bounds__(256) MSM_ACC_WAVES k_accumulate_pieces(const u
     }
 }
 
-// Split buckets (longer than pmax entries: skewed scalars, tiny top windows): partial sums partials[pbase[k] .. + m).  ONE launch, two kinds of workgroups: the leading LONG_BLOCKS workgroups take the long list -- (bucket, segment) items of buckets with
-// LONG_SPAN or more pieces: LDS trees of eight-lane additions per 2048-piece segment, the last-arriving workgroup of a bucket folds the
-// segment sums -- the others one bucket of 2..LONG_SPAN-1 pieces per thread.  On uniform scalars both lists are empty.
+// Split buckets (longer than pmax entries: skewed scalars, tiny top windows): partial sums partials[pbase[k] .. + m).  ONE launch, three kinds of workgroups: the leading LONG_BLOCKS workgroups take the long list -- (bucket, segment) items of buckets with
+// LONG_SPAN or more pieces: a wavefront per bucket up to WAVE_ITEM_MAX pieces, LDS trees of eight-lane additions per LONG_SEG-piece segment beyond (the last-arriving workgroup of a bucket folds the
+// segment sums) --, the next MID_BLOCKS the buckets of 3..LONG_SPAN-1 pieces (and the two-piece ones while they are few) with eight lanes per bucket, the trailing MID2_BLOCKS the two-piece
+// buckets one lane each when there are many.  On uniform scalars only the two-piece list is filled (~5 % of the buckets).
 __device__ __forceinline__ void fold_partials(uint32_t* e, const uint32_t* partials, uint32_t base, uint32_t first, uint32_t stride,
                                               uint32_t count) {
     // (round 6, measured and not kept: folding down to 64 records with one-lane additions before the tree when thousands of items are in flight --
