@@ -145,3 +145,46 @@ def test_reference_held_points_tiled_to_2_pow_16():
             assert not r.is_infinity and (r.affine_std == exp).all(), kw
             c.upload_bases(bases, mh.FORM_MONT)
             assert (c.msm_resident(scalars).affine_std == exp).all(), kw
+
+
+@pytest.mark.parametrize("kind", ["witness-like", "below 2^32", "one hot value", "three distinct"])
+def test_full_size_instances_that_sort_few_or_lumpy_entries(hk, kind):
+    """Scalars that are mostly zero or tiny (a witness vector), or a handful of values: the instance sorts far fewer entries than its plan allows for and one
+    or two buckets hold hundreds of thousands of them.  The kernels that cut such buckets choose the run length from the entries they really sorted
+    (msmplan::effective_psplit; round 6, profiles/NOTES_r6.md section 14) while the workspace was sized on the host: 2^20 points through the device call,
+    the streamed host call and the resident set against the closed form, and the list counters say that the long-bucket path was taken."""
+    import torch
+    n = 1 << 20
+    d_b = torch.empty(n * 16, dtype=torch.int32, device="cuda:0")
+    d_s = torch.empty(n * 8, dtype=torch.int32, device="cuda:0")
+    hk.generate_device(0xB2540F71, 0xB2540F72, n, d_b.data_ptr(), d_s.data_ptr())
+    torch.cuda.synchronize()
+    k = th.generate_scalars_host(0xB2540F71, n, nonzero=True)
+    s = d_s.cpu().numpy().view(np.uint32).reshape(n, 8).copy()
+    rng = np.random.default_rng(7)
+    u = rng.random(n)
+    if kind == "witness-like":  # 40 % zeros, 30 % ones, 10 % below 2^16, 20 % uniform
+        full = s.copy()
+        s[u < 0.8] = 0
+        s[(u >= 0.4) & (u < 0.7), 0] = 1
+        sel = (u >= 0.7) & (u < 0.8)
+        s[sel, 0] = full[sel, 0] & 0xFFFF
+    elif kind == "below 2^32":
+        s[:, 1:] = 0
+    elif kind == "one hot value":  # 95 % of the scalars are one 254-bit value, the rest uniform
+        s[u < 0.95] = s[0]
+    else:
+        s = s[np.arange(n) % 3].copy()
+    exp, einf = _expected(orc.dot_words(k, s))
+    assert einf == 0
+    d_s2 = torch.from_numpy(s.view(np.int32).reshape(-1).copy()).cuda()
+    hb = d_b.cpu().numpy().view(np.uint32).reshape(n, 16)
+    for r in (hk.msm_device(d_b.data_ptr(), d_s2.data_ptr(), n), hk.msm_device(d_b.data_ptr(), d_s2.data_ptr(), n)):
+        assert not r.is_infinity and (r.affine_std == exp).all(), kind
+    counts = hk.list_counts()
+    assert counts["long"] > 0, (kind, counts)  # buckets of eight or more pieces were folded
+    assert (hk.msm(hb, s, mh.FORM_MONT).affine_std == exp).all(), kind  # streamed: every chunk picks its own run length
+    with mh.MsmContext(flags=mh.FLAG_NO_GLV) as c:  # an unsplit plan: twice the windows, other bucket sizes
+        assert (c.msm_device(d_b.data_ptr(), d_s2.data_ptr(), n).affine_std == exp).all(), kind
+    hk.upload_bases(hb, mh.FORM_MONT)
+    assert (hk.msm_resident(s).affine_std == exp).all(), kind
