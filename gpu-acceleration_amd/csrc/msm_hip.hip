@@ -550,7 +550,7 @@ int32_t enqueue_sort(msm_ctx* c, const PipeState& ps, hipStream_t st, bool into)
         if ((rc = ensure(c, c->bigslot, (size_t)sW * ncoarse * 4))) return rc;
         if ((rc = ensure(c, c->big, msmk::BIG_WORDS * 4))) return rc;
         if ((rc = ensure(c, c->ccounts, (size_t)sW * ncoarse * NS * 4))) return rc;
-        if ((rc = ensure(c, c->cregion, ((size_t)sW * ncoarse * 2 + 2) * 4))) return rc;
+        if ((rc = ensure(c, c->cregion, ((size_t)sW * ncoarse * 3 + 4) * 4))) return rc;  // region totals, region starts (+ 1), non-empty buckets per region (k_fine_sort -> k_place_count)
         const uint32_t nregions = sW * ncoarse;
         uint32_t* counts = (uint32_t*)c->ccounts.p;
         uint32_t* rtotal = (uint32_t*)c->cregion.p;
@@ -583,7 +583,7 @@ int32_t enqueue_sort(msm_ctx* c, const PipeState& ps, hipStream_t st, bool into)
         const uint32_t count_blocks = (uint32_t)((tb + msmk::PLACE_COUNT_SPAN - 1) / msmk::PLACE_COUNT_SPAN);
 #define MSM_FINE_AND_PLACE(FB) \
     do { \
-        msmk::k_fine_sort<FB><<<gf, FB, 0, st>>>(tmp, rstart, offsets, srt, nb, fine_bits, idx_bits, ncoarse, bigslot, big, hi); \
+        msmk::k_fine_sort<FB><<<gf, FB, 0, st>>>(tmp, rstart, offsets, srt, nb, fine_bits, idx_bits, ncoarse, bigslot, big, hi, rstart + nregions + 2); \
         if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[EV_SORT], st)); \
         msmk::k_place_count<FB><<<count_blocks + wx * sW, FB, 0, st>>>(tmp, rstart, offsets, srt, nb, fine_bits, idx_bits, ncoarse, bigslot, big, hi, count_blocks, wx, sW, \
                                                                   (uint32_t)tb, ps.pmax, split_arg(c, ps), (uint32_t*)c->phist.p, flags, (uint32_t*)c->longlist.p, \

@@ -42,7 +42,7 @@ constexpr int SCALAR_BITS = 254;
 constexpr int XW = 36;  // words per XYZZ record in HBM: 4 coordinates x 9 limbs
 // flags (u32 words, one set per context): [0] error bits  [4] sorted entries of this (chunk of an) MSM  [6,7] running 64-bit total of
 // sorted entries over the chunks of a streamed MSM  [8] long-list entries  [9] mid-list entries  [10] pieces  [11] partial-sum slots
-constexpr uint32_t FLAG_ERR = 0, FLAG_PAIRS = 4, FLAG_ADDS64 = 6, FLAG_LONG = 8, FLAG_MID = 9, FLAG_PIECES = 10, FLAG_PARTIALS = 11, FLAG_MID2 = 12;
+constexpr uint32_t FLAG_ERR = 0, FLAG_PAIRS = 4, FLAG_ADDS64 = 6, FLAG_LONG = 8, FLAG_MID = 9, FLAG_PIECES = 10, FLAG_PARTIALS = 11, FLAG_MID2 = 12, FLAG_NONEMPTY = 13;
 
 // 16-BIT DIGIT CODES (round 5).  Where a window has at most 2^15 buckets and the two-level LDS sort runs (every default plan without a
 // window table: c <= 16 signed), a digit travels from k_decompose to the two sort kernels that read it as 16 bits: bucket index in bits
@@ -556,7 +556,7 @@ __global__ void k_decompose(const uint32_t* __restrict__ scalars, const uint8_t*
                             uint32_t* __restrict__ phist, uint32_t* __restrict__ pcursor) {
     static_assert(!(HIST && D16), "the global-atomic fallback keeps 32-bit digits");
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) err[FLAG_LONG] = 0, err[FLAG_MID] = 0, err[FLAG_MID2] = 0, err[FLAG_PIECES] = 0, err[FLAG_PARTIALS] = 0;  // list counters of this (chunk of an) MSM: k_piece_count fills them later in the stream
+    if (i == 0) err[FLAG_LONG] = 0, err[FLAG_MID] = 0, err[FLAG_MID2] = 0, err[FLAG_PIECES] = 0, err[FLAG_PARTIALS] = 0, err[FLAG_NONEMPTY] = 0;  // list counters of this (chunk of an) MSM: k_piece_count fills them later in the stream
     if (blockIdx.x == 0) clear_piece_bins(phist, pcursor);
     if (i >= n) return;
     const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
@@ -622,7 +622,7 @@ __global__ void __launch_bounds__(256) k_decompose_glv(const uint32_t* __restric
                                 uint32_t top_shift, uint32_t top_bits, uint32_t spread_mask, uint32_t* __restrict__ phist,
                                 uint32_t* __restrict__ pcursor, const uint32_t* __restrict__ phi_src, uint32_t* __restrict__ phi_dst) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) err[FLAG_LONG] = 0, err[FLAG_MID] = 0, err[FLAG_MID2] = 0, err[FLAG_PIECES] = 0, err[FLAG_PARTIALS] = 0;  // list counters of this (chunk of an) MSM: k_piece_count fills them later in the stream
+    if (i == 0) err[FLAG_LONG] = 0, err[FLAG_MID] = 0, err[FLAG_MID2] = 0, err[FLAG_PIECES] = 0, err[FLAG_PARTIALS] = 0, err[FLAG_NONEMPTY] = 0;  // list counters of this (chunk of an) MSM: k_piece_count fills them later in the stream
     if (blockIdx.x == 0) clear_piece_bins(phist, pcursor);
     if (i >= n) return;
     const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
@@ -873,7 +873,7 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_coarse_hist(const void* __restri
     // list counters and piece bins of THIS sort call (k_piece_count fills them later in the stream; k_decompose zeroes them too -- kept
     // here so that a sort never depends on which kernel ran before it)
     if (st == 0 && w == 0) {
-        if (threadIdx.x == 0) flags[FLAG_LONG] = 0, flags[FLAG_MID] = 0, flags[FLAG_MID2] = 0, flags[FLAG_PIECES] = 0, flags[FLAG_PARTIALS] = 0;
+        if (threadIdx.x == 0) flags[FLAG_LONG] = 0, flags[FLAG_MID] = 0, flags[FLAG_MID2] = 0, flags[FLAG_PIECES] = 0, flags[FLAG_PARTIALS] = 0, flags[FLAG_NONEMPTY] = 0;
         clear_piece_bins(phist, pcursor);
     }
     if (threadIdx.x < COARSE_BINS_MAX) s_h[threadIdx.x] = 0;
@@ -1109,7 +1109,8 @@ template <int FINE_BLOCK>
 __global__ void __launch_bounds__(FINE_BLOCK) k_fine_sort(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ region_start,
                                                           uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted, uint32_t nb,
                                                           uint32_t fine_bits, uint32_t idx_bits, uint32_t ncoarse,
-                                                          const uint32_t* __restrict__ bigslot, uint32_t* __restrict__ big, sort_hi hi) {
+                                                          const uint32_t* __restrict__ bigslot, uint32_t* __restrict__ big, sort_hi hi,
+                                                          uint32_t* __restrict__ ne_region /* per (window, coarse bin): its buckets that hold entries (k_place_count adds them up: msmplan::effective_pmax) */) {
     __shared__ uint32_t s_cur[FINE_BINS_MAX];
     __shared__ uint32_t s_wtot[FINE_BINS_MAX / 64];
     __shared__ uint32_t s_bnd[SUPER_MAX];
@@ -1143,7 +1144,12 @@ __global__ void __launch_bounds__(FINE_BLOCK) k_fine_sort(const uint32_t* __rest
     }
     const uint32_t cb = blockIdx.x, w = blockIdx.y;
     const uint32_t r = w * ncoarse + cb;
-    if (bigslot[r] != BIG_NONE) return;  // oversized region: its batches are shared out to the worker blocks (uniform per workgroup)
+    __shared__ uint32_t s_ne;
+    if (threadIdx.x == 0) s_ne = 0;
+    if (bigslot[r] != BIG_NONE) {  // oversized region: its batches are shared out to the worker blocks (uniform per workgroup)
+        if (threadIdx.x == 0) ne_region[r] = 0;  // (its buckets are not counted: skewed scalars keep the plan's pmax more often)
+        return;
+    }
     const uint32_t rs = region_start[r], re = region_start[r + 1], S = re - rs;
     const uint32_t fine_mask = nfine - 1u, idx_mask = (1u << idx_bits) - 1u;
     const bool staged = S <= CAP;
@@ -1175,7 +1181,12 @@ __global__ void __launch_bounds__(FINE_BLOCK) k_fine_sort(const uint32_t* __rest
     __syncthreads();
     // exclusive prefix of the <= 512 fine counts: every wavefront scans its 64 counts with shuffles, the wavefront totals are joined
     // through LDS (a Hillis-Steele scan in LDS cost this kernel 14 workgroup barriers of 1024 threads)
-    const uint32_t ex = fine_scan(threadIdx.x < nfine ? s_cur[threadIdx.x] : 0u, s_wtot);
+    {   // the region's non-empty buckets (a plain store per region: device-scope adds on shared words cost the sort 5-17 us)
+        const unsigned long long any = __ballot(threadIdx.x < nfine && s_cur[threadIdx.x] != 0u);
+        if ((threadIdx.x & 63u) == 0u && any) atomicAdd(&s_ne, (uint32_t)__popcll(any));  // (LDS; zeroed before the first barrier)
+    }
+    const uint32_t ex = fine_scan(threadIdx.x < nfine ? s_cur[threadIdx.x] : 0u, s_wtot);  // (barriers inside)
+    if (threadIdx.x == 0) ne_region[r] = s_ne;
     if (threadIdx.x < nfine) {
         s_cur[threadIdx.x] = ex;                                                       // local cursor
         offsets[(size_t)w * nb + ((size_t)cb << fine_bits) + threadIdx.x] = rs + ex;  // the bucket's CSC column pointer
@@ -1268,10 +1279,19 @@ constexpr uint32_t PSPLIT_FIXED = 0x80000000u;
 __host__ __device__ __forceinline__ uint32_t psplit_arg(uint32_t psplit, uint32_t shift, bool fixed) {
     return (psplit & 0xFFFFu) | ((shift & 0xFFu) << 16) | (fixed ? PSPLIT_FIXED : 0u);
 }
-__device__ __forceinline__ uint32_t effective_psplit(uint32_t arg, uint32_t entries) {
-    const uint32_t psplit = arg & 0xFFFFu;
-    if (arg & PSPLIT_FIXED) return psplit;
-    return msmplan::effective_psplit(psplit, (arg >> 16) & 0xFFu, entries);
+constexpr uint32_t PSPLIT_EQUAL = 0x40000000u;  // marker on the DECODED run length: buckets up to LONG_SPAN x pmax are cut into equal runs (piece_split)
+// the plan's lengths -> the lengths for THIS instance: pmax raised for sparse instances (msmplan::effective_pmax; what is longer is then cut into equal runs),
+// psplit shortened for instances of few entries (effective_psplit).  Every kernel that cuts buckets calls it first, with the same flag words.
+__device__ __forceinline__ void decode_piece_lengths(uint32_t& pmax, uint32_t& psplit /* in: packed argument; out: run length (| PSPLIT_EQUAL) */, uint32_t entries,
+                                                     uint32_t nonempty) {
+    const uint32_t arg = psplit;
+    uint32_t run = arg & 0xFFFFu;
+    if (!(arg & PSPLIT_FIXED)) {
+        const uint32_t raised = msmplan::effective_pmax(pmax, entries, nonempty);
+        run = msmplan::effective_psplit(run, (arg >> 16) & 0xFFu, entries);
+        if (raised > pmax) pmax = raised, run |= PSPLIT_EQUAL;
+    }
+    psplit = run;
 }
 
 // how a bucket of sz entries is cut: 1 piece up to pmax entries; up to LONG_SPAN * pmax entries into runs of pmax and a remainder (one
@@ -1283,7 +1303,9 @@ __device__ __forceinline__ uint32_t piece_split(uint32_t sz, uint32_t pmax, uint
         *q = sz;
         return 1u;
     }
-    *q = sz <= LONG_SPAN * pmax ? pmax : psplit;
+    if (sz > LONG_SPAN * pmax) *q = psplit & ~PSPLIT_EQUAL;
+    else if (psplit & PSPLIT_EQUAL) *q = (sz + (sz + pmax - 1) / pmax - 1) / ((sz + pmax - 1) / pmax);  // ceil(sz / m), m = ceil(sz / pmax): <= pmax
+    else *q = pmax;
     return (sz + *q - 1) / *q;
 }
 
@@ -1382,7 +1404,7 @@ __global__ void __launch_bounds__(1024) k_piece_count(const uint32_t* __restrict
     __shared__ uint32_t s_n[4], s_base[4];  // [0] mid list, [1] long list, [2] partial-sum slots, [3] two-piece list: reserved once per workgroup
     if (blockIdx.x == 0 && threadIdx.x == 0)  // mixed additions executed so far (msm_timings_t.num_adds), all chunks of a streamed MSM
         *reinterpret_cast<unsigned long long*>(flags + FLAG_ADDS64) += (unsigned long long)flags[FLAG_PAIRS];
-    psplit = effective_psplit(psplit, flags[FLAG_PAIRS]);  // (the packed argument -> the run length for THIS instance's entries)
+    decode_piece_lengths(pmax, psplit, flags[FLAG_PAIRS], flags[FLAG_NONEMPTY]);
     piece_tally_begin(s_hist, s_n, pmax);
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     piece_tally t{2u, 0u, 1u, 0u, 0u};
@@ -1409,7 +1431,23 @@ __global__ void __launch_bounds__(FINE_BLOCK) k_place_count(const uint32_t* __re
                                                             uint32_t* __restrict__ pbase, uint32_t* __restrict__ buckets, uint32_t into) {
     __shared__ uint32_t s_hist[PIECE_BINS + 1];
     __shared__ uint32_t s_n[4], s_pbase[4];
-    psplit = effective_psplit(psplit, flags[FLAG_PAIRS]);
+    // the non-empty buckets k_fine_sort counted per region (region_start + sW * ncoarse + 2: behind the region table)
+    __shared__ uint32_t s_nonempty;
+    if (threadIdx.x == 0) s_nonempty = 0;
+    __syncthreads();
+    {
+        const uint32_t nregions = sW * ncoarse;
+        const uint32_t* ne_region = region_start + nregions + 2;
+        uint32_t part = 0;
+        for (uint32_t i = threadIdx.x; i < nregions; i += FINE_BLOCK) part += ne_region[i];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) part += __shfl_down(part, d, 64);
+        if ((threadIdx.x & 63u) == 0u && part) atomicAdd(&s_nonempty, part);
+    }
+    __syncthreads();
+    const uint32_t nonempty = s_nonempty;
+    if (blockIdx.x == 0 && threadIdx.x == 0) flags[FLAG_NONEMPTY] = nonempty;  // (k_piece_scatter and k_combine_pieces read it there)
+    decode_piece_lengths(pmax, psplit, flags[FLAG_PAIRS], nonempty);
     const uint32_t nfine = 1u << fine_bits, fmask = nfine - 1u;
     if (blockIdx.x < count_blocks) {
         if (blockIdx.x == 0 && threadIdx.x == 0)  // mixed additions executed so far (msm_timings_t.num_adds), all chunks of a streamed MSM
@@ -1501,7 +1539,7 @@ __global__ void __launch_bounds__(1024) k_piece_scatter(const uint32_t* __restri
                                                        const uint32_t* __restrict__ pbase, uint4* __restrict__ plist, uint32_t* __restrict__ flags) {
     __shared__ uint32_t s_start[PIECE_BINS + 1], s_cnt[PIECE_BINS + 1], s_cur[PIECE_BINS + 1];
     __shared__ uint32_t s_wsum[16];
-    psplit = effective_psplit(psplit, flags[FLAG_PAIRS]);
+    decode_piece_lengths(pmax, psplit, flags[FLAG_PAIRS], flags[FLAG_NONEMPTY]);
     {   // thread r owns the bin of length pmax - r (r < pmax); lengths above pmax do not exist, length 0 is never a piece
         const uint32_t len = threadIdx.x < pmax ? pmax - threadIdx.x : 0u;
         const uint32_t h = len ? hist[len] : 0u;
@@ -1557,7 +1595,7 @@ __global__ void __launch_bounds__(1024) k_piece_scatter(const uint32_t* __restri
         const uint4 co = s_co[i];
         const uint32_t pb = pbase[co.x];
         for (uint32_t p = threadIdx.x; p < co.z; p += blockDim.x)  // (listed buckets are long ones: runs of psplit)
-            plist[co.w + p] = make_uint4(co.x, co.y + p * psplit, psplit | (p == 0 ? PF_FIRST : 0u), pb + p);
+            plist[co.w + p] = make_uint4(co.x, co.y + p * (psplit & ~PSPLIT_EQUAL), (psplit & ~PSPLIT_EQUAL) | (p == 0 ? PF_FIRST : 0u), pb + p);
     }
 }
 
@@ -1668,7 +1706,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3))) k
                                                         const uint32_t* __restrict__ long_count, const uint32_t* __restrict__ long_list,
                                                         uint32_t* __restrict__ long_done, uint32_t mid_lane_min, const uint32_t* __restrict__ entries) {
     __shared__ uint32_t e[WIDE_TREE_MAX * XW];
-    psplit = effective_psplit(psplit, *entries);  // (flags + FLAG_PAIRS: what the sort chain of this accumulation counted)
+    decode_piece_lengths(pmax, psplit, entries[0], entries[FLAG_NONEMPTY - FLAG_PAIRS]);  // (entries = flags + FLAG_PAIRS: what the sort chain of this accumulation counted)
     if (blockIdx.x >= LONG_BLOCKS) {
         // mid list: EIGHT lanes per listed bucket (round 6; one lane folding its 2..7 pieces with complete additions took this launch 19 us on uniform
         // scalars -- a lone wavefront's xyzz_add is 6.6 us warm and its ~40 KB of code arrive cold -- and up to 0.45 ms on skewed ones).  Two pieces: one

@@ -3,6 +3,7 @@
 #pragma once
 #include <algorithm>
 #include <cstddef>
+#include <cmath>
 #include <cstdint>
 #include <cstdlib>
 
@@ -105,6 +106,39 @@ constexpr uint32_t SPLIT_ENTRIES_SHIFT = 17;
 #else
 #define MSMPLAN_HD
 #endif
+// The longest WHOLE bucket as the device sees the instance (round 6).  pmax = mean + 2 sigma is planned for buckets that are Poisson around n_v / nb; an instance
+// whose entries sit in a SMALL FRACTION of the buckets -- the reference's own fixture shape, one (base, scalar) sequence repeated T times (metal_msm.rs:706-730): at
+// 2^17 points and T = 128 every window has ~2000 buckets of 128 entries and 30 000 empty ones -- is cut into 8 x the pieces it needs (pmax = 16: eight pieces per
+// bucket, 15 853 buckets for k_combine_pieces' long list: 0.38 ms of a 0.80 ms call against 0.36 on uniform scalars).  The two-level sort counts the NON-EMPTY
+// buckets (k_fine_sort); when there are at most SPARSE_BUCKETS_MAX of them -- whole buckets are then at most one wavefront per SIMD, which a lone wavefront keeps
+// nearly busy -- the kernels that cut buckets raise pmax to the occupancy of those, mean + max(8, 2 sqrt(mean)), but not beyond entries >> 16 (2^16 pieces: a
+// wavefront for every SIMD), and cut what is still longer into EQUAL runs (sizes that are multiples of T then give pieces of one length).  Never below the plan;
+// uniform scalars fill every bucket and change nothing; raising pmax only lowers the piece and partial-sum counts the workspace was sized for.
+// Measured with the count in place but WITHOUT the SPARSE_BUCKETS_MAX bound (tools/fixture_shape_sizes.py, ms, before -> after, sort penalty of the first form
+// taken out): T = 128: 2^17 0.795 -> 0.49, 2^18 0.696 -> 0.60, 2^19 1.009 -> 0.85 (57 000 non-empty buckets), 2^20 1.495 -> 1.57 (103 000: two unequal
+// wavefronts per SIMD); T = 32 (103 000 - 165 000 non-empty from 2^18 on): 2^19 0.830 -> 0.90 => only below 65 536.
+constexpr uint32_t SPARSE_BUCKETS_MAX = 65536;
+MSMPLAN_HD inline uint32_t effective_pmax(uint32_t pmax, uint32_t entries, uint32_t nonempty) {
+    if (nonempty == 0 || nonempty > SPARSE_BUCKETS_MAX) return pmax;  // (0: not counted -- fallback sorts)
+    uint32_t mean = entries / nonempty;
+    if (mean > 65536u) mean = 65536u;  // (the result is capped at PIECE_BINS_MAX anyway)
+    // floor(2 sqrt(mean)), exactly, without the plan's counting loop: every thread of three kernels evaluates this (64 trips cost k_place_count 18 us)
+    uint32_t two_sigma = (uint32_t)sqrtf((float)(4u * mean));
+    while (two_sigma * two_sigma > 4u * mean) two_sigma--;
+    while ((two_sigma + 1u) * (two_sigma + 1u) <= 4u * mean) two_sigma++;
+    uint32_t cand = mean + (two_sigma > 8 ? two_sigma : 8u);
+    // (... except where that would still cut a typical bucket into EIGHT or more pieces -- k_combine_pieces' long list: 2^16 points at T = 128, 8049 buckets of
+    // 128 entries, 0.21 ms -- : there four pieces per bucket, at most 32 entries each (0.125 ms at a lone wavefront's rate bounds what the fewer pieces can
+    // cost): 0.537 -> 0.43 ms.  Not in general: 32-entry pieces at 2^16 points and T = 32 are half the wavefronts for the same work, 0.391 -> 0.438)
+    uint32_t cap = entries >> 16;
+    if (mean >= 8u * cap) {
+        const uint32_t quarter = mean / 4u < 32u ? mean / 4u : 32u;
+        if (cap < quarter) cap = quarter;
+    }
+    if (cand > cap) cand = cap;
+    if (cand > PIECE_BINS_MAX) cand = PIECE_BINS_MAX;
+    return cand > pmax ? cand : pmax;
+}
 // the rule itself (the kernels call it through msmk::effective_psplit; tools/host_asan_check.cpp holds make_piece_plan's bounds against it)
 MSMPLAN_HD inline uint32_t effective_psplit(uint32_t psplit, uint32_t shift, uint32_t entries) {
     const uint32_t want = entries >> shift;  // (shift 0: never shortened)

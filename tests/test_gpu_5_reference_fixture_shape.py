@@ -51,7 +51,7 @@ def tiled_instance(hk, logn, T, seed):
     return d_b, d_s, T * orc.dot_words(k, s)
 
 
-@pytest.mark.parametrize("logn,T", [(16, 8), (16, 128), (20, 8), (20, 128)])
+@pytest.mark.parametrize("logn,T", [(16, 8), (16, 128), (17, 128), (18, 32), (19, 128), (20, 8), (20, 128)])  # (17 .. 19: SPARSE instances -- the kernels raise pmax, msmplan::effective_pmax)
 def test_reference_fixture_shape_every_pair_repeated_T_times(hk, logn, T):
     n = 1 << logn
     d_b, d_s, dot = tiled_instance(hk, logn, T, 0xB2540F01 + 16 * logn + T)

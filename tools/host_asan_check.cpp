@@ -269,18 +269,26 @@ static int check_piece_plan() {
             const uint32_t run_eff = msmplan::effective_psplit(w.psplit, msmplan::SPLIT_ENTRIES_SHIFT, (uint32_t)pairs);
             REQUIRE(run_eff >= 8 || run_eff == w.psplit);
             REQUIRE(run_eff <= w.psplit);
-            size_t pc = 0, pt = 0;
-            for (size_t k = 0; k < tb; k++) {
-                if (!sz[k]) continue;
-                size_t m = 1;
-                if (sz[k] > w.pmax) {
-                    const size_t run = sz[k] <= (size_t)8 * w.pmax ? w.pmax : run_eff;
-                    m = (sz[k] + run - 1) / run;
+            // ... and raise the longest whole bucket to the occupancy of the NON-EMPTY buckets (msmplan::effective_pmax); counted fully, partly (oversized regions are
+            // left out of the count) or not at all
+            size_t nonempty = 0;
+            for (size_t k = 0; k < tb; k++) nonempty += sz[k] != 0;
+            for (const size_t counted : {nonempty, nonempty / 3, (size_t)0}) {
+                const uint32_t pmax_eff = msmplan::effective_pmax(w.pmax, (uint32_t)pairs, (uint32_t)counted);
+                REQUIRE(pmax_eff >= w.pmax && pmax_eff <= msmplan::PIECE_BINS_MAX && (pmax_eff == w.pmax || pmax_eff <= std::max<size_t>(pairs >> 16, 32)));
+                size_t pc = 0, pt = 0;
+                for (size_t k = 0; k < tb; k++) {
+                    if (!sz[k]) continue;
+                    size_t m = 1;
+                    if (sz[k] > pmax_eff) {
+                        const size_t run = sz[k] <= (size_t)8 * pmax_eff ? pmax_eff : run_eff;
+                        m = (sz[k] + run - 1) / run;
+                    }
+                    pc += m;
+                    if (m > 1) pt += m;
                 }
-                pc += m;
-                if (m > 1) pt += m;
+                REQUIRE(pc <= w.max_pieces && pt <= w.max_partials);
             }
-            REQUIRE(pc <= w.max_pieces && pt <= w.max_partials);
         }
     }
     return 0;

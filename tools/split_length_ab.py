@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "gpu-acceleration_amd"), os.path.join(ROOT, "tests")]
 import numpy as np, torch
 from mopro_msm_hip import testhooks as th
-n = 1 << 20
+n = 1 << int(os.environ.get("AB_LOGN", "20"))  # (AB_LOGN: another size)
 def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a).view(np.int32).reshape(-1).copy()).cuda()
 with th.HooksContext() as c:
@@ -28,7 +28,7 @@ mix[(u >= 0.4) & (u < 0.7), 0] = 1
 sel = (u >= 0.7) & (u < 0.8)
 mix[sel, 0] = s[sel, 0] & 0xFFFF
 cases.append(("witness-like", b, mix))
-for T in (8, 128):
+for T in (8, 32, 128):
     L = n // T
     cases.append((f"fixture T={T}", np.tile(b[:L], (T, 1)), np.tile(s[:L], (T, 1))))
 devs = [(l, dev(bb), dev(ss)) for l, bb, ss in cases]
